@@ -1,0 +1,618 @@
+"""CPU oracle: a plain-torch fp32 restatement of the UFVideo hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+The product path (``ufvideo_amd``) never imports anything from ``oracle/``.
+
+What it restates (reference = /root/reference, third-party = transformers 4.46.3 /
+timm 1.0.15 as pinned by the reference's requirements.txt):
+
+* SigLIP vision tower            ufvideo/model/encoder.py:126-146  ->  HF modeling_siglip
+                                 (embeddings :116-187, attention :227-307, MLP :310-322,
+                                 layer :325-357)
+* CLIP vision tower              ufvideo/model/encoder.py:12-93   ->  HF modeling_clip
+* STC connector (+v35, spatial)  ufvideo/model/projector.py:133-250 -> timm RegStage
+* region encoder                 ufvideo/model/layer.py:6-152
+* embedding splice               ufvideo/model/videorefer_arch.py:218-370
+* Qwen2 decoder                  ufvideo/model/videorefer_qwen2.py:129-197 -> HF modeling_qwen2
+                                 (MLP :35-48, rotary :51-135, attention :150-235,
+                                 RMSNorm :238-254, layer :258-299)
+* greedy generate                ufvideo/model/videorefer_qwen2.py:357-459 (QA branch)
+* frame sampling / tokenisation  ufvideo/mm_utils.py:43-54,135-158,381-406
+
+Pinning status (see DESIGN.md "Oracle"): every function here except ``regstage`` is
+checked against outputs of the reference itself (imported in the build container by
+``oracle/gen_fixtures.py``; vectors committed under ``tests/golden/``).
+``regstage`` restates timm's published RegNet bottleneck from its documented semantics;
+timm is absent offline, so for that one function: PARITY UNPINNED.
+
+All tensors are fp32 on CPU.  Weights arrive as flat ``dict[str, Tensor]`` with the
+reference's state-dict key names (HF / timm naming) under a caller-chosen prefix.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+IGNORE_INDEX = -100                                   # ufvideo/constants.py:7
+MODAL_INDEX_MAP = {"<image>": -200, "<video>": -201, "<audio>": -202}   # constants.py:37-41
+
+SD = Dict[str, torch.Tensor]
+
+
+def _g(sd: SD, prefix: str, name: str) -> torch.Tensor:
+    return sd[prefix + name].float()
+
+
+# --------------------------------------------------------------------------------------
+# activations
+# --------------------------------------------------------------------------------------
+def gelu_tanh(x):            # HF ACT2FN["gelu_pytorch_tanh"]
+    return F.gelu(x, approximate="tanh")
+
+
+def quick_gelu(x):           # HF ACT2FN["quick_gelu"]  (CLIP)
+    return x * torch.sigmoid(1.702 * x)
+
+
+_ACT = {"gelu_pytorch_tanh": gelu_tanh, "quick_gelu": quick_gelu, "gelu": F.gelu,
+        "silu": F.silu, "relu": F.relu}
+
+
+# --------------------------------------------------------------------------------------
+# SigLIP / CLIP vision tower
+# --------------------------------------------------------------------------------------
+def vit_encoder_layer(sd: SD, p: str, x: torch.Tensor, heads: int, eps: float, act: str) -> torch.Tensor:
+    """One pre-LN encoder layer (modeling_siglip.py:325-357; CLIP's layer is the same graph)."""
+    B, N, D = x.shape
+    hd = D // heads
+    h = F.layer_norm(x, (D,), _g(sd, p, "layer_norm1.weight"), _g(sd, p, "layer_norm1.bias"), eps)
+    q = F.linear(h, _g(sd, p, "self_attn.q_proj.weight"), _g(sd, p, "self_attn.q_proj.bias"))
+    k = F.linear(h, _g(sd, p, "self_attn.k_proj.weight"), _g(sd, p, "self_attn.k_proj.bias"))
+    v = F.linear(h, _g(sd, p, "self_attn.v_proj.weight"), _g(sd, p, "self_attn.v_proj.bias"))
+    q = q.view(B, N, heads, hd).transpose(1, 2)
+    k = k.view(B, N, heads, hd).transpose(1, 2)
+    v = v.view(B, N, heads, hd).transpose(1, 2)
+    att = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)          # :237
+    att = torch.softmax(att.float(), dim=-1)                            # :241 (fp32 softmax)
+    o = torch.matmul(att, v).transpose(1, 2).reshape(B, N, D)
+    o = F.linear(o, _g(sd, p, "self_attn.out_proj.weight"), _g(sd, p, "self_attn.out_proj.bias"))
+    x = x + o
+    h = F.layer_norm(x, (D,), _g(sd, p, "layer_norm2.weight"), _g(sd, p, "layer_norm2.bias"), eps)
+    h = F.linear(h, _g(sd, p, "mlp.fc1.weight"), _g(sd, p, "mlp.fc1.bias"))
+    h = _ACT[act](h)
+    h = F.linear(h, _g(sd, p, "mlp.fc2.weight"), _g(sd, p, "mlp.fc2.bias"))
+    return x + h
+
+
+def siglip_embeddings(sd: SD, p: str, pixel_values: torch.Tensor, patch: int) -> torch.Tensor:
+    """Conv2d(k=s=patch, valid) -> flatten -> + learned position table (modeling_siglip.py:175-186)."""
+    w = _g(sd, p, "embeddings.patch_embedding.weight")
+    b = _g(sd, p, "embeddings.patch_embedding.bias")
+    e = F.conv2d(pixel_values.float(), w, b, stride=patch)
+    e = e.flatten(2).transpose(1, 2)
+    return e + _g(sd, p, "embeddings.position_embedding.weight")[None]
+
+
+def siglip_tower(sd: SD, cfg: dict, pixel_values: torch.Tensor, prefix: str = "",
+                 select_layer: int = -2, return_all: bool = False):
+    """SiglipVisionTower.forward + feature_select (encoder.py:126-146).
+
+    HF ``hidden_states`` = [embeddings, layer1 out, ..., layerL out]; the reference picks
+    ``hidden_states[select_layer]`` (=-2 -> output of layer L-1), so the last layer,
+    post_layernorm and the pooling head never influence the result and are skipped.
+    """
+    p = prefix
+    L = cfg["num_hidden_layers"]
+    x = siglip_embeddings(sd, p, pixel_values, cfg["patch_size"])
+    hs = [x]
+    n_run = L if return_all else (L + 1 + select_layer if select_layer < 0 else select_layer)
+    for i in range(n_run):
+        x = vit_encoder_layer(sd, f"{p}encoder.layers.{i}.", x, cfg["num_attention_heads"],
+                              cfg.get("layer_norm_eps", 1e-6), cfg.get("hidden_act", "gelu_pytorch_tanh"))
+        hs.append(x)
+    if return_all:
+        return hs
+    return hs[select_layer] if select_layer >= 0 else hs[n_run]
+
+
+def clip_tower(sd: SD, cfg: dict, pixel_values: torch.Tensor, prefix: str = "",
+               select_layer: int = -2, select_feature: str = "patch") -> torch.Tensor:
+    """CLIPVisionTower.forward + feature_select (encoder.py:36-58): class token + position
+    table, pre_layrnorm, encoder layers, CLS dropped for 'patch'."""
+    p = prefix
+    L = cfg["num_hidden_layers"]
+    D = cfg["hidden_size"]
+    eps = cfg.get("layer_norm_eps", 1e-5)
+    w = _g(sd, p, "embeddings.patch_embedding.weight")
+    e = F.conv2d(pixel_values.float(), w, None, stride=cfg["patch_size"]).flatten(2).transpose(1, 2)
+    cls = _g(sd, p, "embeddings.class_embedding").expand(e.shape[0], 1, -1)
+    x = torch.cat([cls, e], dim=1) + _g(sd, p, "embeddings.position_embedding.weight")[None]
+    x = F.layer_norm(x, (D,), _g(sd, p, "pre_layrnorm.weight"), _g(sd, p, "pre_layrnorm.bias"), eps)
+    n_run = L + 1 + select_layer if select_layer < 0 else select_layer
+    for i in range(n_run):
+        x = vit_encoder_layer(sd, f"{p}encoder.layers.{i}.", x, cfg["num_attention_heads"], eps,
+                              cfg.get("hidden_act", "quick_gelu"))
+    if select_feature == "patch":
+        x = x[:, 1:]
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# Projector: timm RegStage restatement + STC connector
+# --------------------------------------------------------------------------------------
+def layernorm2d(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    """timm LayerNorm2d: LayerNorm over the channel dim of an NCHW tensor."""
+    return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, eps).permute(0, 3, 1, 2)
+
+
+def regstage_block(sd: SD, p: str, x: torch.Tensor, eps: float) -> torch.Tensor:
+    """timm.models.regnet.Bottleneck with bottle_ratio=1, group_size=1 (depthwise 3x3),
+    se_ratio=0.25, downsample='conv1x1', act=SiLU, norm=LayerNorm2d.  PARITY UNPINNED
+    (timm 1.0.15 absent offline).  Graph:
+        conv1 1x1 (no bias) -> LN2d -> SiLU
+        conv2 3x3 depthwise pad 1 (no bias) -> LN2d -> SiLU
+        se:   mean(H,W) -> fc1 (+bias) -> SiLU -> fc2 (+bias) -> sigmoid -> scale
+        conv3 1x1 (no bias) -> LN2d
+        + shortcut (1x1 conv + LN2d when in_chs != out_chs, identity otherwise) -> SiLU
+    """
+    sc = x
+    y = F.conv2d(x, _g(sd, p, "conv1.conv.weight"))
+    y = F.silu(layernorm2d(y, _g(sd, p, "conv1.bn.weight"), _g(sd, p, "conv1.bn.bias"), eps))
+    C = y.shape[1]
+    y = F.conv2d(y, _g(sd, p, "conv2.conv.weight"), padding=1, groups=C)
+    y = F.silu(layernorm2d(y, _g(sd, p, "conv2.bn.weight"), _g(sd, p, "conv2.bn.bias"), eps))
+    s = y.mean((2, 3), keepdim=True)
+    s = F.silu(F.conv2d(s, _g(sd, p, "se.fc1.weight"), _g(sd, p, "se.fc1.bias")))
+    s = torch.sigmoid(F.conv2d(s, _g(sd, p, "se.fc2.weight"), _g(sd, p, "se.fc2.bias")))
+    y = y * s
+    y = F.conv2d(y, _g(sd, p, "conv3.conv.weight"))
+    y = layernorm2d(y, _g(sd, p, "conv3.bn.weight"), _g(sd, p, "conv3.bn.bias"), eps)
+    if (p + "downsample.conv.weight") in sd:
+        sc = F.conv2d(sc, _g(sd, p, "downsample.conv.weight"))
+        sc = layernorm2d(sc, _g(sd, p, "downsample.bn.weight"), _g(sd, p, "downsample.bn.bias"), eps)
+    return F.silu(y + sc)
+
+
+def regstage(sd: SD, p: str, x: torch.Tensor, depth: int, eps: float = 1e-5) -> torch.Tensor:
+    for i in range(depth):
+        x = regstage_block(sd, f"{p}b{i + 1}.", x, eps)
+    return x
+
+
+def stc_connector(sd: SD, x: torch.Tensor, prefix: str = "", downsample=(2, 2, 2), padding: int = 0,
+                  depth: int = 4, mlp_depth: int = 2, ln_eps: float = 1e-5) -> torch.Tensor:
+    """STCConnector.forward (projector.py:189-215).  v35 = padding 0, depth 4 (:225-238);
+    'spatial_conv' = downsample (1,2,2), padding 1, depth 0 (:241-244)."""
+    p = prefix
+    b, t, n, d = x.shape
+    hw = int(n ** 0.5)
+    x = x.view(b, t, hw, hw, d).permute(0, 1, 4, 2, 3).reshape(b * t, d, hw, hw)     # (b t) d h w
+    if depth:
+        x = regstage(sd, p + "s1.", x, depth, ln_eps)
+    C = x.shape[1]
+    x = x.view(b, t, C, hw, hw).permute(0, 2, 1, 3, 4)                              # b d t h w
+    x = F.conv3d(x, _g(sd, p, "sampler.0.weight"), _g(sd, p, "sampler.0.bias"),
+                 stride=downsample, padding=padding)
+    x = F.silu(x)
+    nt, nh, nw = x.shape[2:]
+    x = x.permute(0, 2, 1, 3, 4).reshape(b * nt, C, nh, nw)
+    if depth:
+        x = regstage(sd, p + "s2.", x, depth, ln_eps)
+    x = x.view(b, nt, C, nh * nw).permute(0, 1, 3, 2).reshape(b, nt * nh * nw, C)   # b (t h w) d
+    for i in range(mlp_depth):                                                       # build_mlp :125-130
+        if i:
+            x = F.gelu(x)
+        x = F.linear(x, _g(sd, p, f"readout.{2 * i}.weight"), _g(sd, p, f"readout.{2 * i}.bias"))
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# Region encoder  (layer.py)
+# --------------------------------------------------------------------------------------
+def token_merge(x: torch.Tensor, r: int) -> torch.Tensor:
+    """layer.py:6-33 — greedy merge of adjacent tokens with cosine similarity >= the r-th largest."""
+    x1, x2 = x[:, :-1, :], x[:, 1:, :]
+    sim = torch.sum(F.normalize(x1, p=2, dim=-1) * F.normalize(x2, p=2, dim=-1), dim=-1)
+    values, _ = torch.topk(sim.flatten(), r)
+    kth = values[-1]
+    new_tokens, merged = [], []
+    for i in range(sim.shape[1]):
+        merged.append(x[:, i:i + 1, :])
+        if sim[0, i] < kth:
+            new_tokens.append(torch.mean(torch.cat(merged, dim=1), dim=1, keepdim=True))
+            merged = []
+    merged.append(x[:, sim.shape[1]:sim.shape[1] + 1, :])
+    new_tokens.append(torch.mean(torch.cat(merged, dim=1), dim=1, keepdim=True))
+    return torch.cat(new_tokens, dim=1)
+
+
+def mask_pooling(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """layer.py:135-152: bilinear resize -> (>0) -> masked mean. x [n,C,h,w], mask [1,q,H,W]."""
+    if x.shape[-2:] != mask.shape[-2:]:
+        mask = F.interpolate(mask, size=x.shape[-2:], mode="bilinear", align_corners=False)
+    mask = (mask > 0).to(mask.dtype).permute(1, 0, 2, 3)
+    denorm = mask.sum(dim=(-1, -2), keepdim=True) + 1e-8
+    return (x * mask / denorm).sum(-1).sum(-1)
+
+
+def mask_extractor(sd: SD, feats: torch.Tensor, masks: Sequence[torch.Tensor], ann_indices, prefix: str = "",
+                   image_aspect_ratio: str = "square", region_token_num: int = 4):
+    """MaskExtractor.forward (layer.py:63-128). Returns (region tokens [sum, D_llm], region_token_nums)."""
+    p = prefix
+    query_feats, region_token_nums = [], []
+    for idx in range(len(masks)):
+        mask = masks[idx].unsqueeze(0).float()
+        if image_aspect_ratio == "pad":
+            _h, w = mask.shape[-2:]
+            m = max(_h, w)
+            mask = F.pad(mask, ((m - w) // 2, (m - w) - (m - w) // 2, (m - _h) // 2, (m - _h) - (m - _h) // 2, 0, 0, 0, 0))
+        ann_index = [i for index in ann_indices[idx] for i in index]
+        feat = feats[ann_index].float()
+        N = int(pow(feat.shape[1], 0.5))
+        feat = feat.reshape(feat.shape[0], N, N, -1).permute(0, 3, 1, 2)
+        raw = mask_pooling(feat, mask)
+        merged, start = [], 0
+        for index in ann_indices[idx]:
+            mf = raw[start:start + len(index), :].unsqueeze(0)
+            if mf.shape[1] > region_token_num:
+                mf = token_merge(mf, mf.shape[1] - region_token_num)
+            region_token_nums.append(mf.shape[1])
+            merged.append(mf)
+            start += len(index)
+        query_feats.append(torch.cat(merged, dim=1).reshape(-1, raw.shape[-1]))
+    mf = torch.cat(query_feats, dim=0)
+    mf = F.linear(mf, _g(sd, p, "feat_linear.0.weight"), _g(sd, p, "feat_linear.0.bias"))
+    mf = F.gelu(mf)
+    mf = F.linear(mf, _g(sd, p, "feat_linear.2.weight"), _g(sd, p, "feat_linear.2.bias"))
+    return mf, region_token_nums
+
+
+# --------------------------------------------------------------------------------------
+# Embedding splice  (videorefer_arch.py:218-370)
+# --------------------------------------------------------------------------------------
+def splice(embed_table: torch.Tensor, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
+           labels: Optional[torch.Tensor], mm_features: torch.Tensor, mask_feats, region_token_nums,
+           region_token_id: int, have_frame: bool):
+    """prepare_inputs_labels_for_multimodal after the encoders have run.
+
+    Returns (attention_mask, inputs_embeds, labels, mark_mm_token_indices) exactly as the
+    reference builds them, including its quirks: the trailing-span bookkeeping of
+    ``mark_mm_token_indices`` (:320-324), left-padding of the mask with True (:366), and the
+    cur_region_idx/cur_region_pos counters advancing on samples without '<region>' (:293-298).
+    """
+    emb = lambda ids: embed_table[ids]
+    mm_ids = list(MODAL_INDEX_MAP.values())
+    new_embeds, new_labels = [], ([] if labels is not None else None)
+    cur_mm, cur_ridx, cur_rpos = 0, 0, 0
+    mark = []
+    if not have_frame:
+        mask_feats = []
+    for b, ids in enumerate(input_ids):
+        is_mm = torch.zeros_like(ids, dtype=torch.bool)
+        for t in mm_ids:
+            is_mm |= ids == t
+        if int(is_mm.sum()) == 0:                                         # :251-267
+            half = ids.shape[0] // 2
+            new_embeds.append(torch.cat([emb(ids[:half]), emb(ids[half:])], dim=0))
+            if labels is not None:
+                new_labels.append(labels[b])
+            cur_mm += 1; cur_ridx += 1; cur_rpos += 1
+            continue
+        parts, lparts = [], []
+        cur_labels = labels[b] if labels is not None else None
+        pos = torch.where(is_mm)[0]
+        while pos.numel() > 0:                                            # :276-289
+            feats = mm_features[cur_mm]
+            s = int(pos[0])
+            parts.append(emb(ids[:s])); parts.append(feats)
+            if labels is not None:
+                lparts.append(cur_labels[:s])
+                lparts.append(torch.full((feats.shape[0],), IGNORE_INDEX, dtype=labels.dtype))
+                cur_labels = cur_labels[s + 1:]
+            cur_mm += 1
+            ids = ids[s + 1:]
+            is_mm = torch.zeros_like(ids, dtype=torch.bool)
+            for t in mm_ids:
+                is_mm |= ids == t
+            pos = torch.where(is_mm)[0]
+        if ids.numel() > 0:                                               # :291-318
+            ridx = torch.nonzero(ids == region_token_id)
+            if len(ridx) == 0:
+                if have_frame:
+                    parts.append(mask_feats[cur_ridx:cur_ridx + 1][0:0])
+                cur_ridx += 1; cur_rpos += 1
+            _l = 0
+            for r in ridx:
+                r0 = int(r[0])
+                parts.append(emb(ids[_l:r0]))
+                if labels is not None:
+                    lparts.append(cur_labels[_l:r0])
+                n = region_token_nums[cur_rpos]
+                parts.append(mask_feats[cur_ridx:cur_ridx + n])
+                if labels is not None:
+                    lparts.append(torch.full((n,), IGNORE_INDEX, dtype=labels.dtype))
+                cur_ridx += n; cur_rpos += 1
+                _l = r0 + 1
+            if _l < len(ids):
+                parts.append(emb(ids[_l:]))
+                if labels is not None:
+                    lparts.append(cur_labels[_l:])
+        last = parts[-1].shape[0]
+        cat = torch.cat(parts, dim=0)
+        mark.append([cat.shape[0] - last, last])
+        new_embeds.append(cat)
+        if labels is not None:
+            new_labels.append(torch.cat(lparts, dim=0))
+
+    if any(x.shape != new_embeds[0].shape for x in new_embeds):           # :334-359
+        max_len = max(x.shape[0] for x in new_embeds)
+        embeds = torch.stack([torch.cat((x, torch.zeros((max_len - x.shape[0], x.shape[1]), dtype=x.dtype)), 0)
+                              for x in new_embeds], 0)
+        if labels is not None:
+            _nl = new_labels
+            new_labels = torch.stack([torch.cat((x, torch.full((max_len - x.shape[0],), IGNORE_INDEX, dtype=x.dtype)), 0)
+                                      for x in new_labels], 0)
+            if attention_mask is not None:
+                am = []
+                for cur_am, cur_nl, cur_nla in zip(attention_mask, _nl, new_labels):
+                    left = torch.full((cur_nl.shape[0] - labels.shape[1],), True, dtype=attention_mask.dtype)
+                    right = torch.full((cur_nla.shape[0] - cur_nl.shape[0],), False, dtype=attention_mask.dtype)
+                    am.append(torch.cat((left, cur_am, right), 0))
+                attention_mask = torch.stack(am, 0)
+    else:                                                                 # :360-368
+        embeds = torch.stack(new_embeds, 0)
+        if labels is not None:
+            new_labels = torch.stack(new_labels, 0)
+        if attention_mask is not None:
+            left = torch.full((attention_mask.shape[0], embeds.shape[1] - input_ids.shape[1]), True,
+                              dtype=attention_mask.dtype)
+            attention_mask = torch.cat((left, attention_mask), dim=1)
+    return attention_mask, embeds, new_labels, mark
+
+
+# --------------------------------------------------------------------------------------
+# Qwen2 decoder
+# --------------------------------------------------------------------------------------
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """Qwen2RMSNorm (modeling_qwen2.py:238-254)."""
+    v = x.float().pow(2).mean(-1, keepdim=True)
+    return w * (x.float() * torch.rsqrt(v + eps))
+
+
+def rope_cos_sin(positions: torch.Tensor, head_dim: int, theta: float):
+    """Qwen2RotaryEmbedding.forward (:51-102): fp32 outer product, cat(freqs, freqs)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    freqs = positions.float()[:, None] * inv[None, :]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def qwen2_layer(sd: SD, p: str, x: torch.Tensor, cfg: dict, cos, sin, kv: Optional[list], bias_mask):
+    """Qwen2DecoderLayer (:258-299). x [B,S,D]; kv = [k_cache, v_cache] or None; returns (x, new_kv)."""
+    B, S, D = x.shape
+    H, KV = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    hd = cfg.get("head_dim", D // H)
+    eps = cfg.get("rms_norm_eps", 1e-6)
+    h = rmsnorm(x, _g(sd, p, "input_layernorm.weight"), eps)
+    q = F.linear(h, _g(sd, p, "self_attn.q_proj.weight"), _g(sd, p, "self_attn.q_proj.bias")).view(B, S, H, hd).transpose(1, 2)
+    k = F.linear(h, _g(sd, p, "self_attn.k_proj.weight"), _g(sd, p, "self_attn.k_proj.bias")).view(B, S, KV, hd).transpose(1, 2)
+    v = F.linear(h, _g(sd, p, "self_attn.v_proj.weight"), _g(sd, p, "self_attn.v_proj.bias")).view(B, S, KV, hd).transpose(1, 2)
+    c, s = cos[None, None], sin[None, None]
+    q = q * c + rotate_half(q) * s
+    k = k * c + rotate_half(k) * s
+    if kv is not None:
+        k = torch.cat([kv[0], k], dim=2)
+        v = torch.cat([kv[1], v], dim=2)
+    new_kv = [k, v]
+    rep = H // KV
+    kk = k[:, :, None].expand(B, KV, rep, k.shape[2], hd).reshape(B, H, k.shape[2], hd)
+    vv = v[:, :, None].expand(B, KV, rep, v.shape[2], hd).reshape(B, H, v.shape[2], hd)
+    att = torch.matmul(q, kk.transpose(2, 3)) * (hd ** -0.5)
+    att = att + bias_mask
+    att = torch.softmax(att.float(), dim=-1)
+    o = torch.matmul(att, vv).transpose(1, 2).reshape(B, S, H * hd)
+    x = x + F.linear(o, _g(sd, p, "self_attn.o_proj.weight"))
+    h = rmsnorm(x, _g(sd, p, "post_attention_layernorm.weight"), eps)
+    g = F.linear(h, _g(sd, p, "mlp.gate_proj.weight"))
+    u = F.linear(h, _g(sd, p, "mlp.up_proj.weight"))
+    x = x + F.linear(F.silu(g) * u, _g(sd, p, "mlp.down_proj.weight"))
+    return x, new_kv
+
+
+def qwen2_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                  past: Optional[list] = None, prefix: str = "model.", lm_head_key: str = "lm_head.weight",
+                  all_logits: bool = True):
+    """Qwen2ForCausalLM.forward with inputs_embeds (the reference never forwards position_ids,
+    videorefer_qwen2.py:187-197, so positions = arange(past_len, past_len+S)).
+
+    attention_mask: [B, past_len+S] (1 = attend).  Returns dict(logits, hidden_states, past).
+    hidden_states follows HF: [embeds, layer1, ..., layer_{L-1}, final_norm(layer_L)].
+    """
+    B, S, D = inputs_embeds.shape
+    L = cfg["num_hidden_layers"]
+    H = cfg["num_attention_heads"]
+    hd = cfg.get("head_dim", D // H)
+    past_len = 0 if past is None else past[0][0].shape[2]
+    T = past_len + S
+    pos = torch.arange(past_len, T)
+    cos, sin = rope_cos_sin(pos, hd, cfg.get("rope_theta", 1e6))
+    neg = torch.finfo(torch.float32).min
+    causal = torch.full((S, T), 0.0)
+    causal = causal.masked_fill(torch.arange(T)[None, :] > pos[:, None], neg)
+    bias = causal[None, None].expand(B, 1, S, T).clone()
+    if attention_mask is not None:
+        pad = (attention_mask[:, None, None, :T] == 0)
+        bias = bias.masked_fill(pad, neg)
+    x = inputs_embeds.float()
+    hs = [x]
+    new_past = []
+    for i in range(L):
+        x, kv = qwen2_layer(sd, f"{prefix}layers.{i}.", x, cfg, cos, sin, None if past is None else past[i], bias)
+        new_past.append(kv)
+        hs.append(x)
+    x = rmsnorm(x, _g(sd, prefix, "norm.weight"), cfg.get("rms_norm_eps", 1e-6))
+    hs[-1] = x
+    head = sd[lm_head_key].float()
+    logits = F.linear(x if all_logits else x[:, -1:], head)
+    return {"logits": logits, "hidden_states": hs, "past": new_past}
+
+
+def greedy_generate(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, attention_mask: torch.Tensor,
+                    max_new_tokens: int, eos_token_ids: Sequence[int] = (), stop_fn=None,
+                    embed_key: str = "model.embed_tokens.weight", **kw):
+    """HF GenerationMixin greedy search as driven by videorefer_qwen2.py:414-426 (batch 1):
+    prefill with inputs_embeds, then one token at a time through the KV cache; returns only
+    the NEW tokens (HF returns no prompt ids when generation starts from inputs_embeds),
+    plus per-step last-layer hidden states (what `output.hidden_states[o_idx][-1]` holds)."""
+    table = sd[embed_key].float()
+    out = qwen2_forward(sd, cfg, inputs_embeds, attention_mask, None, all_logits=False, **kw)
+    tokens, hiddens = [], [out["hidden_states"][-1]]
+    am = attention_mask
+    for step in range(max_new_tokens):
+        nxt = int(torch.argmax(out["logits"][0, -1]))
+        tokens.append(nxt)
+        if nxt in eos_token_ids or (stop_fn is not None and stop_fn(tokens)):
+            break
+        if step == max_new_tokens - 1:
+            break
+        am = torch.cat([am, torch.ones((am.shape[0], 1), dtype=am.dtype)], dim=1)
+        out = qwen2_forward(sd, cfg, table[torch.tensor([[nxt]])], am, out["past"], all_logits=False, **kw)
+        hiddens.append(out["hidden_states"][-1])
+    return torch.tensor([tokens], dtype=torch.long), hiddens
+
+
+# --------------------------------------------------------------------------------------
+# Integer / host helpers  (mm_utils.py)
+# --------------------------------------------------------------------------------------
+def frame_sample(duration: int, mode: str = "uniform", num_frames: Optional[int] = None, fps=None) -> np.ndarray:
+    """mm_utils.py:135-158."""
+    if mode == "uniform":
+        seg = float(duration - 1) / num_frames
+        ids = [(seg * i + seg * (i + 1)) / 2 for i in range(num_frames)]
+        return np.round(np.array(ids) + 1e-6).astype(int)
+    if mode == "fps":
+        seg_len = min(fps // 1, duration)                                 # NUM_FRAMES_PER_SECOND = 1
+        return np.arange(seg_len // 2, duration, seg_len, dtype=int)
+    raise ImportError(f"Unsupported frame sampling mode: {mode}")
+
+
+def tokenizer_multimodal_token(prompt: str, tokenize, multimodal_token: str = "<image>") -> List[int]:
+    """mm_utils.py:381-406 with `tokenize(str) -> list[int]`."""
+    idx = MODAL_INDEX_MAP.get(multimodal_token, None)
+    if idx is None:
+        return list(tokenize(prompt))
+    chunks = [list(tokenize(c)) for c in prompt.split(multimodal_token)]
+    ids: List[int] = []
+    for i in range(1, 2 * len(chunks)):
+        if i % 2 == 1:
+            ids.extend(chunks[i // 2])
+        else:
+            ids.append(idx)
+    return ids
+
+
+def text_hidden_fcs(sd: SD, x: torch.Tensor, prefix: str = "model.text_hidden_fcs.0.") -> torch.Tensor:
+    """videorefer_arch.py:137-149: Linear -> ReLU -> Linear -> Dropout(0)."""
+    h = F.relu(F.linear(x.float(), _g(sd, prefix, "0.weight"), _g(sd, prefix, "0.bias")))
+    return F.linear(h, _g(sd, prefix, "2.weight"), _g(sd, prefix, "2.bias"))
+
+
+def siglip_preprocess(frames_u8: np.ndarray) -> torch.Tensor:
+    """The arithmetic tail of SiglipImageProcessor after resize: x/255 -> (x-0.5)/0.5, HWC->CHW."""
+    x = torch.from_numpy(np.ascontiguousarray(frames_u8)).float()
+    x = (x * (1.0 / 255.0) - 0.5) / 0.5
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic weights (shared by tests/bench so GPU and CPU paths see identical parameters)
+# --------------------------------------------------------------------------------------
+def _randn(gen, *shape, std=0.02):
+    return torch.randn(*shape, generator=gen) * std
+
+
+def make_siglip_weights(cfg: dict, seed: int = 0, prefix: str = "", std: float = 0.02) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    D, I, P = cfg["hidden_size"], cfg["intermediate_size"], cfg["patch_size"]
+    n = (cfg["image_size"] // P) ** 2
+    sd = {prefix + "embeddings.patch_embedding.weight": _randn(g, D, 3, P, P, std=std),
+          prefix + "embeddings.patch_embedding.bias": _randn(g, D, std=std),
+          prefix + "embeddings.position_embedding.weight": _randn(g, n, D, std=std)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"{prefix}encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + f"self_attn.{nm}.weight"] = _randn(g, D, D, std=std)
+            sd[p + f"self_attn.{nm}.bias"] = _randn(g, D, std=std)
+        for ln in ("layer_norm1", "layer_norm2"):
+            sd[p + ln + ".weight"] = 1.0 + _randn(g, D, std=std)
+            sd[p + ln + ".bias"] = _randn(g, D, std=std)
+        sd[p + "mlp.fc1.weight"] = _randn(g, I, D, std=std); sd[p + "mlp.fc1.bias"] = _randn(g, I, std=std)
+        sd[p + "mlp.fc2.weight"] = _randn(g, D, I, std=std); sd[p + "mlp.fc2.bias"] = _randn(g, D, std=std)
+    return sd
+
+
+def make_regstage_weights(sd: SD, g, p: str, depth: int, cin: int, cout: int, std: float):
+    for i in range(depth):
+        b = f"{p}b{i + 1}."
+        ci = cin if i == 0 else cout
+        rd = int(round(ci * 0.25))
+        sd[b + "conv1.conv.weight"] = _randn(g, cout, ci, 1, 1, std=std)
+        sd[b + "conv2.conv.weight"] = _randn(g, cout, 1, 3, 3, std=0.2)
+        sd[b + "conv3.conv.weight"] = _randn(g, cout, cout, 1, 1, std=std)
+        for c in ("conv1", "conv2", "conv3"):
+            sd[b + c + ".bn.weight"] = 1.0 + _randn(g, cout, std=std)
+            sd[b + c + ".bn.bias"] = _randn(g, cout, std=std)
+        sd[b + "se.fc1.weight"] = _randn(g, rd, cout, 1, 1, std=std); sd[b + "se.fc1.bias"] = _randn(g, rd, std=std)
+        sd[b + "se.fc2.weight"] = _randn(g, cout, rd, 1, 1, std=std); sd[b + "se.fc2.bias"] = _randn(g, cout, std=std)
+        if ci != cout:
+            sd[b + "downsample.conv.weight"] = _randn(g, cout, ci, 1, 1, std=std)
+            sd[b + "downsample.bn.weight"] = 1.0 + _randn(g, cout, std=std)
+            sd[b + "downsample.bn.bias"] = _randn(g, cout, std=std)
+
+
+def make_stc_weights(d_in: int, d_out: int, seed: int = 1, prefix: str = "", depth: int = 4,
+                     downsample=(2, 2, 2), std: float = 0.02) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+    if depth:
+        make_regstage_weights(sd, g, prefix + "s1.", depth, d_in, d_out, std)
+        make_regstage_weights(sd, g, prefix + "s2.", depth, d_out, d_out, std)
+        c = d_out
+    else:
+        c = d_out                                                            # reference builds Conv3d(hidden, hidden)
+    sd[prefix + "sampler.0.weight"] = _randn(g, d_out, c, *downsample, std=std)
+    sd[prefix + "sampler.0.bias"] = _randn(g, d_out, std=std)
+    sd[prefix + "readout.0.weight"] = _randn(g, d_out, d_out, std=std); sd[prefix + "readout.0.bias"] = _randn(g, d_out, std=std)
+    sd[prefix + "readout.2.weight"] = _randn(g, d_out, d_out, std=std); sd[prefix + "readout.2.bias"] = _randn(g, d_out, std=std)
+    return sd
+
+
+def make_qwen2_weights(cfg: dict, seed: int = 2, std: float = 0.02) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    D, I, V = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"]
+    H, KV = cfg["num_attention_heads"], cfg["num_key_value_heads"]
+    hd = cfg.get("head_dim", D // H)
+    sd = {"model.embed_tokens.weight": _randn(g, V, D, std=std), "lm_head.weight": _randn(g, V, D, std=std),
+          "model.norm.weight": 1.0 + _randn(g, D, std=std)}
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"model.layers.{i}."
+        sd[p + "self_attn.q_proj.weight"] = _randn(g, H * hd, D, std=std); sd[p + "self_attn.q_proj.bias"] = _randn(g, H * hd, std=std)
+        sd[p + "self_attn.k_proj.weight"] = _randn(g, KV * hd, D, std=std); sd[p + "self_attn.k_proj.bias"] = _randn(g, KV * hd, std=std)
+        sd[p + "self_attn.v_proj.weight"] = _randn(g, KV * hd, D, std=std); sd[p + "self_attn.v_proj.bias"] = _randn(g, KV * hd, std=std)
+        sd[p + "self_attn.o_proj.weight"] = _randn(g, D, H * hd, std=std)
+        sd[p + "mlp.gate_proj.weight"] = _randn(g, I, D, std=std)
+        sd[p + "mlp.up_proj.weight"] = _randn(g, I, D, std=std)
+        sd[p + "mlp.down_proj.weight"] = _randn(g, D, I, std=std)
+        sd[p + "input_layernorm.weight"] = 1.0 + _randn(g, D, std=std)
+        sd[p + "post_attention_layernorm.weight"] = 1.0 + _randn(g, D, std=std)
+    return sd

@@ -1,0 +1,167 @@
+"""CPU: the oracle (oracle/ref_cpu.py) against golden vectors produced by running the reference
+(oracle/gen_fixtures.py, build container).  These pin the oracle; the -m gpu tests then use the
+oracle as the checker for the HIP path."""
+import numpy as np
+import torch
+
+from conftest import load_golden, t, rel_err
+from oracle import ref_cpu as O
+
+TINY_VIT = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=56,
+                patch_size=14)
+TINY_LLM = dict(vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=512, rope_theta=10000.0, rms_norm_eps=1e-6)
+TOL = 2e-5
+
+
+def test_frame_sample_and_tokenizer_kats():
+    a, _ = load_golden("int_helpers")
+    for k in a:
+        if k.startswith("uniform_"):
+            _, d, n = k.split("_")
+            assert (O.frame_sample(int(d), "uniform", int(n)) == a[k]).all(), k
+        elif k.startswith("fps_"):
+            _, d, fps = k.split("_")
+            assert (O.frame_sample(int(d), "fps", fps=float(fps)) == a[k]).all(), k
+    # SURVEY §8c known answers
+    assert O.frame_sample(17, "uniform", 4).tolist() == [2, 6, 10, 14]
+    assert O.frame_sample(100, "fps", fps=25).tolist() == [12, 37, 62, 87]
+    for i in range(5):
+        mt, prompt = bytes(a[f"tokprompt_{i}"]).decode().split("|", 1)
+        assert O.tokenizer_multimodal_token(prompt, lambda s: [ord(c) for c in s], mt) == a[f"tok_{i}"].tolist()
+    assert O.tokenizer_multimodal_token("ab<video>\ncd<video>e", lambda s: [ord(c) for c in s], "<video>") == \
+        [97, 98, -201, 10, 99, 100, -201, 101]
+
+
+def test_siglip_preprocess_tail():
+    a, _ = load_golden("processor")
+    assert rel_err(O.siglip_preprocess(a["in_1"][None])[0], t(a["out_1"])) < 1e-6
+
+
+def test_siglip_tiny_tower():
+    a, w = load_golden("siglip_tiny")
+    pre = bytes(a["prefix"]).decode()
+    x = t(a["x"])
+    assert rel_err(O.siglip_tower(w, TINY_VIT, x, prefix=pre), t(a["y"])) < TOL
+    hs = O.siglip_tower(w, TINY_VIT, x, prefix=pre, return_all=True)
+    assert rel_err(hs[1], t(a["hs1"])) < TOL and rel_err(hs[3], t(a["hs3"])) < TOL
+    assert torch.equal(hs[2], O.siglip_tower(w, TINY_VIT, x, prefix=pre))      # select_layer=-2 of 3 layers
+
+
+def test_clip_tiny_tower():
+    a, w = load_golden("clip_tiny")
+    cfg = dict(TINY_VIT, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    assert rel_err(O.clip_tower(w, cfg, t(a["x"]), prefix=bytes(a["prefix"]).decode()), t(a["y"])) < TOL
+
+
+def test_siglip_fulldim_layer_seeded():
+    a, _ = load_golden("siglip_fulldim_layer")
+    cfg = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=1, num_attention_heads=16, image_size=336,
+               patch_size=14)
+    sd = O.make_siglip_weights(cfg, seed=int(a["seed_w"]))
+    x = torch.randn(1, 576, 1152, generator=torch.Generator().manual_seed(int(a["seed_x"])))
+    y = O.vit_encoder_layer(sd, "encoder.layers.0.", x, 16, 1e-6, "gelu_pytorch_tanh")
+    assert rel_err(y[0, :4], t(a["y_first4"])) < TOL and rel_err(y[0, -4:], t(a["y_last4"])) < TOL
+    assert abs(y.abs().mean().item() - float(a["y_absmean"])) < 1e-5
+
+
+def _sub(w, pre):
+    return {k[len(pre):]: v for k, v in w.items() if k.startswith(pre)}
+
+
+def test_projector_variants():
+    a, w = load_golden("projector")
+    assert rel_err(O.stc_connector(_sub(w, "sc."), t(a["sc_x"]), downsample=(1, 2, 2), padding=1, depth=0), t(a["sc_y"])) < TOL
+    assert rel_err(O.stc_connector(_sub(w, "v35."), t(a["v35_x"]), downsample=(2, 2, 2), padding=0, depth=0), t(a["v35_y"])) < TOL
+    assert rel_err(O.stc_connector(_sub(w, "stc."), t(a["stc_x"]), downsample=(2, 2, 2), padding=1, depth=0), t(a["stc_y"])) < TOL
+    assert a["sc_y"].shape == (1, 54, 32)        # SURVEY §2.3-C token-count probe
+
+
+def test_regstage_shapes_and_token_rule():
+    # RegStage is parity-unpinned (timm absent offline): check structure + the v35 token rule (T/2)*floor(g/2)^2
+    sd = O.make_stc_weights(16, 32, seed=3)
+    y = O.stc_connector(sd, torch.randn(1, 4, 16, 16), depth=4)
+    assert y.shape == (1, 2 * 2 * 2, 32) and torch.isfinite(y).all()
+
+
+def test_region_encoder():
+    a, w = load_golden("region")
+    masks = [t(a["mask0"]), t(a["mask1"])]
+    ann = [[[0], [1, 2]], [[1, 2, 3, 4, 5, 6]]]
+    y, nums = O.mask_extractor(w, t(a["feats"]), masks, ann)
+    assert nums == a["nums"].tolist()
+    assert rel_err(y, t(a["y"])) < TOL
+    y2, _ = O.mask_extractor(w, t(a["feats"]), masks, ann, image_aspect_ratio="pad")
+    assert rel_err(y2, t(a["y_pad"])) < TOL
+    for r in (1, 3, 5):
+        assert rel_err(O.token_merge(t(a["tm_x"]), r), t(a[f"tm_{r}"])) < TOL
+
+
+CASES = {
+    "vid_region": dict(frame=True, ann=[[[0], [1]]]),
+    "vid_only": dict(frame=False), "img_only": dict(frame=False), "batch_pad": dict(frame=False),
+    "vid_noregion_frame": dict(frame=True, ann=[[[0]]]), "vid_trailing": dict(frame=False),
+}
+
+
+def _encode(w, a, name):
+    vt = "model.vision_tower.vision_tower."
+    if any(k.startswith(vt + "vision_model.") for k in w):
+        vt += "vision_model."
+    video = t(a["video"])
+    imgs = {"vid_region": [video], "vid_only": [video], "img_only": [video[:1].expand(4, -1, -1, -1)],
+            "batch_pad": [video, video.flip(0)], "vid_noregion_frame": [video], "vid_trailing": [video]}[name]
+    feats = torch.stack([O.stc_connector(w, O.siglip_tower(w, TINY_VIT, v, prefix=vt)[None], prefix="model.mm_projector.",
+                                         downsample=(1, 2, 2), padding=1, depth=0)[0] for v in imgs])
+    c = CASES[name]
+    if c["frame"]:
+        fr = t(a["frame"]) if name == "vid_region" else t(a["frame"])[:1]
+        mk = t(a["mask"]) if name == "vid_region" else t(a["mask"])[:1]
+        mf, nums = O.mask_extractor(w, O.siglip_tower(w, TINY_VIT, fr, prefix=vt), [mk], c["ann"], prefix="model.region_encoder.")
+    else:
+        mf, nums = [], []
+    return feats, mf, nums
+
+
+def test_splice_all_cases_bit_exact_indices():
+    a, w = load_golden("model_tiny")
+    R = int(a["region_id"])
+    table = w["model.embed_tokens.weight"]
+    for name, c in CASES.items():
+        feats, mf, nums = _encode(w, a, name)
+        ids = t(a[f"sp_{name}_ids"]); am = t(a[f"sp_{name}_am_in"])
+        for lab in (False, True):
+            labels = None
+            if lab:
+                labels = ids.clone(); labels[labels < 0] = -100
+            tag = f"{name}_{'lab' if lab else 'nolab'}"
+            am_o, emb_o, lab_o, mark_o = O.splice(table, ids, am, labels, feats, mf, nums, R, c["frame"])
+            assert np.array_equal(np.array(mark_o), a[f"sp_{tag}_mark"]), tag
+            assert np.array_equal(am_o.numpy(), a[f"sp_{tag}_am"]), tag
+            if lab:
+                assert np.array_equal(lab_o.numpy(), a[f"sp_{tag}_labels"]), tag
+            assert rel_err(emb_o, t(a[f"sp_{tag}_emb"])) < TOL, tag
+
+
+def test_qwen2_forward_kv_and_generate():
+    a, w = load_golden("model_tiny")
+    emb = t(a["sp_vid_region_nolab_emb"]); am = t(a["sp_vid_region_nolab_am"])
+    o = O.qwen2_forward(w, TINY_LLM, emb, am)
+    assert rel_err(o["logits"], t(a["fw_logits"])) < TOL
+    assert rel_err(o["hidden_states"][-1], t(a["fw_hidden_last"])) < TOL
+    assert rel_err(o["hidden_states"][1], t(a["fw_hidden_1"])) < TOL
+    assert rel_err(o["past"][0][0], t(a["fw_k0"])) < TOL and rel_err(o["past"][0][1], t(a["fw_v0"])) < TOL
+    toks, hid = O.greedy_generate(w, TINY_LLM, emb, am, 8, eos_token_ids=(298,))
+    assert toks.tolist() == a["gen_tokens"].tolist()
+    toks2, _ = O.greedy_generate(w, TINY_LLM, t(a["sp_vid_only_nolab_emb"]), t(a["sp_vid_only_nolab_am"]), 6, (298,))
+    assert toks2.tolist() == a["gen2_tokens"].tolist()
+    assert rel_err(O.text_hidden_fcs(w, t(a["fw_hidden_last"])), t(a["fcs_out"])) < TOL
+
+
+def test_kv_cache_decode_equals_full_forward():
+    sd = O.make_qwen2_weights(TINY_LLM, seed=9)
+    x = torch.randn(1, 11, 64, generator=torch.Generator().manual_seed(1))
+    full = O.qwen2_forward(sd, TINY_LLM, x)
+    pre = O.qwen2_forward(sd, TINY_LLM, x[:, :10])
+    step = O.qwen2_forward(sd, TINY_LLM, x[:, 10:], past=pre["past"])
+    assert rel_err(step["logits"][0, -1], full["logits"][0, -1]) < 1e-5
