@@ -1,0 +1,21 @@
+# Builds the gfx950 HIP library in-tree (the .so travels to the GPU box with the snapshot).
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := ufvideo_amd/csrc
+SRCS  := $(CSRC)/gemm.hip $(CSRC)/attn.hip $(CSRC)/ops.hip
+OBJS  := $(SRCS:.hip=.o)
+LIB   := ufvideo_amd/libufv_hip.so
+FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude
+
+all: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/ufv.h
+	$(HIPCC) $(FLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -f $(OBJS) $(LIB)
+
+.PHONY: all clean

@@ -1,0 +1,131 @@
+/* ufv.h — C ABI of the MI355X (gfx950) hot-path library `libufv_hip.so`.
+ *
+ * The reference (Heven-Pan/UFVideo) has no FFI: its hot path is Python calling torch /
+ * transformers / timm modules.  This header is the boundary a maintainer binds instead of those
+ * modules; each entry point names the reference arithmetic it replaces (file:line relative to
+ * the reference tree, or the pinned third-party module the reference calls there).
+ *
+ * Conventions
+ *  - plain C: raw device pointers + sizes; no C++/torch types cross the boundary.
+ *  - all buffers are caller-owned device memory on the current HIP device; nothing is allocated,
+ *    freed or synchronised inside; every call is enqueued on `stream` (a hipStream_t; NULL = the
+ *    default stream) and returns immediately.
+ *  - return value: 0 = ok, <0 = error (UFV_E*); `ufv_last_error()` returns a thread-local message.
+ *  - bf16 = bfloat16 storage (uint16_t bit pattern), activations bf16, accumulation fp32, the
+ *    residual streams fp32.  "ld*" arguments are row pitches in ELEMENTS.
+ *  - thread-compatible: no global state except the thread-local error string.
+ */
+#ifndef UFV_H_
+#define UFV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UFV_ABI_VERSION 1
+
+/* activation ids (ufv_gemm `act`, ufv_layernorm `act`) */
+#define UFV_ACT_NONE 0
+#define UFV_ACT_GELU_TANH 1  /* HF ACT2FN["gelu_pytorch_tanh"] (SigLIP MLP) */
+#define UFV_ACT_GELU_ERF 2   /* nn.GELU() (projector readout, region encoder) */
+#define UFV_ACT_SILU 3
+#define UFV_ACT_RELU 4
+#define UFV_ACT_QUICK_GELU 5 /* CLIP MLP */
+#define UFV_ACT_SIGMOID 6
+
+/* kernel selector for ufv_gemm */
+#define UFV_GEMM_AUTO 0
+#define UFV_GEMM_FAST 1    /* 128x128x64 MFMA tile kernel; errors out if the shape does not qualify */
+#define UFV_GEMM_GENERIC 2 /* one-thread-per-output kernel, any shape */
+#define UFV_GEMM_GEMV 3    /* weight-streaming kernel for M <= 64 */
+
+/* dtype ids for inputs that may arrive in several formats */
+#define UFV_DT_BF16 0
+#define UFV_DT_F32 1
+#define UFV_DT_F16 2
+
+const char* ufv_last_error(void);
+int ufv_abi_version(void);
+
+/* C[M,N] = epilogue(A[M,K] * W[N,K]^T): every nn.Linear / 1x1 conv / patch-embed / Conv3d-as-GEMM
+ * on the path (torch F.linear under HF modeling_siglip.py:267-270,310-322; modeling_qwen2.py:35-48,
+ * 176-235; projector.py:125-130,153-184).  A, W bf16.  out = act(acc + bias[n]) + resid[m(,% resid_rows)][n];
+ * `out_f32` selects fp32 vs bf16 C.  `swiglu`: W rows packed [16 gate | 16 up] alternating, C has N/2
+ * columns = silu(gate)*up (modeling_qwen2.py:47). */
+int ufv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int out_f32, int M, int N, int K,
+             const float* bias, int act, const float* resid, int ldr, int resid_rows, int swiglu, int kernel,
+             void* stream);
+
+/* y = act(LayerNorm(x) * w + b) per row (nn.LayerNorm: modeling_siglip.py:329-331; timm LayerNorm2d in
+ * NHWC).  x fp32 or bf16 (x_dtype), y bf16 (or fp32 when y_f32). */
+int ufv_layernorm(const void* x, int x_dtype, int ldx, void* y, int y_f32, int ldy, const float* w, const float* b,
+                  int M, int D, float eps, int act, void* stream);
+
+/* out = silu(LN_a(a) + (LN_b(b) | b)) — tail of a timm RegNet bottleneck: conv3 norm + shortcut
+ * (downsample norm when wb != NULL) + act3.  a, b, out bf16 [M, D]. */
+int ufv_ln_add_silu(const void* a, const float* wa, const float* ba, const void* b, const float* wb, const float* bb,
+                    void* out, int M, int D, float eps, void* stream);
+
+/* Qwen2RMSNorm (modeling_qwen2.py:238-254): y = w * (x * rsqrt(mean(x^2) + eps)); x fp32, y bf16 (fp32 if y_f32). */
+int ufv_rmsnorm(const float* x, int ldx, void* y, int y_f32, int ldy, const float* w, int M, int D, float eps,
+                void* stream);
+
+/* softmax(q k^T * scale [+ causal]) v, flash-style, fp32 softmax (modeling_siglip.py:227-247,
+ * modeling_qwen2.py:150-172).  q/k/v/o bf16; element (b, s, h, d) of X lives at
+ * X + b*x_bs + s*x_ss + h*hd + d.  Hq % Hkv == 0 (GQA).  causal: key j visible to query i iff
+ * j <= q_pos0 + i.  kernel: 0 auto, 1 MFMA kernel (hd in {64,72,80,96,128}), 2 generic. */
+int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const void* k, int64_t k_bs, int64_t k_ss, const void* v,
+                  int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int64_t o_ss, int B, int Hq, int Hkv, int Sq,
+                  int Sk, int hd, float scale, int causal, int q_pos0, int kernel, void* stream);
+
+/* RoPE rotate-half (modeling_qwen2.py:105-135) applied in place to the q columns of a fused qkv
+ * buffer [S, ldqkv] and, for k, written together with v into the KV cache rows pos0..pos0+S-1
+ * (cache row = [Hkv*hd k | Hkv*hd v]).  angle = (pos0+s) * inv_freq[i] in fp32. */
+int ufv_rope_kv(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0, void* kv_cache,
+                int ldkv, void* stream);
+
+/* Conv2d(k=s=P, valid) as im2col: pixels [T,C,H,W] (dtype id) -> bf16 [T*(H/P)*(W/P), Kpad],
+ * k = c*P*P + py*P + px, zero-filled to Kpad (modeling_siglip.py:124-130,178-179). */
+int ufv_patchify(const void* pixels, int dtype, void* out, int T, int C, int H, int W, int P, int Kpad, void* stream);
+
+/* depthwise 3x3 (pad 1) -> LayerNorm over C -> SiLU, NHWC bf16 [F,H,W,C]; w9 fp32 [9][C]
+ * (timm ConvNormAct with groups=C inside RegNet Bottleneck; projector.py:153-184). */
+int ufv_dwconv3x3_ln_silu(const void* x, void* y, const float* w9, const float* lnw, const float* lnb, int F, int H, int W,
+                          int C, float eps, void* stream);
+
+/* out[f, c] = mean over P rows of x[f*P + p, c]  (SE squeeze; x bf16 [F*P, C], out bf16 [F, C]) */
+int ufv_colmean(const void* x, void* out, int F, int P, int C, void* stream);
+
+/* x[f*P + p, c] *= gate[f, c]   (SE excite; bf16 in place) */
+int ufv_scale_channels(void* x, const void* gate, int F, int P, int C, void* stream);
+
+/* Conv3d patch gather (kernel = stride = (kt,kh,kw), zero padding `pad` on all three dims):
+ * x bf16 [T,H,W,C] -> out bf16 [To*Ho*Wo, kt*kh*kw*C], k = ((dt*kh+dh)*kw+dw)*C + c (projector.py:164-172,229-237) */
+int ufv_conv3d_gather(const void* x, void* out, int T, int H, int W, int C, int kt, int kh, int kw, int pad, void* stream);
+
+/* dst[dst_idx[i]] = src[src_idx[i]] for rows of `D` elements; src dtype bf16 or f32, dst fp32 or bf16
+ * (embed_tokens gather + splice, videorefer_arch.py:280-316; dst_idx/src_idx int64, NULL = identity) */
+int ufv_gather_rows(const void* src, int src_dtype, int64_t ld_src, const int64_t* src_idx, void* dst, int dst_dtype,
+                    int64_t ld_dst, const int64_t* dst_idx, int n, int D, void* stream);
+
+/* masked mean pooling (layer.py:135-152): feat bf16/f32 [n, P, C] (token-major), mask f32 [q, P] already
+ * resized+binarised; out f32 [q, C]; frame index of mask i = frame_of[i] */
+int ufv_mask_pool(const void* feat, int feat_dtype, const float* mask, const int32_t* frame_of, float* out, int q, int P,
+                  int C, void* stream);
+
+/* greedy sampling: out[0] = argmax(logits[0..N)) with torch.argmax tie-breaking (lowest index) */
+int ufv_argmax(const float* logits, int N, int64_t* out, void* stream);
+
+/* frame batching tail of process_video (mm_utils.py:284,291): u8 HWC frames -> (x/255 - mean)/std -> bf16 NCHW */
+int ufv_preprocess_u8(const uint8_t* frames, void* out, int T, int H, int W, const float* mean3, const float* std3,
+                      void* stream);
+
+/* elementwise convert between bf16 / f32 / f16 (n elements) */
+int ufv_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UFV_H_ */

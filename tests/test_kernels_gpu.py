@@ -1,0 +1,269 @@
+"""GPU: every HIP kernel of the C ABI against a plain PyTorch fp32 reference of the same op."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ufvideo_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = a.float(); b = b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def g(*shape, seed=0, scale=1.0):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=gen) * scale).to(DEV)
+
+
+ACTS = {None: lambda x: x, "gelu_tanh": lambda x: torch.nn.functional.gelu(x, approximate="tanh"),
+        "gelu": torch.nn.functional.gelu, "silu": torch.nn.functional.silu, "relu": torch.relu,
+        "quick_gelu": lambda x: x * torch.sigmoid(1.702 * x), "sigmoid": torch.sigmoid}
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 256, 192), (1000, 384, 1152), (129, 128, 640), (2399, 512, 448)])
+@pytest.mark.parametrize("kernel", [ops.GEMM_FAST, ops.GEMM_GENERIC])
+def test_gemm_plain(M, N, K, kernel):
+    a, w = bf(g(M, K, seed=1)), bf(g(N, K, seed=2, scale=0.05))
+    ref = a.float() @ w.float().t()
+    out = ops.gemm(a, w, kernel=kernel)
+    assert rel(out, ref) < 8e-3
+    out32 = ops.gemm(a, w, out_dtype=torch.float32, kernel=kernel)
+    assert rel(out32, ref) < 2e-5
+
+
+def test_gemm_mfma_layout_asymmetric():
+    # A = I (padded), asymmetric W: catches a swapped row/col map
+    M = N = K = 128
+    a = bf(torch.eye(M, K, device=DEV))
+    w = bf((torch.arange(N, device=DEV)[:, None] * 3 + torch.arange(K, device=DEV)[None, :] * 0.5) % 17)
+    out = ops.gemm(a, w, out_dtype=torch.float32, kernel=ops.GEMM_FAST)
+    assert torch.equal(out, w.float().t().contiguous())
+
+
+@pytest.mark.parametrize("act", list(ACTS))
+def test_gemm_epilogues(act):
+    M, N, K = 200, 256, 128
+    a, w = bf(g(M, K, seed=3)), bf(g(N, K, seed=4, scale=0.1))
+    bias, resid = g(N, seed=5), g(M, N, seed=6)
+    ref = ACTS[act](a.float() @ w.float().t() + bias) + resid
+    for kern in (ops.GEMM_FAST, ops.GEMM_GENERIC):
+        out = ops.gemm(a, w, bias=bias, act=act, resid=resid, out_dtype=torch.float32, kernel=kern)
+        assert rel(out, ref) < 1e-4, (act, kern)
+    # residual broadcast with row modulo (position-embedding table)
+    tab = g(50, N, seed=7)
+    ref2 = a.float() @ w.float().t() + bias + tab[torch.arange(M, device=DEV) % 50]
+    out2 = ops.gemm(a, w, bias=bias, resid=tab, resid_rows=50, out_dtype=torch.float32, kernel=ops.GEMM_FAST)
+    assert rel(out2, ref2) < 1e-4
+    # in-place residual stream update
+    r = resid.clone()
+    ops.gemm(a, w, bias=bias, resid=r, out=r, kernel=ops.GEMM_FAST)
+    assert rel(r, a.float() @ w.float().t() + bias + resid) < 1e-4
+
+
+def pack_swiglu(gate, up):
+    I, K = gate.shape
+    return torch.stack([gate.view(I // 16, 16, K), up.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+
+
+@pytest.mark.parametrize("M,kern", [(300, ops.GEMM_FAST), (300, ops.GEMM_GENERIC), (1, ops.GEMM_GEMV), (5, ops.GEMM_GEMV)])
+def test_gemm_swiglu(M, kern):
+    I, K = 256, 192
+    a = bf(g(M, K, seed=8))
+    gate, up = bf(g(I, K, seed=9, scale=0.1)), bf(g(I, K, seed=10, scale=0.1))
+    ref = torch.nn.functional.silu(a.float() @ gate.float().t()) * (a.float() @ up.float().t())
+    out = ops.gemm(a, pack_swiglu(gate, up), swiglu=True, out_dtype=torch.float32, kernel=kern)
+    assert rel(out, ref) < 1e-4
+
+
+@pytest.mark.parametrize("M", [1, 3, 8, 20, 64])
+def test_gemv(M):
+    N, K = 1000, 1152
+    a, w = bf(g(M, K, seed=11)), bf(g(N, K, seed=12, scale=0.05))
+    bias = g(N, seed=13)
+    ref = torch.relu(a.float() @ w.float().t() + bias)
+    out = ops.gemm(a, w, bias=bias, act="relu", out_dtype=torch.float32, kernel=ops.GEMM_GEMV)
+    assert rel(out, ref) < 1e-4
+
+
+def test_gemm_strided_a_and_errors():
+    buf = bf(g(300, 512, seed=14))
+    a = buf[:, 128:384]
+    w = bf(g(128, 256, seed=15, scale=0.1))
+    assert rel(ops.gemm(a, w, out_dtype=torch.float32, kernel=ops.GEMM_FAST), a.float() @ w.float().t()) < 1e-4
+    with pytest.raises(Exception):
+        ops.gemm(bf(g(64, 100)), bf(g(100, 100)), kernel=ops.GEMM_FAST)     # N, K not tileable -> loud error
+
+
+@pytest.mark.parametrize("D", [64, 1152, 3584])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_layernorm(D, dt):
+    M = 77
+    x = g(M, D, seed=16).to(dt)
+    w, b = 1 + 0.1 * g(D, seed=17), 0.1 * g(D, seed=18)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), w, b, 1e-6)
+    assert rel(ops.layernorm(x, w, b, 1e-6, out_dtype=torch.float32), ref) < 1e-5
+    assert rel(ops.layernorm(x, w, b, 1e-6), ref) < 8e-3
+    refs = torch.nn.functional.silu(ref)
+    assert rel(ops.layernorm(x, w, b, 1e-6, act="silu", out_dtype=torch.float32), refs) < 1e-5
+
+
+def test_ln_add_silu():
+    M, D = 50, 3584
+    a, b = bf(g(M, D, seed=19)), bf(g(M, D, seed=20))
+    wa, ba, wb, bb = 1 + 0.1 * g(D, seed=21), 0.1 * g(D, seed=22), 1 + 0.1 * g(D, seed=23), 0.1 * g(D, seed=24)
+    ln = lambda x, w, b_: torch.nn.functional.layer_norm(x.float(), (D,), w, b_, 1e-5)
+    assert rel(ops.ln_add_silu(a, wa, ba, b, wb, bb, 1e-5), torch.nn.functional.silu(ln(a, wa, ba) + ln(b, wb, bb))) < 8e-3
+    assert rel(ops.ln_add_silu(a, wa, ba, b, None, None, 1e-5), torch.nn.functional.silu(ln(a, wa, ba) + b.float())) < 8e-3
+
+
+@pytest.mark.parametrize("D", [64, 3584])
+def test_rmsnorm(D):
+    x, w = g(33, D, seed=25), 1 + 0.1 * g(D, seed=26)
+    ref = w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert rel(ops.rmsnorm(x, w, 1e-6, out_dtype=torch.float32), ref) < 1e-5
+
+
+def attn_ref(q, k, v, causal, q_pos0=0):
+    # q [B,Sq,Hq,hd], k/v [B,Sk,Hkv,hd]
+    B, Sq, Hq, hd = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    rep = Hq // Hkv
+    qf = q.float().permute(0, 2, 1, 3)
+    kf = k.float().permute(0, 2, 1, 3).repeat_interleave(rep, dim=1)
+    vf = v.float().permute(0, 2, 1, 3).repeat_interleave(rep, dim=1)
+    s = qf @ kf.transpose(-1, -2) * hd ** -0.5
+    if causal:
+        qi = torch.arange(Sq, device=q.device)[:, None] + q_pos0
+        kj = torch.arange(Sk, device=q.device)[None, :]
+        s = s.masked_fill(kj > qi, float("-inf"))
+    o = torch.softmax(s, -1) @ vf
+    return o.permute(0, 2, 1, 3).reshape(B * Sq, Hq * hd)
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,Sq,Sk,causal,kernel", [
+    (72, 4, 4, 576, 576, False, 1), (72, 2, 2, 100, 100, False, 1), (128, 8, 2, 300, 300, True, 1),
+    (128, 4, 4, 257, 257, True, 1), (64, 4, 2, 130, 130, True, 1), (128, 8, 2, 40, 140, True, 1),
+    (16, 4, 2, 61, 61, True, 2), (72, 2, 2, 50, 50, False, 2), (128, 4, 2, 1, 333, True, 2), (128, 4, 2, 1, 333, True, 0),
+    (80, 2, 1, 70, 70, False, 1), (96, 2, 2, 33, 200, False, 1)])
+def test_attention(hd, Hq, Hkv, Sq, Sk, causal, kernel):
+    B = 2
+    # fused qkv buffer like the real path: [B*S, (Hq + 2 Hkv) * hd]
+    S = max(Sq, Sk)
+    q = bf(g(B, Sq, Hq, hd, seed=27))
+    k = bf(g(B, Sk, Hkv, hd, seed=28))
+    v = bf(g(B, Sk, Hkv, hd, seed=29))
+    q_pos0 = Sk - Sq if causal else 0
+    o = ops.attention(q, k, v, B, Hq, Hkv, Sq, Sk, hd, (Sq * Hq * hd, Hq * hd), (Sk * Hkv * hd, Hkv * hd),
+                      (Sk * Hkv * hd, Hkv * hd), causal=causal, q_pos0=q_pos0, kernel=kernel)
+    ref = attn_ref(q, k, v, causal, q_pos0)
+    assert rel(o, ref) < 1.2e-2, rel(o, ref)
+
+
+def test_attention_spike_forces_rescale():
+    # one key dominates late in the sequence -> running max jumps (online-softmax rescale path)
+    B, H, S, hd = 1, 2, 256, 72
+    q, k, v = g(B, S, H, hd, seed=30), g(B, S, H, hd, seed=31), g(B, S, H, hd, seed=32)
+    k[:, 200] = q[:, 5] * 4.0
+    q, k, v = bf(q), bf(k), bf(v)
+    o = ops.attention(q, k, v, B, H, H, S, S, hd, (S * H * hd, H * hd), (S * H * hd, H * hd), (S * H * hd, H * hd), kernel=1)
+    assert rel(o, attn_ref(q, k, v, False)) < 1.2e-2
+
+
+def test_rope_kv():
+    S, Hq, Hkv, hd, pos0 = 37, 4, 2, 128, 11
+    qkv = bf(g(S, (Hq + 2 * Hkv) * hd, seed=33))
+    inv = 1.0 / (1e6 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd)).to(DEV)
+    cache = torch.zeros(64, 2 * Hkv * hd, device=DEV, dtype=torch.bfloat16)
+    ref_in = qkv.float().clone()
+    ops.rope_kv(qkv, S, Hq, Hkv, hd, inv, pos0, cache)
+    pos = torch.arange(pos0, pos0 + S, device=DEV).float()
+    ang = torch.cat([pos[:, None] * inv[None], pos[:, None] * inv[None]], -1)
+    cos, sin = ang.cos()[:, None], ang.sin()[:, None]
+    rot = lambda x: torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1)
+    qr = ref_in[:, :Hq * hd].view(S, Hq, hd); kr = ref_in[:, Hq * hd:(Hq + Hkv) * hd].view(S, Hkv, hd)
+    assert rel(qkv[:, :Hq * hd].float().view(S, Hq, hd), qr * cos + rot(qr) * sin) < 8e-3
+    assert rel(cache[pos0:pos0 + S, :Hkv * hd].float().view(S, Hkv, hd), kr * cos + rot(kr) * sin) < 8e-3
+    assert torch.equal(cache[pos0:pos0 + S, Hkv * hd:], bf(ref_in[:, (Hq + Hkv) * hd:]))
+    assert cache[:pos0].abs().sum() == 0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+def test_patchify(dt):
+    T, C, H, P = 3, 3, 56, 14
+    x = g(T, C, H, H, seed=34).to(dt)
+    out = ops.patchify(x, P, 640)
+    ref = torch.nn.functional.unfold(x.float(), P, stride=P).transpose(1, 2).reshape(T * 16, C * P * P)
+    assert torch.equal(out[:, :588].float(), bf(ref).float())
+    assert out[:, 588:].abs().sum() == 0
+
+
+def test_dwconv_ln_silu_and_se_pieces():
+    F, H, W, C = 3, 6, 6, 256
+    x = bf(g(F, H, W, C, seed=35))
+    w = g(C, 1, 3, 3, seed=36, scale=0.3)
+    lnw, lnb = 1 + 0.1 * g(C, seed=37), 0.1 * g(C, seed=38)
+    w9 = w.view(C, 9).t().contiguous()
+    y = ops.dwconv3x3_ln_silu(x, w9, lnw, lnb, F, H, W, C, 1e-5)
+    xc = x.float().permute(0, 3, 1, 2)
+    r = torch.nn.functional.conv2d(xc, w, padding=1, groups=C).permute(0, 2, 3, 1)
+    r = torch.nn.functional.silu(torch.nn.functional.layer_norm(r, (C,), lnw, lnb, 1e-5))
+    assert rel(y, r) < 8e-3
+    m = ops.colmean(y.view(F * H * W, C), F, H * W)
+    assert rel(m, y.float().view(F, H * W, C).mean(1)) < 8e-3
+    gate = bf(torch.sigmoid(g(F, C, seed=39)))
+    y2 = y.clone().view(F * H * W, C)
+    ops.scale_channels(y2, gate, F, H * W)
+    assert rel(y2.view(F, H * W, C), y.float().view(F, H * W, C) * gate.float()[:, None]) < 8e-3
+
+
+@pytest.mark.parametrize("k,pad", [((2, 2, 2), 0), ((1, 2, 2), 1), ((2, 2, 2), 1)])
+def test_conv3d_gather_matches_conv3d(k, pad):
+    T, H, W, C, Co = 4, 6, 6, 16, 24
+    x = bf(g(T, H, W, C, seed=40))
+    w = bf(g(Co, C, *k, seed=41, scale=0.2))
+    A, (To, Ho, Wo) = ops.conv3d_gather(x, T, H, W, C, k, pad)
+    wp = w.permute(0, 2, 3, 4, 1).reshape(Co, -1).contiguous()
+    out = A.float() @ wp.float().t()
+    ref = torch.nn.functional.conv3d(x.float().permute(3, 0, 1, 2)[None], w.float(), stride=k, padding=pad)[0]
+    assert rel(out, ref.permute(1, 2, 3, 0).reshape(To * Ho * Wo, Co)) < 1e-5
+
+
+def test_gather_rows_and_argmax_and_convert():
+    table = g(100, 64, seed=42)
+    tb = bf(table)
+    idx = torch.tensor([5, 99, 0, 5, 17], device=DEV)
+    dst = torch.zeros(8, 64, device=DEV)
+    didx = torch.tensor([7, 0, 3, 1, 2], device=DEV)
+    ops.gather_rows(tb, idx, dst, didx)
+    assert torch.equal(dst[didx], tb[idx].float()) and dst[4:7].abs().sum() == 0
+    x = g(151748, seed=43)
+    x[1234] = 50.0; x[99999] = 50.0
+    assert ops.argmax(x).item() == 1234 == torch.argmax(x).item()
+    assert ops.argmax(g(7, seed=44)).item() == torch.argmax(g(7, seed=44)).item()
+    for a, b_ in [(torch.float32, torch.bfloat16), (torch.float16, torch.bfloat16), (torch.bfloat16, torch.float32)]:
+        t = g(1000, seed=45).to(a)
+        assert torch.equal(ops.convert(t, b_), t.to(b_))
+
+
+def test_mask_pool_and_preprocess():
+    n, P, C, q = 3, 16, 64, 4
+    feat = g(n, P, C, seed=46)
+    mask = (g(q, P, seed=47) > 0).float()
+    fo = torch.tensor([0, 2, 1, 2], device=DEV, dtype=torch.int32)
+    out = ops.mask_pool(feat, mask, fo)
+    ref = torch.stack([(feat[fo[i]] * mask[i][:, None] / (mask[i].sum() + 1e-8)).sum(0) for i in range(q)])
+    assert rel(out, ref) < 1e-5
+    fr = torch.randint(0, 256, (2, 8, 10, 3), dtype=torch.uint8, device=DEV)
+    o = ops.preprocess_u8(fr, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+    ref = ((fr.float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
+    assert rel(o, ref) < 8e-3

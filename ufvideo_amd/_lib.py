@@ -1,0 +1,68 @@
+"""ctypes binding of include/ufv.h (libufv_hip.so).  The product path has no CPU fallback: if the
+library is missing or a call fails, we raise."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libufv_hip.so")
+
+ACT = {None: 0, "none": 0, "gelu_pytorch_tanh": 1, "gelu_tanh": 1, "gelu": 2, "gelu_erf": 2, "silu": 3, "relu": 4,
+       "quick_gelu": 5, "sigmoid": 6}
+DT_BF16, DT_F32, DT_F16 = 0, 1, 2
+GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, GEMM_GEMV = 0, 1, 2, 3
+
+_p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> argtypes; this table is also what tests/test_abi.py checks against include/ufv.h
+SIGNATURES = {
+    "ufv_gemm": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p],
+    "ufv_layernorm": [_p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _f, _i, _p],
+    "ufv_ln_add_silu": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "ufv_rmsnorm": [_p, _i, _p, _i, _i, _p, _i, _i, _f, _p],
+    "ufv_attention": [_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p],
+    "ufv_rope_kv": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
+    "ufv_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "ufv_dwconv3x3_ln_silu": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "ufv_colmean": [_p, _p, _i, _i, _i, _p],
+    "ufv_scale_channels": [_p, _p, _i, _i, _i, _p],
+    "ufv_conv3d_gather": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ufv_gather_rows": [_p, _i, _l, _p, _p, _i, _l, _p, _i, _i, _p],
+    "ufv_mask_pool": [_p, _i, _p, _p, _p, _i, _i, _i, _p],
+    "ufv_argmax": [_p, _i, _p, _p],
+    "ufv_preprocess_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
+    "ufv_convert": [_p, _i, _p, _i, _l, _p],
+}
+
+_lib = None
+
+
+class UfvError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libufv_hip.so (built in-tree by `make` / __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UfvError(f"{LIB_PATH} not found: build the HIP extension first (make, or __graft_entry__.build()). "
+                       "There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.ufv_last_error.restype = C.c_char_p
+    lib.ufv_last_error.argtypes = []
+    lib.ufv_abi_version.restype = _i
+    lib.ufv_abi_version.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _i
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise UfvError(f"{name} failed ({rc}): {lib.ufv_last_error().decode()}")

@@ -1,0 +1,84 @@
+// Shared device/host helpers for the gfx950 (MI355X / CDNA4) kernels.  HIP only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((void __attribute__((address_space(3)))*)(p))
+#define GLB_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
+
+// ---- error plumbing (ufv_last_error) -------------------------------------------------
+extern "C" const char* ufv_last_error(void);
+void ufv_set_error(const char* fmt, ...);
+#define UFV_OK 0
+#define UFV_EINVAL (-1)
+#define UFV_EHIP (-2)
+#define UFV_EUNSUPPORTED (-3)
+
+#define UFV_CHECK_LAUNCH()                                                         \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            ufv_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+            return UFV_EHIP;                                                       \
+        }                                                                          \
+    } while (0)
+
+#define UFV_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            ufv_set_error(__VA_ARGS__); \
+            return UFV_EINVAL;          \
+        }                               \
+    } while (0)
+
+// ---- activations ----------------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_QUICK_GELU = 5, ACT_SIGMOID = 6 };
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    switch (act) {
+        case ACT_GELU_TANH: {
+            const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+            float u = k0 * (x + k1 * x * x * x);
+            return 0.5f * x * (1.0f + tanhf(u));
+        }
+        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+        case ACT_SILU: return x / (1.0f + __expf(-x));
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
+        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+        default: return x;
+    }
+}
+
+// ---- wave-level reductions (wave = 64 lanes) --------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024, `red` = 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

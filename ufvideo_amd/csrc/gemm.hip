@@ -1,0 +1,321 @@
+// bf16 GEMM  C[M,N] = epilogue(A[M,K] · W[N,K]^T)  for gfx950.
+//
+// Both operands are K-contiguous ("NT" form: activations row-major, nn.Linear weights as
+// stored), which is exactly the MFMA A/B fragment order — no transposes anywhere.
+//
+// Fast kernel: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16, operands staged global->LDS with 16-byte LDS-DMA
+// (global_load_lds_dwordx4), two LDS stages, XOR-swizzled 16-byte chunks so every
+// ds_read_b128 fragment read is bank-conflict free (swizzle applied on the per-lane SOURCE
+// address because the LDS-DMA destination is lane-linear), XCD-aware tile order.
+// The MFMA is issued as mfma(W-frag, A-frag) so that each lane ends up with 4 CONSECUTIVE
+// output columns of one row -> 8/16-byte epilogue accesses for bias / residual / stores.
+//
+// Generic kernel: any shape/alignment, one thread per output, used for tiny problems
+// (region encoder, SE gates, tiny test models).
+#include "common.h"
+#include "../../include/ufv.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
+constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // 64 KiB -> 2 blocks / CU
+
+struct Epi {
+    const float* bias;     // [N] or null
+    const float* resid;    // fp32 [M, ldr] or null (added after activation)
+    void* out;             // bf16 or fp32
+    int ldr, ldc, act;
+    int resid_rows;        // >0: residual row = m % resid_rows (broadcast table, e.g. position embeddings)
+};
+
+template <bool OUT_F32, bool SWIGLU>
+__device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, float v0, float v1, float v2, float v3) {
+    // n is a multiple of 4; the four values are columns n..n+3 of row m
+    float v[4] = {v0, v1, v2, v3};
+    if (e.bias) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], e.act);
+    if (e.resid) {
+        const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
+        const f32x4 r = *reinterpret_cast<const f32x4*>(e.resid + (size_t)mr * e.ldr + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += r[j];
+    }
+    if (OUT_F32) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (size_t)m * e.ldc + n) = o;
+    } else {
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(e.out) + (size_t)m * e.ldc + n) = o;
+    }
+}
+
+template <bool OUT_F32, bool SWIGLU>
+__global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e,
+                                                       int M, int N, int K, int lda, int ldw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware tile order: consecutive launch ids round-robin over 8 XCDs, so give each XCD
+    //      a contiguous run of the tile sequence, and order the sequence in 16-row-tile groups.
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+    const int nwg = tiles_m * tiles_n;
+    int id;
+    {
+        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 16;
+    const int gsz = GM * tiles_n, g = id / gsz, first_m = g * GM;
+    const int gm = min(tiles_m - first_m, GM);
+    const int tm = first_m + (id % gsz) % gm, tn = (id % gsz) / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- LDS-DMA source addresses. One wave-instruction fills 8 rows x 128 B; lane l writes
+    //      LDS chunk (l&7) of row (l>>3) and therefore must FETCH chunk (l&7)^(row&7).
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+    const bf16* a_src[4];
+    const bf16* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + lrow;
+        a_src[i] = A + (size_t)min(m0 + r, M - 1) * lda + lchunk * 8;
+        b_src[i] = W + (size_t)(n0 + r) * ldw + lchunk * 8;
+    }
+    auto stage = [&](int s, int k0) {
+        char* base = smem + s * STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + k0), LDS_PTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + k0), LDS_PTR(base + BM * BK * 2 + i * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];   // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row (lane&15) of a 16-row tile, 16-byte chunk kk*4+(lane>>4), XOR (row&7)
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    const int a_off = (wm * 64 + frow) * 128, b_off = BM * BK * 2 + (wn * 64 + frow) * 128;
+
+    const int nk = K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+        const char* sb = smem + (t & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int coff = ((kk * 4 + fq) ^ fx) << 4;
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 16 * 128 + coff);
+                bf[i] = *reinterpret_cast<const bf16x8*>(sb + b_off + i * 16 * 128 + coff);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[nt][mt][j] = C[m0+wm*64+mt*16+(lane&15)][n0+wn*64+nt*16+(lane>>4)*4+j]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + frow;
+        if (m >= M) continue;
+        if (SWIGLU) {
+            // weight rows were packed [16 gate | 16 up] alternating: nt even = gate, nt odd = up
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int n = ((n0 + wn * 64) >> 1) + p * 16 + fq * 4;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gte = acc[2 * p][mt][j], up = acc[2 * p + 1][mt][j];
+                    v[j] = gte / (1.0f + __expf(-gte)) * up;
+                }
+                epi_store4<OUT_F32, true>(e, m, n, v[0], v[1], v[2], v[3]);
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+                epi_store4<OUT_F32, false>(e, m, n, acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+            }
+        }
+    }
+}
+
+// ---- generic kernel: one thread per output element -------------------------------------------
+template <bool OUT_F32, bool SWIGLU>
+__global__ void gemm_nt_generic(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e, int M, int N, int K,
+                                int lda, int ldw) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;      // output column (post-SWIGLU index when SWIGLU)
+    const int m = blockIdx.y;
+    const int n_out = SWIGLU ? N / 2 : N;
+    if (n >= n_out || m >= M) return;
+    const bf16* a = A + (size_t)m * lda;
+    float v;
+    if (SWIGLU) {
+        const int pg = (n / 16) * 32 + (n % 16);
+        const bf16* wg = W + (size_t)pg * ldw;
+        const bf16* wu = W + (size_t)(pg + 16) * ldw;
+        float g = 0.f, u = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float x = (float)a[k];
+            g += x * (float)wg[k];
+            u += x * (float)wu[k];
+        }
+        v = g / (1.0f + __expf(-g)) * u;
+    } else {
+        const bf16* w = W + (size_t)n * ldw;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += (float)a[k] * (float)w[k];
+        v = s;
+        if (e.bias) v += e.bias[n];
+        v = act_apply(v, e.act);
+    }
+    if (e.resid) v += e.resid[(size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n];
+    if (OUT_F32)
+        reinterpret_cast<float*>(e.out)[(size_t)m * e.ldc + n] = v;
+    else
+        reinterpret_cast<bf16*>(e.out)[(size_t)m * e.ldc + n] = (bf16)v;
+}
+
+// ---- GEMV (M <= 8): one wave per output column, weights streamed once with 16-byte loads -----
+template <bool OUT_F32, bool SWIGLU, int MR>
+__global__ __launch_bounds__(256) void gemv_nt(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e, int M, int N,
+                                               int K, int lda, int ldw) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);       // output index (post-SWIGLU when SWIGLU)
+    const int n_out = SWIGLU ? N / 2 : N;
+    if (n >= n_out) return;
+    const int row0 = SWIGLU ? (n / 16) * 32 + (n % 16) : n;
+    const bf16* w0 = W + (size_t)row0 * ldw;
+    const bf16* w1 = W + (size_t)(row0 + 16) * ldw;
+    const int r0 = blockIdx.y * MR;
+    A += (size_t)r0 * lda;
+    M = min(M - r0, MR);
+    float s0[MR], s1[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) s0[r] = s1[r] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w0 + k);
+        bf16x8 uv;
+        if (SWIGLU) uv = *reinterpret_cast<const bf16x8*>(w1 + k);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            if (r < M) {
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(A + (size_t)r * lda + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s0[r] += (float)av[j] * (float)wv[j];
+                    if (SWIGLU) s1[r] += (float)av[j] * (float)uv[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        if (r >= M) break;
+        float v = wave_sum(s0[r]);
+        if (SWIGLU) {
+            const float u = wave_sum(s1[r]);
+            v = v / (1.0f + __expf(-v)) * u;
+        } else {
+            if (e.bias) v += e.bias[n];
+            v = act_apply(v, e.act);
+        }
+        if (lane == 0) {
+            const int m = r0 + r;
+            if (e.resid) v += e.resid[(size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n];
+            if (OUT_F32)
+                reinterpret_cast<float*>(e.out)[(size_t)m * e.ldc + n] = v;
+            else
+                reinterpret_cast<bf16*>(e.out)[(size_t)m * e.ldc + n] = (bf16)v;
+        }
+    }
+}
+
+template <bool F, bool S>
+int launch_fast(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<F, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            SMEM_BYTES);
+        attr_set = true;
+    }
+    const int tiles = cdiv(M, BM) * (N / BN);
+    hipLaunchKernelGGL((gemm_nt_128<F, S>), dim3(tiles), dim3(256), SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+template <bool F, bool S>
+int launch_any(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, int force, hipStream_t st) {
+    const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && (lda % 8 == 0) && (ldw % 8 == 0) &&
+                         ((uintptr_t)e.out % 16 == 0) && (e.ldc % 4 == 0) && (!e.bias || (uintptr_t)e.bias % 16 == 0) &&
+                         (!e.resid || ((uintptr_t)e.resid % 16 == 0 && e.ldr % 4 == 0));
+    const bool fast_ok = aligned && (N % BN == 0) && (K % BK == 0) && M >= 1;
+    const bool gemv_ok = aligned && (K % 8 == 0) && M <= 64 && (!S || N % 32 == 0);
+    if (force == UFV_GEMM_FAST && !fast_ok) {
+        ufv_set_error("ufv_gemm: fast kernel needs N%%128==0, K%%64==0, 16-byte aligned operands (M=%d N=%d K=%d)", M, N, K);
+        return UFV_EUNSUPPORTED;
+    }
+    if ((force == UFV_GEMM_AUTO && gemv_ok) || force == UFV_GEMM_GEMV) {
+        if (!gemv_ok) {
+            ufv_set_error("ufv_gemm: gemv kernel needs M<=64, K%%8==0 (M=%d N=%d K=%d)", M, N, K);
+            return UFV_EUNSUPPORTED;
+        }
+        const int n_out = S ? N / 2 : N;
+        hipLaunchKernelGGL((gemv_nt<F, S, 8>), dim3(cdiv(n_out, 4), cdiv(M, 8)), dim3(256), 0, st, A, W, e, M, N, K, lda, ldw);
+        UFV_CHECK_LAUNCH();
+        return UFV_OK;
+    }
+    if ((force == UFV_GEMM_AUTO && fast_ok && M > 64) || force == UFV_GEMM_FAST)
+        return launch_fast<F, S>(A, W, e, M, N, K, lda, ldw, st);
+    if (S && N % 32 != 0) {
+        ufv_set_error("ufv_gemm: SWIGLU needs N%%32==0");
+        return UFV_EINVAL;
+    }
+    const int n_out = S ? N / 2 : N;
+    hipLaunchKernelGGL((gemm_nt_generic<F, S>), dim3(cdiv(n_out, 64), M), dim3(64), 0, st, A, W, e, M, N, K, lda, ldw);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+}  // namespace
+
+extern "C" int ufv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int out_f32, int M, int N, int K,
+                        const float* bias, int act, const float* resid, int ldr, int resid_rows, int swiglu, int kernel,
+                        void* stream) {
+    UFV_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "ufv_gemm: bad arguments (M=%d N=%d K=%d)", M, N, K);
+    UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemm: swiglu epilogue takes no bias/activation");
+    Epi e;
+    e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = resid_rows;
+    const bf16* a = reinterpret_cast<const bf16*>(A);
+    const bf16* w = reinterpret_cast<const bf16*>(W);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (out_f32)
+        return swiglu ? launch_any<true, true>(a, w, e, M, N, K, lda, ldw, kernel, st)
+                      : launch_any<true, false>(a, w, e, M, N, K, lda, ldw, kernel, st);
+    return swiglu ? launch_any<false, true>(a, w, e, M, N, K, lda, ldw, kernel, st)
+                  : launch_any<false, false>(a, w, e, M, N, K, lda, ldw, kernel, st);
+}

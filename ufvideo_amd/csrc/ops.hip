@@ -1,0 +1,572 @@
+// HBM-bound kernels of the hot path (gfx950): norms, RoPE + KV-cache store, patchify, the
+// projector's depthwise/SE/Conv3d-gather pieces, row gathers for the embedding splice, argmax,
+// frame preprocessing.  All: 8-16 byte per-lane accesses, one wave (or block) per row, fp32 math.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+#include "../../include/ufv.h"
+
+// ---- error string ------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void ufv_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* ufv_last_error(void) { return g_err; }
+extern "C" int ufv_abi_version(void) { return UFV_ABI_VERSION; }
+
+namespace {
+
+// -------------------------------------------------------------------------------------------------
+// row loaders: a wave owns a row of D (= 4*nv) elements, lane handles vec4 index lane + 64*i
+// -------------------------------------------------------------------------------------------------
+constexpr int MAXV = 16;   // D <= 4096
+
+template <int DT>
+__device__ __forceinline__ f32x4 load4(const void* p, int64_t idx) {
+    if (DT == UFV_DT_F32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + idx);
+    if (DT == UFV_DT_BF16) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p) + idx);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    typedef __attribute__((ext_vector_type(4))) _Float16 h4;
+    const h4 v = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(p) + idx);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <bool F32>
+__device__ __forceinline__ void store4(void* p, int64_t idx, f32x4 v) {
+    if (F32)
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p) + idx) = v;
+    else
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p) + idx) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+}
+
+// LayerNorm statistics of a row held in registers (two-pass, like torch)
+__device__ __forceinline__ void ln_stats(const f32x4* x, int nv, int lane, int D, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
+    mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = x[i][j] - mean;
+                q += d * d;
+            }
+        }
+    rstd = rsqrtf(wave_sum(q) / D + eps);
+}
+
+template <int XDT, bool YF32>
+__global__ __launch_bounds__(256) void layernorm_k(const void* x, int ldx, void* y, int ldy, const float* w, const float* b,
+                                                   int M, int D, float eps, int act) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = D >> 2;
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) v[i] = load4<XDT>(x, (int64_t)row * ldx + 4 * (lane + 64 * i));
+    float mean, rstd;
+    ln_stats(v, nv, lane, D, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            const int c = 4 * (lane + 64 * i);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+            const f32x4 bb = b ? *reinterpret_cast<const f32x4*>(b + c) : f32x4{0, 0, 0, 0};
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = act_apply((v[i][j] - mean) * rstd * ww[j] + bb[j], act);
+            store4<YF32>(y, (int64_t)row * ldy + c, o);
+        }
+}
+
+__global__ __launch_bounds__(256) void ln_add_silu_k(const bf16* a, const float* wa, const float* ba, const bf16* b,
+                                                     const float* wb, const float* bb, bf16* out, int M, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = D >> 2;
+    f32x4 va[MAXV], vb[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            va[i] = load4<UFV_DT_BF16>(a, (int64_t)row * D + 4 * (lane + 64 * i));
+            vb[i] = load4<UFV_DT_BF16>(b, (int64_t)row * D + 4 * (lane + 64 * i));
+        }
+    float ma, ra, mb = 0.f, rb = 1.f;
+    ln_stats(va, nv, lane, D, eps, ma, ra);
+    if (wb) ln_stats(vb, nv, lane, D, eps, mb, rb);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            const int c = 4 * (lane + 64 * i);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wa + c), b1 = *reinterpret_cast<const f32x4*>(ba + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = (va[i][j] - ma) * ra * w1[j] + b1[j];
+                float s = vb[i][j];
+                if (wb) s = (s - mb) * rb * wb[c + j] + bb[c + j];
+                o[j] = act_apply(t + s, ACT_SILU);
+            }
+            store4<false>(out, (int64_t)row * D + c, o);
+        }
+}
+
+template <bool YF32>
+__global__ __launch_bounds__(256) void rmsnorm_k(const float* x, int ldx, void* y, int ldy, const float* w, int M, int D,
+                                                 float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int nv = D >> 2;
+    f32x4 v[MAXV];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            v[i] = load4<UFV_DT_F32>(x, (int64_t)row * ldx + 4 * (lane + 64 * i));
+            q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+    const float r = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            const int c = 4 * (lane + 64 * i);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+            store4<YF32>(y, (int64_t)row * ldy + c, f32x4{ww[0] * (v[i][0] * r), ww[1] * (v[i][1] * r), ww[2] * (v[i][2] * r),
+                                                          ww[3] * (v[i][3] * r)});
+        }
+}
+
+// -------------------------------------------------------------------------------------------------
+// RoPE (rotate-half) on q in place; k roped + v copied into the KV cache
+// one thread per (token, head, pair i < hd/2)
+// -------------------------------------------------------------------------------------------------
+__global__ void rope_kv_k(bf16* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0, bf16* kv,
+                          int ldkv) {
+    const int half = hd >> 1;
+    const int64_t total = (int64_t)S * (Hq + 2 * Hkv) * half;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int i = id % half;
+        const int hh = (id / half) % (Hq + 2 * Hkv);
+        const int s = id / ((int64_t)half * (Hq + 2 * Hkv));
+        bf16* row = qkv + (int64_t)s * ldqkv;
+        if (hh < Hq + Hkv) {
+            const float ang = (float)(pos0 + s) * inv_freq[i];
+            const float c = cosf(ang), sn = sinf(ang);
+            bf16* p = row + hh * hd;
+            const float x1 = (float)p[i], x2 = (float)p[i + half];
+            const float y1 = x1 * c - x2 * sn, y2 = x2 * c + x1 * sn;
+            if (hh < Hq) {
+                p[i] = (bf16)y1;
+                p[i + half] = (bf16)y2;
+            } else {
+                bf16* d = kv + (int64_t)(pos0 + s) * ldkv + (hh - Hq) * hd;
+                d[i] = (bf16)y1;
+                d[i + half] = (bf16)y2;
+            }
+        } else {
+            const int hv = hh - Hq - Hkv;
+            const bf16* p = row + (Hq + Hkv) * hd + hv * hd;
+            bf16* d = kv + (int64_t)(pos0 + s) * ldkv + Hkv * hd + hv * hd;
+            d[i] = p[i];
+            d[i + half] = p[i + half];
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// patchify: pixels [T,C,H,W] -> [T*gh*gw, Kpad], k = c*P*P + py*P + px.  One block per (patch row of
+// the image, frame): reads are contiguous image rows (coalesced NCHW), writes contiguous k runs.
+// -------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void patchify_k(const void* px, bf16* out, int T, int C, int H, int W, int P, int Kpad) {
+    const int gw = W / P, gh = H / P;
+    const int gy = blockIdx.x, t = blockIdx.y;
+    const int K = C * P * P;
+    // elements of this patch row: C * P (py) * W (x) ; x = gx*P + pxl
+    const int n = C * P * W;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int x = e % W, py = (e / W) % P, c = e / (W * P);
+        const int64_t src = (((int64_t)t * C + c) * H + (gy * P + py)) * W + x;
+        float v;
+        if (DT == UFV_DT_F32) v = reinterpret_cast<const float*>(px)[src];
+        else if (DT == UFV_DT_BF16) v = (float)reinterpret_cast<const bf16*>(px)[src];
+        else v = (float)reinterpret_cast<const _Float16*>(px)[src];
+        const int gx = x / P, pxl = x % P;
+        out[((int64_t)(t * gh + gy) * gw + gx) * Kpad + c * P * P + py * P + pxl] = (bf16)v;
+    }
+    // zero pad columns
+    const int padn = Kpad - K;
+    for (int e = threadIdx.x; e < gw * padn; e += blockDim.x) {
+        const int gx = e / padn, k = K + e % padn;
+        out[((int64_t)(t * gh + gy) * gw + gx) * Kpad + k] = (bf16)0.f;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// depthwise 3x3 (pad 1) + LayerNorm(C) + SiLU, NHWC.  One wave per pixel, 4 pixels per block.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv_ln_silu_k(const bf16* x, bf16* y, const float* w9, const float* lnw,
+                                                        const float* lnb, int F, int H, int W, int C, float eps) {
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pix >= F * H * W) return;
+    const int px = pix % W, py = (pix / W) % H, f = pix / (W * H);
+    const int nv = C >> 2;
+    f32x4 v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) v[i] = f32x4{0, 0, 0, 0};
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = py + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = px + dx;
+            if (xx < 0 || xx >= W) continue;
+            const bf16* src = x + ((int64_t)(f * H + yy) * W + xx) * C;
+            const float* wk = w9 + ((dy + 1) * 3 + (dx + 1)) * C;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i)
+                if (lane + 64 * i < nv) {
+                    const int c = 4 * (lane + 64 * i);
+                    const f32x4 xv = load4<UFV_DT_BF16>(src, c);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wk + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[i][j] += xv[j] * wv[j];
+                }
+        }
+    }
+    // the reference rounds the conv output to the activation dtype before the norm: keep fp32 (more accurate)
+    float mean, rstd;
+    ln_stats(v, nv, lane, C, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            const int c = 4 * (lane + 64 * i);
+            const f32x4 ww = *reinterpret_cast<const f32x4*>(lnw + c), bb = *reinterpret_cast<const f32x4*>(lnb + c);
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = act_apply((v[i][j] - mean) * rstd * ww[j] + bb[j], ACT_SILU);
+            store4<false>(y, (int64_t)pix * C + c, o);
+        }
+}
+
+// out[f, c] = mean_p x[f*P + p, c]; block (256 threads = 256 channel-quads?) -> thread per 4 channels
+__global__ __launch_bounds__(256) void colmean_k(const bf16* x, bf16* out, int F, int P, int C) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4, f = blockIdx.y;
+    if (c >= C) return;
+    f32x4 s = {0, 0, 0, 0};
+    const bf16* p = x + (int64_t)f * P * C + c;
+    for (int r = 0; r < P; ++r) {
+        const f32x4 v = load4<UFV_DT_BF16>(p, (int64_t)r * C);
+        s += v;
+    }
+    const float inv = 1.0f / P;
+    store4<false>(out, (int64_t)f * C + c, f32x4{s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv});
+}
+
+__global__ __launch_bounds__(256) void scale_channels_k(bf16* x, const bf16* gate, int F, int P, int C) {
+    const int64_t nv = (int64_t)F * P * C / 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 8;
+        const int c = e % C;
+        const int f = e / ((int64_t)P * C);
+        bf16x8 v = *reinterpret_cast<bf16x8*>(x + e);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(gate + (int64_t)f * C + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * (float)g[j]);
+        *reinterpret_cast<bf16x8*>(x + e) = v;
+    }
+}
+
+// Conv3d gather: out row (to,ho,wo), col ((dt*kh+dh)*kw+dw)*C + c
+__global__ __launch_bounds__(256) void conv3d_gather_k(const bf16* x, bf16* out, int T, int H, int W, int C, int kt, int kh,
+                                                       int kw, int pad, int To, int Ho, int Wo) {
+    const int cv = C / 8;
+    const int64_t total = (int64_t)To * Ho * Wo * kt * kh * kw * cv;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = id % cv;
+        int64_t r = id / cv;
+        const int dw = r % kw; r /= kw;
+        const int dh = r % kh; r /= kh;
+        const int dt = r % kt; r /= kt;
+        const int wo = r % Wo; r /= Wo;
+        const int ho = r % Ho; r /= Ho;
+        const int to = (int)r;
+        const int t = to * kt + dt - pad, y = ho * kh + dh - pad, xx = wo * kw + dw - pad;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t >= 0 && t < T && y >= 0 && y < H && xx >= 0 && xx < W)
+            v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)t * H + y) * W + xx) * C + c8 * 8);
+        *reinterpret_cast<bf16x8*>(out + id * 8) = v;
+    }
+}
+
+// generic row gather/scatter with dtype conversion: one wave per row
+template <int SDT, bool DF32>
+__global__ __launch_bounds__(256) void gather_rows_k(const void* src, int64_t lds_, const int64_t* sidx, void* dst, int64_t ldd,
+                                                     const int64_t* didx, int n, int D) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const int64_t sr = sidx ? sidx[r] : r, dr = didx ? didx[r] : r;
+    for (int c = lane; c < D; c += 64) {
+        float v;
+        if (SDT == UFV_DT_F32) v = reinterpret_cast<const float*>(src)[sr * lds_ + c];
+        else if (SDT == UFV_DT_BF16) v = (float)reinterpret_cast<const bf16*>(src)[sr * lds_ + c];
+        else v = (float)reinterpret_cast<const _Float16*>(src)[sr * lds_ + c];
+        if (DF32) reinterpret_cast<float*>(dst)[dr * ldd + c] = v;
+        else reinterpret_cast<bf16*>(dst)[dr * ldd + c] = (bf16)v;
+    }
+}
+
+// masked mean pooling: out[i, c] = sum_p feat[frame_of[i], p, c] * mask[i, p] / (sum_p mask[i,p] + 1e-8)
+template <int DT>
+__global__ __launch_bounds__(256) void mask_pool_k(const void* feat, const float* mask, const int32_t* frame_of, float* out,
+                                                   int P, int C) {
+    __shared__ float red[16];
+    const int i = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    const float* m = mask + (int64_t)i * P;
+    float cnt = 0.f;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) cnt += m[p];
+    cnt = block_sum(cnt, red) + 1e-8f;
+    if (c >= C) return;
+    const int f = frame_of[i];
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) {
+        const float mv = m[p];
+        if (mv != 0.f) {
+            const int64_t idx = ((int64_t)f * P + p) * C + c;
+            float v;
+            if (DT == UFV_DT_F32) v = reinterpret_cast<const float*>(feat)[idx];
+            else v = (float)reinterpret_cast<const bf16*>(feat)[idx];
+            s += v * mv / cnt;      // same association as the reference: (x * mask / denorm).sum()
+        }
+    }
+    out[(int64_t)i * C + c] = s;
+}
+
+// argmax with lowest-index tie-break (torch.argmax); single block
+__global__ __launch_bounds__(1024) void argmax_k(const float* x, int N, int64_t* out) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float v = x[i];
+        if (v > best || (v == best && i < idx) || (v != v && !(best != best))) {   // NaN wins like torch
+            best = v;
+            idx = i;
+        }
+    }
+    auto better = [](float v, int i, float bv_, int bi_) {
+        const bool vn = v != v, bn = bv_ != bv_;
+        if (vn != bn) return vn;
+        if (vn && bn) return i < bi_;
+        return v > bv_ || (v == bv_ && i < bi_);
+    };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (better(ov, oi, best, idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (better(bv[w], bi[w], best, idx)) { best = bv[w]; idx = bi[w]; }
+        out[0] = idx;
+    }
+}
+
+__global__ __launch_bounds__(256) void preprocess_u8_k(const uint8_t* fr, bf16* out, int T, int H, int W, float m0, float m1,
+                                                       float m2, float s0, float s1, float s2) {
+    const int64_t total = (int64_t)T * 3 * H * W;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int x = id % W, y = (id / W) % H, c = (id / ((int64_t)W * H)) % 3;
+        const int t = id / ((int64_t)3 * W * H);
+        const float v = (float)fr[(((int64_t)t * H + y) * W + x) * 3 + c] * (1.0f / 255.0f);
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        out[id] = (bf16)((v - mean) / sd);
+    }
+}
+
+template <int SDT, int DDT>
+__global__ __launch_bounds__(256) void convert_k(const void* s, void* d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (SDT == UFV_DT_F32) v = reinterpret_cast<const float*>(s)[i];
+        else if (SDT == UFV_DT_BF16) v = (float)reinterpret_cast<const bf16*>(s)[i];
+        else v = (float)reinterpret_cast<const _Float16*>(s)[i];
+        if (DDT == UFV_DT_F32) reinterpret_cast<float*>(d)[i] = v;
+        else if (DDT == UFV_DT_BF16) reinterpret_cast<bf16*>(d)[i] = (bf16)v;
+        else reinterpret_cast<_Float16*>(d)[i] = (_Float16)v;
+    }
+}
+
+inline int grid_for(int64_t n, int per_block = 256) {
+    const int64_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 8192 ? g : 8192);
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int ufv_layernorm(const void* x, int x_dtype, int ldx, void* y, int y_f32, int ldy, const float* w, const float* b,
+                             int M, int D, float eps, int act, void* stream) {
+    UFV_REQUIRE(x && y && w && M > 0 && D > 0, "ufv_layernorm: bad arguments");
+    UFV_REQUIRE(D % 4 == 0 && D <= 4 * 64 * MAXV && ldx % 4 == 0 && ldy % 4 == 0, "ufv_layernorm: D=%d must be a multiple of 4 and <= %d", D, 4 * 64 * MAXV);
+    dim3 g(cdiv(M, 4)), blk(256);
+#define LN_LAUNCH(XD, YF) hipLaunchKernelGGL((layernorm_k<XD, YF>), g, blk, 0, ST(stream), x, ldx, y, ldy, w, b, M, D, eps, act)
+    if (x_dtype == UFV_DT_F32) { if (y_f32) LN_LAUNCH(UFV_DT_F32, true); else LN_LAUNCH(UFV_DT_F32, false); }
+    else if (x_dtype == UFV_DT_BF16) { if (y_f32) LN_LAUNCH(UFV_DT_BF16, true); else LN_LAUNCH(UFV_DT_BF16, false); }
+    else { ufv_set_error("ufv_layernorm: unsupported input dtype %d", x_dtype); return UFV_EINVAL; }
+#undef LN_LAUNCH
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_ln_add_silu(const void* a, const float* wa, const float* ba, const void* b, const float* wb, const float* bb,
+                               void* out, int M, int D, float eps, void* stream) {
+    UFV_REQUIRE(a && wa && ba && b && out && M > 0, "ufv_ln_add_silu: bad arguments");
+    UFV_REQUIRE(D % 4 == 0 && D <= 4 * 64 * MAXV, "ufv_ln_add_silu: D=%d unsupported", D);
+    hipLaunchKernelGGL(ln_add_silu_k, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), (const bf16*)a, wa, ba, (const bf16*)b, wb, bb,
+                       (bf16*)out, M, D, eps);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_rmsnorm(const float* x, int ldx, void* y, int y_f32, int ldy, const float* w, int M, int D, float eps,
+                           void* stream) {
+    UFV_REQUIRE(x && y && w && M > 0, "ufv_rmsnorm: bad arguments");
+    UFV_REQUIRE(D % 4 == 0 && D <= 4 * 64 * MAXV && ldx % 4 == 0 && ldy % 4 == 0, "ufv_rmsnorm: D=%d unsupported", D);
+    if (y_f32) hipLaunchKernelGGL((rmsnorm_k<true>), dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, ldx, y, ldy, w, M, D, eps);
+    else hipLaunchKernelGGL((rmsnorm_k<false>), dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, ldx, y, ldy, w, M, D, eps);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_rope_kv(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0, void* kv_cache,
+                           int ldkv, void* stream) {
+    UFV_REQUIRE(qkv && inv_freq && kv_cache && S > 0 && hd % 2 == 0, "ufv_rope_kv: bad arguments");
+    const int64_t total = (int64_t)S * (Hq + 2 * Hkv) * (hd / 2);
+    hipLaunchKernelGGL(rope_kv_k, dim3(grid_for(total)), dim3(256), 0, ST(stream), (bf16*)qkv, ldqkv, S, Hq, Hkv, hd, inv_freq, pos0,
+                       (bf16*)kv_cache, ldkv);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_patchify(const void* pixels, int dtype, void* out, int T, int C, int H, int W, int P, int Kpad, void* stream) {
+    UFV_REQUIRE(pixels && out && T > 0 && H % P == 0 && W % P == 0 && Kpad >= C * P * P, "ufv_patchify: bad arguments");
+    dim3 g(H / P, T), blk(256);
+    if (dtype == UFV_DT_F32) hipLaunchKernelGGL((patchify_k<UFV_DT_F32>), g, blk, 0, ST(stream), pixels, (bf16*)out, T, C, H, W, P, Kpad);
+    else if (dtype == UFV_DT_BF16) hipLaunchKernelGGL((patchify_k<UFV_DT_BF16>), g, blk, 0, ST(stream), pixels, (bf16*)out, T, C, H, W, P, Kpad);
+    else if (dtype == UFV_DT_F16) hipLaunchKernelGGL((patchify_k<UFV_DT_F16>), g, blk, 0, ST(stream), pixels, (bf16*)out, T, C, H, W, P, Kpad);
+    else { ufv_set_error("ufv_patchify: unsupported dtype %d", dtype); return UFV_EINVAL; }
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_dwconv3x3_ln_silu(const void* x, void* y, const float* w9, const float* lnw, const float* lnb, int F, int H,
+                                     int W, int C, float eps, void* stream) {
+    UFV_REQUIRE(x && y && w9 && lnw && lnb && F > 0, "ufv_dwconv3x3_ln_silu: bad arguments");
+    UFV_REQUIRE(C % 4 == 0 && C <= 4 * 64 * MAXV, "ufv_dwconv3x3_ln_silu: C=%d unsupported", C);
+    hipLaunchKernelGGL(dwconv_ln_silu_k, dim3(cdiv(F * H * W, 4)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F,
+                       H, W, C, eps);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_colmean(const void* x, void* out, int F, int P, int C, void* stream) {
+    UFV_REQUIRE(x && out && F > 0 && P > 0 && C % 4 == 0, "ufv_colmean: bad arguments");
+    hipLaunchKernelGGL(colmean_k, dim3(cdiv(C / 4, 64), F), dim3(64), 0, ST(stream), (const bf16*)x, (bf16*)out, F, P, C);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_scale_channels(void* x, const void* gate, int F, int P, int C, void* stream) {
+    UFV_REQUIRE(x && gate && C % 8 == 0, "ufv_scale_channels: C must be a multiple of 8");
+    hipLaunchKernelGGL(scale_channels_k, dim3(grid_for((int64_t)F * P * C / 8)), dim3(256), 0, ST(stream), (bf16*)x, (const bf16*)gate,
+                       F, P, C);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_conv3d_gather(const void* x, void* out, int T, int H, int W, int C, int kt, int kh, int kw, int pad,
+                                 void* stream) {
+    UFV_REQUIRE(x && out && C % 8 == 0, "ufv_conv3d_gather: C must be a multiple of 8");
+    const int To = (T + 2 * pad - kt) / kt + 1, Ho = (H + 2 * pad - kh) / kh + 1, Wo = (W + 2 * pad - kw) / kw + 1;
+    UFV_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "ufv_conv3d_gather: empty output");
+    const int64_t total = (int64_t)To * Ho * Wo * kt * kh * kw * (C / 8);
+    hipLaunchKernelGGL(conv3d_gather_k, dim3(grid_for(total)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)out, T, H, W, C, kt,
+                       kh, kw, pad, To, Ho, Wo);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_gather_rows(const void* src, int src_dtype, int64_t ld_src, const int64_t* src_idx, void* dst, int dst_dtype,
+                               int64_t ld_dst, const int64_t* dst_idx, int n, int D, void* stream) {
+    if (n == 0) return UFV_OK;
+    UFV_REQUIRE(src && dst && n > 0 && D > 0, "ufv_gather_rows: bad arguments");
+    dim3 g(cdiv(n, 4)), blk(256);
+#define GR(SD, DF) hipLaunchKernelGGL((gather_rows_k<SD, DF>), g, blk, 0, ST(stream), src, ld_src, src_idx, dst, ld_dst, dst_idx, n, D)
+    const bool df32 = dst_dtype == UFV_DT_F32;
+    UFV_REQUIRE(dst_dtype == UFV_DT_F32 || dst_dtype == UFV_DT_BF16, "ufv_gather_rows: dst must be f32 or bf16");
+    if (src_dtype == UFV_DT_F32) { if (df32) GR(UFV_DT_F32, true); else GR(UFV_DT_F32, false); }
+    else if (src_dtype == UFV_DT_BF16) { if (df32) GR(UFV_DT_BF16, true); else GR(UFV_DT_BF16, false); }
+    else if (src_dtype == UFV_DT_F16) { if (df32) GR(UFV_DT_F16, true); else GR(UFV_DT_F16, false); }
+    else { ufv_set_error("ufv_gather_rows: unsupported src dtype"); return UFV_EINVAL; }
+#undef GR
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_mask_pool(const void* feat, int feat_dtype, const float* mask, const int32_t* frame_of, float* out, int q, int P,
+                             int C, void* stream) {
+    if (q == 0) return UFV_OK;
+    UFV_REQUIRE(feat && mask && frame_of && out, "ufv_mask_pool: bad arguments");
+    dim3 g(cdiv(C, 256), q), blk(256);
+    if (feat_dtype == UFV_DT_F32) hipLaunchKernelGGL((mask_pool_k<UFV_DT_F32>), g, blk, 0, ST(stream), feat, mask, frame_of, out, P, C);
+    else if (feat_dtype == UFV_DT_BF16) hipLaunchKernelGGL((mask_pool_k<UFV_DT_BF16>), g, blk, 0, ST(stream), feat, mask, frame_of, out, P, C);
+    else { ufv_set_error("ufv_mask_pool: unsupported dtype"); return UFV_EINVAL; }
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_argmax(const float* logits, int N, int64_t* out, void* stream) {
+    UFV_REQUIRE(logits && out && N > 0, "ufv_argmax: bad arguments");
+    hipLaunchKernelGGL(argmax_k, dim3(1), dim3(1024), 0, ST(stream), logits, N, out);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_preprocess_u8(const uint8_t* frames, void* out, int T, int H, int W, const float* mean3, const float* std3,
+                                 void* stream) {
+    UFV_REQUIRE(frames && out && mean3 && std3 && T > 0, "ufv_preprocess_u8: bad arguments");
+    hipLaunchKernelGGL(preprocess_u8_k, dim3(grid_for((int64_t)T * 3 * H * W)), dim3(256), 0, ST(stream), frames, (bf16*)out, T, H, W,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_convert(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
+    if (n == 0) return UFV_OK;
+    UFV_REQUIRE(src && dst && sd >= 0 && sd <= 2 && dd >= 0 && dd <= 2, "ufv_convert: bad arguments");
+    dim3 g(grid_for(n)), blk(256);
+#define CV(S, D) hipLaunchKernelGGL((convert_k<S, D>), g, blk, 0, ST(stream), src, dst, n)
+    switch (sd * 3 + dd) {
+        case 0: CV(0, 0); break; case 1: CV(0, 1); break; case 2: CV(0, 2); break;
+        case 3: CV(1, 0); break; case 4: CV(1, 1); break; case 5: CV(1, 2); break;
+        case 6: CV(2, 0); break; case 7: CV(2, 1); break; case 8: CV(2, 2); break;
+    }
+#undef CV
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}

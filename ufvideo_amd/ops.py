@@ -1,0 +1,184 @@
+"""Thin torch-tensor wrappers over the C ABI (include/ufv.h).  torch is used only for device
+memory and the current stream; every op below runs a hand-written HIP kernel from csrc/."""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT, DT_BF16, DT_F32, DT_F16, GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, GEMM_GEMV  # noqa: F401
+
+_DT = {torch.bfloat16: DT_BF16, torch.float32: DT_F32, torch.float16: DT_F16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.UfvError(f"{name} must live on the GPU (the hot path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.UfvError(f"{name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def gemm(a, w, bias=None, act=None, resid=None, resid_rows=0, out=None, out_dtype=torch.bfloat16, swiglu=False,
+         kernel=GEMM_AUTO):
+    """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T).  a may be a row-strided view; w contiguous."""
+    _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w")
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=out_dtype)
+    assert out.shape == (M, n_out) and out.stride(1) == 1
+    if bias is not None:
+        _chk(bias, torch.float32, "bias"); assert bias.numel() >= N
+    ldr = 0
+    if resid is not None:
+        _chk(resid, torch.float32, "resid"); ldr = resid.stride(0)
+    _lib.call("ufv_gemm", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+              int(out.dtype == torch.float32), M, N, K, _ptr(bias), ACT[act], _ptr(resid), ldr, resid_rows, int(swiglu),
+              kernel, _stream())
+    return out
+
+
+def layernorm(x, w, b, eps, act=None, out=None, out_dtype=torch.bfloat16):
+    _chk(x, name="x"); _chk(w, torch.float32, "w")
+    M, D = x.shape
+    if out is None:
+        out = torch.empty((M, D), device=x.device, dtype=out_dtype)
+    _lib.call("ufv_layernorm", x.data_ptr(), _DT[x.dtype], x.stride(0), out.data_ptr(), int(out.dtype == torch.float32),
+              out.stride(0), w.data_ptr(), _ptr(b), M, D, float(eps), ACT[act], _stream())
+    return out
+
+
+def ln_add_silu(a, wa, ba, b, wb=None, bb=None, eps=1e-5, out=None):
+    _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
+    assert a.is_contiguous() and b.is_contiguous()
+    M, D = a.shape
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.call("ufv_ln_add_silu", a.data_ptr(), wa.data_ptr(), ba.data_ptr(), b.data_ptr(), _ptr(wb), _ptr(bb), out.data_ptr(),
+              M, D, float(eps), _stream())
+    return out
+
+
+def rmsnorm(x, w, eps, out=None, out_dtype=torch.bfloat16):
+    _chk(x, torch.float32, "x")
+    M, D = x.shape
+    if out is None:
+        out = torch.empty((M, D), device=x.device, dtype=out_dtype)
+    _lib.call("ufv_rmsnorm", x.data_ptr(), x.stride(0), out.data_ptr(), int(out.dtype == torch.float32), out.stride(0),
+              w.data_ptr(), M, D, float(eps), _stream())
+    return out
+
+
+def attention(q, k, v, B, Hq, Hkv, Sq, Sk, hd, q_strides, k_strides, v_strides, scale=None, causal=False, q_pos0=0,
+              out=None, kernel=0):
+    """q/k/v: bf16 tensors (any view); *_strides = (batch stride, token stride) in elements; heads are
+    contiguous blocks of hd along the last dim.  Returns o [B*Sq, Hq*hd] bf16."""
+    if out is None:
+        out = torch.empty((B * Sq, Hq * hd), device=q.device, dtype=torch.bfloat16)
+    scale = hd ** -0.5 if scale is None else scale
+    _lib.call("ufv_attention", q.data_ptr(), q_strides[0], q_strides[1], k.data_ptr(), k_strides[0], k_strides[1],
+              v.data_ptr(), v_strides[0], v_strides[1], out.data_ptr(), Sq * out.stride(0), out.stride(0), B, Hq, Hkv, Sq, Sk,
+              hd, float(scale), int(causal), q_pos0, kernel, _stream())
+    return out
+
+
+def rope_kv(qkv, S, Hq, Hkv, hd, inv_freq, pos0, kv_cache):
+    _chk(qkv, torch.bfloat16, "qkv"); _chk(kv_cache, torch.bfloat16, "kv_cache"); _chk(inv_freq, torch.float32, "inv_freq")
+    _lib.call("ufv_rope_kv", qkv.data_ptr(), qkv.stride(0), S, Hq, Hkv, hd, inv_freq.data_ptr(), pos0, kv_cache.data_ptr(),
+              kv_cache.stride(0), _stream())
+
+
+def patchify(pixels, P, Kpad):
+    _chk(pixels, name="pixels"); assert pixels.is_contiguous()
+    T, Cc, H, W = pixels.shape
+    out = torch.empty((T * (H // P) * (W // P), Kpad), device=pixels.device, dtype=torch.bfloat16)
+    _lib.call("ufv_patchify", pixels.data_ptr(), _DT[pixels.dtype], out.data_ptr(), T, Cc, H, W, P, Kpad, _stream())
+    return out
+
+
+def dwconv3x3_ln_silu(x, w9, lnw, lnb, F, H, W, C, eps):
+    _chk(x, torch.bfloat16, "x"); assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.call("ufv_dwconv3x3_ln_silu", x.data_ptr(), y.data_ptr(), w9.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), F, H, W, C,
+              float(eps), _stream())
+    return y
+
+
+def colmean(x, F, P):
+    C = x.shape[-1]
+    out = torch.empty((F, C), device=x.device, dtype=torch.bfloat16)
+    _lib.call("ufv_colmean", x.data_ptr(), out.data_ptr(), F, P, C, _stream())
+    return out
+
+
+def scale_channels(x, gate, F, P):
+    _lib.call("ufv_scale_channels", x.data_ptr(), gate.data_ptr(), F, P, x.shape[-1], _stream())
+    return x
+
+
+def conv3d_gather(x, T, H, W, C, k, pad):
+    kt, kh, kw = k
+    To, Ho, Wo = (T + 2 * pad - kt) // kt + 1, (H + 2 * pad - kh) // kh + 1, (W + 2 * pad - kw) // kw + 1
+    out = torch.empty((To * Ho * Wo, kt * kh * kw * C), device=x.device, dtype=torch.bfloat16)
+    _lib.call("ufv_conv3d_gather", x.data_ptr(), out.data_ptr(), T, H, W, C, kt, kh, kw, pad, _stream())
+    return out, (To, Ho, Wo)
+
+
+def gather_rows(src, src_idx, dst, dst_idx, n=None):
+    D = src.shape[-1]
+    if n is None:
+        n = (src_idx if src_idx is not None else dst_idx).numel() if (src_idx is not None or dst_idx is not None) else src.shape[0]
+    if n == 0:
+        return dst
+    _lib.call("ufv_gather_rows", src.data_ptr(), _DT[src.dtype], src.stride(0), _ptr(src_idx), dst.data_ptr(), _DT[dst.dtype],
+              dst.stride(0), _ptr(dst_idx), n, D, _stream())
+    return dst
+
+
+def mask_pool(feat, mask, frame_of):
+    """feat [n, P, C] (bf16/f32), mask f32 [q, P], frame_of int32 [q] -> f32 [q, C]"""
+    q, P = mask.shape
+    C = feat.shape[-1]
+    out = torch.empty((q, C), device=feat.device, dtype=torch.float32)
+    _lib.call("ufv_mask_pool", feat.data_ptr(), _DT[feat.dtype], mask.data_ptr(), frame_of.data_ptr(), out.data_ptr(), q, P, C,
+              _stream())
+    return out
+
+
+def argmax(logits, out=None):
+    _chk(logits, torch.float32, "logits")
+    if out is None:
+        out = torch.empty((1,), device=logits.device, dtype=torch.int64)
+    _lib.call("ufv_argmax", logits.data_ptr(), logits.numel(), out.data_ptr(), _stream())
+    return out
+
+
+def preprocess_u8(frames, mean, std):
+    """frames u8 [T,H,W,3] on device -> bf16 [T,3,H,W]"""
+    import ctypes as C
+    T, H, W, _ = frames.shape
+    out = torch.empty((T, 3, H, W), device=frames.device, dtype=torch.bfloat16)
+    m = (C.c_float * 3)(*mean); s = (C.c_float * 3)(*std)
+    _lib.call("ufv_preprocess_u8", frames.data_ptr(), out.data_ptr(), T, H, W, C.cast(m, C.c_void_p), C.cast(s, C.c_void_p),
+              _stream())
+    return out
+
+
+def convert(src, dtype):
+    _chk(src, name="src")
+    if src.dtype == dtype:
+        return src
+    src = src.contiguous()
+    out = torch.empty(src.shape, device=src.device, dtype=dtype)
+    _lib.call("ufv_convert", src.data_ptr(), _DT[src.dtype], out.data_ptr(), _DT[dtype], src.numel(), _stream())
+    return out
