@@ -1,0 +1,155 @@
+"""CPU: product host logic (no GPU compute) against the golden vectors captured from the reference,
+and the C-ABI library's exported symbols against include/ufv.h."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t, ROOT
+from ufvideo_amd import mm_utils as MU
+from ufvideo_amd import constants as C
+from ufvideo_amd.model.videorefer_arch import build_splice_plan, splice_labels_and_mask, splice_index_arrays
+
+
+class CharTok:
+    bos_token_id = None
+
+    def __call__(self, text, add_special_tokens=False):
+        r = type("R", (), {})()
+        r.input_ids = [ord(c) for c in text]
+        return r
+
+
+def test_constants_match_reference_values():
+    assert (C.IGNORE_INDEX, C.IMAGE_TOKEN_INDEX, C.VIDEO_TOKEN_INDEX, C.AUDIO_TOKEN_INDEX) == (-100, -200, -201, -202)
+    assert C.NUM_FRAMES == C.MAX_FRAMES == 32 and C.TEMPORAL_TOKEN_FORMAT.format(7) == "<TEMP-007>"
+    assert C.MODAL_INDEX_MAP == {"<image>": -200, "<video>": -201, "<audio>": -202}
+
+
+def test_frame_sample_kats():
+    a, _ = load_golden("int_helpers")
+    n = 0
+    for k in a:
+        if k.startswith("uniform_"):
+            _, d, nf = k.split("_")
+            assert (MU.frame_sample(int(d), "uniform", int(nf)) == a[k]).all(), k; n += 1
+        elif k.startswith("fps_"):
+            _, d, fps = k.split("_")
+            assert (MU.frame_sample(int(d), "fps", fps=float(fps)) == a[k]).all(), k; n += 1
+    assert n >= 10
+    with pytest.raises(ImportError):
+        MU.frame_sample(10, mode="bogus")
+    with pytest.raises(AssertionError):
+        MU.frame_sample(10, mode="uniform")
+
+
+def test_tokenizer_multimodal_token_and_names():
+    a, _ = load_golden("int_helpers")
+    tok = CharTok()
+    for i in range(5):
+        mt, prompt = bytes(a[f"tokprompt_{i}"]).decode().split("|", 1)
+        assert MU.tokenizer_multimodal_token(prompt, tok, mt, return_tensors="pt").tolist() == a[f"tok_{i}"].tolist()
+    assert MU.tokenizer_multimodal_token("plain", tok, "") == a["tok_plain"].tolist()
+    with pytest.raises(ValueError):
+        MU.tokenizer_multimodal_token("x", tok, "<video>", return_tensors="np")
+    assert MU.get_model_name_from_path("/a/b/UFVideo-7B/") == bytes(a["model_name_a"]).decode()
+    assert MU.get_model_name_from_path("/a/run1/checkpoint-300") == bytes(a["model_name_b"]).decode()
+
+
+def test_expand2square_and_sam_preprocess():
+    from PIL import Image
+    a, _ = load_golden("int_helpers")
+    for i in range(3):
+        out = np.array(MU.expand2square(Image.fromarray(a[f"sq_in_{i}"]), (127, 127, 127)))
+        assert np.array_equal(out, a[f"sq_out_{i}"])
+    assert torch.allclose(MU.sam_preprocess(t(a["sam_pre_in"])), t(a["sam_pre_out"]))
+
+
+def test_image_processor_matches_hf_siglip_processor():
+    a, _ = load_golden("processor")
+    p = MU.UfvImageProcessor(size=56)
+    for i in range(3):
+        o = p.preprocess([a[f"in_{i}"]])["pixel_values"][0]
+        assert (o - t(a[f"out_{i}"])).abs().max() < 1e-6
+    assert p.image_mean == [0.5, 0.5, 0.5] and p.size == {"height": 56, "width": 56}
+
+
+def test_process_video_tail_pads_and_truncates():
+    p = MU.UfvImageProcessor(size=28)
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, (20, 30, 3), dtype=np.uint8) for _ in range(3)]
+    video, fd, h, w, fl = MU.process_video(frames, p, aspect_ratio="square", num_frames=5, frame_idx=[0, 2])
+    assert video.shape == (5, 3, 28, 28) and fd.shape == (2, 3, 28, 28) and (h, w) == (20, 30) and len(fl) == 2
+    assert torch.all(video[3:] == -1.0)                       # black padding frames -> (0/255-0.5)/0.5
+    video2, fd2, *_ = MU.process_video(np.stack(frames), p, aspect_ratio="pad", num_frames=2)
+    assert video2.shape == (2, 3, 28, 28) and fd2 is None
+    with pytest.raises(ValueError):
+        MU.process_video(3.14, p)
+
+
+def test_keywords_stopping_criteria():
+    class Tok(CharTok):
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return ["".join(chr(int(i)) for i in row) for row in ids]
+    crit = MU.KeywordsStoppingCriteria(["</s>"], Tok(), torch.zeros(1, 3, dtype=torch.long))
+    ids = lambda s: torch.tensor([[ord(c) for c in s]])
+    assert crit(ids("abc </s>")) and not crit(ids("abc </s"))
+
+
+CASES = {"vid_region": True, "vid_only": False, "img_only": False, "batch_pad": False, "vid_noregion_frame": True,
+         "vid_trailing": False}
+
+
+def test_splice_plan_bit_exact_against_reference():
+    """mark / attention mask / labels / embedding row placement for every golden splice case."""
+    a, w = load_golden("model_tiny")
+    R = int(a["region_id"])
+    table = w["model.embed_tokens.weight"]
+    mm = t(a["mm_features"])[0]                          # features of `video`
+    for name, have_frame in CASES.items():
+        ids = t(a[f"sp_{name}_ids"]); am = t(a[f"sp_{name}_am_in"])
+        n_mm = int((ids < 0).sum())
+        nums = {"vid_region": [1, 1], "vid_noregion_frame": [1]}.get(name, [])
+        mm_lens = [mm.shape[0]] * n_mm
+        plan = build_splice_plan(ids.tolist(), mm_lens, nums, R, have_frame)
+        for lab in (False, True):
+            labels = None
+            if lab:
+                labels = ids.clone(); labels[labels < 0] = -100
+            tag = f"{name}_{'lab' if lab else 'nolab'}"
+            nl, nm = splice_labels_and_mask(plan, ids, am, labels, mm_lens)
+            assert np.array_equal(np.array(plan.mark), a[f"sp_{tag}_mark"]), tag
+            assert np.array_equal(nm.numpy(), a[f"sp_{tag}_am"]), tag
+            if lab:
+                assert np.array_equal(nl.numpy(), a[f"sp_{tag}_labels"]), tag
+        # text rows land where the reference put embed_tokens rows
+        (ts, td), (ms, md), (rs, rd) = splice_index_arrays(plan, ids.tolist(), mm_lens, [k * mm.shape[0] for k in range(n_mm)])
+        emb = t(a[f"sp_{name}_nolab_emb"]); S = emb.shape[1]
+        flat = emb.reshape(-1, emb.shape[-1])
+        assert torch.equal(flat[td], table[ts]), name
+        assert len(ts) + len(ms) + len(rs) == sum(plan.lengths)
+        if name in ("vid_only", "vid_trailing", "vid_region"):
+            assert torch.allclose(flat[md], mm[ms], atol=1e-6), name
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from ufvideo_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "ufv.h")).read()
+    declared = set(re.findall(r"\b(ufv_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ufv.h but not exported"
+    assert set(_lib.SIGNATURES) | {"ufv_last_error", "ufv_abi_version"} == declared
+    assert _lib.load().ufv_abi_version() == 1
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    from ufvideo_amd import ops, _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.UfvError):
+        ops.gemm(torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(4, 8, dtype=torch.bfloat16))

@@ -1,0 +1,251 @@
+"""GPU: the product path (ufvideo_amd.* -> C ABI -> HIP kernels) against
+  (a) golden vectors produced by the REFERENCE on a tiny model (tests/golden/model_tiny.npz ...), and
+  (b) the CPU oracle at the full UFVideo-7B layer dimensions with seeded weights.
+Tolerance: BASELINE.json asks 1e-3 'bf16 tolerance'; one bf16 rounding alone is 2^-9 = 2e-3 relative,
+so the operational bar is max|d|/max|ref| per stage: <= 2e-2 for bf16-operand stages
+chained over several layers, <= 1e-2 for single ops; index/mask/token tensors are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, t, rel_err  # noqa: E402
+from oracle import ref_cpu as O  # noqa: E402
+from ufvideo_amd import ops  # noqa: E402
+from ufvideo_amd.model import (VideoReferQwen2Config, VideoReferQwen2ForCausalLM, UFVideoForCausalLM, SiglipVisionTower,  # noqa: E402
+                               CLIPVisionTower, STCConnectorV35, STCConnector, SpatialConv, MaskExtractor, build_vision_projector)
+
+DEV = "cuda"
+TINY_VIT = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=56, patch_size=14)
+TINY_LLM = dict(vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=512, rope_theta=10000.0, rms_norm_eps=1e-6)
+
+
+class Args:
+    mm_vision_select_layer = -2
+    mm_vision_select_feature = "patch"
+
+
+class Tok:
+    region_id = 290
+
+    def convert_tokens_to_ids(self, toks):
+        return [self.region_id for _ in toks]
+
+
+def tiny_model():
+    a, w = load_golden("model_tiny")
+    cfg = VideoReferQwen2Config(**TINY_LLM, mm_vision_tower="siglip", mm_vision_select_layer=-2, mm_vision_select_feature="patch",
+                                mm_projector_type="spatial_conv", mm_hidden_size=64, mm_region_encoder_type="pooling",
+                                image_aspect_ratio="square", train_mask_decoder=False, sam_pretrained=None, sam_out_dim=256,
+                                num_frames=4, seg_token_id=299, vision_config=TINY_VIT)
+    m = VideoReferQwen2ForCausalLM(cfg)
+    m.get_vision_tower().load_model()
+    m.load_state_dict(w)
+    m = m.to(DEV)
+    for mod in m.modules():
+        mod.tokenizer = Tok()
+    return m, a, w
+
+
+def test_alias_and_loud_failure():
+    assert UFVideoForCausalLM is VideoReferQwen2ForCausalLM
+    from ufvideo_amd import _lib
+    with pytest.raises(_lib.UfvError):
+        ops.gemm(torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(4, 8, dtype=torch.bfloat16))   # CPU tensors: no fallback
+
+
+def test_siglip_tiny_tower_vs_reference_golden():
+    a, w = load_golden("siglip_tiny")
+    tower = SiglipVisionTower("siglip", Args(), vision_config=TINY_VIT)
+    tower.load_hf_state_dict(w)
+    tower = tower.to(DEV)
+    x = t(a["x"]).to(DEV)
+    y = tower(x)
+    assert y.dtype == x.dtype and y.shape == (3, 16, 64)
+    assert rel_err(y.cpu(), t(a["y"])) < 2e-2
+    # half input like the reference's mm_infer (.half().cuda())
+    y16 = tower(x.half())
+    assert y16.dtype == torch.float16 and rel_err(y16.float().cpu(), t(a["y"])) < 2e-2
+    assert tower.num_patches == 16 and tower.hidden_size == 64 and tower.image_size == 56 and tower.num_patches_per_side == 4
+
+
+def test_clip_tiny_tower_vs_reference_golden():
+    a, w = load_golden("clip_tiny")
+    cfg = dict(TINY_VIT, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    tower = CLIPVisionTower("clip-tiny", Args(), vision_config=cfg)
+    tower.load_hf_state_dict(w)
+    tower = tower.to(DEV)
+    y = tower(t(a["x"]).to(DEV))
+    assert y.shape == (3, 16, 64) and rel_err(y.cpu(), t(a["y"])) < 2e-2
+
+
+def _sub(w, pre):
+    return {k[len(pre):]: v for k, v in w.items() if k.startswith(pre)}
+
+
+def test_projector_variants_vs_reference_golden():
+    a, w = load_golden("projector")
+
+    class Cfg:
+        mm_hidden_size = 32
+        hidden_size = 32
+    for cls, pre, xk, yk in ((SpatialConv, "sc.", "sc_x", "sc_y"), (STCConnector, "stc.", "stc_x", "stc_y")):
+        m = cls(Cfg(), depth=0) if cls is not SpatialConv else cls(Cfg())
+        m.load_state_dict(_sub(w, pre)); m = m.to(DEV)
+        y = m(t(a[xk]).to(DEV))
+        assert y.shape == a[yk].shape and rel_err(y.cpu(), t(a[yk])) < 1e-2, pre
+    m = STCConnectorV35(Cfg(), depth=0); m.load_state_dict(_sub(w, "v35.")); m = m.to(DEV)
+    y = m(t(a["v35_x"]).to(DEV))
+    assert y.shape == a["v35_y"].shape and rel_err(y.cpu(), t(a["v35_y"])) < 1e-2
+
+    class Cfg3:
+        mm_hidden_size = 16
+        hidden_size = 32
+        mm_projector_type = "mlp2x_gelu"
+    m = build_vision_projector(Cfg3()); m.load_state_dict(_sub(w, "mlp.")); m = m.to(DEV)
+    assert rel_err(m(t(a["mlp_x"]).to(DEV)).cpu(), t(a["mlp_y"])) < 1e-2
+
+
+def test_stc_v35_regstage_vs_oracle():
+    class Cfg:
+        mm_hidden_size = 64
+        hidden_size = 128
+    sd = O.make_stc_weights(64, 128, seed=5)
+    m = STCConnectorV35(Cfg()); m.load_state_dict(sd); m = m.to(DEV)
+    x = torch.randn(1, 4, 36, 64, generator=torch.Generator().manual_seed(6))
+    y = m(x.to(DEV))
+    ref = O.stc_connector(sd, x)
+    assert y.shape == ref.shape == (1, 2 * 3 * 3, 128)
+    assert rel_err(y.cpu(), ref) < 2e-2
+
+
+def test_region_encoder_vs_reference_golden():
+    a, w = load_golden("region")
+
+    class Cfg:
+        mm_hidden_size = 16
+        hidden_size = 24
+    ann = [[[0], [1, 2]], [[1, 2, 3, 4, 5, 6]]]
+    for aspect, key in (("square", "y"), ("pad", "y_pad")):
+        m = MaskExtractor(aspect, Cfg()); m.load_state_dict(w); m = m.to(DEV)
+        y, nums = m(t(a["feats"]).to(DEV), [t(a["mask0"]).to(DEV), t(a["mask1"]).to(DEV)], None, ann, None)
+        assert nums == a["nums"].tolist()                         # bit-exact bookkeeping
+        assert rel_err(y.cpu(), t(a[key])) < 1e-2
+
+
+def test_end_to_end_tiny_vs_reference_golden():
+    """encode -> region -> splice -> LLM forward -> greedy generate, all through the HIP path, against what the
+    REFERENCE's own VideoReferQwen2ForCausalLM produced for the same weights and inputs."""
+    m, a, w = tiny_model()
+    video, frame, mask = t(a["video"]).to(DEV), t(a["frame"]).to(DEV), t(a["mask"]).to(DEV)
+    mmf = m.encode_images_or_videos([(video, "video")])
+    assert rel_err(mmf.cpu(), t(a["mm_features"])) < 2e-2
+    assert rel_err(m.get_vision_tower()(video).cpu(), t(a["tower_out"])) < 2e-2
+    # --- splice, every golden case
+    cases = {
+        "vid_region": dict(images=[(video, "video")], frame=[frame], masks=[mask], ann=[[[0], [1]]], fn=[2]),
+        "vid_only": dict(images=[(video, "video")], frame=None, masks=None, ann=None, fn=None),
+        "img_only": dict(images=[(video[:1], "image")], frame=None, masks=None, ann=None, fn=None),
+        "batch_pad": dict(images=[(video, "video"), (video.flip(0), "video")], frame=None, masks=None, ann=None, fn=None),
+        "vid_noregion_frame": dict(images=[(video, "video")], frame=[frame[:1]], masks=[mask[:1]], ann=[[[0]]], fn=[1]),
+        "vid_trailing": dict(images=[(video, "video")], frame=None, masks=None, ann=None, fn=None),
+    }
+    for name, c in cases.items():
+        ids = t(a[f"sp_{name}_ids"]).to(DEV); am = t(a[f"sp_{name}_am_in"]).to(DEV)
+        for lab in (False, True):
+            labels = None
+            if lab:
+                labels = ids.clone(); labels[labels < 0] = -100
+            r = m.prepare_inputs_labels_for_multimodal(ids, am, None, labels, c["images"], c["masks"], c["frame"], c["ann"], c["fn"])
+            none, am2, past, emb, lab2, mark = r
+            tag = f"{name}_{'lab' if lab else 'nolab'}"
+            assert none is None and past is None
+            assert np.array_equal(np.array(mark), a[f"sp_{tag}_mark"]), tag
+            assert np.array_equal(am2.cpu().numpy(), a[f"sp_{tag}_am"]), tag
+            if lab:
+                assert np.array_equal(lab2.cpu().numpy(), a[f"sp_{tag}_labels"]), tag
+            assert emb.shape == a[f"sp_{tag}_emb"].shape and rel_err(emb.cpu(), t(a[f"sp_{tag}_emb"])) < 2e-2, tag
+    # --- forward(inference=True)
+    c = cases["vid_region"]
+    ids = t(a["sp_vid_region_ids"]).to(DEV); am = torch.ones_like(ids)
+    sam = torch.zeros(1, 4, 3, 8, 8, device=DEV)
+    fo = m(input_ids=ids, attention_mask=am, images=c["images"], masks=c["masks"], frame=c["frame"], ann_indices=c["ann"],
+           frame_nums=c["fn"], images_sam=sam, inference=True, output_hidden_states=True, use_cache=True, return_dict=True)
+    assert fo.logits.shape == a["fw_logits"].shape
+    assert rel_err(fo.logits.cpu(), t(a["fw_logits"])) < 3e-2
+    assert rel_err(fo.hidden_states[-1].cpu(), t(a["fw_hidden_last"])) < 3e-2
+    assert rel_err(fo.hidden_states[1].cpu(), t(a["fw_hidden_1"])) < 3e-2
+    assert len(fo.hidden_states) == 3 and fo.past_key_values.get_seq_length() == fo.logits.shape[1]
+    k0 = fo.past_key_values.buf[0][: fo.logits.shape[1], :32].float().view(-1, 2, 16).permute(1, 0, 2)[None]
+    assert rel_err(k0.cpu(), t(a["fw_k0"])) < 3e-2
+    assert rel_err(m.get_model().text_hidden_fcs[0](fo.hidden_states[-1]).cpu(), t(a["fcs_out"])) < 3e-2
+    with pytest.raises(NotImplementedError):
+        m(input_ids=ids, attention_mask=am, images=c["images"], images_sam=sam, inference=False)
+    # --- generate: greedy tokens bit-exact vs the reference
+    gen = m.generate(ids, attention_mask=am, images=c["images"], masks=c["masks"], frame=c["frame"], ann_indices=c["ann"],
+                     frame_nums=c["fn"], images_sam=sam, offset=[0, 1], masks_list=None, label_list=torch.zeros(56, 56),
+                     do_sample=False, max_new_tokens=8, use_cache=True, pad_token_id=0, eos_token_id=298)
+    assert gen["output"].cpu().tolist() == a["gen_tokens"].tolist() and gen["pred_masks"] == []
+    ids2 = t(a["sp_vid_only_ids"]).to(DEV)
+    gen2 = m.generate(ids2, attention_mask=torch.ones_like(ids2), images=cases["vid_only"]["images"], images_sam=sam,
+                      offset=[0, 1], label_list=torch.zeros(56, 56), do_sample=False, max_new_tokens=6, pad_token_id=0,
+                      eos_token_id=298)
+    assert gen2["output"].cpu().tolist() == a["gen2_tokens"].tolist()
+    with pytest.raises(NotImplementedError):
+        m.generate(ids, attention_mask=am, images=c["images"], images_sam=sam, offset=[0, 1], inputs_embeds=torch.zeros(1))
+    with pytest.raises(AssertionError):
+        m.generate(ids, attention_mask=am, images=c["images"], images_sam=sam, offset=[0, 1, 2])
+
+
+def test_generate_eos_and_decode_consistency():
+    """greedy decode through the KV cache == recomputing the full prefix; EOS stops and is included."""
+    m, a, w = tiny_model()
+    emb = t(a["sp_vid_only_nolab_emb"]).to(DEV); am = t(a["sp_vid_only_nolab_am"]).to(DEV)
+    out = m._greedy(emb, am, max_new_tokens=5, eos_token_id=None)
+    toks = out["sequences"][0].tolist()
+    table = w["model.embed_tokens.weight"].to(DEV)
+    full = torch.cat([emb[0], table[toks[:-1]]], 0)[None]
+    logits, *_ = m._decode_batch(full, None, None, False, 0)
+    assert torch.argmax(logits[0, -1]).item() == toks[-1]
+    eos = toks[1]
+    out2 = m._greedy(emb, am, max_new_tokens=5, eos_token_id=eos)
+    assert out2["sequences"][0].tolist() == toks[: toks.index(eos) + 1]        # EOS stops generation and is included
+    o_toks, _ = O.greedy_generate(w, TINY_LLM, emb.cpu(), am.cpu(), 5)
+    assert o_toks[0].tolist() == toks
+
+
+# ---------------------------------------------------------------------------------------------------------
+# full UFVideo-7B layer dimensions vs the CPU oracle (seeded synthetic weights)
+# ---------------------------------------------------------------------------------------------------------
+def test_fulldim_siglip_layers_vs_oracle():
+    cfg = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=3, num_attention_heads=16, image_size=336, patch_size=14)
+    sd = O.make_siglip_weights(cfg, seed=11)
+    tower = SiglipVisionTower("siglip", Args(), vision_config=cfg)
+    tower.load_hf_state_dict(sd); tower = tower.to(DEV)
+    x = torch.randn(2, 3, 336, 336, generator=torch.Generator().manual_seed(13))
+    y = tower(x.to(DEV))                       # hidden_states[-2] = 2 layers
+    ref = O.siglip_tower(sd, cfg, x)
+    assert y.shape == ref.shape == (2, 576, 1152)
+    assert rel_err(y.cpu(), ref) < 2e-2
+
+
+def test_fulldim_qwen2_layer_vs_oracle():
+    cfg = dict(vocab_size=512, hidden_size=3584, intermediate_size=18944, num_hidden_layers=1, num_attention_heads=28,
+               num_key_value_heads=4, rope_theta=1e6, rms_norm_eps=1e-6)
+    sd = O.make_qwen2_weights(cfg, seed=12)
+    mc = VideoReferQwen2Config(**cfg, train_mask_decoder=True)
+    m = VideoReferQwen2ForCausalLM(mc)
+    m.load_state_dict(sd, strict=True); m = m.to(DEV)
+    S = 300
+    x = torch.randn(1, S, 3584, generator=torch.Generator().manual_seed(14)) * 0.5
+    logits, cache, hs, normed = m._decode_batch(x.to(DEV), None, None, True, 0)
+    ref = O.qwen2_forward(sd, cfg, x)
+    assert rel_err(normed.cpu(), ref["hidden_states"][-1][0]) < 2e-2
+    assert rel_err(logits.cpu(), ref["logits"]) < 2e-2
+    # decode one more token through the cache
+    x1 = torch.randn(1, 1, 3584, generator=torch.Generator().manual_seed(15)) * 0.5
+    l1, *_ = m._decode_batch(x1.to(DEV), None, cache, False, 1)
+    ref1 = O.qwen2_forward(sd, cfg, x1, past=ref["past"])
+    assert rel_err(l1.cpu(), ref1["logits"]) < 2e-2

@@ -1,0 +1,94 @@
+"""Parameter containers: nested nn.Modules whose state_dict keys equal the reference's
+(HF / timm names), plus helpers to turn them into kernel-ready (packed) device buffers."""
+import torch
+import torch.nn as nn
+
+
+class Holder(nn.Module):
+    """Empty named container; parameters are attached with `put`."""
+
+    def put(self, dotted, tensor):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, Holder())
+            mod = getattr(mod, p)
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+    def get(self, dotted):
+        mod = self
+        for p in dotted.split("."):
+            mod = getattr(mod, p)
+        return mod
+
+
+def init_tensor(shape, kind, gen, std, device, dtype):
+    """kind: 'w' normal(0,std), 'one' ones, 'zero' zeros."""
+    if kind == "one":
+        return torch.ones(shape, device=device, dtype=dtype)
+    if kind == "zero":
+        return torch.zeros(shape, device=device, dtype=dtype)
+    t = torch.empty(shape, device=device, dtype=torch.float32).normal_(0.0, std, generator=gen)
+    return t.to(dtype)
+
+
+class PackedModule(Holder):
+    """Base for modules that keep reference-named parameters and derive packed kernel buffers from
+    them on first use.  Moving / casting / loading the module invalidates the packed buffers."""
+
+    def __init__(self):
+        super().__init__()
+        self._packed = None
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    def invalidate(self):
+        self._packed = None
+        for m in self.modules():
+            if isinstance(m, PackedModule):
+                m._packed = None
+
+    def packed(self):
+        if self._packed is None:
+            with torch.no_grad():
+                self._packed = self._pack()
+        return self._packed
+
+    def _pack(self):
+        raise NotImplementedError
+
+
+def bf(t):
+    return t.detach().to(torch.bfloat16).contiguous()
+
+
+def f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def pad_rows(w, n):
+    """zero-pad dim 0 of a 2-D/1-D tensor to n"""
+    if w.shape[0] == n:
+        return w
+    out = torch.zeros((n,) + tuple(w.shape[1:]), device=w.device, dtype=w.dtype)
+    out[: w.shape[0]] = w
+    return out
+
+
+def pad_cols(w, k):
+    if w.shape[1] == k:
+        return w
+    out = torch.zeros((w.shape[0], k), device=w.device, dtype=w.dtype)
+    out[:, : w.shape[1]] = w
+    return out
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m

@@ -1,0 +1,400 @@
+"""`VideoReferQwen2ForCausalLM` (alias `UFVideoForCausalLM`) with the reference's call surface
+(ufvideo/model/videorefer_qwen2.py:113-528): forward(inference=True) and generate().
+
+The decoder arithmetic (HF Qwen2: RMSNorm, q/k/v + bias, RoPE rotate-half, causal GQA attention,
+o_proj, SwiGLU MLP, final norm, lm_head) runs as HIP kernels through the C ABI:
+  RMSNorm -> fused-QKV MFMA GEMM(+bias) -> RoPE + KV-cache store -> flash attention (hd 128, GQA)
+  -> o_proj GEMM (+fp32 residual) -> RMSNorm -> gate/up GEMM with SwiGLU epilogue -> down GEMM (+residual).
+The residual stream is fp32; GEMM operands bf16; accumulation fp32.  Decode (1 token) takes the
+weight-streaming GEMV kernel and the generic attention kernel.  The greedy loop, stopping criteria
+and [SEG] bookkeeping are host code mirroring HF GenerationMixin as the reference drives it.
+"""
+import json
+import os
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ._params import Holder, PackedModule, init_tensor, bf, f32, pad_rows, round_up
+from .videorefer_arch import VideoReferMetaModel, VideoReferMetaForCausalLM
+
+
+class ModelOutput(dict):
+    """dict with attribute access (stands in for HF CausalLMOutputWithPast / GenerateOutput)."""
+    __getattr__ = dict.get
+    __setattr__ = dict.__setitem__
+
+
+class VideoReferQwen2Config:
+    model_type = "videorefer_qwen2"
+
+    def __init__(self, vocab_size=151936, hidden_size=4096, intermediate_size=22016, num_hidden_layers=32,
+                 num_attention_heads=32, num_key_value_heads=32, max_position_embeddings=32768, rms_norm_eps=1e-6,
+                 rope_theta=10000.0, eos_token_id=None, pad_token_id=None, bos_token_id=None, **kwargs):
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.intermediate_size = intermediate_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.num_key_value_heads = num_key_value_heads
+        self.max_position_embeddings = max_position_embeddings
+        self.rms_norm_eps = rms_norm_eps
+        self.rope_theta = rope_theta
+        self.eos_token_id = eos_token_id
+        self.pad_token_id = pad_token_id
+        self.bos_token_id = bos_token_id
+        self.model_type = "videorefer_qwen2"
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def head_dim(self):
+        return self.__dict__.get("_head_dim") or self.hidden_size // self.num_attention_heads
+
+    @head_dim.setter
+    def head_dim(self, v):
+        self.__dict__["_head_dim"] = v
+
+    @classmethod
+    def from_pretrained(cls, path, **kw):
+        with open(os.path.join(path, "config.json")) as f:
+            d = json.load(f)
+        if isinstance(d.get("rope_parameters"), dict):
+            d.setdefault("rope_theta", d["rope_parameters"].get("rope_theta", 10000.0))
+        d.update(kw)
+        return cls(**d)
+
+    def to_dict(self):
+        return {k: v for k, v in self.__dict__.items() if not k.startswith("_")}
+
+
+QWEN2_7B = dict(vocab_size=151748, hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
+                num_key_value_heads=4, max_position_embeddings=32768, rms_norm_eps=1e-6, rope_theta=1e6)
+
+
+class KVCache:
+    """Per layer one bf16 buffer [max_len, 2*Hkv*hd] (row = [k heads | v heads] of one token)."""
+
+    def __init__(self, n_layers, max_len, width, device):
+        self.buf = [torch.empty((max_len, width), device=device, dtype=torch.bfloat16) for _ in range(n_layers)]
+        self.max_len, self.len = max_len, 0
+
+    def get_seq_length(self, layer_idx=0):
+        return self.len
+
+    def __len__(self):
+        return len(self.buf)
+
+    def ensure(self, need):
+        if need <= self.max_len:
+            return
+        new_len = max(need, self.max_len * 2)
+        for i, b in enumerate(self.buf):
+            nb = torch.empty((new_len, b.shape[1]), device=b.device, dtype=b.dtype)
+            nb[: self.len] = b[: self.len]
+            self.buf[i] = nb
+        self.max_len = new_len
+
+
+def pack_swiglu(gate, up):
+    """interleave rows in blocks of 16: [g0..15 | u0..15 | g16..31 | u16..31 ...] (see csrc/gemm.hip)"""
+    I, K = gate.shape
+    assert I % 16 == 0
+    return torch.stack([gate.view(I // 16, 16, K), up.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
+
+
+class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
+    """Decoder body: embed_tokens, layers.N.*, norm (HF Qwen2Model names) + the multimodal modules."""
+
+    def __init__(self, config, device=None, dtype=torch.bfloat16, seed=0, std=0.02):
+        PackedModule.__init__(self)
+        self.config = config
+        gen = torch.Generator(device=device if device is not None else "cpu").manual_seed(seed + 2)
+        mk = lambda shape, kind="w": init_tensor(shape, kind, gen, std, device, dtype)
+        D, I, V = config.hidden_size, config.intermediate_size, config.vocab_size
+        H, KV, hd = config.num_attention_heads, config.num_key_value_heads, config.head_dim
+        self.put("embed_tokens.weight", mk((V, D)))
+        for i in range(config.num_hidden_layers):
+            p = f"layers.{i}."
+            self.put(p + "self_attn.q_proj.weight", mk((H * hd, D))); self.put(p + "self_attn.q_proj.bias", mk((H * hd,), "zero"))
+            self.put(p + "self_attn.k_proj.weight", mk((KV * hd, D))); self.put(p + "self_attn.k_proj.bias", mk((KV * hd,), "zero"))
+            self.put(p + "self_attn.v_proj.weight", mk((KV * hd, D))); self.put(p + "self_attn.v_proj.bias", mk((KV * hd,), "zero"))
+            self.put(p + "self_attn.o_proj.weight", mk((D, H * hd)))
+            self.put(p + "mlp.gate_proj.weight", mk((I, D)))
+            self.put(p + "mlp.up_proj.weight", mk((I, D)))
+            self.put(p + "mlp.down_proj.weight", mk((D, I)))
+            self.put(p + "input_layernorm.weight", mk((D,), "one"))
+            self.put(p + "post_attention_layernorm.weight", mk((D,), "one"))
+        self.put("norm.weight", mk((D,), "one"))
+        self.init_mm_modules(config, device=device, dtype=dtype, seed=seed)
+
+    def embed_table(self):
+        return self.packed()["embed"]
+
+    def _pack(self):
+        cfg = self.config
+        hd = cfg.head_dim
+        pk = {"embed": bf(self.embed_tokens.weight), "norm": f32(self.norm.weight),
+              "inv_freq": (1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.norm.weight.device)}
+        layers = []
+        for i in range(cfg.num_hidden_layers):
+            L = self.layers.get(str(i))
+            a, m = L.self_attn, L.mlp
+            layers.append(dict(
+                ln1=f32(L.input_layernorm.weight), ln2=f32(L.post_attention_layernorm.weight),
+                wqkv=bf(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
+                bqkv=f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)),
+                wo=bf(a.o_proj.weight), wgu=pack_swiglu(bf(m.gate_proj.weight), bf(m.up_proj.weight)), wd=bf(m.down_proj.weight)))
+        pk["layers"] = layers
+        return pk
+
+    # ---- decoder over one sequence: x fp32 [S, D] (modified in place), positions pos0..pos0+S-1 -----------
+    def run_layers(self, x, cache: KVCache, pos0, collect_hidden=None):
+        cfg, pk = self.config, self.packed()
+        S, D = x.shape
+        H, KV, hd, eps = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.rms_norm_eps
+        cache.ensure(pos0 + S)
+        dev = x.device
+        h = torch.empty((S, D), device=dev, dtype=torch.bfloat16)
+        qkv = torch.empty((S, (H + 2 * KV) * hd), device=dev, dtype=torch.bfloat16)
+        o = torch.empty((S, H * hd), device=dev, dtype=torch.bfloat16)
+        act = torch.empty((S, cfg.intermediate_size), device=dev, dtype=torch.bfloat16)
+        Sk = pos0 + S
+        for li, L in enumerate(pk["layers"]):
+            kvb = cache.buf[li]
+            ops.rmsnorm(x, L["ln1"], eps, out=h)
+            ops.gemm(h, L["wqkv"], bias=L["bqkv"], out=qkv)
+            ops.rope_kv(qkv, S, H, KV, hd, pk["inv_freq"], pos0, kvb)
+            ops.attention(qkv, kvb, kvb[:, KV * hd:], 1, H, KV, S, Sk, hd, (0, qkv.stride(0)), (0, kvb.stride(0)),
+                          (0, kvb.stride(0)), causal=True, q_pos0=pos0, out=o)
+            ops.gemm(o, L["wo"], resid=x, out=x)
+            ops.rmsnorm(x, L["ln2"], eps, out=h)
+            ops.gemm(h, L["wgu"], swiglu=True, out=act)
+            ops.gemm(act, L["wd"], resid=x, out=x)
+            if collect_hidden is not None and li < len(pk["layers"]) - 1:
+                collect_hidden.append(x.clone())
+        cache.len = Sk
+        return x
+
+    def final_norm(self, x, out_dtype=torch.float32):
+        return ops.rmsnorm(x, self.packed()["norm"], self.config.rms_norm_eps, out_dtype=out_dtype)
+
+
+class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
+    config_class = VideoReferQwen2Config
+
+    def __init__(self, config, device=None, dtype=torch.bfloat16, seed=0, std=0.02, **kwargs):
+        PackedModule.__init__(self)
+        self.config = config
+        self.model = VideoReferQwen2Model(config, device=device, dtype=dtype, seed=seed, std=std)
+        self.vocab_size = config.vocab_size
+        gen = torch.Generator(device=device if device is not None else "cpu").manual_seed(seed + 5)
+        self.put("lm_head.weight", init_tensor((config.vocab_size, config.hidden_size), "w", gen, std, device, dtype))
+        self.generation_config = ModelOutput(eos_token_id=config.eos_token_id, pad_token_id=config.pad_token_id)
+        self.requires_grad_(False)
+
+    # ---- plumbing expected by the reference's callers ------------------------------------------------
+    def get_model(self):
+        return self.model
+
+    @property
+    def device(self):
+        return self.lm_head.weight.device
+
+    @property
+    def dtype(self):
+        return self.lm_head.weight.dtype
+
+    def _pack(self):
+        V = self.config.vocab_size
+        return {"lm_head": bf(self.lm_head.weight), "lm_head_pad": None, "V": V}
+
+    def _lm_head_padded(self):
+        pk = self.packed()
+        if pk["lm_head_pad"] is None:
+            pk["lm_head_pad"] = pad_rows(pk["lm_head"], round_up(pk["V"], 128))
+        return pk["lm_head_pad"]
+
+    def resize_token_embeddings(self, n):
+        D = self.config.hidden_size
+        for holder, name in ((self.model.embed_tokens, "weight"), (self.lm_head, "weight")):
+            old = getattr(holder, name)
+            new = torch.zeros((n, D), device=old.device, dtype=old.dtype)
+            k = min(n, old.shape[0])
+            new[:k] = old[:k]
+            if n > k:          # HF initialises new rows to the mean embedding
+                new[k:] = old.float().mean(0, keepdim=True).to(old.dtype)
+            setattr(holder, name, nn.Parameter(new, requires_grad=False))
+        self.config.vocab_size = self.vocab_size = n
+        self.invalidate(); self.model.invalidate()
+
+    def load_state_dict(self, sd, strict=True):
+        """Accepts the reference's keys; vision-tower keys may come with or without `vision_model.`;
+        SAM2 (`model.mask_encoder.*`) and unused tower-head keys are ignored."""
+        own = self.state_dict()
+        new = {}
+        vt = "model.vision_tower.vision_tower."
+        for k, v in sd.items():
+            if k.startswith("model.mask_encoder."):
+                continue
+            if k.startswith(vt) and not k.startswith(vt + "vision_model."):
+                k = vt + "vision_model." + k[len(vt):]
+            if k in own:
+                new[k] = v
+        missing = [k for k in own if k not in new]
+        if strict and missing:
+            raise KeyError(f"missing weights: {missing[:6]}{' ...' if len(missing) > 6 else ''}")
+        res = nn.Module.load_state_dict(self, new, strict=False)
+        for m in self.modules():
+            if isinstance(m, PackedModule):
+                m._packed = None
+        return res
+
+    # ---- decoder over a batch ----------------------------------------------------------------------------
+    def _decode_batch(self, inputs_embeds, attention_mask, past_key_values, output_hidden_states, logits_to_keep):
+        """inputs_embeds [B,S,D] fp32 (device).  Right padding is trimmed per sample via attention_mask."""
+        cfg = self.config
+        B, S, D = inputs_embeds.shape
+        width = 2 * cfg.num_key_value_heads * cfg.head_dim
+        if B != 1:
+            raise NotImplementedError("the accelerated decoder runs batch 1 (the reference's inference batch, SURVEY F8)")
+        pos0 = 0 if past_key_values is None else past_key_values.get_seq_length()
+        valid = S
+        if attention_mask is not None:
+            am = attention_mask[0].to(torch.bool)
+            total = int(am.sum().item())
+            if not bool(am[:total].all()):
+                raise NotImplementedError("only right-padded attention masks are supported")
+            valid = total - pos0
+        cache = past_key_values or KVCache(cfg.num_hidden_layers, max(valid + 64, 256), width, inputs_embeds.device)
+        x = inputs_embeds[0, :valid].to(torch.float32).contiguous().clone()
+        hs = [x.clone()] if output_hidden_states else None
+        x = self.model.run_layers(x, cache, pos0, collect_hidden=hs)
+        normed = self.model.final_norm(x)                                    # fp32 [valid, D]
+        if output_hidden_states:
+            hs.append(normed)
+        pk = self.packed()
+        V = pk["V"]
+        if logits_to_keep == 1:
+            last = ops.convert(normed[-1:].contiguous(), torch.bfloat16)
+            logits = ops.gemm(last, pk["lm_head"], out_dtype=torch.float32).view(1, 1, V)
+        else:
+            hb = ops.convert(normed, torch.bfloat16)
+            logits = ops.gemm(hb, self._lm_head_padded(), out_dtype=torch.float32)[:, :V].unsqueeze(0)
+        return logits, cache, hs, normed
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None, masks=None,
+                frame=None, ann_indices=None, frame_nums=None, return_dict=None, images_sam=None, offset=None,
+                masks_list=None, label_list=None, inference=False, video_file=None, **kwargs):
+        # the reference dereferences images_sam unconditionally (videorefer_qwen2.py:155)
+        batch_size, num_frames_sam = images_sam.shape[:2]
+        if not inference:
+            raise NotImplementedError("training forward (CE + mask BCE/DICE, SURVEY §8 row a12) is not built yet")
+        if inputs_embeds is None:
+            (input_ids, attention_mask, past_key_values, inputs_embeds, labels, _) = self.prepare_inputs_labels_for_multimodal(
+                input_ids, attention_mask, past_key_values, labels, images, masks, frame, ann_indices, frame_nums, video_file)
+        if inputs_embeds is None:            # text-only / decode step: embed the ids
+            flat = input_ids.reshape(-1).to(self.device)
+            e = torch.empty((flat.numel(), self.config.hidden_size), device=self.device, dtype=torch.float32)
+            ops.gather_rows(self.model.embed_table(), flat, e, None)
+            inputs_embeds = e.view(*input_ids.shape, -1)
+        logits, cache, hs, _ = self._decode_batch(inputs_embeds, attention_mask, past_key_values, bool(output_hidden_states),
+                                                 kwargs.get("logits_to_keep", 0))
+        return ModelOutput(loss=None, logits=logits, past_key_values=cache if use_cache is not False else None,
+                           hidden_states=tuple(h.unsqueeze(0) for h in hs) if hs is not None else None, attentions=None)
+
+    __call__ = forward
+
+    # ---- generate ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, inputs=None, images=None, masks=None, frame=None, ann_indices=None, frame_nums=None, images_sam=None,
+                 offset=None, masks_list=None, label_list=None, inference=True, **kwargs):
+        position_ids = kwargs.pop("position_ids", None)
+        attention_mask = kwargs.pop("attention_mask", None)
+        if "inputs_embeds" in kwargs:
+            raise NotImplementedError("`inputs_embeds` is not supported")
+        batch_size, num_frames_sam = images_sam.shape[:2]
+        assert batch_size == len(offset) - 1
+        seg_id = getattr(self.config, "seg_token_id", None)
+        seg_token_mask = (inputs == seg_id) if seg_id is not None else torch.zeros_like(inputs, dtype=torch.bool)
+        seg_token_mask = torch.cat([seg_token_mask[:, 1:], torch.zeros_like(seg_token_mask[:, :1])], dim=1)
+        past_key_values = None
+        if images is not None:
+            (input_ids, attention_mask, past_key_values, inputs_embeds, _, mark_mm_token_index) = \
+                self.prepare_inputs_labels_for_multimodal(input_ids=inputs, attention_mask=attention_mask, past_key_values=None,
+                                                          labels=None, images=images, masks=masks, frame=frame,
+                                                          ann_indices=ann_indices, frame_nums=frame_nums)
+        else:
+            raise NotImplementedError("generate() without images is not used by the reference's callers")
+        if bool(seg_token_mask.any()):
+            # segmentation branch (ref :461-518) needs the SAM2 head
+            raise NotImplementedError("[SEG] in the prompt needs the SAM2 mask decoder (SURVEY §8 row a11), not built yet")
+        out = self._greedy(inputs_embeds, attention_mask, **kwargs)
+        toks = out["sequences"]
+        if seg_id is not None and toks.numel() > 1 and bool((toks[0, 1:] == seg_id).any()):
+            raise NotImplementedError("a generated [SEG] needs the SAM2 mask decoder (SURVEY §8 row a11), not built yet")
+        self.last_generate = out
+        return {"output": toks, "pred_masks": []}
+
+    def _greedy(self, inputs_embeds, attention_mask, max_new_tokens=20, eos_token_id=None, stopping_criteria=None,
+                do_sample=False, pad_token_id=None, use_cache=True, **unused):
+        """HF greedy search from inputs_embeds (batch 1): returns only the new tokens; EOS included."""
+        if do_sample:
+            raise NotImplementedError("sampling is outside the accelerated path; the reference's default is greedy")
+        eos = eos_token_id if eos_token_id is not None else self.generation_config.eos_token_id
+        eos = set(eos) if isinstance(eos, (list, tuple)) else ({eos} if eos is not None else set())
+        dev = inputs_embeds.device
+        S = inputs_embeds.shape[1] if attention_mask is None else int(attention_mask[0].sum().item())
+        width = 2 * self.config.num_key_value_heads * self.config.head_dim
+        cache = KVCache(self.config.num_hidden_layers, S + max_new_tokens + 8, width, dev)
+        logits, cache, _, normed = self._decode_batch(inputs_embeds, attention_mask, cache, False, 1)
+        hidden_steps = [normed]
+        tokens = []
+        tok_buf = torch.empty((1,), device=dev, dtype=torch.int64)
+        table = self.model.embed_table()
+        D = self.config.hidden_size
+        for step in range(max_new_tokens):
+            ops.argmax(logits.view(-1), out=tok_buf)
+            t = int(tok_buf.item())
+            tokens.append(t)
+            done = t in eos
+            if not done and stopping_criteria:
+                ids = torch.tensor([tokens], dtype=torch.long, device=dev)
+                done = any(bool(c(ids, None)) for c in stopping_criteria)
+            if done or step == max_new_tokens - 1:
+                break
+            e = torch.empty((1, D), device=dev, dtype=torch.float32)
+            ops.gather_rows(table, tok_buf, e, None)
+            logits, cache, _, normed = self._decode_batch(e.view(1, 1, D), None, cache, False, 1)
+            hidden_steps.append(normed)
+        return {"sequences": torch.tensor([tokens], dtype=torch.long, device=dev), "hidden_last": hidden_steps, "cache": cache}
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
+        images = kwargs.pop("images", None)
+        _inputs = {"input_ids": input_ids, "past_key_values": past_key_values, "inputs_embeds": inputs_embeds, **kwargs}
+        if images is not None:
+            _inputs["images"] = images
+        return _inputs
+
+    @classmethod
+    def from_pretrained(cls, path, config=None, device=None, dtype=torch.bfloat16, **kw):
+        """Loads config.json + *.safetensors from a local directory (no network)."""
+        config = config or VideoReferQwen2Config.from_pretrained(path)
+        model = cls(config, device=device, dtype=dtype)
+        from safetensors.torch import load_file
+        sd = {}
+        for f in sorted(os.listdir(path)):
+            if f.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(path, f)))
+        if not sd:
+            raise FileNotFoundError(f"no *.safetensors under {path}")
+        if getattr(model.get_vision_tower(), "is_loaded", True) is False:
+            model.get_vision_tower().load_model(device=device, dtype=dtype)
+        model.load_state_dict(sd, strict=False)
+        return model
+
+
+UFVideoForCausalLM = VideoReferQwen2ForCausalLM        # the name BASELINE.json uses
