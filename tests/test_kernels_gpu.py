@@ -30,7 +30,8 @@ ACTS = {None: lambda x: x, "gelu_tanh": lambda x: torch.nn.functional.gelu(x, ap
         "quick_gelu": lambda x: x * torch.sigmoid(1.702 * x), "sigmoid": torch.sigmoid}
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 256, 192), (1000, 384, 1152), (129, 128, 640), (2399, 512, 448)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 256, 192), (1000, 384, 1152), (129, 128, 640), (2399, 512, 448),
+                                   (2399, 3584, 128), (2399, 4608, 64), (2500, 3584, 192)])   # last three: 160/192-row tiles
 @pytest.mark.parametrize("kernel", [ops.GEMM_FAST, ops.GEMM_GENERIC])
 def test_gemm_plain(M, N, K, kernel):
     a, w = bf(g(M, K, seed=1)), bf(g(N, K, seed=2, scale=0.05))

@@ -18,9 +18,14 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
-constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // 64 KiB -> 2 blocks / CU
+constexpr int BN = 128, BK = 64;
+// block tile = (32*MT) x 128 x 64, MT in {4,5,6}: 128/160/192 rows.  The row count is picked per launch so
+// that the tile count fills the 512 resident blocks (2 per CU) with as little tail as possible.
+template <int MT> struct Tile {
+    static constexpr int BM = 32 * MT;
+    static constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 / 36 / 40 KiB
+    static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // 64 / 72 / 80 KiB -> 2 blocks / CU
+};
 
 struct Epi {
     const float* bias;     // [N] or null
@@ -56,9 +61,10 @@ __device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, float v0,
     }
 }
 
-template <bool OUT_F32, bool SWIGLU>
+template <bool OUT_F32, bool SWIGLU, int MT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e,
                                                        int M, int N, int K, int lda, int ldw) {
+    constexpr int BM = Tile<MT>::BM, STAGE_BYTES = Tile<MT>::STAGE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,32 +88,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A
     // ---- LDS-DMA source addresses. One wave-instruction fills 8 rows x 128 B; lane l writes
     //      LDS chunk (l&7) of row (l>>3) and therefore must FETCH chunk (l&7)^(row&7).
     const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
-    const bf16* a_src[4];
+    const bf16* a_src[MT];
     const bf16* b_src[4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = (wave * MT + i) * 8 + lrow;
+        a_src[i] = A + (size_t)min(m0 + r, M - 1) * lda + lchunk * 8;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + lrow;
-        a_src[i] = A + (size_t)min(m0 + r, M - 1) * lda + lchunk * 8;
         b_src[i] = W + (size_t)(n0 + r) * ldw + lchunk * 8;
     }
     auto stage = [&](int s, int k0) {
-        char* base = smem + s * STAGE_BYTES + wave * 4096;
+        char* abase = smem + s * STAGE_BYTES + wave * (MT * 1024);
+        char* bbase = smem + s * STAGE_BYTES + BM * BK * 2 + wave * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + k0), LDS_PTR(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + k0), LDS_PTR(base + BM * BK * 2 + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < MT; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + k0), LDS_PTR(abase + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + k0), LDS_PTR(bbase + i * 1024), 16, 0, 0);
     };
 
-    f32x4 acc[4][4];   // [nt][mt]
+    f32x4 acc[4][MT];   // [nt][mt]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets: row (lane&15) of a 16-row tile, 16-byte chunk kk*4+(lane>>4), XOR (row&7)
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
-    const int a_off = (wm * 64 + frow) * 128, b_off = BM * BK * 2 + (wn * 64 + frow) * 128;
+    const int a_off = (wm * (BM / 2) + frow) * 128, b_off = BM * BK * 2 + (wn * 64 + frow) * 128;
 
     const int nk = K / BK;
     stage(0, 0);
@@ -119,26 +131,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int coff = ((kk * 4 + fq) ^ fx) << 4;
-            bf16x8 af[4], bf[4];
+            bf16x8 af[MT], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 16 * 128 + coff);
-                bf[i] = *reinterpret_cast<const bf16x8*>(sb + b_off + i * 16 * 128 + coff);
-            }
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_off + i * 16 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bf[i] = *reinterpret_cast<const bf16x8*>(sb + b_off + i * 16 * 128 + coff);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // ---- epilogue: acc[nt][mt][j] = C[m0+wm*64+mt*16+(lane&15)][n0+wn*64+nt*16+(lane>>4)*4+j]
+    // ---- epilogue: acc[nt][mt][j] = C[m0+wm*(BM/2)+mt*16+(lane&15)][n0+wn*64+nt*16+(lane>>4)*4+j]
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + frow;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * (BM / 2) + mt * 16 + frow;
         if (m >= M) continue;
         if (SWIGLU) {
             // weight rows were packed [16 gate | 16 up] alternating: nt even = gate, nt odd = up
@@ -254,18 +265,41 @@ __global__ __launch_bounds__(256) void gemv_nt(const bf16* __restrict__ A, const
     }
 }
 
-template <bool F, bool S>
-int launch_fast(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
+template <bool F, bool S, int MT>
+int launch_fast_mt(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<F, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            SMEM_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<F, S, MT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Tile<MT>::SMEM_BYTES);
         attr_set = true;
     }
-    const int tiles = cdiv(M, BM) * (N / BN);
-    hipLaunchKernelGGL((gemm_nt_128<F, S>), dim3(tiles), dim3(256), SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
+    const int tiles = cdiv(M, Tile<MT>::BM) * (N / BN);
+    hipLaunchKernelGGL((gemm_nt_128<F, S, MT>), dim3(tiles), dim3(256), Tile<MT>::SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
+}
+
+// rows per block tile: minimise (rounds of 512 resident blocks) x (rows per tile)
+inline int pick_mt(int M, int N) {
+    int best = 4;
+    long best_cost = -1;
+    for (int mt = 4; mt <= 6; ++mt) {
+        const long tiles = (long)cdiv(M, 32 * mt) * (N / BN);
+        const long cost = ((tiles + 511) / 512) * 32 * mt;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mt; }
+    }
+    return best;
+}
+
+template <bool F, bool S>
+int launch_fast(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
+    if (!S) {
+        switch (pick_mt(M, N)) {
+            case 5: return launch_fast_mt<F, S, 5>(A, W, e, M, N, K, lda, ldw, st);
+            case 6: return launch_fast_mt<F, S, 6>(A, W, e, M, N, K, lda, ldw, st);
+        }
+    }
+    return launch_fast_mt<F, S, 4>(A, W, e, M, N, K, lda, ldw, st);
 }
 
 template <bool F, bool S>
