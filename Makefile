@@ -2,14 +2,14 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := ufvideo_amd/csrc
-SRCS  := $(CSRC)/gemm.hip $(CSRC)/attn.hip $(CSRC)/ops.hip
+SRCS  := $(CSRC)/gemm.hip $(CSRC)/gemm256.hip $(CSRC)/attn.hip $(CSRC)/ops.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := ufvideo_amd/libufv_hip.so
 FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -Iinclude
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/ufv.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_epi.h include/ufv.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

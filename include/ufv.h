@@ -40,6 +40,7 @@ extern "C" {
 #define UFV_GEMM_FAST 1    /* 128x128x64 MFMA tile kernel; errors out if the shape does not qualify */
 #define UFV_GEMM_GENERIC 2 /* one-thread-per-output kernel, any shape */
 #define UFV_GEMM_GEMV 3    /* weight-streaming kernel for M <= 64 */
+#define UFV_GEMM_FAST256 4 /* 256x256x64 8-wave ping-pong MFMA kernel (large M) */
 
 /* dtype ids for inputs that may arrive in several formats */
 #define UFV_DT_BF16 0

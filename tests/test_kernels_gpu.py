@@ -268,3 +268,31 @@ def test_mask_pool_and_preprocess():
     o = ops.preprocess_u8(fr, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
     ref = ((fr.float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
     assert rel(o, ref) < 8e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 384, 192), (1000, 768, 1152), (2399, 1024, 448),
+                                   (300, 128, 64), (4096, 3456, 256)])
+def test_gemm256_bitwise_equals_128_kernel(M, N, K):
+    """The 256x256 ping-pong kernel accumulates k in the same order with the same MFMA as the 128-wide kernel, so
+    any difference is a staging race / wrong tile: compare bit for bit, several launches."""
+    a, w = bf(g(M, K, seed=51)), bf(g(N, K, seed=52, scale=0.05))
+    bias, resid = g(N, seed=53), g(M, N, seed=54)
+    ref = ops.gemm(a, w, bias=bias, act="gelu_tanh", resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST)
+    for _ in range(5):
+        out = ops.gemm(a, w, bias=bias, act="gelu_tanh", resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST256)
+        assert torch.equal(out, ref)
+    refb = ops.gemm(a, w, kernel=ops.GEMM_FAST)
+    assert torch.equal(ops.gemm(a, w, kernel=ops.GEMM_FAST256), refb)
+    assert rel(refb, a.float() @ w.float().t()) < 8e-3
+
+
+def test_gemm256_swiglu_and_layout():
+    M, I, K = 700, 512, 256
+    a = bf(g(M, K, seed=55))
+    gate, up = bf(g(I, K, seed=56, scale=0.1)), bf(g(I, K, seed=57, scale=0.1))
+    wp = pack_swiglu(gate, up)
+    ref = ops.gemm(a, wp, swiglu=True, out_dtype=torch.float32, kernel=ops.GEMM_FAST)
+    assert torch.equal(ops.gemm(a, wp, swiglu=True, out_dtype=torch.float32, kernel=ops.GEMM_FAST256), ref)
+    eye = bf(torch.eye(256, 256, device=DEV))
+    w = bf((torch.arange(256, device=DEV)[:, None] * 3 + torch.arange(256, device=DEV)[None, :] * 0.5) % 17)
+    assert torch.equal(ops.gemm(eye, w, out_dtype=torch.float32, kernel=ops.GEMM_FAST256), w.float().t().contiguous())

@@ -15,6 +15,7 @@
 // (region encoder, SE gates, tiny test models).
 #include "common.h"
 #include "../../include/ufv.h"
+#include "gemm_epi.h"
 
 namespace {
 
@@ -26,40 +27,6 @@ template <int MT> struct Tile {
     static constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 / 36 / 40 KiB
     static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // 64 / 72 / 80 KiB -> 2 blocks / CU
 };
-
-struct Epi {
-    const float* bias;     // [N] or null
-    const float* resid;    // fp32 [M, ldr] or null (added after activation)
-    void* out;             // bf16 or fp32
-    int ldr, ldc, act;
-    int resid_rows;        // >0: residual row = m % resid_rows (broadcast table, e.g. position embeddings)
-};
-
-template <bool OUT_F32, bool SWIGLU>
-__device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, float v0, float v1, float v2, float v3) {
-    // n is a multiple of 4; the four values are columns n..n+3 of row m
-    float v[4] = {v0, v1, v2, v3};
-    if (e.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += b[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], e.act);
-    if (e.resid) {
-        const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
-        const f32x4 r = *reinterpret_cast<const f32x4*>(e.resid + (size_t)mr * e.ldr + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += r[j];
-    }
-    if (OUT_F32) {
-        f32x4 o = {v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (size_t)m * e.ldc + n) = o;
-    } else {
-        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(e.out) + (size_t)m * e.ldc + n) = o;
-    }
-}
 
 template <bool OUT_F32, bool SWIGLU, int MT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e,
@@ -162,13 +129,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A
                     const float gte = acc[2 * p][mt][j], up = acc[2 * p + 1][mt][j];
                     v[j] = gte / (1.0f + __expf(-gte)) * up;
                 }
-                epi_store4<OUT_F32, true>(e, m, n, v[0], v[1], v[2], v[3]);
+                epi_store4<OUT_F32>(e, m, n, v[0], v[1], v[2], v[3]);
             }
         } else {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-                epi_store4<OUT_F32, false>(e, m, n, acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+                epi_store4<OUT_F32>(e, m, n, acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
             }
         }
     }
@@ -291,6 +258,14 @@ inline int pick_mt(int M, int N) {
     return best;
 }
 
+// 256x256 ping-pong kernel (1 block / CU) vs 128-wide tiles (2 blocks / CU).  Measured on MI355X (tools/
+// bench_kernels.py): it wins where there are many whole rounds of tiles and M is small enough that the A panel
+// stays L2-resident (gate/up: 1137 vs 973 TF/s); elsewhere the 128-wide kernel is still ahead.
+inline bool prefer256(int M, int N, int K) {
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    return t256 >= 1280 && M <= 4096 && K >= 2048;
+}
+
 template <bool F, bool S>
 int launch_fast(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
     if (!S) {
@@ -323,6 +298,13 @@ int launch_any(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, 
         UFV_CHECK_LAUNCH();
         return UFV_OK;
     }
+    const bool big_ok = fast_ok && M >= 256;
+    if (force == UFV_GEMM_FAST256 && !big_ok) {
+        ufv_set_error("ufv_gemm: 256-tile kernel needs M>=256, N%%128==0, K%%64==0 (M=%d N=%d K=%d)", M, N, K);
+        return UFV_EUNSUPPORTED;
+    }
+    if (force == UFV_GEMM_FAST256 || (force == UFV_GEMM_AUTO && big_ok && prefer256(M, N, K)))
+        return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, st);
     if ((force == UFV_GEMM_AUTO && fast_ok && M > 64) || force == UFV_GEMM_FAST)
         return launch_fast<F, S>(A, W, e, M, N, K, lda, ldw, st);
     if (S && N % 32 != 0) {

@@ -1,0 +1,191 @@
+// bf16 GEMM, 256x256x64 block tile, 8 waves, ping-pong schedule ("8 phases" per two K-tiles) for gfx950.
+//
+//   C[M,N] = epilogue(A[M,K] * W[N,K]^T), same epilogues and operand conventions as gemm.hip.
+//
+// Structure (one block per CU, 128 KiB LDS = 2 K-tile buffers x {A0,A1,B0,B1} half-tiles of 128 rows x 64 k):
+//  * 8 waves = 2 (rows) x 4 (cols); wave (wr,wc) owns 64 rows of EACH A half and 32 columns of EACH B half, so a
+//    wave's 128x64 output splits into 4 quadrants (A half x B half) and every LDS half-tile is read in few phases:
+//        phase 0: read A0,B0 -> quadrant (0,0)      phase 1: read B1 -> (0,1)
+//        phase 2: read A1    -> quadrant (1,1)      phase 3: read B0 -> (1,0)
+//  * each phase = [ds_read fragments; issue ONE half-tile of LDS-DMA prefetch] s_barrier [16 MFMA] s_barrier.
+//    Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while its
+//    partner is in its load segment.
+//  * prefetch runs through the whole loop with a COUNTED s_waitcnt vmcnt(4) once per K-tile (never 0 inside the
+//    loop): staging order A1[t+1], B0[t+1], A0[t+2], B1[t+2] in phases 0..3 of K-tile t.
+//      WAR: a half-tile buffer is re-staged exactly 2 phases after its last ds_read (safe for the lagging group);
+//      RAW: the wait in phase 3 retires everything up to B0[t+1]; first read is in the next phase, two barriers later.
+//  * operands: 128-byte rows, 16-byte chunks XOR-swizzled by (row & 7) through the LDS-DMA SOURCE address.
+#include "common.h"
+#include "../../include/ufv.h"
+#include "gemm_epi.h"
+
+namespace {
+
+constexpr int SMEM256 = 131072;
+
+template <bool OUT_F32, bool SWIGLU>
+__global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e, int M,
+                                                       int N, int K, int lda, int ldw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
+    const int nwg = tiles_m * tiles_n;
+    int id;
+    {
+        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 8;
+    const int gsz = GM * tiles_n, g = id / gsz, first_m = g * GM;
+    const int gm = min(tiles_m - first_m, GM);
+    const int tm = first_m + (id % gsz) % gm, tn = (id % gsz) / gm;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int nk = K / 64;
+
+    // ---- LDS-DMA sources: half-tile `which` (0=A0 1=A1 2=B0 3=B1), two 8-row pieces per wave
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+    const bf16* src[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = h * 128 + (wave * 2 + i) * 8 + lrow;
+            src[h][i] = A + (size_t)min(m0 + r, M - 1) * lda + lchunk * 8;
+            src[2 + h][i] = W + (size_t)min(n0 + r, N - 1) * ldw + lchunk * 8;
+        }
+    auto stage = [&](int d, int which, int kt) {
+        if (kt < nk) {
+            char* dst = smem + d * 65536 + which * 16384 + wave * 2048;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][0] + kt * 64), LDS_PTR(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][1] + kt * 64), LDS_PTR(dst + 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][8];   // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    const int a_row_off = (wr * 64 + frow) * 128;     // + (mt&3)*2048 inside the half
+    const int b_row_off = (wc * 32 + frow) * 128;     // + (nt&1)*2048 inside the half
+    const int coff0 = ((0 + fq) ^ fx) << 4, coff1 = ((4 + fq) ^ fx) << 4;
+
+    bf16x8 afr[4][2], bfr[2][2];
+    auto read_a = [&](const char* half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            afr[i][0] = *reinterpret_cast<const bf16x8*>(half + a_row_off + i * 2048 + coff0);
+            afr[i][1] = *reinterpret_cast<const bf16x8*>(half + a_row_off + i * 2048 + coff1);
+        }
+    };
+    auto read_b = [&](const char* half) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bfr[i][0] = *reinterpret_cast<const bf16x8*>(half + b_row_off + i * 2048 + coff0);
+            bfr[i][1] = *reinterpret_cast<const bf16x8*>(half + b_row_off + i * 2048 + coff1);
+        }
+    };
+#define UFV_SYNC_THEN_MMA(NTB, MTB)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
+        _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                     \
+            _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                 \
+                acc[NTB + n_][MTB + m_] =                                                                    \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n_][kk], afr[m_][kk], acc[NTB + n_][MTB + m_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_barrier();
+
+    // ---- prologue: K-tile 0 complete, A0/B1 of K-tile 1 in flight
+    stage(0, 0, 0); stage(0, 2, 0); stage(0, 3, 0); stage(0, 1, 0);
+    stage(1, 0, 1); stage(1, 3, 1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // waves 4-7 run one barrier behind
+
+    for (int t = 0; t < nk; ++t) {
+        const int d = t & 1;
+        const char* buf = smem + d * 65536;
+        // phase 0: A0, B0 -> quadrant (0,0); prefetch A1[t+1]
+        read_b(buf + 32768);
+        read_a(buf);
+        stage(d ^ 1, 1, t + 1);
+        UFV_SYNC_THEN_MMA(0, 0)
+        // phase 1: B1 -> quadrant (0,1); prefetch B0[t+1]
+        read_b(buf + 49152);
+        stage(d ^ 1, 2, t + 1);
+        UFV_SYNC_THEN_MMA(2, 0)
+        // phase 2: A1 -> quadrant (1,1); prefetch A0[t+2]
+        read_a(buf + 16384);
+        stage(d, 0, t + 2);
+        UFV_SYNC_THEN_MMA(2, 4)
+        // phase 3: B0 -> quadrant (1,0); prefetch B1[t+2]; retire K-tile t+1
+        read_b(buf + 32768);
+        stage(d, 3, t + 2);
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UFV_SYNC_THEN_MMA(0, 4)
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the stagger barrier
+#undef UFV_SYNC_THEN_MMA
+
+    // ---- epilogue: acc[nt][mt][j] = C[m0 + (mt>>2)*128 + wr*64 + (mt&3)*16 + frow][n0 + (nt>>1)*128 + wc*32 + (nt&1)*16 + fq*4 + j]
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = m0 + (mt >> 2) * 128 + wr * 64 + (mt & 3) * 16 + frow;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            const int nb = n0 + nh * 128;
+            if (nb >= N) continue;
+            if (SWIGLU) {
+                const int n = ((nb + wc * 32) >> 1) + fq * 4;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gte = acc[2 * nh][mt][j], up = acc[2 * nh + 1][mt][j];
+                    v[j] = gte / (1.0f + __expf(-gte)) * up;
+                }
+                epi_store4<OUT_F32>(e, m, n, v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int nt = 2 * nh + q, n = nb + wc * 32 + q * 16 + fq * 4;
+                    epi_store4<OUT_F32>(e, m, n, acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+template <bool F, bool S>
+static int launch256_t(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SMEM256);
+        attr_set = true;
+    }
+    const int tiles = cdiv(M, 256) * cdiv(N, 256);
+    hipLaunchKernelGGL((gemm_nt_256<F, S>), dim3(tiles), dim3(512), SMEM256, st, A, W, e, M, N, K, lda, ldw);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+int ufv_launch_gemm256(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
+                       bool swiglu, hipStream_t st) {
+    if (out_f32) return swiglu ? launch256_t<true, true>(A, W, e, M, N, K, lda, ldw, st) : launch256_t<true, false>(A, W, e, M, N, K, lda, ldw, st);
+    return swiglu ? launch256_t<false, true>(A, W, e, M, N, K, lda, ldw, st) : launch256_t<false, false>(A, W, e, M, N, K, lda, ldw, st);
+}
