@@ -12,7 +12,7 @@ HBM) -> ViT -> projector -> embedding splice -> prefill through the last-positio
 collective), weak scaling.
 
 `roofline` is reported for the dominant kernel of the step, the gate/up projection GEMM with the SwiGLU
-epilogue (`gemm_nt_128<bf16 out, swiglu>`: M=2399, N=37888, K=3584, 28 launches per step, ~25 % of
+epilogue (`gemm_nt_256<bf16 out, swiglu>`, csrc/gemm256.hip: M=2399, N=37888, K=3584, 28 launches per step, ~25 % of
 the step): algorithmic FLOPs 2*M*N*K per launch / its mean launch duration measured with HIP events
 on the launch stream inside the timed region.  `cpu_baseline` times the CPU oracle (oracle/ref_cpu.py,
 fp32 torch eager, a port of the reference's CPU path) on a bounded sample and extrapolates by FLOPs.
@@ -206,7 +206,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("gemm_nt_128_swiglu_hbm_bytes_per_launch")
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_128<bf16,swiglu> gate/up M=%d N=%d K=%d" % (ks["M"], ks["N"], ks["K"]),
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256<bf16,swiglu> gate/up M=%d N=%d K=%d" % (ks["M"], ks["N"], ks["K"]),
                                "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                                "traffic": traffic, "launch_ms": round(ks["mean_ms"], 4), "launches": ks["launches"]}
         step_tf = sum(FLOPS.values()) * args.frames / 32 / (dt / args.steps) / 1e12
