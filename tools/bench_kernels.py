@@ -32,9 +32,10 @@ for name, (M, N, K, sw) in shapes.items():
     out = torch.empty(M, N // 2 if sw else N, device=dev, dtype=torch.bfloat16)
     ms = timeit(lambda: ops.gemm(a, w, out=out, swiglu=bool(sw), kernel=ops.GEMM_FAST))
     ms2 = timeit(lambda: ops.gemm(a, w, out=out, swiglu=bool(sw), kernel=ops.GEMM_FAST256))
+    ms3 = timeit(lambda: ops.gemm(a, w, out=out, swiglu=bool(sw)))
     tf = 2.0 * M * N * K / ms / 1e9; tf2 = 2.0 * M * N * K / ms2 / 1e9
     res[name] = dict(ms=round(ms, 4), tflops=round(tf, 1), ms256=round(ms2, 4), tflops256=round(tf2, 1))
-    print(f"{name:10s} M={M:6d} N={N:6d} K={K:6d}  k128 {ms:8.3f} ms {tf:7.1f} TF/s | k256 {ms2:8.3f} ms {tf2:7.1f} TF/s", flush=True)
+    print(f"{name:10s} M={M:6d} N={N:6d} K={K:6d}  k128 {ms:8.3f} ms {tf:7.1f} TF/s | k256 {ms2:8.3f} ms {tf2:7.1f} TF/s | auto {ms3:8.3f} ms", flush=True)
 
 if not only or "attn" in only:
     # ViT attention: 32 frames x 16 heads x 576 x 72

@@ -57,6 +57,32 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     }
 }
 
+template <int ACT>
+__device__ __forceinline__ float act_apply_t(float x) {
+    if (ACT == ACT_GELU_TANH) {
+        const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+        return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
+    }
+    if (ACT == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+    if (ACT == ACT_SILU) return x / (1.0f + __expf(-x));
+    if (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
+    if (ACT == ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
+    if (ACT == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-x));
+    return x;
+}
+
+// run BODY with a compile-time activation id `ACT_` chosen from the runtime value (wave-uniform branch)
+#define UFV_ACT_SWITCH(act_, ...)                                        \
+    switch (act_) {                                                      \
+        case ACT_GELU_TANH: { constexpr int ACT_ = ACT_GELU_TANH; __VA_ARGS__; } break;   \
+        case ACT_GELU_ERF: { constexpr int ACT_ = ACT_GELU_ERF; __VA_ARGS__; } break;     \
+        case ACT_SILU: { constexpr int ACT_ = ACT_SILU; __VA_ARGS__; } break;             \
+        case ACT_RELU: { constexpr int ACT_ = ACT_RELU; __VA_ARGS__; } break;             \
+        case ACT_QUICK_GELU: { constexpr int ACT_ = ACT_QUICK_GELU; __VA_ARGS__; } break; \
+        case ACT_SIGMOID: { constexpr int ACT_ = ACT_SIGMOID; __VA_ARGS__; } break;       \
+        default: { constexpr int ACT_ = ACT_NONE; __VA_ARGS__; } break;                   \
+    }
+
 // ---- wave-level reductions (wave = 64 lanes) --------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

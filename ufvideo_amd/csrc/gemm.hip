@@ -28,6 +28,38 @@ template <int MT> struct Tile {
     static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;       // 64 / 72 / 80 KiB -> 2 blocks / CU
 };
 
+// acc[nt][mt][j] = C[m0+wm*(BM/2)+mt*16+(lane&15)][n0+wn*64+nt*16+(lane>>4)*4+j]
+template <bool OUT_F32, bool SWIGLU, int MT, int ACT>
+__device__ __forceinline__ void epilogue128(const f32x4 (&acc)[4][MT], const Epi& e, int M, int m0, int n0, int wm, int wn,
+                                            int frow, int fq) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * (16 * MT) + mt * 16 + frow;
+        if (m < M) {
+            if (SWIGLU) {
+                // weight rows were packed [16 gate | 16 up] alternating: nt even = gate, nt odd = up
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int n = ((n0 + wn * 64) >> 1) + p * 16 + fq * 4;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gte = acc[2 * p][mt][j], up = acc[2 * p + 1][mt][j];
+                        v[j] = gte / (1.0f + __expf(-gte)) * up;
+                    }
+                    epi_store4<OUT_F32, ACT_NONE>(e, m, n, v[0], v[1], v[2], v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+                    epi_store4<OUT_F32, ACT>(e, m, n, acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+                }
+            }
+        }
+    }
+}
+
 template <bool OUT_F32, bool SWIGLU, int MT>
 __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e,
                                                        int M, int N, int K, int lda, int ldw) {
@@ -113,32 +145,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A
         __syncthreads();
     }
 
-    // ---- epilogue: acc[nt][mt][j] = C[m0+wm*(BM/2)+mt*16+(lane&15)][n0+wn*64+nt*16+(lane>>4)*4+j]
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wm * (BM / 2) + mt * 16 + frow;
-        if (m >= M) continue;
-        if (SWIGLU) {
-            // weight rows were packed [16 gate | 16 up] alternating: nt even = gate, nt odd = up
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int n = ((n0 + wn * 64) >> 1) + p * 16 + fq * 4;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float gte = acc[2 * p][mt][j], up = acc[2 * p + 1][mt][j];
-                    v[j] = gte / (1.0f + __expf(-gte)) * up;
-                }
-                epi_store4<OUT_F32>(e, m, n, v[0], v[1], v[2], v[3]);
-            }
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-                epi_store4<OUT_F32>(e, m, n, acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
-            }
-        }
-    }
+    // ---- epilogue (activation resolved once so the body stays unrolled)
+    UFV_ACT_SWITCH(e.act, (epilogue128<OUT_F32, SWIGLU, MT, ACT_>(acc, e, M, m0, n0, wm, wn, frow, fq)))
 }
 
 // ---- generic kernel: one thread per output element -------------------------------------------
@@ -258,12 +266,21 @@ inline int pick_mt(int M, int N) {
     return best;
 }
 
-// 256x256 ping-pong kernel (1 block / CU) vs 128-wide tiles (2 blocks / CU).  Measured on MI355X (tools/
-// bench_kernels.py): it wins where there are many whole rounds of tiles and M is small enough that the A panel
-// stays L2-resident (gate/up: 1137 vs 973 TF/s); elsewhere the 128-wide kernel is still ahead.
+// Kernel choice.  Both kernels are modelled as (rounds of resident tiles) x (outputs per CU per round) / (relative
+// rate at this K depth); rates fitted to tools/bench_kernels.py on MI355X: the persistent 256x256 ping-pong
+// kernel sustains ~1.2-1.3x the 128-wide kernel and hides its prologue/epilogue across tile seams, the 128-wide
+// one has the finer tile grid (2 blocks/CU, 128/160/192-row tiles) for small outputs.
 inline bool prefer256(int M, int N, int K) {
+    const double nk = K / 64.0;
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    return t256 >= 1280 && M <= 4096 && K >= 2048;
+    const double c256 = (double)((t256 + 255) / 256) * 65536.0 / (1.30 / (1.0 + 5.0 / nk));
+    double c128 = 1e30;
+    for (int mt = 4; mt <= 6; ++mt) {
+        const long t = (long)cdiv(M, 32 * mt) * (N / BN);
+        const double c = (double)((t + 511) / 512) * (32.0 * mt * 128 * 2) / (1.05 / (1.0 + 8.0 / nk));
+        if (c < c128) c128 = c;
+    }
+    return c256 < c128;
 }
 
 template <bool F, bool S>

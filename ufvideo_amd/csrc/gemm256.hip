@@ -14,6 +14,8 @@
 //    loop): staging order A1[t+1], B0[t+1], A0[t+2], B1[t+2] in phases 0..3 of K-tile t.
 //      WAR: a half-tile buffer is re-staged exactly 2 phases after its last ds_read (safe for the lagging group);
 //      RAW: the wait in phase 3 retires everything up to B0[t+1]; first read is in the next phase, two barriers later.
+//  * persistent: one block per CU walks tiles b, b+G, ...; the next tile's prologue DMA is issued before the
+//    current tile's epilogue stores (its bias is fetched first so no ordinary load queues behind the DMA).
 //  * operands: 128-byte rows, 16-byte chunks XOR-swizzled by (row & 7) through the LDS-DMA SOURCE address.
 #include "common.h"
 #include "../../include/ufv.h"
@@ -22,6 +24,40 @@
 namespace {
 
 constexpr int SMEM256 = 131072;
+
+// acc[nt][mt][j] = C[m0 + (mt>>2)*128 + wr*64 + (mt&3)*16 + frow][n0 + (nt>>1)*128 + wc*32 + (nt&1)*16 + fq*4 + j]
+template <bool OUT_F32, bool SWIGLU, int ACT>
+__device__ __forceinline__ void epilogue256(const f32x4 (&acc)[4][8], const Epi& e, int M, int N, int m0, int n0, int wr, int wc,
+                                            int frow, int fq, f32x4 bias0, f32x4 bias1, f32x4 bias2, f32x4 bias3) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = m0 + (mt >> 2) * 128 + wr * 64 + (mt & 3) * 16 + frow;
+        if (m < M) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const int nb = n0 + nh * 128;
+                if (nb < N) {
+                    if (SWIGLU) {
+                        const int n = ((nb + wc * 32) >> 1) + fq * 4;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float gte = acc[2 * nh][mt][j], up = acc[2 * nh + 1][mt][j];
+                            v[j] = gte / (1.0f + __expf(-gte)) * up;
+                        }
+                        epi_store4b<OUT_F32, ACT_NONE>(e, m, n, v[0], v[1], v[2], v[3], f32x4{0, 0, 0, 0});
+                    } else {
+                        const int n = nb + wc * 32 + fq * 4;
+                        epi_store4b<OUT_F32, ACT>(e, m, n, acc[2 * nh][mt][0], acc[2 * nh][mt][1], acc[2 * nh][mt][2],
+                                                  acc[2 * nh][mt][3], nh ? bias2 : bias0);
+                        epi_store4b<OUT_F32, ACT>(e, m, n + 16, acc[2 * nh + 1][mt][0], acc[2 * nh + 1][mt][1],
+                                                  acc[2 * nh + 1][mt][2], acc[2 * nh + 1][mt][3], nh ? bias3 : bias1);
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <bool OUT_F32, bool SWIGLU>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e, int M,
@@ -33,29 +69,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A
 
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     const int nwg = tiles_m * tiles_n;
-    int id;
-    {
-        const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
-        id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-    }
-    constexpr int GM = 8;
-    const int gsz = GM * tiles_n, g = id / gsz, first_m = g * GM;
-    const int gm = min(tiles_m - first_m, GM);
-    const int tm = first_m + (id % gsz) % gm, tn = (id % gsz) / gm;
-    const int m0 = tm * 256, n0 = tn * 256;
     const int nk = K / 64;
+    const int G = gridDim.x;                       // persistent: block b walks tiles b, b+G, ...
+    // tile sequence position -> (tm, tn): within a round of G tiles give each XCD (launch id % 8) a contiguous run,
+    // and order the sequence in groups of 8 row-tiles so that concurrent tiles share A/W panels in L2.
+    auto tile_of = [&](int round, int& m0_, int& n0_) -> bool {
+        const int base = round * G;
+        const int cnt = min(G, nwg - base);          // tiles in this round
+        const int bid = blockIdx.x;
+        if (bid >= cnt) return false;
+        const int q = cnt >> 3, r = cnt & 7, x = bid & 7;
+        const int id = base + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+        constexpr int GM = 8;
+        const int gsz = GM * tiles_n, g = id / gsz, first_m = g * GM;
+        const int gm = min(tiles_m - first_m, GM);
+        m0_ = (first_m + (id % gsz) % gm) * 256;
+        n0_ = ((id % gsz) / gm) * 256;
+        return true;
+    };
 
     // ---- LDS-DMA sources: half-tile `which` (0=A0 1=A1 2=B0 3=B1), two 8-row pieces per wave
     const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
     const bf16* src[4][2];
+    auto set_src = [&](int m0_, int n0_) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = h * 128 + (wave * 2 + i) * 8 + lrow;
-            src[h][i] = A + (size_t)min(m0 + r, M - 1) * lda + lchunk * 8;
-            src[2 + h][i] = W + (size_t)min(n0 + r, N - 1) * ldw + lchunk * 8;
-        }
+            for (int i = 0; i < 2; ++i) {
+                const int r = h * 128 + (wave * 2 + i) * 8 + lrow;
+                src[h][i] = A + (size_t)min(m0_ + r, M - 1) * lda + lchunk * 8;
+                src[2 + h][i] = W + (size_t)min(n0_ + r, N - 1) * ldw + lchunk * 8;
+            }
+    };
     auto stage = [&](int d, int which, int kt) {
         if (kt < nk) {
             char* dst = smem + d * 65536 + which * 16384 + wave * 2048;
@@ -63,17 +108,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A
             __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][1] + kt * 64), LDS_PTR(dst + 1024), 16, 0, 0);
         }
     };
-
-    f32x4 acc[4][8];   // [nt][mt]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto prologue_loads = [&]() {      // K-tile 0 complete + A0/B1 of K-tile 1
+        stage(0, 0, 0); stage(0, 2, 0); stage(0, 3, 0); stage(0, 1, 0);
+        stage(1, 0, 1); stage(1, 3, 1);
+    };
 
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int a_row_off = (wr * 64 + frow) * 128;     // + (mt&3)*2048 inside the half
     const int b_row_off = (wc * 32 + frow) * 128;     // + (nt&1)*2048 inside the half
     const int coff0 = ((0 + fq) ^ fx) << 4, coff1 = ((4 + fq) ^ fx) << 4;
+
+    int m0, n0;
+    bool have = tile_of(0, m0, n0);
+    if (have) { set_src(m0, n0); prologue_loads(); }
+    for (int round = 0; have; ++round) {
+    f32x4 acc[4][8];   // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 afr[4][2], bfr[2][2];
     auto read_a = [&](const char* half) {
@@ -105,9 +158,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_barrier();
 
-    // ---- prologue: K-tile 0 complete, A0/B1 of K-tile 1 in flight
-    stage(0, 0, 0); stage(0, 2, 0); stage(0, 3, 0); stage(0, 1, 0);
-    stage(1, 0, 1); stage(1, 3, 1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -139,33 +189,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A
     if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the stagger barrier
 #undef UFV_SYNC_THEN_MMA
 
-    // ---- epilogue: acc[nt][mt][j] = C[m0 + (mt>>2)*128 + wr*64 + (mt&3)*16 + frow][n0 + (nt>>1)*128 + wc*32 + (nt&1)*16 + fq*4 + j]
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-        const int m = m0 + (mt >> 2) * 128 + wr * 64 + (mt & 3) * 16 + frow;
-        if (m >= M) continue;
-#pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-            const int nb = n0 + nh * 128;
-            if (nb >= N) continue;
-            if (SWIGLU) {
-                const int n = ((nb + wc * 32) >> 1) + fq * 4;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float gte = acc[2 * nh][mt][j], up = acc[2 * nh + 1][mt][j];
-                    v[j] = gte / (1.0f + __expf(-gte)) * up;
-                }
-                epi_store4<OUT_F32>(e, m, n, v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int nt = 2 * nh + q, n = nb + wc * 32 + q * 16 + fq * 4;
-                    epi_store4<OUT_F32>(e, m, n, acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
-                }
-            }
-        }
+
+    // ---- tile seam: every wave has finished its LDS reads (final barrier above) -> start the NEXT tile's
+    //      LDS-DMA prologue now so that it lands under this tile's epilogue stores.  The bias of THIS tile is
+    //      fetched first so that no ordinary load has to wait behind the DMA queue.
+    f32x4 bias0 = {0, 0, 0, 0}, bias1 = bias0, bias2 = bias0, bias3 = bias0;
+    if (!SWIGLU && e.bias) {
+        const int nA = min(n0, N - 128) + wc * 32 + fq * 4, nB = min(n0 + 128, N - 128) + wc * 32 + fq * 4;
+        bias0 = *reinterpret_cast<const f32x4*>(e.bias + nA);
+        bias1 = *reinterpret_cast<const f32x4*>(e.bias + nA + 16);
+        bias2 = *reinterpret_cast<const f32x4*>(e.bias + nB);
+        bias3 = *reinterpret_cast<const f32x4*>(e.bias + nB + 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    const int cm0 = m0, cn0 = n0;
+    have = tile_of(round + 1, m0, n0);
+    if (have) { set_src(m0, n0); prologue_loads(); }
+    // ---- epilogue (activation resolved once per tile so the body unrolls with acc in registers)
+    UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias0, bias1, bias2, bias3)))
+    }   // persistent tile loop
 }
 
 }  // namespace
@@ -178,8 +220,16 @@ static int launch256_t(const bf16* A, const bf16* W, const Epi& e, int M, int N,
                                   SMEM256);
         attr_set = true;
     }
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
     const int tiles = cdiv(M, 256) * cdiv(N, 256);
-    hipLaunchKernelGGL((gemm_nt_256<F, S>), dim3(tiles), dim3(512), SMEM256, st, A, W, e, M, N, K, lda, ldw);
+    const int grid = tiles < n_cu ? tiles : n_cu;          // persistent: one block per CU walks the tiles
+    hipLaunchKernelGGL((gemm_nt_256<F, S>), dim3(grid), dim3(512), SMEM256, st, A, W, e, M, N, K, lda, ldw);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }

@@ -10,7 +10,7 @@ struct Epi {
     int resid_rows;        // >0: residual row = m % resid_rows (broadcast table, e.g. position embeddings)
 };
 
-template <bool OUT_F32>
+template <bool OUT_F32, int ACT>
 __device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, float v0, float v1, float v2, float v3) {
     // n is a multiple of 4; the four values are columns n..n+3 of row m
     float v[4] = {v0, v1, v2, v3};
@@ -20,7 +20,7 @@ __device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, float v0,
         for (int j = 0; j < 4; ++j) v[j] += b[j];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], e.act);
+    for (int j = 0; j < 4; ++j) v[j] = act_apply_t<ACT>(v[j]);
     if (e.resid) {
         const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
         const f32x4 r = *reinterpret_cast<const f32x4*>(e.resid + (size_t)mr * e.ldr + n);
@@ -36,6 +36,27 @@ __device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, float v0,
     }
 }
 
+
+// same as epi_store4 with the bias already in registers (ignored when e.bias is null)
+template <bool OUT_F32, int ACT>
+__device__ __forceinline__ void epi_store4b(const Epi& e, int m, int n, float v0, float v1, float v2, float v3, f32x4 b) {
+    float v[4] = {v0, v1, v2, v3};      // b = bias already in registers (zeros when there is none)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = act_apply_t<ACT>(v[j] + b[j]);
+    if (e.resid) {
+        const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
+        const f32x4 r = *reinterpret_cast<const f32x4*>(e.resid + (size_t)mr * e.ldr + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += r[j];
+    }
+    if (OUT_F32) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (size_t)m * e.ldc + n) = o;
+    } else {
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(e.out) + (size_t)m * e.ldc + n) = o;
+    }
+}
 
 int ufv_launch_gemm256(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
                        bool swiglu, hipStream_t st);
