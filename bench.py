@@ -205,7 +205,7 @@ def main():
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("gemm_nt_128_swiglu_hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get("gemm_nt_256_swiglu_hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256<bf16,swiglu> gate/up M=%d N=%d K=%d" % (ks["M"], ks["N"], ks["K"]),
                                "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                                "traffic": traffic, "launch_ms": round(ks["mean_ms"], 4), "launches": ks["launches"]}
