@@ -16,6 +16,42 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// 8 fp32 -> bf16x8 with packed converts (v_cvt_pk_bf16_f32), no byte permutes
+__device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    const bf16x2 p0 = __builtin_convertvector((f32x2){a0, a1}, bf16x2), p1 = __builtin_convertvector((f32x2){a2, a3}, bf16x2);
+    const bf16x2 p2 = __builtin_convertvector((f32x2){a4, a5}, bf16x2), p3 = __builtin_convertvector((f32x2){a6, a7}, bf16x2);
+    const bf16x4 q0 = __builtin_shufflevector(p0, p1, 0, 1, 2, 3), q1 = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
+    return __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Eight ds_read_b64_tr_b16 for one 32-row d-tile of V^T (4 chunks of 16 keys x {keys 0-3, keys 8-11} sub-blocks), issued
+// from inline asm: hipcc's builtin for this instruction makes it wait vmcnt(0) for every LDS-DMA in flight (no alias
+// info), which would drain the K/V prefetch ring each iteration.  The caller counts lgkmcnt by hand.
+template <int PV_, int BASE>
+__device__ __forceinline__ void tr_read8(unsigned addr, bf16x4 (&v)[8]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%9\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %2, %8 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %3, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %5, %8 offset:%14\n\t"
+        "ds_read_b64_tr_b16 %6, %8 offset:%15\n\t"
+        "ds_read_b64_tr_b16 %7, %8 offset:%16"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(addr), "n"(BASE + 0 * 16 * PV_), "n"(BASE + 0 * 16 * PV_ + 8 * PV_), "n"(BASE + 1 * 16 * PV_),
+          "n"(BASE + 1 * 16 * PV_ + 8 * PV_), "n"(BASE + 2 * 16 * PV_), "n"(BASE + 2 * 16 * PV_ + 8 * PV_),
+          "n"(BASE + 3 * 16 * PV_), "n"(BASE + 3 * 16 * PV_ + 8 * PV_)
+        : "memory");
+}
+
 struct AttnArgs {
     const bf16 *q, *k, *v;
     bf16* o;
@@ -37,7 +73,7 @@ struct Cfg {
 };
 
 template <int HD, int NW, bool CAUSAL>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_mfma(AttnArgs a) {
+__global__ __launch_bounds__(NW * 64, (HD <= 96 ? 3 : 2)) void attn_fwd_mfma(AttnArgs a) {
     using C = Cfg<HD>;
     constexpr int KS = C::KS, DT = C::DT, KC = C::KC, VC = C::VC, PK = C::PK, PV = C::PV, STAGE = C::STAGE;
     constexpr int NT = NW * 64;
@@ -109,8 +145,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_mfma(AttnArgs a) {
     for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float sl2 = a.scale * 1.4426950408889634f;     // scores kept in the log2 domain
+    float m_run = -INFINITY, l_run = 0.f;                 // running max (log2 domain, scaled) and partial row sum
+    const float sl2 = a.scale * 1.4426950408889634f;
+    constexpr float RESCALE_THR = 6.0f;                   // defer the O rescale while the row max grows by < 2^6
 
     // per-lane LDS offsets
     const int k_off = l31 * PK + h * 16;                                  // + hh*32*PK + ks*32
@@ -123,64 +160,72 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_mfma(AttnArgs a) {
         if (t + 1 < ntiles) issue_loads(t + 1);
         const char* kb = smem + (t & 1) * STAGE;
         const char* vb = kb + 64 * PK;
+        const int kbase_idx = t * 64;
+        // ---- S^T[key][q] for 64 keys: two 32x32 tiles
+        f32x16 s0, s1;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int kbase_idx = t * 64 + hh * 32;
-            if (kbase_idx >= kmax) break;                       // block-uniform
-            // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
-            f32x16 s;
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + hh * 32 * PK + k_off + ks * 32);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-            }
-            // ---- online softmax over keys (register index) for query column l31
-            float tmax = -INFINITY;
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kb + k_off + ks * 32);
+            const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kb + 32 * PK + k_off + ks * 32);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
+        }
+        // ---- masking only where a tile can contain invalid keys (sequence end / causal diagonal): wave-uniform
+        bool need_mask = kbase_idx + 64 > a.Sk;
+        if (CAUSAL) need_mask = need_mask || (kbase_idx + 63 > a.q_pos0 + q0);
+        if (need_mask) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kj = kbase_idx + (r & 3) + 8 * (r >> 2) + 4 * h;
-                bool ok = kj < a.Sk;
-                if (CAUSAL) ok = ok && (kj <= a.q_pos0 + qi);
-                s[r] = ok ? s[r] * sl2 : -INFINITY;
-                tmax = fmaxf(tmax, s[r]);
+                bool ok0 = kj < a.Sk, ok1 = kj + 32 < a.Sk;
+                if (CAUSAL) { ok0 = ok0 && (kj <= a.q_pos0 + qi); ok1 = ok1 && (kj + 32 <= a.q_pos0 + qi); }
+                s0[r] = ok0 ? s0[r] : -INFINITY;
+                s1[r] = ok1 ? s1[r] : -INFINITY;
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mnew = fmaxf(m_run, tmax);
-            const float alpha = (m_run == -INFINITY) ? 0.f : exp2f(m_run - mnew);
-            const float msub = (mnew == -INFINITY) ? 0.f : mnew;
-            float psum = 0.f;
+        }
+        // ---- row max (raw scores), lane pair exchange, deferred rescale
+        float tmax = fmaxf(s0[0], s1[0]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(s[r] - msub);     // exp2(-inf) = 0 for masked keys
-                psum += s[r];
-            }
-            l_run = l_run * alpha + psum;
-            m_run = mnew;
+        for (int r = 1; r < 16; ++r) tmax = max3f(tmax, s0[r], s1[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+        if (__any(tmax > m_run + RESCALE_THR)) {
+            const float mnew = fmaxf(m_run, tmax);
+            const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - mnew);   // exp2(-inf) = 0 on the first tile
+            l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < DT; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-            // ---- P^T as B operand: k-step sp uses registers 8sp..8sp+7
-            bf16x8 pf[2];
+            m_run = mnew;
+        }
+        // ---- P = exp2(s*scale*log2e - m): one FMA + one v_exp per element; masked keys give exp2(-inf) = 0
+        const float msub = (m_run == -INFINITY) ? 0.f : m_run;
+        float psum = 0.f;
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp)
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -msub));
+            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -msub));
+            psum += s0[r] + s1[r];
+        }
+        l_run += psum;
+        // ---- P^T as B operand: k-step sp of half hh uses registers 8sp..8sp+7
+        bf16x8 pf[4];
+        pf[0] = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
+        pf[1] = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
+        pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
+        pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
+        // ---- O^T[d][q] += sum_key V[key][d] P[key][q]; V^T fragments via transposed LDS reads
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[sp][j] = (bf16)s[8 * sp + j];
-            // ---- O^T[d][q] += sum_key V[key][d] P[key][q]; V^T fragment via transposed LDS reads
+        for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const char* vp = vb + (hh * 32 + 16 * sp) * PV + v_off + dt * 64;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf16x4 __attribute__((address_space(3)))*)(vp));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (bf16x4 __attribute__((address_space(3)))*)(vp + 8 * PV));
-                    const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sp], oacc[dt], 0, 0, 0);
-                }
+            for (int c = 0; c < 4; ++c) {           // c = hh*2 + sp : 16-key chunk
+                const char* vp = vb + (16 * c) * PV + v_off + dt * 64;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp + 8 * PV));
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], oacc[dt], 0, 0, 0);
             }
         }
         if (t + 1 < ntiles) write_lds((t + 1) & 1);
@@ -188,6 +233,224 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_mfma(AttnArgs a) {
     }
 
     // ---- normalise and store O[q][d], d = 32dt + (r&3) + 8(r>>2) + 4h  (4 consecutive d per register quad)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qi < a.Sq) {
+        bf16* op = a.o + b * a.o_bs + (int64_t)qi * a.o_ss + hq * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = dt * 32 + g4 * 8 + h * 4;
+                if (d0 < HD) {
+                    bf16x4 ov = {(bf16)(oacc[dt][g4 * 4 + 0] * inv), (bf16)(oacc[dt][g4 * 4 + 1] * inv),
+                                 (bf16)(oacc[dt][g4 * 4 + 2] * inv), (bf16)(oacc[dt][g4 * 4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(op + d0) = ov;
+                }
+            }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (head dims whose row is an odd number of 16-byte chunks, e.g. 72): K/V tiles are copied
+// global -> LDS by global_load_lds (no staging registers) into a 3-stage ring, TWO tiles ahead of the compute,
+// retired with a counted s_waitcnt vmcnt and a raw s_barrier (one per 64-key tile).  Rows keep their natural
+// pitch (HD*2 bytes = odd number of 16-B slots -> conflict-free ds_read_b128 K fragments); the zero padding of
+// the QK^T contraction (72 -> 80) lives in the Q fragment, so the K "pad" chunk may alias the next row.
+// ---------------------------------------------------------------------------------------------------------
+template <int HD, int NW, bool CAUSAL>
+__global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(AttnArgs a) {
+    constexpr int KS = (HD + 15) / 16, DT = (HD + 31) / 32;
+    constexpr int PK = HD * 2, PV = HD * 2;                 // natural row pitch
+    constexpr int TILEB = 64 * PK, NI = TILEB / 1024;       // bytes / 1-KiB DMA pieces per operand tile
+    static_assert(TILEB % 1024 == 0 && (HD % 8) == 0 && ((HD / 8) & 1) == 1, "row must be an odd number of 16-B chunks");
+    constexpr int STG = 2 * TILEB + 256;                    // [K tile][16 B zeros + pad][V tile][tail pad]
+    constexpr int VOFF = TILEB + 128;
+    constexpr int NPW = (2 * NI + NW - 1) / NW;             // DMA pieces per wave per tile (max)
+    constexpr int NPW_MIN = (2 * NI) / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    // 1-D grid; consecutive launch ids go to different XCDs, so give the q-tiles of one (batch, head) ids that are
+    // 8 apart: they then share one XCD's L2 for their common K/V.
+    const int nqt = (a.Sq + 32 * NW - 1) / (32 * NW);
+    int qt, hq, b;
+    {
+        const int id = blockIdx.x, x = id & 7, slot = id >> 3;
+        const int groups = a.Hq * a.B;                       // (head, batch) pairs
+        const int gper = (groups + 7) >> 3;                  // pairs per XCD
+        const int gi = slot / nqt;
+        const int g = x * gper + gi;
+        qt = slot % nqt;
+        if (g >= groups || gi >= gper) return;
+        hq = g % a.Hq; b = g / a.Hq;
+        if (CAUSAL) qt = nqt - 1 - qt;
+    }
+    const int hkv = hq / (a.Hq / a.Hkv);
+    const int qblk0 = qt * 32 * NW, q0 = qblk0 + wave * 32;
+    const int qi = q0 + l31;
+
+    bf16x8 qf[KS];
+    {
+        const bf16* qp = a.q + b * a.q_bs + (int64_t)min(qi, a.Sq - 1) * a.q_ss + hq * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + h * 8;
+            if (d0 < HD) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + d0);
+            else qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // Q in registers before any DMA is in flight
+    int kmax = a.Sk;
+    if (CAUSAL) kmax = min(a.Sk, a.q_pos0 + min(qblk0 + 32 * NW, a.Sq));
+    const int ntiles = (kmax + 63) / 64;
+
+    const bf16* kbase = a.k + b * a.k_bs + hkv * HD;
+    const bf16* vbase = a.v + b * a.v_bs + hkv * HD;
+    // this wave's DMA pieces: piece j = wave + i*NW, j < 2*NI; op = j / NI (0 K, 1 V); lane -> (row, chunk)
+    int p_row[NPW], p_chunk[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int j = wave + i * NW, jj = j % NI;
+        const int c16 = jj * 64 + lane;
+        p_row[i] = c16 / (HD / 8);
+        p_chunk[i] = c16 % (HD / 8);
+    }
+    auto dma_tile = [&](int stage, int tile) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int j = wave + i * NW;
+            if (j < 2 * NI) {
+                const bool isv = j >= NI;
+                const int jj = j - (isv ? NI : 0);
+                const int row = min(tile * 64 + p_row[i], a.Sk - 1);
+                const bf16* src = (isv ? vbase + (int64_t)row * a.v_ss : kbase + (int64_t)row * a.k_ss) + p_chunk[i] * 8;
+                char* dst = smem + stage * STG + (isv ? VOFF : 0) + jj * 1024;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst), 16, 0, 0);
+            }
+        }
+    };
+    // zero the 16 bytes after every K tile (read as the d>=HD tail of the last key row)
+    if (tid < 3 * 4) reinterpret_cast<float*>(smem + (tid >> 2) * STG + TILEB)[tid & 3] = 0.f;
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sl2 = a.scale * 1.4426950408889634f;
+    constexpr float RESCALE_THR = 6.0f;
+    const int k_off = l31 * PK + h * 16;
+    const int v_off = (4 * h + ((lane & 15) >> 2)) * PV + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+    dma_tile(0, 0);
+    if (ntiles > 1) dma_tile(1, 1);
+    if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW_MIN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int st = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 2 < ntiles) dma_tile(st == 0 ? 2 : st - 1, t + 2);       // ring slot (t+2)%3 == (st+2)%3
+        const char* kb = smem + st * STG;
+        const char* vb = kb + VOFF;
+        const int kbase_idx = t * 64;
+        // ---- S^T[key][q] for 64 keys: two 32x32 tiles
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kb + k_off + ks * 32);
+            const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kb + 32 * PK + k_off + ks * 32);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
+        }
+        // ---- V^T fragments for the first two d-tiles: issued now (K fragment reads have been consumed by the MFMAs
+        //      above, so the LDS queue holds nothing else) and landing under the softmax arithmetic below.
+        const unsigned vaddr = (unsigned)(uintptr_t)LDS_PTR(vb + v_off);
+        bf16x4 vr[2][8];                                                // two register sets, d-tile dt uses set dt&1
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tr_read8<PV, 0>(vaddr, vr[0]);
+        if (DT > 1) tr_read8<PV, 64>(vaddr, vr[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- masking only where a tile can contain invalid keys (sequence end / causal diagonal): wave-uniform
+        bool need_mask = kbase_idx + 64 > a.Sk;
+        if (CAUSAL) need_mask = need_mask || (kbase_idx + 63 > a.q_pos0 + q0);
+        if (need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kj = kbase_idx + (r & 3) + 8 * (r >> 2) + 4 * h;
+                bool ok0 = kj < a.Sk, ok1 = kj + 32 < a.Sk;
+                if (CAUSAL) { ok0 = ok0 && (kj <= a.q_pos0 + qi); ok1 = ok1 && (kj + 32 <= a.q_pos0 + qi); }
+                s0[r] = ok0 ? s0[r] : -INFINITY;
+                s1[r] = ok1 ? s1[r] : -INFINITY;
+            }
+        }
+        // ---- row max (raw scores), lane pair exchange, deferred rescale
+        float tmax = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = max3f(tmax, s0[r], s1[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+        if (__any(tmax > m_run + RESCALE_THR)) {
+            const float mnew = fmaxf(m_run, tmax);
+            const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - mnew);   // exp2(-inf) = 0 on the first tile
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = mnew;
+        }
+        // ---- P = exp2(s*scale*log2e - m): one FMA + one v_exp per element; masked keys give exp2(-inf) = 0
+        const float msub = (m_run == -INFINITY) ? 0.f : m_run;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -msub));
+            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -msub));
+            psum += s0[r] + s1[r];
+        }
+        l_run += psum;
+        // ---- P^T as B operand: k-step sp of half hh uses registers 8sp..8sp+7
+        bf16x8 pf[4];
+        pf[0] = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
+        pf[1] = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
+        pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
+        pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
+        // ---- O^T[d][q] += sum_key V[key][d] P[key][q]; V^T fragments via transposed LDS reads
+        {
+            static_assert(DT <= 4, "V fragment register sets");
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                if (dt + 1 < DT) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // set dt landed, set dt+1 in flight
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {       // c = hh*2 + sp : 16-key chunk
+                    const bf16x8 vf = __builtin_shufflevector(vr[dt & 1][2 * c], vr[dt & 1][2 * c + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], oacc[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (dt + 2 < DT) {                   // refill this set for d-tile dt+2 (its MFMAs above have issued)
+                    if (dt == 0) tr_read8<PV, 128>(vaddr, vr[0]);
+                    else tr_read8<PV, 192>(vaddr, vr[1]);
+                }
+            }
+        }
+        // tile t+1 must have landed (every wave waits for its own pieces, then the barrier publishes them);
+        // tile t+2 stays in flight across the barrier.
+        if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW_MIN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        st = (st == 2) ? 0 : st + 1;
+    }
+
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qi < a.Sq) {
@@ -276,6 +539,25 @@ int launch_mfma(const AttnArgs& a, int causal, hipStream_t st) {
     return UFV_OK;
 }
 
+template <int HD, int NW>
+int launch_mfma_dma(const AttnArgs& a, int causal, hipStream_t st) {
+    constexpr int smem = 3 * (2 * 64 * HD * 2 + 256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_dma<HD, NW, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_dma<HD, NW, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    const int nqt = cdiv(a.Sq, 32 * NW), groups = a.Hq * a.B, gper = (groups + 7) / 8;
+    dim3 grid(8 * gper * nqt);
+    if (causal) hipLaunchKernelGGL((attn_fwd_mfma_dma<HD, NW, true>), grid, dim3(NW * 64), smem, st, a);
+    else hipLaunchKernelGGL((attn_fwd_mfma_dma<HD, NW, false>), grid, dim3(NW * 64), smem, st, a);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
 }  // namespace
 
 extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const void* k, int64_t k_bs, int64_t k_ss,
@@ -293,14 +575,17 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
                          (q_bs % 8 == 0) && (k_bs % 8 == 0) && (v_bs % 8 == 0) && (o_bs % 4 == 0);
     const bool hd_ok = (hd == 64 || hd == 72 || hd == 80 || hd == 96 || hd == 128);
     const bool mfma_ok = aligned && hd_ok;
-    if (kernel == 1 && !mfma_ok) {
+    if ((kernel == 1 || kernel == 3) && !mfma_ok) {
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
     }
-    if (kernel == 1 || (kernel == 0 && mfma_ok && Sq >= 16)) {
+    if (kernel == 1 || kernel == 3 || kernel == 4 || (kernel == 0 && mfma_ok && Sq >= 16)) {
+        const bool six = (Sq % 192 == 0) && (Sq % 128 != 0);     // e.g. 576 ViT tokens: 3 blocks of 6 waves, no idle wave
         switch (hd) {
             case 64: return launch_mfma<64, 4>(a, causal, st);
-            case 72: return launch_mfma<72, 4>(a, causal, st);
+            case 72: if (kernel == 3) return launch_mfma<72, 4>(a, causal, st);      // register-staged variant (diagnostic)
+                     if (Sq % 288 == 0 && kernel != 4) return launch_mfma_dma<72, 9>(a, causal, st);   // 576 ViT tokens = 2 blocks of 9 waves
+                     return six ? launch_mfma_dma<72, 6>(a, causal, st) : launch_mfma_dma<72, 4>(a, causal, st);
             case 80: return launch_mfma<80, 4>(a, causal, st);
             case 96: return launch_mfma<96, 4>(a, causal, st);
             case 128: return launch_mfma<128, 4>(a, causal, st);
