@@ -97,9 +97,14 @@ class KernelTimer:
         return dict(mean_ms=float(np.mean(ms)), launches=len(ms), M=M, N=N, K=K, flops=2.0 * M * N * K)
 
 
-def one_step(model, video, ids, am, cache):
+def one_step(model, video, ids, am, cache, frameshard=False):
     cache.len = 0
-    _, am2, _, emb, _, _ = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, [(video, "video")], None, None, None, None)
+    mmf = None
+    if frameshard:
+        from ufvideo_amd.parallel import encode_frame_sharded
+        mmf = encode_frame_sharded(model, video)[None]
+    _, am2, _, emb, _, _ = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, [(video, "video")], None, None, None, None,
+                                                                      mm_features=mmf)
     logits, *_ = model._decode_batch(emb, am2, cache, False, 1)
     return logits, emb.shape[1]
 
@@ -142,6 +147,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=T_FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["replica", "frameshard"], default="replica",
+                    help="replica: one clip per GPU per step (default, weak scaling); frameshard: ONE clip per step, frames "
+                         "sharded over the ranks for tower+projector, RCCL all-gather of visual tokens, decoder on every rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,14 +179,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    fs = args.mode == "frameshard" and world > 1
     with torch.no_grad():
         for _ in range(args.warmup):
-            logits, S = one_step(model, video, ids, am, cache)
+            logits, S = one_step(model, video, ids, am, cache, fs)
         barrier()
         timer.on = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            logits, S = one_step(model, video, ids, am, cache)
+            logits, S = one_step(model, video, ids, am, cache, fs)
         barrier()
         dt = time.perf_counter() - t0
         timer.on = False
@@ -189,14 +198,14 @@ def main():
         dt = float(tt.item())
 
     tokens_per_clip = (args.frames // 2) * ((IMG // 14) // 2) ** 2
-    value = world * args.steps * tokens_per_clip / dt
+    value = (1 if fs else world) * args.steps * tokens_per_clip / dt
     out = {
         "metric": "video-tokens/sec (encode+prefill), UFVideo-7B 32f@336px", "value": round(value, 1), "unit": "video-tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if fs else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"UFVideo-7B dims, {args.frames} frames {IMG}x{IMG}, bf16, prompt 96 ids -> S={S}, "
                                f"encode+project+splice+prefill to last-position logits; clip replicas per GPU",
-                   "video_tokens_per_clip": tokens_per_clip, "llm_seq_len": S, "parallelism": f"clip-dp{world}"},
+                   "video_tokens_per_clip": tokens_per_clip, "llm_seq_len": S, "parallelism": (f"frameshard{world}+allgather" if fs else f"clip-dp{world}")},
     }
     if rank == 0:
         ks = timer.summary()

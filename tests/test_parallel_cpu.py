@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: the N>1 logic (frame partition, token all-gather order, clip sharding, the
+bench's barrier/max-reduce timing protocol).  HIP kernels are not involved: the encoder is a deterministic stub."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ufvideo_amd import parallel as P
+
+
+def test_frame_chunks_and_clip_shards():
+    assert P.frame_chunks(32, 8) == [(i * 4, i * 4 + 4) for i in range(8)]
+    assert P.frame_chunks(64, 8)[3] == (24, 32)
+    assert P.frame_chunks(4, 8) == [(0, 2), (2, 4)] + [(4, 4)] * 6              # more ranks than frame pairs
+    assert P.frame_chunks(6, 2) == [(0, 4), (4, 6)]                               # uneven, still stride-aligned
+    with pytest.raises(ValueError):
+        P.frame_chunks(5, 2)
+    got = sum((P.shard_clips(10, r, 4) for r in range(4)), [])
+    assert got == list(range(10)) and P.shard_clips(10, 3, 4) == [9]
+
+
+class _Proj:
+    downsample = (2, 2, 2)
+
+
+class _Inner:
+    mm_projector = _Proj()
+
+
+class _Model:
+    class config:
+        hidden_size = 8
+
+    def get_model(self):
+        return _Inner()
+
+
+def _stub_encode(frames):
+    # two tokens per frame pair, value = (sum of the pair's frame ids, index) -> order-sensitive
+    t = frames.shape[0]
+    ids = frames[:, 0, 0, 0].view(t // 2, 2).sum(1)
+    tok = torch.stack([ids, ids + 0.5], dim=1).reshape(-1, 1)
+    return tok.expand(-1, 8).contiguous()
+
+
+def _worker(rank, world, port, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        video = torch.arange(T, dtype=torch.float32).view(T, 1, 1, 1).expand(T, 3, 2, 2).contiguous()
+        out = P.encode_frame_sharded(_Model(), video, encode_fn=_stub_encode)
+        ref = _stub_encode(video)
+        ok = torch.equal(out, ref)
+        # bench.py's timing protocol: barrier, local time, MAX over ranks
+        dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        q.put((rank, ok, float(t.item()), tuple(out.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T", [8, 6, 2])
+def test_frame_sharded_encode_world2_gloo(T):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, tmax, shape in res:
+        assert ok, f"rank {rank}: gathered tokens differ from the single-process encode"
+        assert tmax == 2.0 and shape == (T, 8)

@@ -229,14 +229,16 @@ class VideoReferMetaForCausalLM(ABC):
         raise Exception(f"Unsupported projector type {kind}!!!")
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, attention_mask, past_key_values, labels, images, masks, frame,
-                                             ann_indices, frame_nums, video_file=""):
+                                             ann_indices, frame_nums, video_file="", mm_features=None):
         """-> (None, attention_mask, past_key_values, inputs_embeds [B,S,D] fp32, labels, mark_mm_token_indices)
-        (ref :218-370)."""
+        (ref :218-370).  `mm_features` (extension): visual tokens computed elsewhere, e.g. by
+        parallel.encode_frame_sharded, skip the local encode."""
         vision_tower = self.get_vision_tower()
         if vision_tower is None or images is None or input_ids.shape[1] == 1:
             return input_ids, attention_mask, past_key_values, None, labels, None
         model = self.get_model()
-        mm_features = self.encode_images_or_videos(images)                       # [n_mm, tok, D] fp32
+        if mm_features is None:
+            mm_features = self.encode_images_or_videos(images)                   # [n_mm, tok, D] fp32
         if frame is not None:
             frame_cns = torch.cat(frame, dim=0)
             first = vision_tower.encode(frame_cns)
