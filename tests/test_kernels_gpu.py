@@ -298,3 +298,20 @@ def test_gemm256_swiglu_and_layout():
     eye = bf(torch.eye(256, 256, device=DEV))
     w = bf((torch.arange(256, device=DEV)[:, None] * 3 + torch.arange(256, device=DEV)[None, :] * 0.5) % 17)
     assert torch.equal(ops.gemm(eye, w, out_dtype=torch.float32, kernel=ops.GEMM_FAST256), w.float().t().contiguous())
+
+
+def test_rope_kv_scalar_path():
+    # head_dim 24 (hd/2 not a multiple of 8) takes the scalar kernel
+    S, Hq, Hkv, hd, pos0 = 5, 2, 1, 24, 3
+    qkv = bf(g(S, (Hq + 2 * Hkv) * hd, seed=60))
+    inv = 1.0 / (1e4 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd)).to(DEV)
+    cache = torch.zeros(16, 2 * Hkv * hd, device=DEV, dtype=torch.bfloat16)
+    ref_in = qkv.float().clone()
+    ops.rope_kv(qkv, S, Hq, Hkv, hd, inv, pos0, cache)
+    pos = torch.arange(pos0, pos0 + S, device=DEV).float()
+    ang = torch.cat([pos[:, None] * inv[None], pos[:, None] * inv[None]], -1)
+    cos, sin = ang.cos()[:, None], ang.sin()[:, None]
+    rot = lambda x: torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1)
+    qr = ref_in[:, :Hq * hd].view(S, Hq, hd)
+    assert rel(qkv[:, :Hq * hd].float().view(S, Hq, hd), qr * cos + rot(qr) * sin) < 8e-3
+    assert torch.equal(cache[pos0:pos0 + S, Hkv * hd:], bf(ref_in[:, (Hq + Hkv) * hd:]))

@@ -150,8 +150,46 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const float* x, int ldx, void* 
 // RoPE (rotate-half) on q in place; k roped + v copied into the KV cache
 // one thread per (token, head, pair i < hd/2)
 // -------------------------------------------------------------------------------------------------
-__global__ void rope_kv_k(bf16* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0, bf16* kv,
-                          int ldkv) {
+__global__ __launch_bounds__(256) void rope_kv_k(bf16* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0,
+                                                 bf16* kv, int ldkv) {
+    // thread = (token s, head hh of q|k|v, chunk of 8 pairs): hd/2 must be a multiple of 8 (vector path) else scalar loop
+    const int half = hd >> 1, cpr = half >> 3;               // chunks per row-half
+    const int H = Hq + 2 * Hkv;
+    const int64_t total = (int64_t)S * H * cpr;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = id % cpr;
+        const int hh = (id / cpr) % H;
+        const int s = id / ((int64_t)cpr * H);
+        bf16* row = qkv + (int64_t)s * ldqkv;
+        const int i0 = ch * 8;
+        if (hh < Hq + Hkv) {
+            bf16* p = row + hh * hd;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p + i0), b2 = *reinterpret_cast<const bf16x8*>(p + half + i0);
+            bf16x8 y1, y2;
+            const float pos = (float)(pos0 + s);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ang = pos * inv_freq[i0 + j];
+                const float c = cosf(ang), sn = sinf(ang);
+                const float x1 = (float)a[j], x2 = (float)b2[j];
+                y1[j] = (bf16)(x1 * c - x2 * sn);
+                y2[j] = (bf16)(x2 * c + x1 * sn);
+            }
+            bf16* d = (hh < Hq) ? p : kv + (int64_t)(pos0 + s) * ldkv + (hh - Hq) * hd;
+            *reinterpret_cast<bf16x8*>(d + i0) = y1;
+            *reinterpret_cast<bf16x8*>(d + half + i0) = y2;
+        } else {
+            const int hv = hh - Hq - Hkv;
+            const bf16* p = row + (Hq + Hkv) * hd + hv * hd;
+            bf16* d = kv + (int64_t)(pos0 + s) * ldkv + Hkv * hd + hv * hd;
+            *reinterpret_cast<bf16x8*>(d + i0) = *reinterpret_cast<const bf16x8*>(p + i0);
+            *reinterpret_cast<bf16x8*>(d + half + i0) = *reinterpret_cast<const bf16x8*>(p + half + i0);
+        }
+    }
+}
+
+__global__ void rope_kv_scalar_k(bf16* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0, bf16* kv,
+                                 int ldkv) {
     const int half = hd >> 1;
     const int64_t total = (int64_t)S * (Hq + 2 * Hkv) * half;
     for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
@@ -165,14 +203,9 @@ __global__ void rope_kv_k(bf16* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, 
             bf16* p = row + hh * hd;
             const float x1 = (float)p[i], x2 = (float)p[i + half];
             const float y1 = x1 * c - x2 * sn, y2 = x2 * c + x1 * sn;
-            if (hh < Hq) {
-                p[i] = (bf16)y1;
-                p[i + half] = (bf16)y2;
-            } else {
-                bf16* d = kv + (int64_t)(pos0 + s) * ldkv + (hh - Hq) * hd;
-                d[i] = (bf16)y1;
-                d[i + half] = (bf16)y2;
-            }
+            bf16* d = (hh < Hq) ? p : kv + (int64_t)(pos0 + s) * ldkv + (hh - Hq) * hd;
+            d[i] = (bf16)y1;
+            d[i + half] = (bf16)y2;
         } else {
             const int hv = hh - Hq - Hkv;
             const bf16* p = row + (Hq + Hkv) * hd + hv * hd;
@@ -217,59 +250,94 @@ __global__ __launch_bounds__(256) void patchify_k(const void* px, bf16* out, int
 // -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dwconv_ln_silu_k(const bf16* x, bf16* y, const float* w9, const float* lnw,
                                                         const float* lnb, int F, int H, int W, int C, float eps) {
+    // one wave per pixel; lane owns 8-channel chunks lane + 64*i (16-byte loads), C <= 4096
+    constexpr int MAXC = 8;
     const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pix >= F * H * W) return;
     const int px = pix % W, py = (pix / W) % H, f = pix / (W * H);
-    const int nv = C >> 2;
-    f32x4 v[MAXV];
+    const int nc = C >> 3;
+    float v[MAXC][8];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) v[i] = f32x4{0, 0, 0, 0};
+    for (int i = 0; i < MAXC; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+#pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
         const int yy = py + dy;
         if (yy < 0 || yy >= H) continue;
+#pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             const int xx = px + dx;
             if (xx < 0 || xx >= W) continue;
             const bf16* src = x + ((int64_t)(f * H + yy) * W + xx) * C;
             const float* wk = w9 + ((dy + 1) * 3 + (dx + 1)) * C;
 #pragma unroll
-            for (int i = 0; i < MAXV; ++i)
-                if (lane + 64 * i < nv) {
-                    const int c = 4 * (lane + 64 * i);
-                    const f32x4 xv = load4<UFV_DT_BF16>(src, c);
-                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wk + c);
+            for (int i = 0; i < MAXC; ++i)
+                if (lane + 64 * i < nc) {
+                    const int c = 8 * (lane + 64 * i);
+                    const bf16x8 xv = *reinterpret_cast<const bf16x8*>(src + c);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wk + c), w1 = *reinterpret_cast<const f32x4*>(wk + c + 4);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[i][j] += xv[j] * wv[j];
+                    for (int j = 0; j < 4; ++j) {
+                        v[i][j] += (float)xv[j] * w0[j];
+                        v[i][4 + j] += (float)xv[4 + j] * w1[j];
+                    }
                 }
         }
     }
-    // the reference rounds the conv output to the activation dtype before the norm: keep fp32 (more accurate)
-    float mean, rstd;
-    ln_stats(v, nv, lane, C, eps, mean, rstd);
+    // LayerNorm over C (two-pass in registers), then SiLU
+    float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (lane + 64 * i < nv) {
-            const int c = 4 * (lane + 64 * i);
-            const f32x4 ww = *reinterpret_cast<const f32x4*>(lnw + c), bb = *reinterpret_cast<const f32x4*>(lnb + c);
-            f32x4 o;
+    for (int i = 0; i < MAXC; ++i)
+        if (lane + 64 * i < nc)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = act_apply((v[i][j] - mean) * rstd * ww[j] + bb[j], ACT_SILU);
-            store4<false>(y, (int64_t)pix * C + c, o);
+            for (int j = 0; j < 8; ++j) sum += v[i][j];
+    const float mean = wave_sum(sum) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+        if (lane + 64 * i < nc)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[i][j] - mean;
+                q += d * d;
+            }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+        if (lane + 64 * i < nc) {
+            const int c = 8 * (lane + 64 * i);
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnw + c), g1 = *reinterpret_cast<const f32x4*>(lnw + c + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(lnb + c), b1 = *reinterpret_cast<const f32x4*>(lnb + c + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (bf16)act_apply_t<ACT_SILU>((v[i][j] - mean) * rstd * g0[j] + b0[j]);
+                o[4 + j] = (bf16)act_apply_t<ACT_SILU>((v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
+            }
+            *reinterpret_cast<bf16x8*>(y + (int64_t)pix * C + c) = o;
         }
 }
 
-// out[f, c] = mean_p x[f*P + p, c]; block (256 threads = 256 channel-quads?) -> thread per 4 channels
-__global__ __launch_bounds__(256) void colmean_k(const bf16* x, bf16* out, int F, int P, int C) {
-    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4, f = blockIdx.y;
-    if (c >= C) return;
+// out[f, c] = mean_p x[f*P + p, c].  Block = 8 row groups x 64 lanes, lane owns 4 channels (256 channels / block);
+// row groups stride over the P rows and are combined through LDS.
+__global__ __launch_bounds__(512) void colmean_k(const bf16* x, bf16* out, int F, int P, int C) {
+    __shared__ f32x4 part[8][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4, f = blockIdx.y;
     f32x4 s = {0, 0, 0, 0};
-    const bf16* p = x + (int64_t)f * P * C + c;
-    for (int r = 0; r < P; ++r) {
-        const f32x4 v = load4<UFV_DT_BF16>(p, (int64_t)r * C);
-        s += v;
+    if (c < C) {
+        const bf16* p = x + (int64_t)f * P * C + c;
+        for (int r = g; r < P; r += 8) s += load4<UFV_DT_BF16>(p, (int64_t)r * C);
     }
-    const float inv = 1.0f / P;
-    store4<false>(out, (int64_t)f * C + c, f32x4{s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv});
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) s += part[i][lane];
+        const float inv = 1.0f / P;
+        store4<false>(out, (int64_t)f * C + c, f32x4{s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv});
+    }
 }
 
 __global__ __launch_bounds__(256) void scale_channels_k(bf16* x, const bf16* gate, int F, int P, int C) {
@@ -456,9 +524,16 @@ extern "C" int ufv_rmsnorm(const float* x, int ldx, void* y, int y_f32, int ldy,
 extern "C" int ufv_rope_kv(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0, void* kv_cache,
                            int ldkv, void* stream) {
     UFV_REQUIRE(qkv && inv_freq && kv_cache && S > 0 && hd % 2 == 0, "ufv_rope_kv: bad arguments");
-    const int64_t total = (int64_t)S * (Hq + 2 * Hkv) * (hd / 2);
-    hipLaunchKernelGGL(rope_kv_k, dim3(grid_for(total)), dim3(256), 0, ST(stream), (bf16*)qkv, ldqkv, S, Hq, Hkv, hd, inv_freq, pos0,
-                       (bf16*)kv_cache, ldkv);
+    const bool vec = (hd % 16 == 0) && (ldqkv % 8 == 0) && (ldkv % 8 == 0) && ((uintptr_t)qkv % 16 == 0) && ((uintptr_t)kv_cache % 16 == 0);
+    if (vec) {
+        const int64_t total = (int64_t)S * (Hq + 2 * Hkv) * (hd / 16);
+        hipLaunchKernelGGL(rope_kv_k, dim3(grid_for(total)), dim3(256), 0, ST(stream), (bf16*)qkv, ldqkv, S, Hq, Hkv, hd, inv_freq, pos0,
+                           (bf16*)kv_cache, ldkv);
+    } else {
+        const int64_t total = (int64_t)S * (Hq + 2 * Hkv) * (hd / 2);
+        hipLaunchKernelGGL(rope_kv_scalar_k, dim3(grid_for(total)), dim3(256), 0, ST(stream), (bf16*)qkv, ldqkv, S, Hq, Hkv, hd, inv_freq,
+                           pos0, (bf16*)kv_cache, ldkv);
+    }
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
@@ -477,7 +552,7 @@ extern "C" int ufv_patchify(const void* pixels, int dtype, void* out, int T, int
 extern "C" int ufv_dwconv3x3_ln_silu(const void* x, void* y, const float* w9, const float* lnw, const float* lnb, int F, int H,
                                      int W, int C, float eps, void* stream) {
     UFV_REQUIRE(x && y && w9 && lnw && lnb && F > 0, "ufv_dwconv3x3_ln_silu: bad arguments");
-    UFV_REQUIRE(C % 4 == 0 && C <= 4 * 64 * MAXV, "ufv_dwconv3x3_ln_silu: C=%d unsupported", C);
+    UFV_REQUIRE(C % 8 == 0 && C <= 4096, "ufv_dwconv3x3_ln_silu: C=%d must be a multiple of 8 and <= 4096", C);
     hipLaunchKernelGGL(dwconv_ln_silu_k, dim3(cdiv(F * H * W, 4)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F,
                        H, W, C, eps);
     UFV_CHECK_LAUNCH();
@@ -486,7 +561,7 @@ extern "C" int ufv_dwconv3x3_ln_silu(const void* x, void* y, const float* w9, co
 
 extern "C" int ufv_colmean(const void* x, void* out, int F, int P, int C, void* stream) {
     UFV_REQUIRE(x && out && F > 0 && P > 0 && C % 4 == 0, "ufv_colmean: bad arguments");
-    hipLaunchKernelGGL(colmean_k, dim3(cdiv(C / 4, 64), F), dim3(64), 0, ST(stream), (const bf16*)x, (bf16*)out, F, P, C);
+    hipLaunchKernelGGL(colmean_k, dim3(cdiv(C / 4, 64), F), dim3(512), 0, ST(stream), (const bf16*)x, (bf16*)out, F, P, C);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
