@@ -81,6 +81,14 @@ int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const void* k, int6
                   int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int64_t o_ss, int B, int Hq, int Hkv, int Sq,
                   int Sk, int hd, float scale, int causal, int q_pos0, int kernel, void* stream);
 
+/* Decode-step attention (one query token against the KV cache; modeling_qwen2.py:150-172 with q_len 1): keys are
+ * split over `nsplit` blocks per head and merged; `ws` = ufv_attention_decode_ws_bytes(...) bytes of scratch.
+ * q element (b, h, d) at q + b*q_bs + h*hd + d; k/v as in ufv_attention; o at o + b*o_bs + h*hd + d. */
+int ufv_attention_decode_ws_bytes(int B, int Hq, int hd, int nsplit);
+int ufv_attention_decode(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_ss, const void* v, int64_t v_bs,
+                         int64_t v_ss, void* o, int64_t o_bs, int B, int Hq, int Hkv, int Sk, int hd, float scale, void* ws,
+                         int nsplit, void* stream);
+
 /* RoPE rotate-half (modeling_qwen2.py:105-135) applied in place to the q columns of a fused qkv
  * buffer [S, ldqkv] and, for k, written together with v into the KV cache rows pos0..pos0+S-1
  * (cache row = [Hkv*hd k | Hkv*hd v]).  angle = (pos0+s) * inv_freq[i] in fp32. */
@@ -122,6 +130,36 @@ int ufv_argmax(const float* logits, int N, int64_t* out, void* stream);
 /* frame batching tail of process_video (mm_utils.py:284,291): u8 HWC frames -> (x/255 - mean)/std -> bf16 NCHW */
 int ufv_preprocess_u8(const uint8_t* frames, void* out, int T, int H, int W, const float* mean3, const float* std3,
                       void* stream);
+
+/* ---- one-call greedy decode step (replaces HF GenerationMixin's per-token Qwen2ForCausalLM.forward under
+ * videorefer_qwen2.py:414-426).  All pointers are device memory prepared by the caller (packed weights as for the
+ * op-level calls: wqkv = [q|k|v] rows, wgu = gate/up rows interleaved in blocks of 16). */
+typedef struct {
+    const void* wqkv;   /* bf16 [(Hq+2Hkv)*hd, d] */
+    const float* bqkv;  /* f32  [(Hq+2Hkv)*hd] */
+    const void* wo;     /* bf16 [d, Hq*hd] */
+    const void* wgu;    /* bf16 [2*d_ff, d] (SwiGLU packing) */
+    const void* wd;     /* bf16 [d, d_ff] */
+    const float* ln1;   /* f32 [d] input_layernorm */
+    const float* ln2;   /* f32 [d] post_attention_layernorm */
+    void* kv_cache;     /* bf16 [max_len, ldkv]: row = [Hkv*hd k | Hkv*hd v] */
+} ufv_qwen2_layer;
+
+typedef struct {
+    int32_t n_layers, d, n_q, n_kv, hd, d_ff, vocab, ldkv, max_len, attn_splits;
+    float eps;
+    const float* inv_freq; /* f32 [hd/2] */
+    const float* norm;     /* f32 [d] */
+    const void* embed;     /* bf16 [vocab, d] */
+    const void* lm_head;   /* bf16 [vocab, d] */
+    const ufv_qwen2_layer* layers;
+} ufv_qwen2_model;
+
+int64_t ufv_qwen2_decode_ws_bytes(const ufv_qwen2_model* m);
+/* token_dev: previous token id (device int64[1]); pos: its position (= number of cached tokens); writes logits f32
+ * [vocab], optional hidden_out f32 [d] (final-norm hidden state), next_token_dev = argmax. */
+int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* token_dev, int pos, void* ws, int64_t ws_bytes, float* logits,
+                          float* hidden_out, int64_t* next_token_dev, void* stream);
 
 /* elementwise convert between bf16 / f32 / f16 (n elements) */
 int ufv_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);

@@ -315,3 +315,12 @@ def test_rope_kv_scalar_path():
     qr = ref_in[:, :Hq * hd].view(S, Hq, hd)
     assert rel(qkv[:, :Hq * hd].float().view(S, Hq, hd), qr * cos + rot(qr) * sin) < 8e-3
     assert torch.equal(cache[pos0:pos0 + S, Hkv * hd:], bf(ref_in[:, (Hq + Hkv) * hd:]))
+
+
+@pytest.mark.parametrize("hd,Hq,Hkv,Sk,nsplit", [(128, 28, 4, 2400, 16), (128, 4, 2, 5, 16), (16, 4, 2, 61, 3), (64, 8, 8, 700, 1)])
+def test_attention_decode(hd, Hq, Hkv, Sk, nsplit):
+    q = bf(g(1, 1, Hq, hd, seed=70))
+    kv = bf(g(Sk + 3, 2 * Hkv * hd, seed=71))                 # cache rows [k | v]
+    o = ops.attention_decode(q.view(1, Hq * hd), kv, kv[:, Hkv * hd:], Hq, Hkv, Sk, hd, kv.stride(0), kv.stride(0), nsplit=nsplit)
+    k = kv[:Sk, :Hkv * hd].view(1, Sk, Hkv, hd); v = kv[:Sk, Hkv * hd:].view(1, Sk, Hkv, hd)
+    assert rel(o, attn_ref(q, k, v, True, Sk - 1)) < 1.2e-2

@@ -1,0 +1,20 @@
+"""Diagnostic: greedy decode latency (ms/token) after a config-#2 prefill, full UFVideo-7B dims, synthetic weights."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+model = bench.build_model(dev)
+video, ids, am = bench.synthetic_inputs(dev)
+with torch.no_grad():
+    _, am2, _, emb, _, _ = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, [(video, "video")], None, None, None, None)
+    for n in (8, 64):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = model._greedy(emb, am2, max_new_tokens=n, eos_token_id=None)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"generate {n} tokens: {dt*1e3:.1f} ms total (incl. prefill)")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out8 = model._greedy(emb, am2, max_new_tokens=8, eos_token_id=None); torch.cuda.synchronize(); t8 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out72 = model._greedy(emb, am2, max_new_tokens=72, eos_token_id=None); torch.cuda.synchronize(); t72 = time.perf_counter() - t0
+    print(f"decode: {(t72 - t8) / 64 * 1e3:.2f} ms/token  (weights 15.2 GB bf16 -> {(15.2e9 / ((t72 - t8) / 64)) / 1e12:.2f} TB/s effective)")

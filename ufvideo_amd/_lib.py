@@ -31,7 +31,18 @@ SIGNATURES = {
     "ufv_argmax": [_p, _i, _p, _p],
     "ufv_preprocess_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
     "ufv_convert": [_p, _i, _p, _i, _l, _p],
+    "ufv_attention_decode": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _i, _p],
+    "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
 }
+
+
+class Qwen2Layer(C.Structure):
+    _fields_ = [("wqkv", _p), ("bqkv", _p), ("wo", _p), ("wgu", _p), ("wd", _p), ("ln1", _p), ("ln2", _p), ("kv_cache", _p)]
+
+
+class Qwen2Model(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_layers", "d", "n_q", "n_kv", "hd", "d_ff", "vocab", "ldkv", "max_len", "attn_splits")] + \
+               [("eps", _f), ("inv_freq", _p), ("norm", _p), ("embed", _p), ("lm_head", _p), ("layers", C.POINTER(Qwen2Layer))]
 
 _lib = None
 
@@ -57,6 +68,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = _i
+    lib.ufv_attention_decode_ws_bytes.argtypes = [_i, _i, _i, _i]
+    lib.ufv_attention_decode_ws_bytes.restype = _i
+    lib.ufv_qwen2_decode_ws_bytes.argtypes = [_p]
+    lib.ufv_qwen2_decode_ws_bytes.restype = _l
     _lib = lib
     return lib
 

@@ -469,6 +469,105 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Decode attention (Sq == 1): HBM/L2-bound streaming of the KV cache.  Keys are split over blocks (flash-decoding):
+// grid (nsplit, Hq, B); a wave reads 64/CPR keys per 16-byte load instruction (CPR = hd/8 lanes per key row),
+// scores go to LDS, each block writes an un-normalised partial (max, sum, o[hd]); attn_decode_combine merges them.
+// ---------------------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_split(AttnArgs a, float* ws, int nsplit) {
+    constexpr int CPR = HD / 8, KPI = 64 / CPR;            // lanes per key row, keys per wave instruction
+    extern __shared__ __attribute__((aligned(16))) char smem_d[];
+    float* sc = reinterpret_cast<float*>(smem_d);           // [keys in this split]
+    __shared__ float red[16];
+    __shared__ float opart[4][HD];
+    const int split = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, hkv = hq / (a.Hq / a.Hkv);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / CPR, ch = lane % CPR;
+    const int nk = a.Sk;                                    // Sq == 1 with q_pos0 = Sk-1: every cached key is visible
+    const int per = (nk + nsplit - 1) / nsplit;
+    const int k0 = split * per, k1 = min(nk, k0 + per), n = max(k1 - k0, 0);
+    float* out = ws + ((size_t)(b * a.Hq + hq) * nsplit + split) * (HD + 2);
+    if (n == 0) {
+        if (tid == 0) { out[0] = -INFINITY; out[1] = 0.f; }
+        for (int d = tid; d < HD; d += 256) out[2 + d] = 0.f;
+        return;
+    }
+    const bf16* qp = a.q + b * a.q_bs + hq * HD;
+    const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qp + ch * 8);
+    float qf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[j] = (float)qv[j] * a.scale;
+    const bf16* kb = a.k + b * a.k_bs + hkv * HD + ch * 8;
+    const bf16* vb = a.v + b * a.v_bs + hkv * HD + ch * 8;
+    // ---- scores
+    float mx = -INFINITY;
+    for (int j0 = wave * KPI; j0 < n; j0 += 4 * KPI) {
+        const int j = j0 + sub;
+        float s = 0.f;
+        if (j < n) {
+            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kb + (int64_t)(k0 + j) * a.k_ss);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qf[e] * (float)kv[e];
+        }
+#pragma unroll
+        for (int o = 1; o < CPR; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (j < n && ch == 0) sc[j] = s;
+        if (j < n) mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const float p = __expf(sc[j] - mx);
+        sc[j] = p;
+        sum += p;
+    }
+    sum = block_sum(sum, red + 4);
+    __syncthreads();
+    // ---- o = sum_j p_j v_j : lane accumulates its 8-d chunk over keys j = j0 + sub
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j0 = wave * KPI; j0 < n; j0 += 4 * KPI) {
+        const int j = j0 + sub;
+        if (j < n) {
+            const float p = sc[j];
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vb + (int64_t)(k0 + j) * a.v_ss);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += p * (float)vv[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    if (sub == 0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) opart[wave][ch * 8 + e] = acc[e];
+    __syncthreads();
+    for (int d = tid; d < HD; d += 256) out[2 + d] = opart[0][d] + opart[1][d] + opart[2][d] + opart[3][d];
+    if (tid == 0) { out[0] = mx; out[1] = sum; }
+}
+
+template <int HD>
+__global__ void attn_decode_combine(const float* ws, bf16* o, int64_t o_bs, int Hq, int nsplit) {
+    const int hq = blockIdx.x, b = blockIdx.y;
+    const float* base = ws + (size_t)(b * Hq + hq) * nsplit * (HD + 2);
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, base[s * (HD + 2)]);
+    for (int d = threadIdx.x; d < HD; d += blockDim.x) {
+        float num = 0.f, den = 0.f;
+        for (int s = 0; s < nsplit; ++s) {
+            const float* p = base + s * (HD + 2);
+            const float w = (p[0] == -INFINITY) ? 0.f : __expf(p[0] - m);
+            num += w * p[2 + d];
+            den += w * p[1];
+        }
+        o[b * o_bs + hq * HD + d] = (bf16)(num / den);
+    }
+}
+
 // ---- generic: one block per (q row, head, batch); scores in LDS -----------------------------------
 __global__ __launch_bounds__(256) void attn_generic(AttnArgs a, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
@@ -596,4 +695,41 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
     hipLaunchKernelGGL(attn_generic, dim3(Sq, Hq, B), dim3(256), smem, st, a, causal);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
+}
+
+template <int HD>
+static int launch_decode(const AttnArgs& a, float* ws, int nsplit, hipStream_t st) {
+    const int per = cdiv(a.Sk, nsplit);
+    hipLaunchKernelGGL((attn_decode_split<HD>), dim3(nsplit, a.Hq, a.B), dim3(256), per * sizeof(float), st, a, ws, nsplit);
+    hipLaunchKernelGGL((attn_decode_combine<HD>), dim3(a.Hq, a.B), dim3(HD < 64 ? 64 : HD), 0, st, ws, a.o, a.o_bs, a.Hq, nsplit);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_attention_decode_ws_bytes(int B, int Hq, int hd, int nsplit) {
+    return (int)(sizeof(float) * (size_t)B * Hq * nsplit * (hd + 2));
+}
+
+extern "C" int ufv_attention_decode(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_ss, const void* v,
+                                    int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int B, int Hq, int Hkv, int Sk, int hd,
+                                    float scale, void* ws, int nsplit, void* stream) {
+    UFV_REQUIRE(q && k && v && o && ws && B > 0 && Hq > 0 && Hkv > 0 && Sk > 0 && nsplit > 0, "ufv_attention_decode: bad arguments");
+    UFV_REQUIRE(Hq % Hkv == 0, "ufv_attention_decode: Hq must be a multiple of Hkv");
+    UFV_REQUIRE(cdiv(Sk, nsplit) * sizeof(float) <= 48 * 1024, "ufv_attention_decode: too many keys per split (Sk=%d nsplit=%d)", Sk, nsplit);
+    AttnArgs a;
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
+    a.q_bs = q_bs; a.q_ss = 0; a.k_bs = k_bs; a.k_ss = k_ss; a.v_bs = v_bs; a.v_ss = v_ss; a.o_bs = o_bs; a.o_ss = 0;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = 1; a.Sk = Sk; a.hd = hd; a.scale = scale; a.q_pos0 = Sk - 1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && (k_ss % 8 == 0) &&
+                         (v_ss % 8 == 0) && (k_bs % 8 == 0) && (v_bs % 8 == 0) && (q_bs % 8 == 0);
+    UFV_REQUIRE(aligned, "ufv_attention_decode: q/k/v rows must be 16-byte aligned");
+    switch (hd) {
+        case 16: return launch_decode<16>(a, (float*)ws, nsplit, st);
+        case 32: return launch_decode<32>(a, (float*)ws, nsplit, st);
+        case 64: return launch_decode<64>(a, (float*)ws, nsplit, st);
+        case 128: return launch_decode<128>(a, (float*)ws, nsplit, st);
+    }
+    ufv_set_error("ufv_attention_decode: head_dim %d not supported (16/32/64/128)", hd);
+    return UFV_EUNSUPPORTED;
 }

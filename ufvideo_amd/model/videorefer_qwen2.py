@@ -16,7 +16,9 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from .. import ops
+import ctypes
+
+from .. import ops, _lib
 from ._params import Holder, PackedModule, init_tensor, bf, f32, pad_rows, round_up
 from .videorefer_arch import VideoReferMetaModel, VideoReferMetaForCausalLM
 
@@ -348,29 +350,50 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         eos = set(eos) if isinstance(eos, (list, tuple)) else ({eos} if eos is not None else set())
         dev = inputs_embeds.device
         S = inputs_embeds.shape[1] if attention_mask is None else int(attention_mask[0].sum().item())
-        width = 2 * self.config.num_key_value_heads * self.config.head_dim
-        cache = KVCache(self.config.num_hidden_layers, S + max_new_tokens + 8, width, dev)
+        cfg = self.config
+        width = 2 * cfg.num_key_value_heads * cfg.head_dim
+        cache = KVCache(cfg.num_hidden_layers, S + max_new_tokens + 8, width, dev)
         logits, cache, _, normed = self._decode_batch(inputs_embeds, attention_mask, cache, False, 1)
         hidden_steps = [normed]
         tokens = []
-        tok_buf = torch.empty((1,), device=dev, dtype=torch.int64)
-        table = self.model.embed_table()
-        D = self.config.hidden_size
-        for step in range(max_new_tokens):
-            ops.argmax(logits.view(-1), out=tok_buf)
-            t = int(tok_buf.item())
+        tok = torch.empty((1,), device=dev, dtype=torch.int64)
+        nxt = torch.empty((1,), device=dev, dtype=torch.int64)
+        ops.argmax(logits.view(-1), out=tok)
+        step = self._decode_step_ctx(cache)
+        for i in range(max_new_tokens):
+            t = int(tok.item())                                   # the only host<->device sync per token
             tokens.append(t)
             done = t in eos
             if not done and stopping_criteria:
                 ids = torch.tensor([tokens], dtype=torch.long, device=dev)
                 done = any(bool(c(ids, None)) for c in stopping_criteria)
-            if done or step == max_new_tokens - 1:
+            if done or i == max_new_tokens - 1:
                 break
-            e = torch.empty((1, D), device=dev, dtype=torch.float32)
-            ops.gather_rows(table, tok_buf, e, None)
-            logits, cache, _, normed = self._decode_batch(e.view(1, 1, D), None, cache, False, 1)
-            hidden_steps.append(normed)
+            hid = torch.empty((1, cfg.hidden_size), device=dev, dtype=torch.float32)
+            _lib.call("ufv_qwen2_decode_step", ctypes.byref(step["model"]), tok.data_ptr(), cache.len, step["ws"].data_ptr(),
+                      step["ws"].numel(), step["logits"].data_ptr(), hid.data_ptr(), nxt.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream)
+            cache.len += 1
+            hidden_steps.append(hid)
+            tok, nxt = nxt, tok
         return {"sequences": torch.tensor([tokens], dtype=torch.long, device=dev), "hidden_last": hidden_steps, "cache": cache}
+
+    def _decode_step_ctx(self, cache):
+        """ctypes view of the packed decoder + this generation's KV cache for ufv_qwen2_decode_step (include/ufv.h)."""
+        cfg, pk, head = self.config, self.model.packed(), self.packed()
+        L = cfg.num_hidden_layers
+        layers = (_lib.Qwen2Layer * L)()
+        for i, w in enumerate(pk["layers"]):
+            layers[i] = _lib.Qwen2Layer(w["wqkv"].data_ptr(), w["bqkv"].data_ptr(), w["wo"].data_ptr(), w["wgu"].data_ptr(),
+                                        w["wd"].data_ptr(), w["ln1"].data_ptr(), w["ln2"].data_ptr(), cache.buf[i].data_ptr())
+        m = _lib.Qwen2Model(n_layers=L, d=cfg.hidden_size, n_q=cfg.num_attention_heads, n_kv=cfg.num_key_value_heads, hd=cfg.head_dim,
+                            d_ff=cfg.intermediate_size, vocab=head["V"], ldkv=cache.buf[0].stride(0), max_len=cache.max_len,
+                            attn_splits=16, eps=cfg.rms_norm_eps, inv_freq=pk["inv_freq"].data_ptr(), norm=pk["norm"].data_ptr(),
+                            embed=pk["embed"].data_ptr(), lm_head=head["lm_head"].data_ptr(), layers=layers)
+        nbytes = _lib.load().ufv_qwen2_decode_ws_bytes(ctypes.byref(m))
+        dev = cache.buf[0].device
+        return {"model": m, "layers": layers, "ws": torch.empty((nbytes,), device=dev, dtype=torch.uint8),
+                "logits": torch.empty((head["V"],), device=dev, dtype=torch.float32)}
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
         images = kwargs.pop("images", None)

@@ -92,6 +92,18 @@ def attention(q, k, v, B, Hq, Hkv, Sq, Sk, hd, q_strides, k_strides, v_strides, 
     return out
 
 
+def attention_decode(q, k, v, Hq, Hkv, Sk, hd, k_ss, v_ss, scale=None, nsplit=16, out=None, ws=None):
+    """One query token (q [1, Hq*hd] bf16) against Sk cached keys/values (token stride k_ss/v_ss elements)."""
+    if out is None:
+        out = torch.empty((1, Hq * hd), device=q.device, dtype=torch.bfloat16)
+    if ws is None:
+        ws = torch.empty((_lib.load().ufv_attention_decode_ws_bytes(1, Hq, hd, nsplit),), device=q.device, dtype=torch.uint8)
+    scale = hd ** -0.5 if scale is None else scale
+    _lib.call("ufv_attention_decode", q.data_ptr(), 0, k.data_ptr(), 0, k_ss, v.data_ptr(), 0, v_ss, out.data_ptr(), 0, 1, Hq, Hkv,
+              Sk, hd, float(scale), ws.data_ptr(), nsplit, _stream())
+    return out
+
+
 def rope_kv(qkv, S, Hq, Hkv, hd, inv_freq, pos0, kv_cache):
     _chk(qkv, torch.bfloat16, "qkv"); _chk(kv_cache, torch.bfloat16, "kv_cache"); _chk(inv_freq, torch.float32, "inv_freq")
     _lib.call("ufv_rope_kv", qkv.data_ptr(), qkv.stride(0), S, Hq, Hkv, hd, inv_freq.data_ptr(), pos0, kv_cache.data_ptr(),
