@@ -124,6 +124,18 @@ int ufv_gather_rows(const void* src, int src_dtype, int64_t ld_src, const int64_
 int ufv_mask_pool(const void* feat, int feat_dtype, const float* mask, const int32_t* frame_of, float* out, int q, int P,
                   int C, void* stream);
 
+/* ---- SAM2 image-encoder pieces (ufvideo/model/sam2.py) -------------------------------------------------------- */
+/* general Conv2d im2col (Hiera PatchEmbed 7x7/s4/p3, sam2.py:954-984): pixels [B,C,H,W] -> bf16 [B*Ho*Wo, Kpad] */
+int ufv_im2col(const void* pixels, int dtype, void* out, int B, int C, int H, int W, int ks, int stride, int pad, int Kpad,
+               void* stream);
+/* MaxPool2d(2,2) over a token grid (Hiera q-pooling / pooled shortcut, sam2.py:986-998): rows [Bw*H*W] x C, f32 or bf16 */
+int ufv_maxpool2x2(const void* x, int dtype, int64_t ldx, void* out, int64_t ldo, int Bw, int H, int W, int C, void* stream);
+/* dst[dst_idx[i]] += src[i] (window un-partition + residual add, sam2.py:927-951,1126); dst f32, idx<0 = padding */
+int ufv_add_rows(const void* src, int src_dtype, int64_t ld_src, float* dst, int64_t ld_dst, const int64_t* dst_idx, int n, int D,
+                 void* stream);
+/* FPN top-down path, nearest x2 (sam2.py:885-896): x[b,y,x,:] += prev[b,y/2,x/2,:], f32 NHWC */
+int ufv_upsample2x_add(float* x, const float* prev, int B, int H, int W, int C, void* stream);
+
 /* greedy sampling: out[0] = argmax(logits[0..N)) with torch.argmax tie-breaking (lowest index) */
 int ufv_argmax(const float* logits, int N, int64_t* out, void* stream);
 

@@ -616,3 +616,179 @@ def make_qwen2_weights(cfg: dict, seed: int = 2, std: float = 0.02) -> SD:
         sd[p + "input_layernorm.weight"] = 1.0 + _randn(g, D, std=std)
         sd[p + "post_attention_layernorm.weight"] = 1.0 + _randn(g, D, std=std)
     return sd
+
+
+# --------------------------------------------------------------------------------------
+# SAM2 image encoder: Hiera trunk + FPN neck  (ufvideo/model/sam2.py:784-1258, 1736-1797)
+# --------------------------------------------------------------------------------------
+def hiera_schedule(cfg: dict):
+    """Per-block (dim, dim_out, heads, window, q_stride) exactly as Hiera.__init__ derives them (sam2.py:1167-1226)."""
+    stages, window_spec = cfg["stages"], cfg["window_spec"]
+    depth = sum(stages)
+    stage_ends = [sum(stages[:i]) - 1 for i in range(1, len(stages) + 1)]
+    q_pool_blocks = [x + 1 for x in stage_ends[:-1]][:cfg.get("q_pool", 3)]
+    glob = cfg.get("global_att_blocks", ())
+    embed_dim, heads, cur_stage = cfg["embed_dim"], cfg["num_heads"], 1
+    blocks = []
+    for i in range(depth):
+        dim_out = embed_dim
+        window = window_spec[cur_stage - 1]            # lags one block behind the stage change
+        if glob is not None and i in glob:
+            window = 0
+        if i - 1 in stage_ends:
+            dim_out = int(embed_dim * cfg.get("dim_mul", 2.0))
+            heads = int(heads * cfg.get("head_mul", 2.0))
+            cur_stage += 1
+        blocks.append(dict(dim=embed_dim, dim_out=dim_out, heads=heads, window=window, q_stride=2 if i in q_pool_blocks else 0))
+        embed_dim = dim_out
+    return blocks, stage_ends
+
+
+def _window_partition(x, ws):
+    B, H, W, C = x.shape
+    ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+    if ph or pw:
+        x = F.pad(x, (0, 0, 0, pw, 0, ph))
+    Hp, Wp = H + ph, W + pw
+    x = x.view(B, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws, ws, C)
+    return x, (Hp, Wp)
+
+
+def _window_unpartition(w, ws, pad_hw, hw):
+    Hp, Wp = pad_hw
+    H, W = hw
+    B = w.shape[0] // (Hp * Wp // ws // ws)
+    x = w.view(B, Hp // ws, Wp // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, -1)
+    return x[:, :H, :W, :]
+
+
+def hiera_block(sd: SD, p: str, x: torch.Tensor, blk: dict) -> torch.Tensor:
+    """MultiScaleBlock.forward (sam2.py:1099-1131); x [B,H,W,C]."""
+    dim, dim_out, heads, ws, qs = blk["dim"], blk["dim_out"], blk["heads"], blk["window"], blk["q_stride"]
+    pool = (lambda t: F.max_pool2d(t.permute(0, 3, 1, 2), qs, qs).permute(0, 2, 3, 1)) if qs else (lambda t: t)
+    shortcut = x
+    x = F.layer_norm(x, (dim,), _g(sd, p, "norm1.weight"), _g(sd, p, "norm1.bias"), 1e-6)
+    if dim != dim_out:
+        shortcut = pool(F.linear(x, _g(sd, p, "proj.weight"), _g(sd, p, "proj.bias")))
+    H, W = x.shape[1], x.shape[2]
+    pad_hw = (H, W)
+    if ws > 0:
+        x, pad_hw = _window_partition(x, ws)
+    B, h, w, _ = x.shape
+    qkv = F.linear(x, _g(sd, p, "attn.qkv.weight"), _g(sd, p, "attn.qkv.bias")).reshape(B, h * w, 3, heads, -1)
+    q, k, v = torch.unbind(qkv, 2)
+    if qs:
+        q = pool(q.reshape(B, h, w, -1))
+        h, w = q.shape[1:3]
+        q = q.reshape(B, h * w, heads, -1)
+    hd = q.shape[-1]
+    att = torch.softmax((q.transpose(1, 2) @ k.transpose(1, 2).transpose(-1, -2)) * hd ** -0.5, dim=-1)
+    o = (att @ v.transpose(1, 2)).transpose(1, 2).reshape(B, h, w, -1)
+    o = F.linear(o, _g(sd, p, "attn.proj.weight"), _g(sd, p, "attn.proj.bias"))
+    if qs:
+        ws2 = ws // qs
+        H, W = shortcut.shape[1:3]
+        pad_hw = (H + (ws2 - H % ws2) % ws2, W + (ws2 - W % ws2) % ws2) if ws2 > 0 else (H, W)
+        if ws > 0:
+            o = _window_unpartition(o, ws2, pad_hw, (H, W))
+    elif ws > 0:
+        o = _window_unpartition(o, ws, pad_hw, (H, W))
+    x = shortcut + o
+    h2 = F.layer_norm(x, (dim_out,), _g(sd, p, "norm2.weight"), _g(sd, p, "norm2.bias"), 1e-6)
+    h2 = F.gelu(F.linear(h2, _g(sd, p, "mlp.layers.0.weight"), _g(sd, p, "mlp.layers.0.bias")))
+    return x + F.linear(h2, _g(sd, p, "mlp.layers.1.weight"), _g(sd, p, "mlp.layers.1.bias"))
+
+
+def hiera_pos_embed(sd: SD, p: str, hw) -> torch.Tensor:
+    """Hiera._get_pos_embed (sam2.py:1232-1241) -> [1, h, w, C]."""
+    pe = F.interpolate(_g(sd, p, "pos_embed"), size=hw, mode="bicubic")
+    win = _g(sd, p, "pos_embed_window")
+    pe = pe + win.tile([x // y for x, y in zip(pe.shape, win.shape)])
+    return pe.permute(0, 2, 3, 1)
+
+
+def hiera_forward(sd: SD, cfg: dict, img: torch.Tensor, prefix: str = "") -> List[torch.Tensor]:
+    """Hiera.forward (sam2.py:1243-1258): stage-end features, NCHW, highest resolution first."""
+    p = prefix
+    x = F.conv2d(img.float(), _g(sd, p, "patch_embed.proj.weight"), _g(sd, p, "patch_embed.proj.bias"), stride=4, padding=3)
+    x = x.permute(0, 2, 3, 1)
+    x = x + hiera_pos_embed(sd, p, x.shape[1:3])
+    blocks, stage_ends = hiera_schedule(cfg)
+    outs = []
+    for i, blk in enumerate(blocks):
+        x = hiera_block(sd, f"{p}blocks.{i}.", x, blk)
+        if i in stage_ends:
+            outs.append(x.permute(0, 3, 1, 2))
+    return outs
+
+
+def position_embedding_sine(shape_bchw, num_pos_feats: int = 256, temperature: float = 10000.0) -> torch.Tensor:
+    """PositionEmbeddingSine.forward with normalize=True, scale=2*pi (sam2.py:1797-1830)."""
+    B, _, H, W = shape_bchw
+    npf = num_pos_feats // 2
+    y = torch.arange(1, H + 1, dtype=torch.float32).view(1, -1, 1).repeat(B, 1, W)
+    x = torch.arange(1, W + 1, dtype=torch.float32).view(1, 1, -1).repeat(B, H, 1)
+    eps, scale = 1e-6, 2 * math.pi
+    y = y / (y[:, -1:, :] + eps) * scale
+    x = x / (x[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(npf, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / npf)
+    px, py = x[:, :, :, None] / dim_t, y[:, :, :, None] / dim_t
+    px = torch.stack((px[:, :, :, 0::2].sin(), px[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[:, :, :, 0::2].sin(), py[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3).permute(0, 3, 1, 2)
+
+
+def fpn_neck(sd: SD, feats: List[torch.Tensor], prefix: str = "", top_down_levels=(2, 3), d_model: int = 256):
+    """FpnNeck.forward, nearest top-down, fuse 'sum' (sam2.py:871-903).  feats: highest resolution first.
+    Returns (out, pos) lists in the same order."""
+    n = len(feats) - 1
+    out, pos, prev = [None] * len(feats), [None] * len(feats), None
+    for i in range(n, -1, -1):
+        lat = F.conv2d(feats[i], _g(sd, prefix, f"convs.{n - i}.conv.weight"), _g(sd, prefix, f"convs.{n - i}.conv.bias"))
+        if i in top_down_levels and prev is not None:
+            prev = lat + F.interpolate(prev.float(), scale_factor=2.0, mode="nearest")
+        else:
+            prev = lat
+        out[i] = prev
+        pos[i] = position_embedding_sine(prev.shape, d_model)
+    return out, pos
+
+
+def sam2_image_encoder(sd: SD, cfg: dict, img: torch.Tensor, prefix: str = "", scalp: int = 1):
+    """ImageEncoder.forward (sam2.py:798-812)."""
+    feats, pos = fpn_neck(sd, hiera_forward(sd, cfg, img, prefix + "trunk."), prefix + "neck.", cfg.get("fpn_top_down_levels", (2, 3)),
+                          cfg.get("d_model", 256))
+    if scalp > 0:
+        feats, pos = feats[:-scalp], pos[:-scalp]
+    return {"vision_features": feats[-1], "vision_pos_enc": pos, "backbone_fpn": feats}
+
+
+def make_hiera_weights(cfg: dict, seed: int = 20, prefix: str = "trunk.", std: float = 0.02) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    blocks, _ = hiera_schedule(cfg)
+    E = cfg["embed_dim"]
+    bs = cfg.get("window_pos_embed_bkg_spatial_size", (7, 7))
+    sd = {prefix + "patch_embed.proj.weight": _randn(g, E, 3, 7, 7, std=0.05), prefix + "patch_embed.proj.bias": _randn(g, E, std=std),
+          prefix + "pos_embed": _randn(g, 1, E, *bs, std=std), prefix + "pos_embed_window": _randn(g, 1, E, cfg["window_spec"][0], cfg["window_spec"][0], std=std)}
+    for i, b in enumerate(blocks):
+        p = f"{prefix}blocks.{i}."
+        d, do = b["dim"], b["dim_out"]
+        sd[p + "norm1.weight"] = 1 + _randn(g, d, std=std); sd[p + "norm1.bias"] = _randn(g, d, std=std)
+        sd[p + "attn.qkv.weight"] = _randn(g, 3 * do, d, std=std); sd[p + "attn.qkv.bias"] = _randn(g, 3 * do, std=std)
+        sd[p + "attn.proj.weight"] = _randn(g, do, do, std=std); sd[p + "attn.proj.bias"] = _randn(g, do, std=std)
+        sd[p + "norm2.weight"] = 1 + _randn(g, do, std=std); sd[p + "norm2.bias"] = _randn(g, do, std=std)
+        sd[p + "mlp.layers.0.weight"] = _randn(g, 4 * do, do, std=std); sd[p + "mlp.layers.0.bias"] = _randn(g, 4 * do, std=std)
+        sd[p + "mlp.layers.1.weight"] = _randn(g, do, 4 * do, std=std); sd[p + "mlp.layers.1.bias"] = _randn(g, do, std=std)
+        if d != do:
+            sd[p + "proj.weight"] = _randn(g, do, d, std=std); sd[p + "proj.bias"] = _randn(g, do, std=std)
+    return sd
+
+
+def make_fpn_weights(channel_list, d_model=256, seed=21, prefix="neck.", std=0.02) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for i, c in enumerate(channel_list):
+        sd[prefix + f"convs.{i}.conv.weight"] = _randn(g, d_model, c, 1, 1, std=std)
+        sd[prefix + f"convs.{i}.conv.bias"] = _randn(g, d_model, std=std)
+    return sd

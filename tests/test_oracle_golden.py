@@ -165,3 +165,23 @@ def test_kv_cache_decode_equals_full_forward():
     pre = O.qwen2_forward(sd, TINY_LLM, x[:, :10])
     step = O.qwen2_forward(sd, TINY_LLM, x[:, 10:], past=pre["past"])
     assert rel_err(step["logits"][0, -1], full["logits"][0, -1]) < 1e-5
+
+
+def test_sam2_image_encoder_tiny():
+    """Hiera trunk + FPN neck restatement vs the reference's own classes (oracle/gen_fixtures_sam2.py)."""
+    a, w = load_golden("sam2_encoder_tiny")
+    cfg = dict(embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4),
+               window_pos_embed_bkg_spatial_size=(7, 7), d_model=32)
+    x = t(a["x"])
+    stages = O.hiera_forward(w, cfg, x, prefix="trunk.")
+    for i, s in enumerate(stages):
+        assert rel_err(s, t(a[f"stage{i}"])) < 3e-5
+    out = O.sam2_image_encoder(w, cfg, x)
+    for i, f in enumerate(out["backbone_fpn"]):
+        assert rel_err(f, t(a[f"fpn{i}"])) < 3e-5
+    assert rel_err(out["vision_pos_enc"][0], t(a["pos0"])) < 1e-6
+    blocks, ends = O.hiera_schedule(dict(embed_dim=144, num_heads=2, stages=(2, 6, 36, 4), global_att_blocks=(23, 33, 43),
+                                         window_spec=(8, 4, 16, 8)))
+    assert ends == [1, 7, 43, 47] and [b["q_stride"] for b in blocks].count(2) == 3
+    assert {b["dim_out"] // b["heads"] for b in blocks} == {72}                   # SURVEY F5: head_dim 72 at every stage
+    assert [blocks[i]["window"] for i in (0, 2, 8, 23, 44)] == [8, 8, 4, 0, 16]

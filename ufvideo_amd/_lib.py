@@ -31,6 +31,10 @@ SIGNATURES = {
     "ufv_argmax": [_p, _i, _p, _p],
     "ufv_preprocess_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
     "ufv_convert": [_p, _i, _p, _i, _l, _p],
+    "ufv_im2col": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ufv_maxpool2x2": [_p, _i, _l, _p, _l, _i, _i, _i, _i, _p],
+    "ufv_add_rows": [_p, _i, _l, _p, _l, _p, _i, _i, _p],
+    "ufv_upsample2x_add": [_p, _p, _i, _i, _i, _i, _p],
     "ufv_attention_decode": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
 }

@@ -383,9 +383,11 @@ __global__ __launch_bounds__(256) void gather_rows_k(const void* src, int64_t ld
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= n) return;
     const int64_t sr = sidx ? sidx[r] : r, dr = didx ? didx[r] : r;
+    if (dr < 0) return;
     for (int c = lane; c < D; c += 64) {
         float v;
-        if (SDT == UFV_DT_F32) v = reinterpret_cast<const float*>(src)[sr * lds_ + c];
+        if (sr < 0) v = 0.f;                      // padding row (window partition past the image edge)
+        else if (SDT == UFV_DT_F32) v = reinterpret_cast<const float*>(src)[sr * lds_ + c];
         else if (SDT == UFV_DT_BF16) v = (float)reinterpret_cast<const bf16*>(src)[sr * lds_ + c];
         else v = (float)reinterpret_cast<const _Float16*>(src)[sr * lds_ + c];
         if (DF32) reinterpret_cast<float*>(dst)[dr * ldd + c] = v;
@@ -475,6 +477,80 @@ __global__ __launch_bounds__(256) void convert_k(const void* s, void* d, int64_t
         if (DDT == UFV_DT_F32) reinterpret_cast<float*>(d)[i] = v;
         else if (DDT == UFV_DT_BF16) reinterpret_cast<bf16*>(d)[i] = (bf16)v;
         else reinterpret_cast<_Float16*>(d)[i] = (_Float16)v;
+    }
+}
+
+// general im2col for Conv2d(k, stride, pad): pixels [B,C,H,W] -> bf16 [B*Ho*Wo, Kpad], k = c*ks*ks + ky*ks + kx
+template <int DT>
+__global__ __launch_bounds__(256) void im2col_k(const void* px, bf16* out, int B, int C, int H, int W, int ks, int stride, int pad,
+                                                int Ho, int Wo, int Kpad) {
+    const int K = C * ks * ks;
+    const int64_t total = (int64_t)B * Ho * Wo * Kpad;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int k = id % Kpad;
+        const int64_t row = id / Kpad;
+        float v = 0.f;
+        if (k < K) {
+            const int kx = k % ks, ky = (k / ks) % ks, c = k / (ks * ks);
+            const int ox = row % Wo, oy = (row / Wo) % Ho, b = row / ((int64_t)Wo * Ho);
+            const int y = oy * stride + ky - pad, x = ox * stride + kx - pad;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                const int64_t src = (((int64_t)b * C + c) * H + y) * W + x;
+                if (DT == UFV_DT_F32) v = reinterpret_cast<const float*>(px)[src];
+                else if (DT == UFV_DT_BF16) v = (float)reinterpret_cast<const bf16*>(px)[src];
+                else v = (float)reinterpret_cast<const _Float16*>(px)[src];
+            }
+        }
+        out[id] = (bf16)v;
+    }
+}
+
+// 2x2/s2 max pool over a token grid: x rows [Bw*H*W] (pitch ldx) x C -> out rows [Bw*(H/2)*(W/2)] (pitch ldo)
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool2x2_k(const void* x, int64_t ldx, void* out, int64_t ldo, int Bw, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)Bw * Ho * Wo * C;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int c = id % C;
+        const int64_t r = id / C;
+        const int ox = r % Wo, oy = (r / Wo) % Ho, b = r / ((int64_t)Wo * Ho);
+        const int64_t r00 = ((int64_t)b * H + 2 * oy) * W + 2 * ox;
+        float m;
+        if (DT == UFV_DT_F32) {
+            const float* p = reinterpret_cast<const float*>(x);
+            m = fmaxf(fmaxf(p[r00 * ldx + c], p[(r00 + 1) * ldx + c]), fmaxf(p[(r00 + W) * ldx + c], p[(r00 + W + 1) * ldx + c]));
+            reinterpret_cast<float*>(out)[r * ldo + c] = m;
+        } else {
+            const bf16* p = reinterpret_cast<const bf16*>(x);
+            m = fmaxf(fmaxf((float)p[r00 * ldx + c], (float)p[(r00 + 1) * ldx + c]),
+                      fmaxf((float)p[(r00 + W) * ldx + c], (float)p[(r00 + W + 1) * ldx + c]));
+            reinterpret_cast<bf16*>(out)[r * ldo + c] = (bf16)m;
+        }
+    }
+}
+
+// dst[didx[i]][:] += src[i][:]  (fp32 dst; rows with didx < 0 are padding and skipped); one wave per row
+template <int SDT>
+__global__ __launch_bounds__(256) void add_rows_k(const void* src, int64_t lds_, float* dst, int64_t ldd, const int64_t* didx, int n, int D) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const int64_t dr = didx ? didx[r] : r;
+    if (dr < 0) return;
+    for (int c = lane; c < D; c += 64) {
+        const float v = (SDT == UFV_DT_F32) ? reinterpret_cast<const float*>(src)[(int64_t)r * lds_ + c]
+                                            : (float)reinterpret_cast<const bf16*>(src)[(int64_t)r * lds_ + c];
+        dst[dr * ldd + c] += v;
+    }
+}
+
+// FPN top-down: x[b, y, x, :] += prev[b, y/2, x/2, :]   (nearest x2 upsample, fp32 NHWC)
+__global__ __launch_bounds__(256) void upsample2x_add_k(float* x, const float* prev, int B, int H, int W, int C) {
+    const int64_t total = (int64_t)B * H * W * C;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int c = id % C;
+        const int64_t r = id / C;
+        const int xx = r % W, yy = (r / W) % H, b = r / ((int64_t)W * H);
+        x[id] += prev[(((int64_t)b * (H / 2) + yy / 2) * (W / 2) + xx / 2) * C + c];
     }
 }
 
@@ -642,6 +718,49 @@ extern "C" int ufv_convert(const void* src, int sd, void* dst, int dd, int64_t n
         case 6: CV(2, 0); break; case 7: CV(2, 1); break; case 8: CV(2, 2); break;
     }
 #undef CV
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_im2col(const void* pixels, int dtype, void* out, int B, int C, int H, int W, int ks, int stride, int pad, int Kpad,
+                          void* stream) {
+    UFV_REQUIRE(pixels && out && B > 0 && ks > 0 && stride > 0 && Kpad >= C * ks * ks, "ufv_im2col: bad arguments");
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    UFV_REQUIRE(Ho > 0 && Wo > 0, "ufv_im2col: empty output");
+    dim3 g(grid_for((int64_t)B * Ho * Wo * Kpad)), blk(256);
+    if (dtype == UFV_DT_F32) hipLaunchKernelGGL((im2col_k<UFV_DT_F32>), g, blk, 0, ST(stream), pixels, (bf16*)out, B, C, H, W, ks, stride, pad, Ho, Wo, Kpad);
+    else if (dtype == UFV_DT_BF16) hipLaunchKernelGGL((im2col_k<UFV_DT_BF16>), g, blk, 0, ST(stream), pixels, (bf16*)out, B, C, H, W, ks, stride, pad, Ho, Wo, Kpad);
+    else if (dtype == UFV_DT_F16) hipLaunchKernelGGL((im2col_k<UFV_DT_F16>), g, blk, 0, ST(stream), pixels, (bf16*)out, B, C, H, W, ks, stride, pad, Ho, Wo, Kpad);
+    else { ufv_set_error("ufv_im2col: unsupported dtype %d", dtype); return UFV_EINVAL; }
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_maxpool2x2(const void* x, int dtype, int64_t ldx, void* out, int64_t ldo, int Bw, int H, int W, int C, void* stream) {
+    UFV_REQUIRE(x && out && Bw > 0 && H >= 2 && W >= 2 && C > 0, "ufv_maxpool2x2: bad arguments");
+    dim3 g(grid_for((int64_t)Bw * (H / 2) * (W / 2) * C)), blk(256);
+    if (dtype == UFV_DT_F32) hipLaunchKernelGGL((maxpool2x2_k<UFV_DT_F32>), g, blk, 0, ST(stream), x, ldx, out, ldo, Bw, H, W, C);
+    else if (dtype == UFV_DT_BF16) hipLaunchKernelGGL((maxpool2x2_k<UFV_DT_BF16>), g, blk, 0, ST(stream), x, ldx, out, ldo, Bw, H, W, C);
+    else { ufv_set_error("ufv_maxpool2x2: unsupported dtype %d", dtype); return UFV_EINVAL; }
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_add_rows(const void* src, int src_dtype, int64_t ld_src, float* dst, int64_t ld_dst, const int64_t* dst_idx, int n, int D,
+                            void* stream) {
+    if (n == 0) return UFV_OK;
+    UFV_REQUIRE(src && dst && n > 0 && D > 0, "ufv_add_rows: bad arguments");
+    dim3 g(cdiv(n, 4)), blk(256);
+    if (src_dtype == UFV_DT_F32) hipLaunchKernelGGL((add_rows_k<UFV_DT_F32>), g, blk, 0, ST(stream), src, ld_src, dst, ld_dst, dst_idx, n, D);
+    else if (src_dtype == UFV_DT_BF16) hipLaunchKernelGGL((add_rows_k<UFV_DT_BF16>), g, blk, 0, ST(stream), src, ld_src, dst, ld_dst, dst_idx, n, D);
+    else { ufv_set_error("ufv_add_rows: unsupported dtype %d", src_dtype); return UFV_EINVAL; }
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_upsample2x_add(float* x, const float* prev, int B, int H, int W, int C, void* stream) {
+    UFV_REQUIRE(x && prev && B > 0 && H % 2 == 0 && W % 2 == 0, "ufv_upsample2x_add: bad arguments");
+    hipLaunchKernelGGL(upsample2x_add_k, dim3(grid_for((int64_t)B * H * W * C)), dim3(256), 0, ST(stream), x, prev, B, H, W, C);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }

@@ -6,6 +6,7 @@ import torch
 from .encoder import build_vision_tower, SiglipVisionTower, CLIPVisionTower, VisionConfig  # noqa: F401
 from .layer import MaskExtractor, token_merge, build_region_encoder  # noqa: F401
 from .projector import build_vision_projector, load_mm_projector, STCConnector, STCConnectorV35, SpatialConv  # noqa: F401
+from .sam2 import Hiera, FpnNeck, ImageEncoder, PositionEmbeddingSine, build_sam2_image_encoder  # noqa: F401
 from .videorefer_qwen2 import (VideoReferQwen2Config, VideoReferQwen2Model, VideoReferQwen2ForCausalLM,  # noqa: F401
                                UFVideoForCausalLM, KVCache, QWEN2_7B)
 

@@ -167,6 +167,37 @@ def mask_pool(feat, mask, frame_of):
     return out
 
 
+def im2col(pixels, ks, stride, pad, Kpad):
+    _chk(pixels, name="pixels"); assert pixels.is_contiguous()
+    B, Cc, H, W = pixels.shape
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    out = torch.empty((B * Ho * Wo, Kpad), device=pixels.device, dtype=torch.bfloat16)
+    _lib.call("ufv_im2col", pixels.data_ptr(), _DT[pixels.dtype], out.data_ptr(), B, Cc, H, W, ks, stride, pad, Kpad, _stream())
+    return out, (Ho, Wo)
+
+
+def maxpool2x2(x, Bw, H, W, C, out=None):
+    """x rows [Bw*H*W] (any row pitch) -> [Bw*(H/2)*(W/2), C] same dtype"""
+    if out is None:
+        out = torch.zeros((Bw * (H // 2) * (W // 2), x.shape[1] if x.shape[1] >= C else C), device=x.device, dtype=x.dtype)
+    _lib.call("ufv_maxpool2x2", x.data_ptr(), _DT[x.dtype], x.stride(0), out.data_ptr(), out.stride(0), Bw, H, W, C, _stream())
+    return out
+
+
+def add_rows(src, dst, dst_idx, D=None):
+    _chk(dst, torch.float32, "dst")
+    n = src.shape[0]
+    _lib.call("ufv_add_rows", src.data_ptr(), _DT[src.dtype], src.stride(0), dst.data_ptr(), dst.stride(0), _ptr(dst_idx), n,
+              D if D is not None else src.shape[1], _stream())
+    return dst
+
+
+def upsample2x_add(x, prev, B, H, W, C):
+    _chk(x, torch.float32, "x"); _chk(prev, torch.float32, "prev")
+    _lib.call("ufv_upsample2x_add", x.data_ptr(), prev.data_ptr(), B, H, W, C, _stream())
+    return x
+
+
 def argmax(logits, out=None):
     _chk(logits, torch.float32, "logits")
     if out is None:
