@@ -76,7 +76,8 @@ int ufv_rmsnorm(const float* x, int ldx, void* y, int y_f32, int ldy, const floa
 /* softmax(q k^T * scale [+ causal]) v, flash-style, fp32 softmax (modeling_siglip.py:227-247,
  * modeling_qwen2.py:150-172).  q/k/v/o bf16; element (b, s, h, d) of X lives at
  * X + b*x_bs + s*x_ss + h*hd + d.  Hq % Hkv == 0 (GQA).  causal: key j visible to query i iff
- * j <= q_pos0 + i.  kernel: 0 auto, 1 MFMA kernel (hd in {64,72,80,96,128}), 2 generic. */
+ * j <= q_pos0 + i.  kernel: 0 auto, 1 MFMA kernel (hd in {64,72,80,96,128}), 2 generic,
+ * 5 few-keys kernel (Sk <= 64, hd 16|32, non-causal: SAM2 image->token cross attention). */
 int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const void* k, int64_t k_bs, int64_t k_ss, const void* v,
                   int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int64_t o_ss, int B, int Hq, int Hkv, int Sq,
                   int Sk, int hd, float scale, int causal, int q_pos0, int kernel, void* stream);
@@ -172,6 +173,23 @@ int64_t ufv_qwen2_decode_ws_bytes(const ufv_qwen2_model* m);
  * [vocab], optional hidden_out f32 [d] (final-norm hidden state), next_token_dev = argmax. */
 int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* token_dev, int pos, void* ws, int64_t ws_bytes, float* logits,
                           float* hidden_out, int64_t* next_token_dev, void* stream);
+
+/* ---- SAM2 prompt/mask heads (sam2.py MaskDecoder.predict_masks :2094-2174, _forward_sam_heads :3276-3452) ---- */
+/* out[m,:] = a[m,:] + b[m % b_rows,:] (b may be NULL = plain convert); a/out f32|bf16, b f32.  The `queries + query_pe`
+ * / `keys + key_pe` adds of TwoWayAttentionBlock (:1384-1412) and the no_mem_embed / no_mask_embed broadcasts. */
+int ufv_add_bcast(const void* a, int a_dtype, int64_t lda, const float* b, int64_t ldb, int b_rows, void* out, int out_dtype,
+                  int64_t ldo, int64_t M, int C, void* stream);
+/* masks[b,i,Y,X] = sum_c hyper[b,i,c] * gelu(up2[b,Y/2,X/2,((Y&1)*2+(X&1))*C8+c] + s0[b,Y,X,c]): pixel shuffle of the second
+ * ConvTranspose2d (computed as a GEMM, 4 taps side by side), + feat_s0, GELU, `hyper_in @ upscaled` (:2150-2162).
+ * up2 bf16 [B*h*w, ld_up], s0 bf16 [B*2h*2w, ld_s0], hyper f32 [B,nm,C8], out f32 [B,nm,2h,2w]. */
+int ufv_sam_mask_head(const void* up2, int64_t ld_up, const void* s0, int64_t ld_s0, const float* hyper, float* out, int B, int h,
+                      int w, int C8, int nm, void* stream);
+/* F.interpolate(mode="bilinear", align_corners=False) on f32 planes [Hs,Ws] -> [Hd,Wd]; with sel != NULL image n reads
+ * plane n*planes_per + sel_off + sel[n] (best-IoU mask pick of _forward_sam_heads :3409-3421 fused into the resize). */
+int ufv_resize_bilinear(const float* src, const int32_t* sel, int planes_per, int sel_off, float* dst, int N, int Hs, int Ws, int Hd,
+                        int Wd, void* stream);
+/* out[m] = argmax_j x[m, j], j < N (torch.argmax tie-breaking) */
+int ufv_argmax_rows(const float* x, int64_t ld, int M, int N, int32_t* out, void* stream);
 
 /* elementwise convert between bf16 / f32 / f16 (n elements) */
 int ufv_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);

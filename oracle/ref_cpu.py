@@ -792,3 +792,160 @@ def make_fpn_weights(channel_list, d_model=256, seed=21, prefix="neck.", std=0.0
         sd[prefix + f"convs.{i}.conv.weight"] = _randn(g, d_model, c, 1, 1, std=std)
         sd[prefix + f"convs.{i}.conv.bias"] = _randn(g, d_model, std=std)
     return sd
+
+
+# --------------------------------------------------------------------------------------
+# SAM2 heads with a language token as sparse prompt  (sam2.py:1260-1497 two-way transformer,
+# :1565-1730 prompt encoder, :1940-2174 mask decoder, :3276-3452 _forward_sam_heads, :3174-3275 track_step)
+# --------------------------------------------------------------------------------------
+def _sam_attention(sd: SD, p: str, q, k, v, heads: int):
+    """sam2.py `Attention.forward` (:1430-1497): projections to internal_dim, SDPA, out_proj."""
+    q = F.linear(q, _g(sd, p, "q_proj.weight"), _g(sd, p, "q_proj.bias"))
+    k = F.linear(k, _g(sd, p, "k_proj.weight"), _g(sd, p, "k_proj.bias"))
+    v = F.linear(v, _g(sd, p, "v_proj.weight"), _g(sd, p, "v_proj.bias"))
+    B, Nq, C = q.shape
+    hd = C // heads
+    sp = lambda t: t.reshape(B, t.shape[1], heads, hd).transpose(1, 2)
+    att = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * hd ** -0.5, dim=-1)
+    o = (att @ sp(v)).transpose(1, 2).reshape(B, Nq, C)
+    return F.linear(o, _g(sd, p, "out_proj.weight"), _g(sd, p, "out_proj.bias"))
+
+
+def _ln(sd, p, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), _g(sd, p, "weight"), _g(sd, p, "bias"), eps)
+
+
+def _mlp(sd: SD, p: str, x, n_layers: int, sigmoid: bool = False):
+    for i in range(n_layers):
+        x = F.linear(x, _g(sd, p, f"layers.{i}.weight"), _g(sd, p, f"layers.{i}.bias"))
+        if i < n_layers - 1:
+            x = F.relu(x)
+    return torch.sigmoid(x) if sigmoid else x
+
+
+def sam_two_way_transformer(sd: SD, p: str, src, pos_src, tokens, depth: int = 2, heads: int = 8):
+    """TwoWayTransformer.forward (:1298-1333); src/pos_src [B, HW, C], tokens [B, N, C]."""
+    queries, keys = tokens, src
+    for i in range(depth):
+        lp = f"{p}layers.{i}."
+        if i == 0:                                            # skip_first_layer_pe
+            queries = _sam_attention(sd, lp + "self_attn.", queries, queries, queries, heads)
+        else:
+            q = queries + tokens
+            queries = queries + _sam_attention(sd, lp + "self_attn.", q, q, queries, heads)
+        queries = _ln(sd, lp + "norm1.", queries)
+        q, k = queries + tokens, keys + pos_src
+        queries = _ln(sd, lp + "norm2.", queries + _sam_attention(sd, lp + "cross_attn_token_to_image.", q, k, keys, heads))
+        queries = _ln(sd, lp + "norm3.", queries + _mlp(sd, lp + "mlp.", queries, 2))
+        q, k = queries + tokens, keys + pos_src
+        keys = _ln(sd, lp + "norm4.", keys + _sam_attention(sd, lp + "cross_attn_image_to_token.", k, q, queries, heads))
+    q, k = queries + tokens, keys + pos_src
+    queries = _ln(sd, p + "norm_final_attn.", queries + _sam_attention(sd, p + "final_attn_token_to_image.", q, k, keys, heads))
+    return queries, keys
+
+
+def sam_dense_pe(gauss: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """PositionEmbeddingRandom.forward (:1869-1879) -> [C, h, w]."""
+    grid = torch.ones((h, w), dtype=torch.float32)
+    y, x = (grid.cumsum(0) - 0.5) / h, (grid.cumsum(1) - 0.5) / w
+    c = (2 * torch.stack([x, y], dim=-1) - 1) @ gauss.float()
+    c = 2 * np.pi * c
+    return torch.cat([torch.sin(c), torch.cos(c)], dim=-1).permute(2, 0, 1)
+
+
+def _layernorm2d_cf(x, w, b, eps=1e-6):
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    return w[:, None, None] * ((x - u) / torch.sqrt(s + eps)) + b[:, None, None]
+
+
+def sam_heads_language(sd: SD, backbone_features, high_res_features, language_embd, image_size: int, prefix: str = ""):
+    """_forward_sam_heads (:3276-3452) for the only prompt form the reference's inference uses: one dummy point
+    (label -1) + its padding point + the language embedding, no mask prompt, multimask_output=True.
+    backbone_features [B,C,h,w]; high_res_features = [feat_s0 [B,C/8,4h,4w], feat_s1 [B,C/4,2h,2w]]; language_embd [B,1,C].
+    Returns dict(low_res_multimasks, ious, low_res_masks, high_res_masks, object_score_logits)."""
+    p, d = prefix, prefix + "sam_mask_decoder."
+    B, C, h, w = backbone_features.shape
+    nap = _g(sd, p, "sam_prompt_encoder.not_a_point_embed.weight")                       # [1, C]
+    sparse = torch.cat([nap[None].expand(B, 2, C), language_embd.float()], dim=1)       # 2 not-a-point tokens + language
+    dense = _g(sd, p, "sam_prompt_encoder.no_mask_embed.weight").reshape(1, C, 1, 1)
+    image_pe = sam_dense_pe(sd[p + "sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"], h, w)[None]
+    out_tok = torch.cat([_g(sd, d, "obj_score_token.weight"), _g(sd, d, "iou_token.weight"), _g(sd, d, "mask_tokens.weight")], 0)
+    tokens = torch.cat([out_tok[None].expand(B, -1, -1), sparse], dim=1)
+    src = (backbone_features.float() + dense).flatten(2).permute(0, 2, 1)
+    pos = image_pe.expand(B, -1, -1, -1).flatten(2).permute(0, 2, 1)
+    hs, src = sam_two_way_transformer(sd, d + "transformer.", src, pos, tokens)
+    iou_tok, mask_toks = hs[:, 1], hs[:, 2:6]
+    src = src.transpose(1, 2).reshape(B, C, h, w)
+    feat_s0, feat_s1 = high_res_features
+    up = F.conv_transpose2d(src, _g(sd, d, "output_upscaling.0.weight"), _g(sd, d, "output_upscaling.0.bias"), stride=2)
+    up = F.gelu(_layernorm2d_cf(up + feat_s1.float(), _g(sd, d, "output_upscaling.1.weight"), _g(sd, d, "output_upscaling.1.bias")))
+    up = F.gelu(F.conv_transpose2d(up, _g(sd, d, "output_upscaling.3.weight"), _g(sd, d, "output_upscaling.3.bias"), stride=2) + feat_s0.float())
+    hyper = torch.stack([_mlp(sd, d + f"output_hypernetworks_mlps.{i}.", mask_toks[:, i], 3) for i in range(4)], dim=1)
+    b, c, H, W = up.shape
+    masks = (hyper @ up.reshape(b, c, H * W)).reshape(b, -1, H, W)
+    iou = _mlp(sd, d + "iou_prediction_head.", iou_tok, 3, sigmoid=True)
+    obj = _mlp(sd, d + "pred_obj_score_head.", hs[:, 0], 3)
+    masks, iou = masks[:, 1:], iou[:, 1:]                                               # multimask_output=True
+    best = torch.argmax(iou, dim=-1)
+    bi = torch.arange(B)
+    low = masks[bi, best].unsqueeze(1)
+    high = F.interpolate(masks, size=(image_size, image_size), mode="bilinear", align_corners=False)[bi, best].unsqueeze(1)
+    return dict(low_res_multimasks=masks, ious=iou, low_res_masks=low, high_res_masks=high, object_score_logits=obj, best=best)
+
+
+def sam2_language_masks(sd: SD, cfg: dict, images, language_embd, prefix: str = ""):
+    """What `SAM2.get_sam2_embeddings` + `language_embd_inference` (sam2.py:378-410) compute for frames that are all
+    initial conditioning frames: forward_image (+conv_s0/conv_s1, :2804-2816) -> + no_mem_embed (:2980-2984) ->
+    SAM heads with the language token -> best-IoU low-res mask -> bilinear to the frame size.  images [F,3,S,S],
+    language_embd [F,1,C] -> mask logits [F,1,S,S]."""
+    p = prefix
+    enc = sam2_image_encoder(sd, cfg, images, prefix=p + "image_encoder.")
+    fpn = enc["backbone_fpn"]
+    d = p + "sam_mask_decoder."
+    s0 = F.conv2d(fpn[0], _g(sd, d, "conv_s0.weight"), _g(sd, d, "conv_s0.bias"))
+    s1 = F.conv2d(fpn[1], _g(sd, d, "conv_s1.weight"), _g(sd, d, "conv_s1.bias"))
+    pix = fpn[2] + _g(sd, p, "no_mem_embed").reshape(1, -1, 1, 1)
+    out = sam_heads_language(sd, pix, [s0, s1], language_embd, images.shape[-1], prefix=p)
+    out["video_res_masks"] = F.interpolate(out["low_res_masks"], size=images.shape[-2:], mode="bilinear", align_corners=False)
+    return out
+
+
+def make_sam_head_weights(C: int = 256, seed: int = 22, prefix: str = "", std: float = 0.05) -> SD:
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    R = lambda *s, sc=std: _randn(g, *s, std=sc)
+    def lin(p, o, i):
+        sd[p + "weight"] = R(o, i); sd[p + "bias"] = R(o)
+    def lnorm(p, n):
+        sd[p + "weight"] = 1 + R(n); sd[p + "bias"] = R(n)
+    def attn(p, internal):
+        lin(p + "q_proj.", internal, C); lin(p + "k_proj.", internal, C); lin(p + "v_proj.", internal, C); lin(p + "out_proj.", C, internal)
+    pe, d = prefix + "sam_prompt_encoder.", prefix + "sam_mask_decoder."
+    sd[pe + "pe_layer.positional_encoding_gaussian_matrix"] = R(2, C // 2, sc=1.0)
+    sd[pe + "not_a_point_embed.weight"] = R(1, C, sc=0.5); sd[pe + "no_mask_embed.weight"] = R(1, C, sc=0.5)
+    for i in range(4):
+        sd[pe + f"point_embeddings.{i}.weight"] = R(1, C)
+    sd[prefix + "no_mem_embed"] = R(1, 1, C, sc=0.2)
+    t = d + "transformer."
+    for i in range(2):
+        lp = t + f"layers.{i}."
+        attn(lp + "self_attn.", C); attn(lp + "cross_attn_token_to_image.", C // 2); attn(lp + "cross_attn_image_to_token.", C // 2)
+        for n in ("norm1.", "norm2.", "norm3.", "norm4."):
+            lnorm(lp + n, C)
+        lin(lp + "mlp.layers.0.", 2048 if C == 256 else 4 * C, C); lin(lp + "mlp.layers.1.", C, 2048 if C == 256 else 4 * C)
+    attn(t + "final_attn_token_to_image.", C // 2); lnorm(t + "norm_final_attn.", C)
+    sd[d + "iou_token.weight"] = R(1, C, sc=0.5); sd[d + "mask_tokens.weight"] = R(4, C, sc=0.5); sd[d + "obj_score_token.weight"] = R(1, C, sc=0.5)
+    sd[d + "output_upscaling.0.weight"] = R(C, C // 4, 2, 2); sd[d + "output_upscaling.0.bias"] = R(C // 4)
+    lnorm(d + "output_upscaling.1.", C // 4)
+    sd[d + "output_upscaling.3.weight"] = R(C // 4, C // 8, 2, 2); sd[d + "output_upscaling.3.bias"] = R(C // 8)
+    sd[d + "conv_s0.weight"] = R(C // 8, C, 1, 1); sd[d + "conv_s0.bias"] = R(C // 8)
+    sd[d + "conv_s1.weight"] = R(C // 4, C, 1, 1); sd[d + "conv_s1.bias"] = R(C // 4)
+    for i in range(4):
+        hp = d + f"output_hypernetworks_mlps.{i}."
+        lin(hp + "layers.0.", C, C); lin(hp + "layers.1.", C, C); lin(hp + "layers.2.", C // 8, C)
+    ip = d + "iou_prediction_head."
+    lin(ip + "layers.0.", 256, C); lin(ip + "layers.1.", 256, 256); lin(ip + "layers.2.", 4, 256)
+    op = d + "pred_obj_score_head."
+    lin(op + "layers.0.", C, C); lin(op + "layers.1.", C, C); lin(op + "layers.2.", 1, C)
+    return sd

@@ -185,3 +185,22 @@ def test_sam2_image_encoder_tiny():
     assert ends == [1, 7, 43, 47] and [b["q_stride"] for b in blocks].count(2) == 3
     assert {b["dim_out"] // b["heads"] for b in blocks} == {72}                   # head_dim 72 at every stage
     assert [blocks[i]["window"] for i in (0, 2, 8, 23, 44)] == [8, 8, 4, 0, 16]
+
+
+def test_sam2_heads_language_prompt():
+    """SAM heads restatement vs the reference's SAM2Base.track_step with a language token (gen_fixtures_sam2_heads.py).
+    Weights are regenerated from the seeds stored with the vectors."""
+    a, _ = load_golden("sam2_heads_tiny")
+    s_trunk, s_neck, s_heads = a["seeds"].tolist()[:3]
+    cfg = dict(embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4),
+               window_pos_embed_bkg_spatial_size=(7, 7), d_model=256)
+    sd = {}
+    sd.update(O.make_hiera_weights(cfg, seed=s_trunk, prefix="image_encoder.trunk."))
+    sd.update(O.make_fpn_weights([128, 64, 32, 16], 256, seed=s_neck, prefix="image_encoder.neck."))
+    sd.update(O.make_sam_head_weights(256, seed=s_heads))
+    out = O.sam2_language_masks(sd, cfg, t(a["x"]), t(a["lang"]))
+    assert rel_err(out["low_res_multimasks"], t(a["multimasks"])) < 1e-4
+    assert rel_err(out["ious"], t(a["ious"])) < 1e-4 and rel_err(out["object_score_logits"], t(a["obj"])) < 1e-4
+    assert rel_err(out["low_res_masks"], t(a["pred_masks"])) < 1e-4 and rel_err(out["high_res_masks"], t(a["high_res"])) < 1e-4
+    assert rel_err(out["video_res_masks"], t(a["video_res"])) < 1e-4
+    assert out["best"].tolist() == t(a["ious"]).argmax(-1).tolist()

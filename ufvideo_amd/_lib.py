@@ -35,6 +35,10 @@ SIGNATURES = {
     "ufv_maxpool2x2": [_p, _i, _l, _p, _l, _i, _i, _i, _i, _p],
     "ufv_add_rows": [_p, _i, _l, _p, _l, _p, _i, _i, _p],
     "ufv_upsample2x_add": [_p, _p, _i, _i, _i, _i, _p],
+    "ufv_add_bcast": [_p, _i, _l, _p, _l, _i, _p, _i, _l, _l, _i, _p],
+    "ufv_sam_mask_head": [_p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ufv_resize_bilinear": [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _p],
+    "ufv_argmax_rows": [_p, _l, _i, _i, _p, _p],
     "ufv_attention_decode": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
 }

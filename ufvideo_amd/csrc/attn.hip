@@ -618,6 +618,51 @@ __global__ __launch_bounds__(256) void attn_generic(AttnArgs a, int causal) {
         op[d] = (bf16)((part[d] + part[a.hd + d] + part[2 * a.hd + d] + part[3 * a.hd + d]) / sum);
 }
 
+// ---- few keys (Sk <= 64, hd 16/32): one thread per (query row, head); K/V of the batch element in LDS as fp32 -------
+// SAM2 image->token cross attention: 4096 image queries against 9 prompt tokens (sam2.py:1405-1412).
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fewkeys(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    float* ks = reinterpret_cast<float*>(smem_f);               // [Sk][Hkv*HD]
+    const int b = blockIdx.y, C = a.Hkv * HD;
+    float* vs = ks + a.Sk * C;
+    for (int i = threadIdx.x; i < a.Sk * C; i += 256) {
+        const int j = i / C, c = i - j * C;
+        ks[i] = (float)a.k[b * a.k_bs + (int64_t)j * a.k_ss + c];
+        vs[i] = (float)a.v[b * a.v_bs + (int64_t)j * a.v_ss + c];
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.Sq * a.Hq) return;
+    const int qi = t / a.Hq, hq = t - qi * a.Hq, hkv = hq / (a.Hq / a.Hkv);
+    const bf16* qp = a.q + b * a.q_bs + (int64_t)qi * a.q_ss + hq * HD;
+    float q[HD], acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; d += 8) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q[d + j] = (float)v[j] * a.scale; acc[d + j] = 0.f; }
+    }
+    float mx = -INFINITY, sum = 0.f;
+    for (int j = 0; j < a.Sk; ++j) {
+        const float* kr = ks + j * C + hkv * HD;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s += q[d] * kr[d];
+        const float mn = fmaxf(mx, s), corr = __expf(mx - mn), p = __expf(s - mn);
+        const float* vr = vs + j * C + hkv * HD;
+        sum = sum * corr + p;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = acc[d] * corr + p * vr[d];
+        mx = mn;
+    }
+    const float inv = 1.f / sum;
+    bf16* op = a.o + b * a.o_bs + (int64_t)qi * a.o_ss + hq * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4)
+        *reinterpret_cast<bf16x4*>(op + d) = (bf16x4){(bf16)(acc[d] * inv), (bf16)(acc[d + 1] * inv), (bf16)(acc[d + 2] * inv), (bf16)(acc[d + 3] * inv)};
+}
+
 template <int HD, int NW>
 int launch_mfma(const AttnArgs& a, int causal, hipStream_t st) {
     constexpr int smem = 2 * Cfg<HD>::STAGE;
@@ -689,6 +734,19 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
             case 96: return launch_mfma<96, 4>(a, causal, st);
             case 128: return launch_mfma<128, 4>(a, causal, st);
         }
+    }
+    const bool few_ok = aligned && !causal && Sk <= 64 && (hd == 16 || hd == 32) && (size_t)Sk * Hkv * hd * 8 <= 64 * 1024;
+    if (kernel == 5 && !few_ok) {
+        ufv_set_error("ufv_attention: few-keys kernel needs Sk<=64, hd in {16,32}, non-causal, aligned rows (Sk=%d hd=%d)", Sk, hd);
+        return UFV_EUNSUPPORTED;
+    }
+    if (kernel == 5 || (kernel == 0 && few_ok && Sq >= 64)) {
+        const size_t sm = (size_t)Sk * Hkv * hd * 8;
+        dim3 grid(cdiv(Sq * Hq, 256), B);
+        if (hd == 16) hipLaunchKernelGGL((attn_fewkeys<16>), grid, dim3(256), sm, st, a);
+        else hipLaunchKernelGGL((attn_fewkeys<32>), grid, dim3(256), sm, st, a);
+        UFV_CHECK_LAUNCH();
+        return UFV_OK;
     }
     const size_t smem = sizeof(float) * ((size_t)hd * 5 + 16 + Sk);
     UFV_REQUIRE(smem <= 64 * 1024, "ufv_attention: generic kernel supports Sk <= ~16000 (Sk=%d hd=%d)", Sk, hd);

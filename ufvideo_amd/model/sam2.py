@@ -2,8 +2,10 @@
 (ufvideo/model/sam2.py: `Hiera` :1134-1258, `MultiScaleBlock` :1049-1131, `MultiScaleAttention` :1000-1046,
 `PatchEmbed` :954-984, `FpnNeck` :815-903, `ImageEncoder` :784-812, `PositionEmbeddingSine` :1736-1830).
 
-This is the heavy part of the segmentation head (~1.8 TFLOP per 1024x1024 frame).  The prompt
-encoder / mask decoder / video-predictor bookkeeping are not built yet.
+This is the heavy part of the segmentation head (~1.8 TFLOP per 1024x1024 frame).  The SAM
+heads driven by the LLM's [SEG] embedding (`PromptEncoder` :1565-1735, `TwoWayTransformer` :1260-1497, `MaskDecoder`
+:1940-2224, `_forward_sam_heads` :3276-3452) and the `SAM2` wrapper's inference entry points
+(`get_sam2_embeddings` / `language_embd_inference`, :378-413) follow below the encoder.
 
 Execution model: tokens stay NHWC / token-major; the residual stream is fp32; every Linear (qkv, proj, MLP, the
 dim-changing shortcut, the 7x7/s4 patch-embed conv via im2col, the FPN 1x1 convs) is an MFMA GEMM; window
@@ -334,6 +336,347 @@ class ImageEncoder(nn.Module):
         if self.scalp > 0:
             feats, pos = feats[: -self.scalp], pos[: -self.scalp]
         return {"vision_features": feats[-1], "vision_pos_enc": pos, "backbone_fpn": feats}
+
+
+# ======================================================================================================================
+# SAM heads with the language token as the sparse prompt
+# ======================================================================================================================
+class PromptEncoder(Holder):
+    """Parameters of sam2.py `PromptEncoder` (:1565-1735).  The reference's inference path feeds it one dummy point with
+    label -1 (+ its padding point) and no mask, so only `not_a_point_embed`, `no_mask_embed` and the random-Fourier dense
+    position encoding are ever used; the point / mask-downscaling parameters are kept so checkpoints load by name."""
+
+    def __init__(self, embed_dim=256, mask_in_chans=16, device=None, dtype=torch.bfloat16, seed=22, std=0.02):
+        super().__init__()
+        self.embed_dim = embed_dim
+        gen = torch.Generator(device=device if device is not None else "cpu").manual_seed(seed)
+        mk = lambda shape, kind="w", sd=std: init_tensor(shape, kind, gen, sd, device, dtype)
+        self.put("pe_layer.positional_encoding_gaussian_matrix", init_tensor((2, embed_dim // 2), "w", gen, 1.0, device, torch.float32))
+        for i in range(4):
+            self.put(f"point_embeddings.{i}.weight", mk((1, embed_dim)))
+        self.put("not_a_point_embed.weight", mk((1, embed_dim)))
+        self.put("no_mask_embed.weight", mk((1, embed_dim)))
+        c4 = mask_in_chans // 4
+        self.put("mask_downscaling.0.weight", mk((c4, 1, 2, 2))); self.put("mask_downscaling.0.bias", mk((c4,), "zero"))
+        self.put("mask_downscaling.1.weight", mk((c4,), "one")); self.put("mask_downscaling.1.bias", mk((c4,), "zero"))
+        self.put("mask_downscaling.3.weight", mk((mask_in_chans, c4, 2, 2))); self.put("mask_downscaling.3.bias", mk((mask_in_chans,), "zero"))
+        self.put("mask_downscaling.4.weight", mk((mask_in_chans,), "one")); self.put("mask_downscaling.4.bias", mk((mask_in_chans,), "zero"))
+        self.put("mask_downscaling.6.weight", mk((embed_dim, mask_in_chans, 1, 1))); self.put("mask_downscaling.6.bias", mk((embed_dim,), "zero"))
+        self._pe_cache = {}
+
+    def _apply(self, fn, *a, **k):
+        self._pe_cache = {}
+        return super()._apply(fn, *a, **k)
+
+    @torch.no_grad()
+    def dense_pe_tokens(self, h, w):
+        """PositionEmbeddingRandom over the (h, w) grid (:1869-1879), token-major fp32 [h*w, C]; input independent."""
+        if (h, w) not in self._pe_cache:
+            g = self.pe_layer.positional_encoding_gaussian_matrix.detach().float()
+            y = (torch.arange(h, device=g.device, dtype=torch.float32) + 0.5) / h
+            x = (torch.arange(w, device=g.device, dtype=torch.float32) + 0.5) / w
+            c = torch.stack([x.view(1, w).expand(h, w), y.view(h, 1).expand(h, w)], dim=-1)
+            c = (2 * math.pi) * ((2 * c - 1) @ g)
+            self._pe_cache[(h, w)] = torch.cat([torch.sin(c), torch.cos(c)], dim=-1).reshape(h * w, -1).contiguous()
+        return self._pe_cache[(h, w)]
+
+    def get_dense_pe(self, size):
+        h, w = size
+        return self.dense_pe_tokens(h, w).view(h, w, -1).permute(2, 0, 1)[None]
+
+
+class MaskDecoder(PackedModule):
+    """sam2.py `MaskDecoder` (:1940-2224) with its `TwoWayTransformer` (depth 2, 8 heads, mlp 2048, attention
+    downsample 2), 4 mask tokens, IoU head with sigmoid, object-score MLP and the high-res-feature convs."""
+
+    def __init__(self, transformer_dim=256, depth=2, num_heads=8, mlp_dim=2048, num_multimask_outputs=3, iou_head_hidden_dim=256,
+                 device=None, dtype=torch.bfloat16, seed=23, std=0.02):
+        super().__init__()
+        C = self.transformer_dim = transformer_dim
+        self.depth, self.num_heads, self.mlp_dim = depth, num_heads, mlp_dim
+        self.num_mask_tokens = num_multimask_outputs + 1
+        gen = torch.Generator(device=device if device is not None else "cpu").manual_seed(seed)
+        mk = lambda shape, kind="w": init_tensor(shape, kind, gen, std, device, dtype)
+
+        def lin(p, o, i):
+            self.put(p + "weight", mk((o, i))); self.put(p + "bias", mk((o,), "zero"))
+
+        def norm(p, n):
+            self.put(p + "weight", mk((n,), "one")); self.put(p + "bias", mk((n,), "zero"))
+
+        def attn(p, internal):
+            for nme in ("q_proj.", "k_proj.", "v_proj."):
+                lin(p + nme, internal, C)
+            lin(p + "out_proj.", C, internal)
+
+        for i in range(depth):
+            lp = f"transformer.layers.{i}."
+            attn(lp + "self_attn.", C); attn(lp + "cross_attn_token_to_image.", C // 2); attn(lp + "cross_attn_image_to_token.", C // 2)
+            for n in ("norm1.", "norm2.", "norm3.", "norm4."):
+                norm(lp + n, C)
+            lin(lp + "mlp.layers.0.", mlp_dim, C); lin(lp + "mlp.layers.1.", C, mlp_dim)
+        attn("transformer.final_attn_token_to_image.", C // 2); norm("transformer.norm_final_attn.", C)
+        self.put("iou_token.weight", mk((1, C))); self.put("mask_tokens.weight", mk((self.num_mask_tokens, C)))
+        self.put("obj_score_token.weight", mk((1, C)))
+        self.put("output_upscaling.0.weight", mk((C, C // 4, 2, 2))); self.put("output_upscaling.0.bias", mk((C // 4,), "zero"))
+        norm("output_upscaling.1.", C // 4)
+        self.put("output_upscaling.3.weight", mk((C // 4, C // 8, 2, 2))); self.put("output_upscaling.3.bias", mk((C // 8,), "zero"))
+        self.put("conv_s0.weight", mk((C // 8, C, 1, 1))); self.put("conv_s0.bias", mk((C // 8,), "zero"))
+        self.put("conv_s1.weight", mk((C // 4, C, 1, 1))); self.put("conv_s1.bias", mk((C // 4,), "zero"))
+        for i in range(self.num_mask_tokens):
+            hp = f"output_hypernetworks_mlps.{i}."
+            lin(hp + "layers.0.", C, C); lin(hp + "layers.1.", C, C); lin(hp + "layers.2.", C // 8, C)
+        lin("iou_prediction_head.layers.0.", iou_head_hidden_dim, C); lin("iou_prediction_head.layers.1.", iou_head_hidden_dim, iou_head_hidden_dim)
+        lin("iou_prediction_head.layers.2.", self.num_mask_tokens, iou_head_hidden_dim)
+        lin("pred_obj_score_head.layers.0.", C, C); lin("pred_obj_score_head.layers.1.", C, C); lin("pred_obj_score_head.layers.2.", 1, C)
+
+    def _pack(self):
+        C = self.transformer_dim
+        g = self.get
+        wb = lambda name: (bf(g(name).weight), f32(g(name).bias))
+        cat_w = lambda *names: bf(torch.cat([g(n).weight for n in names], 0))
+        cat_b = lambda *names: f32(torch.cat([g(n).bias for n in names], 0))
+
+        def cross(p):     # token->image attention: q on tokens, (k | v) on the image tokens in one GEMM
+            return dict(q=wb(p + "q_proj"), wkv=cat_w(p + "k_proj", p + "v_proj"), wk32=f32(g(p + "k_proj").weight),
+                        bkv=cat_b(p + "k_proj", p + "v_proj"), o=wb(p + "out_proj"))
+
+        layers = []
+        for i in range(self.depth):
+            lp = f"transformer.layers.{i}."
+            sa, i2t = lp + "self_attn.", lp + "cross_attn_image_to_token."
+            layers.append(dict(
+                sa_qk=(cat_w(sa + "q_proj", sa + "k_proj"), cat_b(sa + "q_proj", sa + "k_proj")), sa_v=wb(sa + "v_proj"), sa_o=wb(sa + "out_proj"),
+                t2i=cross(lp + "cross_attn_token_to_image."),
+                i2t=dict(q=wb(i2t + "q_proj"), wq32=f32(g(i2t + "q_proj").weight), k=wb(i2t + "k_proj"), v=wb(i2t + "v_proj"), o=wb(i2t + "out_proj")),
+                n=[(f32(g(lp + f"norm{j}").weight), f32(g(lp + f"norm{j}").bias)) for j in (1, 2, 3, 4)],
+                m1=wb(lp + "mlp.layers.0"), m2=wb(lp + "mlp.layers.1")))
+        pk = dict(layers=layers, final=cross("transformer.final_attn_token_to_image."),
+                  nf=(f32(g("transformer.norm_final_attn").weight), f32(g("transformer.norm_final_attn").bias)))
+        pk["out_tok"] = f32(torch.cat([self.obj_score_token.weight, self.iou_token.weight, self.mask_tokens.weight], 0))
+        # 1x1 convs on the high-res FPN levels; N padded to one 128-wide tile
+        pk["s0"] = (bf(_pad2(self.conv_s0.weight.reshape(C // 8, C), 128, C)), f32(_pad1(self.conv_s0.bias, 128)))
+        pk["s1"] = (bf(_pad2(self.conv_s1.weight.reshape(C // 4, C), 128, C)), f32(_pad1(self.conv_s1.bias, 128)))
+        # ConvTranspose2d(k=2,s=2) as a GEMM: output column (dy*2+dx)*Cout + co
+        up = self.output_upscaling
+        w0, w3 = up.get("0").weight, up.get("3").weight
+        pk["dc1"] = (bf(w0.permute(2, 3, 1, 0).reshape(4 * (C // 4), C)), f32(up.get("0").bias.repeat(4)))
+        pk["dc2"] = (bf(w3.permute(2, 3, 1, 0).reshape(4 * (C // 8), C // 4)), f32(up.get("3").bias.repeat(4)))
+        pk["ln_up"] = (f32(up.get("1").weight), f32(up.get("1").bias))
+        pk["hyper"] = [[wb(f"output_hypernetworks_mlps.{i}.layers.{j}") for j in range(3)] for i in range(self.num_mask_tokens)]
+        pk["iou"] = [wb(f"iou_prediction_head.layers.{j}") for j in range(3)]
+        pk["obj"] = [wb(f"pred_obj_score_head.layers.{j}") for j in range(3)]
+        pk["tables"] = {}
+        return pk
+
+    def pos_tables(self, pe_tokens):
+        """k_proj(keys + pos) = k_proj(keys) + (pos @ Wk^T + bk): the position term is input independent, so it is a
+        per-grid fp32 table added in the GEMM epilogue (row-modulo residual) instead of a pass over the image tokens."""
+        pk = self.packed()
+        key = (pe_tokens.data_ptr(), pe_tokens.shape[0])
+        if key not in pk["tables"]:
+            C = self.transformer_dim
+            pe = pe_tokens.float()
+            t = {}
+            for name, blk in [(f"t2i{i}", L["t2i"]) for i, L in enumerate(pk["layers"])] + [("final", pk["final"])]:
+                tab = blk["bkv"][None].repeat(pe.shape[0], 1)
+                tab[:, : C // 2] += pe @ blk["wk32"].t()
+                t[name] = tab.contiguous()
+            for i, L in enumerate(pk["layers"]):
+                t[f"i2t{i}"] = (pe @ L["i2t"]["wq32"].t() + L["i2t"]["q"][1][None]).contiguous()
+            pk["tables"][key] = t
+        return pk["tables"][key]
+
+
+def _pixel_shuffle_index(B, h, w, device):
+    """destination row in [B, 2h, 2w] of source row (b, y, x, dy, dx) of a k2/s2 transposed conv run as a GEMM"""
+    b = torch.arange(B).view(B, 1, 1, 1, 1)
+    y = torch.arange(h).view(1, h, 1, 1, 1)
+    x = torch.arange(w).view(1, 1, w, 1, 1)
+    dy = torch.arange(2).view(1, 1, 1, 2, 1)
+    dx = torch.arange(2).view(1, 1, 1, 1, 2)
+    return ((b * 2 * h + 2 * y + dy) * 2 * w + 2 * x + dx).reshape(-1).to(device)
+
+
+class SAM2Base(nn.Module):
+    """The slice of sam2.py `SAM2Base` / `SAM2VideoPredictor` that the reference's inference reaches
+    (`language_embd_inference` :378-406): every frame receives the language token as an *initial conditioning* frame, so
+    `track_step` (:3174-3275) adds `no_mem_embed`, runs the SAM heads and `propagate_in_video` (:4071-4153) returns those
+    stored masks resized to the frame size.  The memory encoder / memory attention only feed non-conditioning frames,
+    which this call pattern never has, so they are not built (their checkpoint keys are ignored on load)."""
+
+    def __init__(self, image_encoder, image_size=1024, device=None, dtype=torch.bfloat16, seed=22):
+        super().__init__()
+        self.image_encoder = image_encoder
+        self.image_size = image_size
+        self.hidden_dim = image_encoder.neck.d_model
+        self.sam_prompt_encoder = PromptEncoder(self.hidden_dim, device=device, dtype=dtype, seed=seed)
+        self.sam_mask_decoder = MaskDecoder(self.hidden_dim, device=device, dtype=dtype, seed=seed + 1)
+        gen = torch.Generator(device=device if device is not None else "cpu").manual_seed(seed + 2)
+        self.no_mem_embed = nn.Parameter(init_tensor((1, 1, self.hidden_dim), "w", gen, 0.02, device, dtype), requires_grad=False)
+        self._ps_cache = {}
+
+    # ---- forward_image (:2804-2816) in token-major form -------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_image_tokens(self, images):
+        """images [F,3,S,S] -> [(fp32 tokens [F*h*w, 256], h, w)] for the 3 kept FPN levels, highest resolution first."""
+        enc = self.image_encoder
+        B = images.shape[0]
+        outs = enc.neck.forward_tokens(enc.trunk.forward_tokens(images), B)
+        return outs[: len(outs) - enc.scalp] if enc.scalp > 0 else outs
+
+    def _ps_index(self, B, h, w, device):
+        key = (B, h, w, str(device))
+        if key not in self._ps_cache:
+            self._ps_cache[key] = _pixel_shuffle_index(B, h, w, device)
+        return self._ps_cache[key]
+
+    @staticmethod
+    def _attn(q, k, v, B, H, Sq, Sk, hd):
+        return ops.attention(q, k, v, B, H, H, Sq, Sk, hd, (Sq * q.stride(0), q.stride(0)), (Sk * k.stride(0), k.stride(0)),
+                             (Sk * v.stride(0), v.stride(0)))
+
+    # ---- _forward_sam_heads (:3276-3452) with point_inputs=None, mask_inputs=None, multimask_output=True ------------------
+    @torch.no_grad()
+    def forward_sam_heads_tokens(self, feats, B, language_embd, out_size=None):
+        """feats from `forward_image_tokens`; language_embd [B, 1, C] (or [B, C]).  Returns dict with low_res_multimasks
+        [B,3,4h,4w], ious [B,3], object_score_logits [B,1], best int32 [B], low_res_masks [B,1,4h,4w] and high_res_masks
+        [B,1,*out_size] (default image_size), all fp32."""
+        dec, pe = self.sam_mask_decoder, self.sam_prompt_encoder
+        pk = dec.packed()
+        (t0, h0, w0), (t1, h1, w1), (t2, h, w) = feats
+        C, H, hw, dev = self.hidden_dim, dec.num_heads, feats[2][1] * feats[2][2], t2.device
+        assert (h0, w0, h1, w1) == (4 * h, 4 * w, 2 * h, 2 * w) and t2.shape[0] == B * hw
+        BF, F32 = torch.bfloat16, torch.float32
+        tabs = dec.pos_tables(pe.dense_pe_tokens(h, w))
+        # prompt tokens: [obj_score, iou, 4 x mask] output tokens + 2 x not_a_point + the language embedding
+        nap = pe.not_a_point_embed.weight.detach().float()
+        lang = language_embd.reshape(B, 1, C).to(device=dev, dtype=F32)
+        tokens = torch.cat([pk["out_tok"][None].expand(B, -1, -1), nap[None].expand(B, 2, C), lang], dim=1).reshape(-1, C).contiguous()
+        T = tokens.shape[0] // B
+        # image tokens + no_mem_embed (:2980-2984) + dense no-mask embedding (:1716-1720), both per-channel vectors
+        vec = (self.no_mem_embed.detach().float().reshape(1, C) + pe.no_mask_embed.weight.detach().float().reshape(1, C)).contiguous()
+        keys = ops.add_bcast(t2, vec, out_dtype=F32)
+        keys_bf = ops.convert(keys, BF)
+        queries = tokens
+        for i, L in enumerate(pk["layers"]):
+            # (1) self attention of the prompt tokens (layer 0: no position term, output replaces the queries)
+            q_in = ops.add_bcast(queries, tokens if i > 0 else None, out_dtype=BF)
+            v_in = ops.convert(queries, BF) if i > 0 else q_in
+            qk = ops.gemm(q_in, L["sa_qk"][0], bias=L["sa_qk"][1])
+            vv = ops.gemm(v_in, L["sa_v"][0], bias=L["sa_v"][1])
+            o = self._attn(qk, qk[:, C:], vv, B, H, T, T, C // H)
+            queries = ops.gemm(o, L["sa_o"][0], bias=L["sa_o"][1], resid=queries if i > 0 else None, out_dtype=F32)
+            queries = ops.layernorm(queries, *L["n"][0], 1e-5, out_dtype=F32)
+            # (2) tokens attend to the image
+            queries = self._token_to_image(queries, tokens, keys_bf, L["t2i"], tabs[f"t2i{i}"], L["n"][1], B, T, hw)
+            # (3) token MLP
+            f = ops.gemm(ops.convert(queries, BF), L["m1"][0], bias=L["m1"][1], act="relu")
+            queries = ops.layernorm(ops.gemm(f, L["m2"][0], bias=L["m2"][1], resid=queries, out_dtype=F32), *L["n"][2], 1e-5, out_dtype=F32)
+            # (4) image attends to the tokens
+            I = L["i2t"]
+            qi = ops.gemm(keys_bf, I["q"][0], resid=tabs[f"i2t{i}"], resid_rows=hw)
+            kt = ops.gemm(ops.add_bcast(queries, tokens, out_dtype=BF), I["k"][0], bias=I["k"][1])
+            vt = ops.gemm(ops.convert(queries, BF), I["v"][0], bias=I["v"][1])
+            o = self._attn(qi, kt, vt, B, H, hw, T, (C // 2) // H)
+            keys = ops.layernorm(ops.gemm(o, I["o"][0], bias=I["o"][1], resid=keys, out_dtype=F32), *L["n"][3], 1e-5, out_dtype=F32)
+            keys_bf = ops.convert(keys, BF)
+        hs = self._token_to_image(queries, tokens, keys_bf, pk["final"], tabs["final"], pk["nf"], B, T, hw)
+        hs_bf = ops.convert(hs, BF).view(B, T * C)
+        tok = lambda j: hs_bf[:, j * C:(j + 1) * C]
+        # upscaling with the high-res skips (:2137-2149)
+        s0 = ops.gemm(ops.convert(t0, BF), pk["s0"][0], bias=pk["s0"][1])                                # bf16 [B*16hw, 128], 32 used
+        s1 = ops.gemm(ops.convert(t1, BF), pk["s1"][0], bias=pk["s1"][1], out_dtype=F32)                 # f32 [B*4hw, 128], 64 used
+        up1 = ops.gemm(keys_bf, pk["dc1"][0], bias=pk["dc1"][1])                                         # [B*hw, 4*64]
+        ops.add_rows(up1.view(-1, C // 4), s1, self._ps_index(B, h, w, dev), D=C // 4)
+        u = ops.layernorm(s1[:, : C // 4], *pk["ln_up"], 1e-6, act="gelu")                               # LayerNorm2d + GELU
+        up2 = ops.gemm(u, pk["dc2"][0], bias=pk["dc2"][1])                                               # [B*4hw, 4*32]
+        nm = dec.num_mask_tokens
+        hyper = torch.empty((B, nm, C // 8), device=dev, dtype=F32)
+        for j in range(nm):
+            x = tok(2 + j)
+            for li, (wj, bj) in enumerate(pk["hyper"][j]):
+                x = ops.gemm(x, wj, bias=bj, act="relu") if li < 2 else ops.gemm(x, wj, bias=bj, out=hyper[:, j])
+        masks = ops.sam_mask_head(up2, s0, hyper, B, h1, w1, C // 8)         # [B, 4, 4h, 4w]
+        x = tok(1)
+        x = ops.gemm(ops.gemm(x, pk["iou"][0][0], bias=pk["iou"][0][1], act="relu"), pk["iou"][1][0], bias=pk["iou"][1][1], act="relu")
+        ious = ops.gemm(x, pk["iou"][2][0], bias=pk["iou"][2][1], act="sigmoid", out_dtype=F32)          # [B, 4]
+        x = tok(0)
+        x = ops.gemm(ops.gemm(x, pk["obj"][0][0], bias=pk["obj"][0][1], act="relu"), pk["obj"][1][0], bias=pk["obj"][1][1], act="relu")
+        obj = ops.gemm(x, pk["obj"][2][0], bias=pk["obj"][2][1], out_dtype=F32)
+        best = ops.argmax_rows(ious[:, 1:])                                                             # multimask_output: drop token 0
+        S = (self.image_size, self.image_size) if out_size is None else tuple(out_size)
+        return dict(low_res_multimasks=masks[:, 1:], ious=ious[:, 1:], object_score_logits=obj, best=best,
+                    low_res_masks=ops.resize_bilinear(masks, (h0, w0), sel=best, sel_off=1),
+                    high_res_masks=ops.resize_bilinear(masks, S, sel=best, sel_off=1))
+
+    def _token_to_image(self, queries, tokens, keys_bf, A, table, norm, B, T, hw):
+        C, H = self.hidden_dim, self.sam_mask_decoder.num_heads
+        q = ops.gemm(ops.add_bcast(queries, tokens, out_dtype=torch.bfloat16), A["q"][0], bias=A["q"][1])
+        kv = ops.gemm(keys_bf, A["wkv"], resid=table, resid_rows=hw)
+        o = self._attn(q, kv, kv[:, C // 2:], B, H, T, hw, (C // 2) // H)
+        return ops.layernorm(ops.gemm(o, A["o"][0], bias=A["o"][1], resid=queries, out_dtype=torch.float32), norm[0], norm[1], 1e-5,
+                             out_dtype=torch.float32)
+
+    # ---- SAM2VideoPredictor surface used by the wrapper -----------------------------------------------------------------------
+    def init_state(self, images):
+        """sam2.py:3792-3843 (only the fields this path reads)."""
+        return {"images": images, "num_frames": len(images), "video_height": self.image_size, "video_width": self.image_size,
+                "cached_features": {}}
+
+
+class SAM2(nn.Module):
+    """sam2.py `SAM2` wrapper (:86-460): `get_sam2_embeddings(images)` -> state, `language_embd_inference(state, embeds)`
+    -> mask logits [F, n_obj, S, S].  Frames are encoded in batches of `frame_batch` and their FPN tokens are kept in the
+    state, so several [SEG] embeddings share one encoder pass (the reference re-encodes every frame per embedding)."""
+
+    def __init__(self, ckpt_path=None, device=None, dtype=torch.bfloat16, image_encoder=None, image_size=1024, frame_batch=8, seed=20):
+        super().__init__()
+        if ckpt_path is not None:
+            raise NotImplementedError("load SAM2 weights through VideoReferQwen2ForCausalLM.from_pretrained / load_state_dict")
+        enc = image_encoder if image_encoder is not None else build_sam2_image_encoder(device=device, dtype=dtype, seed=seed)
+        self.sam2_model = SAM2Base(enc, image_size=image_size, device=device, dtype=dtype, seed=seed + 2)
+        self.hidden_dim = self.sam2_model.hidden_dim
+        self.img_mean = (0.485, 0.456, 0.406)
+        self.img_std = (0.229, 0.224, 0.225)
+        self.frame_batch = frame_batch
+
+    def preprocess_image(self, image, dtype=torch.bfloat16):
+        image = image / 255.0
+        mean = torch.tensor(self.img_mean, dtype=dtype, device=image.device)[:, None, None]
+        std = torch.tensor(self.img_std, dtype=dtype, device=image.device)[:, None, None]
+        return (image - mean) / std
+
+    def get_sam2_embeddings(self, images):
+        return self.sam2_model.init_state(images)
+
+    get_sam2_embeddings_inference = get_sam2_embeddings
+
+    @torch.no_grad()
+    def _features(self, state, lo, hi):
+        key = (lo, hi)
+        if key not in state["cached_features"]:
+            imgs = state["images"][lo:hi]
+            imgs = imgs if torch.is_tensor(imgs) else torch.stack(list(imgs))
+            state["cached_features"][key] = self.sam2_model.forward_image_tokens(imgs.to(torch.bfloat16).contiguous())
+        return state["cached_features"][key]
+
+    @torch.no_grad()
+    def language_embd_inference(self, inference_state, language_embd):
+        """language_embd: per frame, per object, a [C] embedding (list of lists / list of [n_obj, C] tensors)."""
+        F_, n_obj = len(language_embd), len(language_embd[0])
+        assert F_ == inference_state["num_frames"]
+        S = (inference_state["video_height"], inference_state["video_width"])
+        out = []
+        for lo in range(0, F_, self.frame_batch):
+            hi = min(F_, lo + self.frame_batch)
+            feats = self._features(inference_state, lo, hi)
+            per_obj = []
+            for oi in range(n_obj):
+                emb = torch.stack([torch.as_tensor(language_embd[f][oi]).reshape(-1) for f in range(lo, hi)])
+                per_obj.append(self.sam2_model.forward_sam_heads_tokens(feats, hi - lo, emb, out_size=S)["high_res_masks"])
+            out.append(torch.cat(per_obj, dim=1))
+        return torch.cat(out, dim=0)
 
 
 def build_sam2_image_encoder(device=None, dtype=torch.bfloat16, seed=20):

@@ -198,6 +198,53 @@ def upsample2x_add(x, prev, B, H, W, C):
     return x
 
 
+def add_bcast(a, b=None, out=None, out_dtype=torch.bfloat16):
+    """out[m] = a[m] + b[m % b.shape[0]] (b fp32 table or None); a fp32|bf16 rows of any pitch."""
+    _chk(a, name="a")
+    M, C = a.shape
+    if out is None:
+        out = torch.empty((M, C), device=a.device, dtype=out_dtype)
+    if b is not None:
+        _chk(b, torch.float32, "b"); assert b.shape[1] == C
+    _lib.call("ufv_add_bcast", a.data_ptr(), _DT[a.dtype], a.stride(0), _ptr(b), b.stride(0) if b is not None else 0,
+              b.shape[0] if b is not None else 0, out.data_ptr(), _DT[out.dtype], out.stride(0), M, C, _stream())
+    return out
+
+
+def sam_mask_head(up2, s0, hyper, B, h, w, C8=32):
+    """up2 bf16 [B*h*w, >=4*C8], s0 bf16 [B*4*h*w, >=C8], hyper f32 [B, nm, C8] -> f32 [B, nm, 2h, 2w]"""
+    _chk(up2, torch.bfloat16, "up2"); _chk(s0, torch.bfloat16, "s0"); _chk(hyper, torch.float32, "hyper")
+    assert hyper.is_contiguous() and hyper.shape[0] == B and hyper.shape[2] == C8
+    nm = hyper.shape[1]
+    out = torch.empty((B, nm, 2 * h, 2 * w), device=up2.device, dtype=torch.float32)
+    _lib.call("ufv_sam_mask_head", up2.data_ptr(), up2.stride(0), s0.data_ptr(), s0.stride(0), hyper.data_ptr(), out.data_ptr(),
+              B, h, w, C8, nm, _stream())
+    return out
+
+
+def resize_bilinear(src, size, sel=None, sel_off=0):
+    """F.interpolate(src, size, mode="bilinear", align_corners=False) for f32 [N, P, Hs, Ws].  Without `sel` every
+    plane is resized ([N, P, Hd, Wd]); with sel int32 [N] only plane sel_off + sel[n] of image n ([N, 1, Hd, Wd])."""
+    _chk(src, torch.float32, "src"); assert src.is_contiguous() and src.dim() == 4
+    N, P, Hs, Ws = src.shape
+    Hd, Wd = size
+    if sel is None:
+        out = torch.empty((N, P, Hd, Wd), device=src.device, dtype=torch.float32)
+        _lib.call("ufv_resize_bilinear", src.data_ptr(), None, 1, 0, out.data_ptr(), N * P, Hs, Ws, Hd, Wd, _stream())
+    else:
+        assert sel.dtype == torch.int32 and sel.numel() == N
+        out = torch.empty((N, 1, Hd, Wd), device=src.device, dtype=torch.float32)
+        _lib.call("ufv_resize_bilinear", src.data_ptr(), sel.data_ptr(), P, sel_off, out.data_ptr(), N, Hs, Ws, Hd, Wd, _stream())
+    return out
+
+
+def argmax_rows(x):
+    _chk(x, torch.float32, "x")
+    out = torch.empty((x.shape[0],), device=x.device, dtype=torch.int32)
+    _lib.call("ufv_argmax_rows", x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], out.data_ptr(), _stream())
+    return out
+
+
 def argmax(logits, out=None):
     _chk(logits, torch.float32, "logits")
     if out is None:
