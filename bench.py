@@ -47,7 +47,7 @@ def build_model(device, frames=T_FRAMES):
     cfg = VideoReferQwen2Config(**QWEN2_7B, mm_vision_tower="siglip-so400m-patch14-384", mm_vision_select_layer=-2,
                                 mm_vision_select_feature="patch", mm_projector_type="stc_connector_v35", mm_hidden_size=1152,
                                 mm_region_encoder_type="pooling", image_aspect_ratio="square", train_mask_decoder=False,
-                                sam_pretrained=None, sam_out_dim=256, num_frames=frames, seg_token_id=151747,
+                                sam_pretrained=None, sam_out_dim=256, num_frames=frames, seg_token_id=151747, sam2_trunk=None,
                                 vision_config=VISION)
     model = VideoReferQwen2ForCausalLM(cfg, device=device, seed=0)
     model.get_vision_tower().load_model(device=device, seed=7)

@@ -317,6 +317,10 @@ def build_ref_model(workdir, projector="spatial_conv"):
                 p_.add_(torch.randn_like(p_) * 0.05)
             else:
                 p_.mul_(3.0)          # make logits less flat so argmax is robust
+    # transformers >= 5 installs its hidden-state capture hooks lazily and, when the LLM's first forward comes AFTER the
+    # tower's, a second time on the nested tower -- `hidden_states[-2]` of the tower then silently means a different layer.
+    # (4.46.3, the reference's pin, has no such hooks.)  One LLM forward first installs them exactly once, top-down.
+    RQ.Qwen2ForCausalLM.forward(model, inputs_embeds=torch.zeros(1, 2, cfg.hidden_size), output_hidden_states=True)
     tok = CharTok(); tok.region_id = 290
     for m_ in model.modules():
         m_.tokenizer = tok

@@ -20,13 +20,13 @@ TINY = dict(embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4
 SEEDS = dict(trunk=40, neck=41, heads=42, x=43, lang=44)
 
 
-def build_reference(image_size=128):
+def build_reference(image_size=128, cls=None):
     trunk = RS.Hiera(**{k: v for k, v in TINY.items() if k != "d_model"})
     neck = RS.FpnNeck(position_encoding=RS.PositionEmbeddingSine(num_pos_feats=256), d_model=256, backbone_channel_list=trunk.channel_list,
                       fpn_top_down_levels=[2, 3], fpn_interp_model="nearest")
     enc = RS.ImageEncoder(trunk=trunk, neck=neck, scalp=1)
     w = RS.SAM2.__new__(RS.SAM2); torch.nn.Module.__init__(w)
-    m = RS.SAM2Base(image_encoder=enc, memory_attention=RS.SAM2.build_memory_attention(w), memory_encoder=RS.SAM2.build_memory_encoder(w),
+    m = (cls or RS.SAM2Base)(image_encoder=enc, memory_attention=RS.SAM2.build_memory_attention(w), memory_encoder=RS.SAM2.build_memory_encoder(w),
                     num_maskmem=7, image_size=image_size, sigmoid_scale_for_mem_enc=20.0, sigmoid_bias_for_mem_enc=-10.0,
                     use_mask_input_as_output_without_sam=True, directly_add_no_mem_embed=True, use_high_res_features_in_sam=True,
                     multimask_output_in_sam=True, iou_prediction_use_sigmoid=True, use_obj_ptrs_in_encoder=True, add_tpos_enc_to_obj_ptrs=False,

@@ -949,3 +949,42 @@ def make_sam_head_weights(C: int = 256, seed: int = 22, prefix: str = "", std: f
     op = d + "pred_obj_score_head."
     lin(op + "layers.0.", C, C); lin(op + "layers.1.", C, C); lin(op + "layers.2.", 1, C)
     return sd
+
+
+def seg_language_logits(sam_sd: SD, sam_cfg: dict, images_sam: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+    """`SAM2.language_embd_inference(state, [emb] * T)` (sam2.py:378-406): emb [n, C] is n objects on each of the T frames;
+    each (frame, object) is an independent initial conditioning frame; `propagate_in_video` yields [n, 1, S, S] per frame and
+    the results are concatenated over frames -> [T * n, 1, S, S], frame-major."""
+    T, n = images_sam.shape[0], emb.shape[0]
+    per_obj = [sam2_language_masks(sam_sd, sam_cfg, images_sam, emb[o].reshape(1, 1, -1).expand(T, 1, -1))["video_res_masks"] for o in range(n)]
+    return torch.cat(per_obj, dim=1).reshape(T * n, 1, *images_sam.shape[-2:])
+
+
+def seg_masks_generated(sd: SD, tokens, hiddens, seg_id: int, sam_sd: SD, sam_cfg: dict, images_sam, out_hw):
+    """videorefer_qwen2.py:428-458 after greedy generation: step o contributes `hidden_states[o][-1]` when token o+1 is [SEG]
+    (step 0's state covers the whole prompt), each row of text_hidden_fcs(states) is one single-object SAM2 query.
+    -> (list of bool [T, h, w], list of logits [T, S, S])"""
+    toks = tokens[0].tolist()
+    hit = [o for o in range(len(toks) - 1) if toks[o + 1] == seg_id]
+    if not hit:
+        return [], []
+    states = torch.cat([hiddens[o][0] for o in hit], dim=0)
+    emb = text_hidden_fcs(sd, states)
+    masks, logits = [], []
+    for e in emb:
+        lg = seg_language_logits(sam_sd, sam_cfg, images_sam, e[None])
+        logits.append(lg[:, 0])
+        masks.append(torch.sigmoid(F.interpolate(lg, size=tuple(out_hw), mode="bilinear", align_corners=False)[:, 0]) > 0.5)
+    return masks, logits
+
+
+def seg_masks_prompt(sd: SD, ids, mark, hidden_last, seg_id: int, sam_sd: SD, sam_cfg: dict, images_sam, out_hw):
+    """videorefer_qwen2.py:461-518 ([SEG] already in the prompt, batch 1): the shifted [SEG] mask restricted to the trailing
+    text segment (`mark` = [start, length] from the splice) selects rows of text_hidden_fcs(last hidden state); all n of them
+    go to SAM2 together -> bool [T * n, h, w] + logits [T * n, S, S]."""
+    m = torch.as_tensor(ids)[0] == seg_id
+    m = torch.cat([m[1:], torch.zeros(1, dtype=torch.bool)])
+    sel = torch.cat([torch.zeros(int(mark[0]), dtype=torch.bool), m[-int(mark[1]):]])
+    emb = text_hidden_fcs(sd, hidden_last[0])[sel]
+    lg = seg_language_logits(sam_sd, sam_cfg, images_sam, emb)
+    return torch.sigmoid(F.interpolate(lg, size=tuple(out_hw), mode="bilinear", align_corners=False)[:, 0]) > 0.5, lg[:, 0]

@@ -34,15 +34,29 @@ class Tok:
         return [self.region_id for _ in toks]
 
 
-def tiny_model():
+SAM_TINY = dict(embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4),
+                window_pos_embed_bkg_spatial_size=(7, 7))
+
+
+def tiny_model(sam2_trunk=None, sam_seeds=None):
     a, w = load_golden("model_tiny")
     cfg = VideoReferQwen2Config(**TINY_LLM, mm_vision_tower="siglip", mm_vision_select_layer=-2, mm_vision_select_feature="patch",
                                 mm_projector_type="spatial_conv", mm_hidden_size=64, mm_region_encoder_type="pooling",
                                 image_aspect_ratio="square", train_mask_decoder=False, sam_pretrained=None, sam_out_dim=256,
-                                num_frames=4, seg_token_id=299, vision_config=TINY_VIT)
+                                num_frames=4, seg_token_id=299, vision_config=TINY_VIT, sam2_trunk=sam2_trunk)
     m = VideoReferQwen2ForCausalLM(cfg)
     m.get_vision_tower().load_model()
-    m.load_state_dict(w)
+    if sam_seeds is not None:                      # the seeded tiny SAM2 of oracle/gen_fixtures_seg.py, under the checkpoint's key names
+        scfg = dict(SAM_TINY, d_model=256)
+        sam = {}
+        sam.update(O.make_hiera_weights(scfg, seed=sam_seeds[0], prefix="image_encoder.trunk."))
+        sam.update(O.make_fpn_weights([128, 64, 32, 16], 256, seed=sam_seeds[1], prefix="image_encoder.neck."))
+        sam.update(O.make_sam_head_weights(256, seed=sam_seeds[2]))
+        w = dict(w); w.update({"model.mask_encoder.sam2_model." + k: v for k, v in sam.items()})
+        missing = m.load_state_dict(w, strict=False).missing_keys
+        assert all("mask_downscaling" in k for k in missing), missing
+    else:
+        m.load_state_dict(w)
     m = m.to(DEV)
     for mod in m.modules():
         mod.tokenizer = Tok()
@@ -249,3 +263,51 @@ def test_fulldim_qwen2_layer_vs_oracle():
     l1, *_ = m._decode_batch(x1.to(DEV), None, cache, False, 1)
     ref1 = O.qwen2_forward(sd, cfg, x1, past=ref["past"])
     assert rel_err(l1.cpu(), ref1["logits"]) < 2e-2
+
+
+def test_generate_seg_branches_vs_reference_golden():
+    """[SEG] -> SAM2 masks through generate(), both branches, vs the reference's own generate() (oracle/gen_fixtures_seg.py).
+    Boolean masks must agree wherever the logit is not within bf16 noise of zero."""
+    a, _ = load_golden("seg_tiny")
+    m, am_, w = tiny_model(sam2_trunk=dict(SAM_TINY, image_size=128), sam_seeds=a["sam_seeds"].tolist())
+    sam = t(a["images_sam"]).to(DEV)
+    video = t(am_["video"]).to(DEV)
+    ids = t(am_["sp_vid_only_ids"]).to(DEV)
+
+    def check(got_bool, got_logits, ref_bool, ref_logits=None, what=""):
+        if ref_logits is not None:
+            assert rel_err(got_logits.cpu(), ref_logits) < 5e-2, what
+        big = torch.nn.functional.interpolate(got_logits[:, None], size=got_bool.shape[-2:], mode="bilinear", align_corners=False)[:, 0]
+        sure = (big.abs() > 0.06 * got_logits.abs().max()).cpu()
+        diff = (got_bool.cpu() != ref_bool) & sure
+        assert diff.sum() == 0 and sure.float().mean() > 0.5, (what, int(diff.sum()), float(sure.float().mean()))
+
+    # generated [SEG] (the tiny model emits token 1 at every step): S prompt positions from step 0 + one per later step
+    m.config.seg_token_id = int(a["gen_seg_id"])
+    enc = m.get_model().mask_encoder
+    calls = []
+    orig = enc.language_embd_inference
+    enc.language_embd_inference = lambda st, e: calls.append(orig(st, e)) or calls[-1]
+    gen = m.generate(ids, attention_mask=torch.ones_like(ids), images=[(video, "video")], images_sam=sam, offset=[0, 1],
+                     label_list=torch.zeros(40, 50), do_sample=False, max_new_tokens=6, pad_token_id=0, eos_token_id=298)
+    assert gen["output"].cpu().tolist() == am_["gen2_tokens"].tolist()
+    assert len(gen["pred_masks"]) == a["gen_masks"].shape[0] == len(calls)
+    keep = a["gen_logits_idx"].tolist()
+    for i, pm in enumerate(gen["pred_masks"]):
+        assert pm.shape == (2, 40, 50) and pm.dtype == torch.bool
+        check(pm, calls[i][:, 0], t(a["gen_masks"][i]), t(a["gen_logits"][keep.index(i)]) if i in keep else None, f"gen {i}")
+    # [SEG] in the prompt: two of them -> frame-major [T * 2, h, w]
+    m.config.seg_token_id = 299
+    calls.clear()
+    ids2 = t(a["prompt_ids"]).to(DEV)
+    out = m.generate(ids2, attention_mask=torch.ones_like(ids2), images=[(video, "video")], images_sam=sam, offset=[0, 1],
+                     label_list=[torch.zeros(33, 47)], do_sample=False, max_new_tokens=6, pad_token_id=0, eos_token_id=298)
+    assert len(out["pred_masks"]) == 1 and out["pred_masks"][0].shape == (4, 33, 47) and out["gt_masks"] is None
+    assert rel_err(out["output"].hidden_states[-1].cpu(), t(a["prompt_hidden_last"])) < 3e-2
+    check(out["pred_masks"][0], calls[0][:, 0], t(a["prompt_masks"][0]), t(a["prompt_logits"]), "prompt")
+    # without the SAM2 head the branch fails loudly
+    m2, _, _ = tiny_model()
+    m2.config.seg_token_id = 299
+    with pytest.raises(NotImplementedError):
+        m2.generate(ids2, attention_mask=torch.ones_like(ids2), images=[(video, "video")], images_sam=sam, offset=[0, 1],
+                    label_list=[torch.zeros(33, 47)], max_new_tokens=2)

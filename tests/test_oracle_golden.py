@@ -204,3 +204,39 @@ def test_sam2_heads_language_prompt():
     assert rel_err(out["low_res_masks"], t(a["pred_masks"])) < 1e-4 and rel_err(out["high_res_masks"], t(a["high_res"])) < 1e-4
     assert rel_err(out["video_res_masks"], t(a["video_res"])) < 1e-4
     assert out["best"].tolist() == t(a["ious"]).argmax(-1).tolist()
+
+
+def _seg_setup():
+    a, _ = load_golden("seg_tiny")
+    m, w = load_golden("model_tiny")
+    cfg = dict(embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_blocks=(4,), window_spec=(8, 4, 8, 4),
+               window_pos_embed_bkg_spatial_size=(7, 7), d_model=256)
+    s_trunk, s_neck, s_heads = a["sam_seeds"].tolist()
+    sam = {}
+    sam.update(O.make_hiera_weights(cfg, seed=s_trunk, prefix="image_encoder.trunk."))
+    sam.update(O.make_fpn_weights([128, 64, 32, 16], 256, seed=s_neck, prefix="image_encoder.neck."))
+    sam.update(O.make_sam_head_weights(256, seed=s_heads))
+    return a, m, w, cfg, sam
+
+
+def test_seg_branches_of_generate():
+    """[SEG] -> masks glue of generate() vs the reference's own generate() (oracle/gen_fixtures_seg.py)."""
+    a, m, w, cfg, sam = _seg_setup()
+    images_sam = t(a["images_sam"])[0]
+    # generated [SEG]: step 0 contributes every prompt position, later steps one state each
+    toks, hid = O.greedy_generate(w, TINY_LLM, t(m["sp_vid_only_nolab_emb"]), t(m["sp_vid_only_nolab_am"]), 6, (298,))
+    assert toks.tolist() == m["gen2_tokens"].tolist()
+    masks, logits = O.seg_masks_generated(w, toks, hid, int(a["gen_seg_id"]), sam, cfg, images_sam, (40, 50))
+    S = t(m["sp_vid_only_nolab_emb"]).shape[1]
+    assert len(masks) == a["gen_masks"].shape[0] == S + 4
+    for j, i in enumerate(a["gen_logits_idx"].tolist()):
+        assert rel_err(logits[i], t(a["gen_logits"][j])) < 2e-4
+    got = torch.stack(masks).numpy()
+    assert (got != a["gen_masks"]).mean() < 1e-4
+    # [SEG] in the prompt: the LLM forward over the re-spliced prompt, then the same glue
+    tab, e1 = w["model.embed_tokens.weight"].float(), t(m["sp_vid_only_nolab_emb"])[0]
+    e2 = torch.cat([e1[:-2], tab[299][None], tab[9][None], tab[299][None]], 0)[None]
+    hl = O.qwen2_forward(w, TINY_LLM, e2, torch.ones(1, e2.shape[1], dtype=torch.long), None)["hidden_states"][-1]
+    assert rel_err(hl, t(a["prompt_hidden_last"])) < 1e-5
+    pm, pl = O.seg_masks_prompt(w, a["prompt_ids"], [S - 3 + 0, 4], t(a["prompt_hidden_last"]), 299, sam, cfg, images_sam, (33, 47))
+    assert rel_err(pl, t(a["prompt_logits"])) < 2e-4 and (pm.numpy() != a["prompt_masks"][0]).mean() < 1e-4

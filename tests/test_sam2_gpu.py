@@ -175,4 +175,4 @@ def test_sam_heads_vs_reference_golden():
     assert ((ref_bin != got_bin) & ~unsure).sum() == 0
     # two objects per frame share the cached encoder features
     two = m.language_embd_inference(state, [torch.stack([lang[0, 0], lang[1, 0]]), torch.stack([lang[1, 0], lang[0, 0]])])
-    assert two.shape == (2, 2, 128, 128) and torch.equal(two[:, :1], masks) and len(state["cached_features"]) == 1
+    assert two.shape == (4, 1, 128, 128) and torch.equal(two[0::2], masks) and len(state["cached_features"]) == 1

@@ -627,7 +627,8 @@ class SAM2Base(nn.Module):
 
 class SAM2(nn.Module):
     """sam2.py `SAM2` wrapper (:86-460): `get_sam2_embeddings(images)` -> state, `language_embd_inference(state, embeds)`
-    -> mask logits [F, n_obj, S, S].  Frames are encoded in batches of `frame_batch` and their FPN tokens are kept in the
+    -> mask logits [F * n_obj, 1, S, S] (frame-major, what concatenating `propagate_in_video`'s per-frame
+    [n_obj, 1, S, S] outputs gives, :398-406).  Frames are encoded in batches of `frame_batch` and their FPN tokens are kept in the
     state, so several [SEG] embeddings share one encoder pass (the reference re-encodes every frame per embedding)."""
 
     def __init__(self, ckpt_path=None, device=None, dtype=torch.bfloat16, image_encoder=None, image_size=1024, frame_batch=8, seed=20):
@@ -675,7 +676,7 @@ class SAM2(nn.Module):
             for oi in range(n_obj):
                 emb = torch.stack([torch.as_tensor(language_embd[f][oi]).reshape(-1) for f in range(lo, hi)])
                 per_obj.append(self.sam2_model.forward_sam_heads_tokens(feats, hi - lo, emb, out_size=S)["high_res_masks"])
-            out.append(torch.cat(per_obj, dim=1))
+            out.append(torch.cat(per_obj, dim=1).reshape(-1, 1, *S))
         return torch.cat(out, dim=0)
 
 

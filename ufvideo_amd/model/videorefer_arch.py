@@ -187,8 +187,23 @@ class VideoReferMetaModel:
         return vt
 
     def initialize_sam_modules(self, config, device=None, dtype=torch.bfloat16, seed=4):
-        # SAM2 (Hiera-L trunk + mask decoder) is SURVEY §8 row a11 ("next"): not built in this round.
-        self.mask_encoder = None
+        """ref :124-149.  `config.sam2_trunk`: "hiera_l" (the reference's SAM2-L, default), a dict of Hiera kwargs
+        (+ optional image_size) for reduced test configurations, or None to leave the segmentation head out."""
+        trunk = getattr(config, "sam2_trunk", "hiera_l")
+        if trunk is None or trunk == "none":
+            self.mask_encoder = None
+        else:
+            from .sam2 import SAM2, Hiera, FpnNeck, ImageEncoder, PositionEmbeddingSine
+            if isinstance(trunk, dict):
+                kw = dict(trunk)
+                size = kw.pop("image_size", 1024)
+                tr = Hiera(**kw, device=device, dtype=dtype, seed=seed + 10)
+                neck = FpnNeck(PositionEmbeddingSine(256), d_model=256, backbone_channel_list=tr.channel_list, fpn_top_down_levels=[2, 3],
+                               fpn_interp_model="nearest", device=device, dtype=dtype, seed=seed + 11)
+                self.mask_encoder = SAM2(image_encoder=ImageEncoder(tr, neck, scalp=1), image_size=size, device=device, dtype=dtype,
+                                         seed=seed + 12)
+            else:
+                self.mask_encoder = SAM2(device=device, dtype=dtype, seed=seed + 12)
         self.text_hidden_fcs = TextHiddenFcs(config.hidden_size, getattr(config, "sam_out_dim", 256), device=device,
                                              dtype=dtype, seed=seed)
 

@@ -234,13 +234,11 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
 
     def load_state_dict(self, sd, strict=True):
         """Accepts the reference's keys; vision-tower keys may come with or without `vision_model.`;
-        SAM2 (`model.mask_encoder.*`) and unused tower-head keys are ignored."""
+        SAM2 memory modules (unused at inference, see model/sam2.py) and unused tower-head keys are ignored."""
         own = self.state_dict()
         new = {}
         vt = "model.vision_tower.vision_tower."
         for k, v in sd.items():
-            if k.startswith("model.mask_encoder."):
-                continue
             if k.startswith(vt) and not k.startswith(vt + "vision_model."):
                 k = vt + "vision_model." + k[len(vt):]
             if k in own:
@@ -332,14 +330,48 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         else:
             raise NotImplementedError("generate() without images is not used by the reference's callers")
         if bool(seg_token_mask.any()):
-            # segmentation branch (ref :461-518) needs the SAM2 head
-            raise NotImplementedError("[SEG] in the prompt needs the SAM2 mask decoder (SURVEY §8 row a11), not built yet")
+            # [SEG] already in the prompt (ref :461-518): one forward, embeddings from the trailing text segment
+            logits, cache, hs, normed = self._decode_batch(inputs_embeds, attention_mask, None, True, 0)
+            mm_feat_index, mm_input = mark_mm_token_index[0][0], mark_mm_token_index[0][1]
+            sel = torch.cat([torch.zeros((1, mm_feat_index), dtype=torch.bool, device=seg_token_mask.device),
+                             seg_token_mask[:, -mm_input:]], dim=1)[0]
+            rows = torch.nonzero(sel.to(normed.device)).reshape(-1)
+            pred_embeddings = [self.get_model().text_hidden_fcs[0](normed[rows])]          # batch 1: one list entry [n, 256]
+            pred_masks = [self._seg_masks(e, images_sam, label_list[i].shape) for i, e in enumerate(pred_embeddings)]
+            output = ModelOutput(loss=None, logits=logits, past_key_values=cache, attentions=None,
+                                 hidden_states=tuple(h.unsqueeze(0) for h in hs))
+            return {"output": output, "pred_masks": pred_masks, "gt_masks": masks_list}
         out = self._greedy(inputs_embeds, attention_mask, **kwargs)
         toks = out["sequences"]
-        if seg_id is not None and toks.numel() > 1 and bool((toks[0, 1:] == seg_id).any()):
-            raise NotImplementedError("a generated [SEG] needs the SAM2 mask decoder (SURVEY §8 row a11), not built yet")
         self.last_generate = out
-        return {"output": toks, "pred_masks": []}
+        pred_masks = []
+        if seg_id is not None and toks.numel() > 1:
+            # generated [SEG] (ref :428-458): step o contributes its last-layer hidden state when token o+1 is [SEG]; step 0's
+            # hidden state spans the whole prompt, exactly as HF's `output.hidden_states[0][-1]` does in the reference.
+            hit = (toks[0, 1:] == seg_id).nonzero().reshape(-1).tolist()
+            if hit:
+                states = torch.cat([out["hidden_last"][o] for o in hit], dim=0)
+                emb = self.get_model().text_hidden_fcs[0](states)                           # [n, 256]
+                shape = label_list.shape if torch.is_tensor(label_list) else label_list[0].shape
+                state = self._sam_state(images_sam)
+                pred_masks = [self._seg_masks(e.unsqueeze(0), images_sam, shape, state=state) for e in emb]
+        return {"output": toks, "pred_masks": pred_masks}
+
+    def _sam_state(self, images_sam):
+        enc = self.get_model().mask_encoder
+        if enc is None:
+            raise NotImplementedError("[SEG] needs the SAM2 head: build the model with config.sam2_trunk set (default 'hiera_l')")
+        return enc.get_sam2_embeddings(images_sam.squeeze(0))
+
+    def _seg_masks(self, language_embeddings, images_sam, out_hw, state=None):
+        """ref :441-452 / :501-512: `language_embd_inference(state, [emb] * T)` -> bilinear to the label size ->
+        `[:, 0]` -> sigmoid > 0.5.  emb [n, 256] -> bool [T * n, h, w], frame-major."""
+        enc = self.get_model().mask_encoder
+        state = state if state is not None else self._sam_state(images_sam)
+        T = images_sam.shape[1]
+        masks = enc.language_embd_inference(state, [language_embeddings] * T)                # [T*n, 1, S, S] logits
+        masks = ops.resize_bilinear(masks.contiguous(), tuple(out_hw))[:, 0]
+        return masks > 0                                                                   # == sigmoid(masks) > 0.5
 
     def _greedy(self, inputs_embeds, attention_mask, max_new_tokens=20, eos_token_id=None, stopping_criteria=None,
                 do_sample=False, pad_token_id=None, use_cache=True, **unused):
