@@ -79,7 +79,7 @@ class KernelTimer:
         timer = self
 
         def gemm(a, w, *args, **kw):
-            if timer.on and kw.get("swiglu") and a.shape[0] > 64:
+            if timer.on and kw.get("swiglu") and a.shape[0] > 64 and not isinstance(w, ops_mod.Fp8Weight):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 out = orig(a, w, *args, **kw)
@@ -88,6 +88,18 @@ class KernelTimer:
                 return out
             return orig(a, w, *args, **kw)
         ops_mod.gemm = gemm
+        orig8 = ops_mod.gemm_fp8
+
+        def gemm_fp8(aq, sa, w, *args, **kw):       # fp8 mode: the GEMM alone (the activation quantisation is its own kernel)
+            if timer.on and kw.get("swiglu") and aq.shape[0] > 64:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = orig8(aq, sa, w, *args, **kw)
+                e.record()
+                timer.pairs.append((s, e, aq.shape[0], w.shape[0], aq.shape[1]))
+                return out
+            return orig8(aq, sa, w, *args, **kw)
+        ops_mod.gemm_fp8 = gemm_fp8
 
     def summary(self):
         if not self.pairs:
@@ -147,6 +159,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=T_FRAMES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE config #5a: W8A8 e4m3 GEMMs (not the headline bf16 run)")
     ap.add_argument("--mode", choices=["replica", "frameshard"], default="replica",
                     help="replica: one clip per GPU per step (default, weak scaling); frameshard: ONE clip per step, frames "
                          "sharded over the ranks for tower+projector, RCCL all-gather of visual tokens, decoder on every rank")
@@ -170,6 +183,8 @@ def main():
     timer = KernelTimer(); timer.wrap(ops)
 
     model = build_model(device, args.frames)
+    if args.fp8:
+        model.set_gemm_dtype("fp8")
     video, ids, am = synthetic_inputs(device, args.frames)
     cfg = model.config
     cache = KVCache(cfg.num_hidden_layers, 2304 * args.frames // 32 + 128, 2 * cfg.num_key_value_heads * cfg.head_dim, device)
@@ -202,8 +217,8 @@ def main():
     out = {
         "metric": "video-tokens/sec (encode+prefill), UFVideo-7B 32f@336px", "value": round(value, 1), "unit": "video-tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "strong" if fs else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"UFVideo-7B dims, {args.frames} frames {IMG}x{IMG}, bf16, prompt 96 ids -> S={S}, "
+        "higher_is_better": True, "scaling": "strong" if fs else "weak", "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
+        "config": {"workload": f"UFVideo-7B dims, {args.frames} frames {IMG}x{IMG}, {'W8A8 e4m3 GEMMs (config #5a), bf16 elsewhere' if args.fp8 else 'bf16'}, prompt 96 ids -> S={S}, "
                                f"encode+project+splice+prefill to last-position logits; clip replicas per GPU",
                    "video_tokens_per_clip": tokens_per_clip, "llm_seq_len": S, "parallelism": (f"frameshard{world}+allgather" if fs else f"clip-dp{world}")},
     }
@@ -212,15 +227,16 @@ def main():
         if ks:
             ach = ks["flops"] / (ks["mean_ms"] * 1e-3) / 1e12
             traffic = None
+            peak = 2 * MFMA_PEAK_TFLOPS if args.fp8 else MFMA_PEAK_TFLOPS
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and not args.fp8:
                 traffic = json.load(open(pmc)).get("gemm_nt_256_swiglu_hbm_bytes_per_launch")
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256<bf16,swiglu> gate/up M=%d N=%d K=%d" % (ks["M"], ks["N"], ks["K"]),
-                               "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256<%s,swiglu> gate/up M=%d N=%d K=%d" % ("fp8" if args.fp8 else "bf16", ks["M"], ks["N"], ks["K"]),
+                               "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                                "traffic": traffic, "launch_ms": round(ks["mean_ms"], 4), "launches": ks["launches"]}
         step_tf = sum(FLOPS.values()) * args.frames / 32 / (dt / args.steps) / 1e12
         out["step_tflops"] = round(step_tf, 1)
-        out["step_frac_of_mfma_peak"] = round(step_tf / MFMA_PEAK_TFLOPS, 4)
+        out["step_frac_of_mfma_peak"] = round(step_tf / (2 * MFMA_PEAK_TFLOPS if args.fp8 else MFMA_PEAK_TFLOPS), 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64))
         print(json.dumps(out), flush=True)

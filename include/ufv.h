@@ -174,6 +174,16 @@ int64_t ufv_qwen2_decode_ws_bytes(const ufv_qwen2_model* m);
 int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* token_dev, int pos, void* ws, int64_t ws_bytes, float* logits,
                           float* hidden_out, int64_t* next_token_dev, void* stream);
 
+/* ---- W8A8 fp8 GEMM path (SURVEY §8f row 1 / BASELINE config #5a; not in the reference, which runs bf16/fp16) ----
+ * OCP e4m3 operands with one fp32 scale per row: x[m,k] ~ q[m,k] * scale[m], scale = max|x[m,:]| / 448. */
+int ufv_quantize_fp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, float* scale, int M, int K, void* stream);
+int ufv_dequantize_fp8(const void* q, int64_t ldq, const float* scale, float* out, int64_t ldo, int M, int K, void* stream);
+/* ufv_gemm with e4m3 A [M,K] (a_scale [M]) and W [N,K] (w_scale [N]):  C = epilogue((Aq Wq^T) * a_scale[m] * w_scale[n]).
+ * v_mfma_f32_16x16x128_f8f6f4 tiles (N % 128 == 0, K % 128 == 0) or the fp8 GEMV (M <= 64, K % 16 == 0); same epilogues. */
+int ufv_gemm_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, void* C, int ldc,
+                 int out_f32, int M, int N, int K, const float* bias, int act, const float* resid, int ldr, int resid_rows,
+                 int swiglu, int kernel, void* stream);
+
 /* ---- SAM2 prompt/mask heads (sam2.py MaskDecoder.predict_masks :2094-2174, _forward_sam_heads :3276-3452) ---- */
 /* out[m,:] = a[m,:] + b[m % b_rows,:] (b may be NULL = plain convert); a/out f32|bf16, b f32.  The `queries + query_pe`
  * / `keys + key_pe` adds of TwoWayAttentionBlock (:1384-1412) and the no_mem_embed / no_mask_embed broadcasts. */

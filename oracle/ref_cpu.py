@@ -988,3 +988,54 @@ def seg_masks_prompt(sd: SD, ids, mark, hidden_last, seg_id: int, sam_sd: SD, sa
     emb = text_hidden_fcs(sd, hidden_last[0])[sel]
     lg = seg_language_logits(sam_sd, sam_cfg, images_sam, emb)
     return torch.sigmoid(F.interpolate(lg, size=tuple(out_hw), mode="bilinear", align_corners=False)[:, 0]) > 0.5, lg[:, 0]
+
+
+# --------------------------------------------------------------------------------------
+# W8A8 fp8 (OCP e4m3) restatement for config #5a (not a reference feature: the reference runs bf16/fp16; this states
+# the arithmetic the fp8 GEMM path must reproduce, include/ufv.h `ufv_quantize_fp8` / `ufv_gemm_fp8`)
+# --------------------------------------------------------------------------------------
+def quantize_fp8_rows(x: torch.Tensor):
+    """scale[m] = max|x[m]| / 448; q = round-to-nearest-even e4m3fn(x / scale) -> (dequantised values fp32, scale, codes uint8)."""
+    x = x.float()
+    amax = x.abs().amax(dim=1, keepdim=True)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q8 = (x / scale).to(torch.float8_e4m3fn)
+    return q8.float(), scale[:, 0], q8.view(torch.uint8)
+
+
+def gemm_fp8(a: torch.Tensor, w: torch.Tensor, bias=None):
+    """(q(a) q(w)^T) * sa[m] * sw[n] (+ bias) with per-token / per-output-channel e4m3 quantisation, fp32 accumulation."""
+    qa, sa, _ = quantize_fp8_rows(a)
+    qw, sw, _ = quantize_fp8_rows(w)
+    y = (qa @ qw.t()) * sa[:, None] * sw[None, :]
+    return y if bias is None else y + bias.float()
+
+
+class fp8_linear_mode:
+    """Context manager: inside it every `F.linear` of this module whose weight fits the fp8 MFMA tiles (N % 128 == 0,
+    K % 128 == 0 -- the rule `PackedModule.gw` applies) runs the W8A8 restatement `gemm_fp8`; activations are first rounded
+    to bf16, as the HIP path quantises the bf16 tensor the previous kernel wrote."""
+
+    class _Shim:
+        def __init__(self, real):
+            self._real = real
+
+        def __getattr__(self, name):
+            return getattr(self._real, name)
+
+        def linear(self, x, w, b=None):
+            if w.dim() == 2 and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0:
+                shp = x.shape
+                y = gemm_fp8(x.reshape(-1, shp[-1]).to(torch.bfloat16), w.to(torch.bfloat16), b)
+                return y.reshape(*shp[:-1], w.shape[0])
+            return self._real.linear(x, w, b)
+
+    def __enter__(self):
+        g = globals()
+        self._saved = g["F"]
+        g["F"] = fp8_linear_mode._Shim(self._saved)
+        return self
+
+    def __exit__(self, *exc):
+        globals()["F"] = self._saved
+        return False

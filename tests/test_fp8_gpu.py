@@ -1,0 +1,123 @@
+"""GPU: W8A8 fp8 (OCP e4m3) GEMM path -- quantisation codes bit-exact vs the CPU restatement, GEMM (128- and 256-wide MFMA
+tiles, GEMV, every epilogue) vs the restatement's dequantised product."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import rel_err  # noqa: E402
+from oracle import ref_cpu as O  # noqa: E402
+from ufvideo_amd import ops, _lib  # noqa: E402
+
+DEV = "cuda"
+
+
+def rms_rel(a, b):
+    return ((a.float() - b.float()).pow(2).mean().sqrt() / b.float().pow(2).mean().sqrt()).item()
+
+
+def test_quantize_codes_bit_exact():
+    g = torch.Generator().manual_seed(3)
+    for dt in (torch.float32, torch.bfloat16):
+        x = (torch.randn(37, 256, generator=g) * torch.logspace(-3, 2, 37)[:, None]).to(dt)
+        x[5] = 0
+        x[6, 3] = 1000.0
+        q, s = ops.quantize_fp8(x.to(DEV))
+        deq, sr, codes = O.quantize_fp8_rows(x)
+        assert torch.equal(s.cpu(), sr) and torch.equal(q.cpu(), codes)
+        assert torch.equal(ops.dequantize_fp8(q, s).cpu(), deq * sr[:, None])
+    # strided input rows
+    big = torch.randn(16, 512, generator=g).to(DEV)
+    q, s = ops.quantize_fp8(big[:, 128:384])
+    assert torch.equal(q.cpu(), O.quantize_fp8_rows(big[:, 128:384].cpu())[2])
+
+
+@pytest.mark.parametrize("M,N,K,kernel", [(300, 256, 256, ops.GEMM_FAST), (300, 256, 256, ops.GEMM_FAST256), (1000, 384, 1152, ops.GEMM_AUTO),
+                                          (515, 512, 128, ops.GEMM_FAST256), (7, 200, 272, ops.GEMM_GEMV), (64, 128, 3584, ops.GEMM_AUTO),
+                                          (2399, 1280, 3584, ops.GEMM_FAST), (2399, 1280, 3584, ops.GEMM_FAST256)])
+def test_gemm_fp8_vs_restatement(M, N, K, kernel):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    ref = O.gemm_fp8(a, w, bias)
+    W = ops.Fp8Weight(w.to(DEV))
+    aq, sa = ops.quantize_fp8(a.to(DEV))
+    out = ops.gemm_fp8(aq, sa, W, bias=bias.to(DEV), out_dtype=torch.float32, kernel=kernel)
+    assert rel_err(out.cpu(), ref) < 2e-6 * K ** 0.5 + 1e-5          # same products, fp32 accumulation in a different order
+    # and the quantisation error itself stays at the e4m3 level vs the unquantised product
+    full = a.float() @ w.float().t() + bias
+    assert rel_err(out.cpu(), full) < 4e-2
+
+
+def test_gemm_fp8_epilogues_and_dispatch():
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 520, 512, 384
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16); w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    resid = torch.randn(M, N, generator=g); tab = torch.randn(8, N, generator=g); bias = torch.randn(N, generator=g)
+    W = ops.Fp8Weight(w.to(DEV))
+    base = O.gemm_fp8(a, w)
+    for kern in (ops.GEMM_FAST, ops.GEMM_FAST256):
+        y = ops.gemm(a.to(DEV), W, bias=bias.to(DEV), act="gelu", resid=resid.to(DEV), out_dtype=torch.float32, kernel=kern)
+        assert rel_err(y.cpu(), torch.nn.functional.gelu(base + bias) + resid) < 1e-4
+        y = ops.gemm(a.to(DEV), W, resid=tab.to(DEV), resid_rows=8, kernel=kern)
+        assert rel_err(y.float().cpu(), base + tab[torch.arange(M) % 8]) < 1e-2
+        # SwiGLU: weight rows interleaved [16 gate | 16 up]
+        gate, up = base[:, : N // 2], base[:, N // 2:]
+        wi = torch.stack([w[: N // 2].view(-1, 16, K), w[N // 2:].view(-1, 16, K)], 1).reshape(N, K)
+        y = ops.gemm(a.to(DEV), ops.Fp8Weight(wi.to(DEV)), swiglu=True, out_dtype=torch.float32, kernel=kern)
+        assert rel_err(y.cpu(), torch.nn.functional.silu(gate) * up) < 1e-4
+    with pytest.raises(_lib.UfvError):
+        aq, sa = ops.quantize_fp8(a.to(DEV)[:, :200].contiguous())
+        ops.gemm_fp8(aq, sa, ops.Fp8Weight(w.to(DEV)[:, :200].contiguous()))        # K % 128 != 0 and M > 64: no silent fallback
+
+
+def test_fulldim_layers_fp8_vs_restatement():
+    """One full-dim Qwen2 layer and two SigLIP layers with every large GEMM in W8A8, vs the CPU restatement that quantises at
+    the same points (oracle.fp8_linear_mode), and vs the bf16 path (difference must stay at the e4m3 level)."""
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
+    from ufvideo_amd.model.encoder import SiglipVisionTower, VisionConfig
+    cfg = dict(vocab_size=512, hidden_size=3584, intermediate_size=18944, num_hidden_layers=1, num_attention_heads=28,
+               num_key_value_heads=4, rope_theta=1e6, rms_norm_eps=1e-6)
+    sd = O.make_qwen2_weights(cfg, seed=12)
+    m = VideoReferQwen2ForCausalLM(VideoReferQwen2Config(**cfg, train_mask_decoder=True))
+    m.load_state_dict(sd, strict=True); m = m.to(DEV)
+    x = torch.randn(1, 300, 3584, generator=torch.Generator().manual_seed(14)) * 0.5
+    _, _, _, bf16_out = m._decode_batch(x.to(DEV), None, None, True, 0)
+    m.set_gemm_dtype("fp8")
+    assert isinstance(m.model.packed()["layers"][0]["wgu8"], ops.Fp8Weight)
+    logits, cache, hs, normed = m._decode_batch(x.to(DEV), None, None, True, 0)
+    with O.fp8_linear_mode():
+        ref = O.qwen2_forward(sd, cfg, x)
+    # e4m3 rounding is discontinuous: a 1-ulp bf16 difference in a GEMM input flips ~6 % of its codes, so two correct
+    # implementations decorrelate at the model level.  Kernel-level parity is exact (tests above); here the HIP result must be
+    # closer to the fp8 restatement than to the unquantised path, and the quantisation error itself must stay at e4m3 level.
+    e_ref, e_16 = rms_rel(normed.cpu(), ref["hidden_states"][-1][0]), rms_rel(normed.cpu(), bf16_out.cpu())
+    assert e_ref < e_16 < 0.15, (e_ref, e_16)
+    # decode after an fp8 prefill still runs (bf16 weights, one-call step) and matches the restatement's next-token logits
+    x1 = torch.randn(1, 1, 3584, generator=torch.Generator().manual_seed(15)) * 0.5
+    l1, *_ = m._decode_batch(x1.to(DEV), None, cache, False, 1)
+    with O.fp8_linear_mode():
+        ref1 = O.qwen2_forward(sd, cfg, x1, past=ref["past"])
+    assert rms_rel(l1.cpu(), ref1["logits"]) < 0.15
+
+
+def test_fulldim_siglip_fp8_vs_restatement():
+    from ufvideo_amd.model.encoder import SiglipVisionTower
+    from ufvideo_amd.model._params import set_gemm_dtype
+
+    class Args:
+        mm_vision_select_layer = -2
+        mm_vision_select_feature = "patch"
+
+    vit = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=3, num_attention_heads=16, image_size=336, patch_size=14)
+    sd = O.make_siglip_weights(vit, seed=11)
+    tower = SiglipVisionTower("siglip", Args(), vision_config=vit)
+    tower.load_hf_state_dict(sd); tower = tower.to(DEV)
+    x = torch.randn(2, 3, 336, 336, generator=torch.Generator().manual_seed(13))
+    y16 = tower(x.to(DEV)).float().cpu()
+    set_gemm_dtype(tower, "fp8")
+    y8 = tower(x.to(DEV)).float().cpu()
+    with O.fp8_linear_mode():
+        ref = O.siglip_tower(sd, vit, x)
+    assert rms_rel(y8, ref) < rms_rel(y8, y16) < 0.15, (rms_rel(y8, ref), rms_rel(y8, y16))

@@ -60,10 +60,15 @@ __device__ __forceinline__ void epilogue128(const f32x4 (&acc)[4][MT], const Epi
     }
 }
 
-template <bool OUT_F32, bool SWIGLU, int MT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e,
+// FP8: operands are OCP e4m3 bytes (K-tile = 128 elements = the same 128-byte LDS rows), one
+// v_mfma_f32_16x16x128_f8f6f4 per fragment pair (2x the bf16 MFMA rate), per-row scales applied to the accumulators.
+template <bool OUT_F32, bool SWIGLU, int MT, bool FP8>
+__global__ __launch_bounds__(256, 2) void gemm_nt_128(const void* __restrict__ Av, const void* __restrict__ Wv, Epi e,
                                                        int M, int N, int K, int lda, int ldw) {
     constexpr int BM = Tile<MT>::BM, STAGE_BYTES = Tile<MT>::STAGE_BYTES;
+    constexpr int ES = FP8 ? 1 : 2;                          // bytes per operand element
+    const char* A = reinterpret_cast<const char*>(Av);
+    const char* W = reinterpret_cast<const char*>(Wv);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,19 +92,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A
     // ---- LDS-DMA source addresses. One wave-instruction fills 8 rows x 128 B; lane l writes
     //      LDS chunk (l&7) of row (l>>3) and therefore must FETCH chunk (l&7)^(row&7).
     const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
-    const bf16* a_src[MT];
-    const bf16* b_src[4];
+    const char* a_src[MT];
+    const char* b_src[4];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int r = (wave * MT + i) * 8 + lrow;
-        a_src[i] = A + (size_t)min(m0 + r, M - 1) * lda + lchunk * 8;
+        a_src[i] = A + (size_t)min(m0 + r, M - 1) * lda * ES + lchunk * 16;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + lrow;
-        b_src[i] = W + (size_t)(n0 + r) * ldw + lchunk * 8;
+        b_src[i] = W + (size_t)(n0 + r) * ldw * ES + lchunk * 16;
     }
-    auto stage = [&](int s, int k0) {
+    auto stage = [&](int s, int k0) {      // k0 = byte offset of the K-tile inside a row
         char* abase = smem + s * STAGE_BYTES + wave * (MT * 1024);
         char* bbase = smem + s * STAGE_BYTES + BM * BK * 2 + wave * 4096;
 #pragma unroll
@@ -120,13 +125,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int a_off = (wm * (BM / 2) + frow) * 128, b_off = BM * BK * 2 + (wn * 64 + frow) * 128;
 
-    const int nk = K / BK;
+    const int nk = K * ES / 128;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
+        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * 128);
         const char* sb = smem + (t & 1) * STAGE_BYTES;
+        if constexpr (FP8) {
+            // lane (row r, k-group g) feeds bytes 32g..32g+31 of its row = 16-byte chunks 2g and 2g+1
+            const int c0 = ((2 * fq) ^ fx) << 4, c1 = ((2 * fq + 1) ^ fx) << 4;
+            i32x8 af[MT], bf[4];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + a_off + i * 16 * 128 + c0);
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + a_off + i * 16 * 128 + c1);
+                af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(sb + b_off + i * 16 * 128 + c0);
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(sb + b_off + i * 16 * 128 + c1);
+                bf[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bf[nt], af[mt], acc[nt][mt], 0, 0, 0, 0, 0, 0);
+        } else {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int coff = ((kk * 4 + fq) ^ fx) << 4;
@@ -141,8 +168,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const bf16* __restrict__ A
                 for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nt], af[mt], acc[nt][mt], 0, 0, 0);
         }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+
+    if constexpr (FP8) {     // de-quantise: acc[nt][mt][j] *= scale_m[row] * scale_n[col]
+        f32x4 sn[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) sn[nt] = *reinterpret_cast<const f32x4*>(e.scale_n + n0 + wn * 64 + nt * 16 + fq * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float sm = e.scale_m[min(m0 + wm * (16 * MT) + mt * 16 + frow, M - 1)];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] *= sn[nt] * sm;
+        }
     }
 
     // ---- epilogue (activation resolved once so the body stays unrolled)
@@ -240,16 +280,81 @@ __global__ __launch_bounds__(256) void gemv_nt(const bf16* __restrict__ A, const
     }
 }
 
-template <bool F, bool S, int MT>
-int launch_fast_mt(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
+// ---- GEMV with fp8 operands (M <= 64): weights streamed once, 16 e4m3 bytes per lane per load; dequantised in registers
+template <bool OUT_F32, bool SWIGLU, int MR>
+__global__ __launch_bounds__(256) void gemv_nt_fp8(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W, Epi e, int M, int N,
+                                                   int K, int lda, int ldw) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n_out = SWIGLU ? N / 2 : N;
+    if (n >= n_out) return;
+    const int row0 = SWIGLU ? (n / 16) * 32 + (n % 16) : n;
+    const uint8_t* w0 = W + (size_t)row0 * ldw;
+    const uint8_t* w1 = W + (size_t)(row0 + 16) * ldw;
+    const int r0 = blockIdx.y * MR;
+    A += (size_t)r0 * lda;
+    const int Mb = min(M - r0, MR);
+    float s0[MR], s1[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) s0[r] = s1[r] = 0.f;
+    auto unpack = [](const i32x4 v, float (&f)[16]) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            f[4 * d + 0] = __builtin_amdgcn_cvt_f32_fp8(v[d], 0);
+            f[4 * d + 1] = __builtin_amdgcn_cvt_f32_fp8(v[d], 1);
+            f[4 * d + 2] = __builtin_amdgcn_cvt_f32_fp8(v[d], 2);
+            f[4 * d + 3] = __builtin_amdgcn_cvt_f32_fp8(v[d], 3);
+        }
+    };
+    for (int k = lane * 16; k < K; k += 1024) {
+        float wv[16], uv[16];
+        unpack(*reinterpret_cast<const i32x4*>(w0 + k), wv);
+        if (SWIGLU) unpack(*reinterpret_cast<const i32x4*>(w1 + k), uv);
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            if (r < Mb) {
+                float av[16];
+                unpack(*reinterpret_cast<const i32x4*>(A + (size_t)r * lda + k), av);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    s0[r] += av[j] * wv[j];
+                    if (SWIGLU) s1[r] += av[j] * uv[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        if (r >= Mb) break;
+        const int m = r0 + r;
+        float v = wave_sum(s0[r]) * e.scale_m[m] * e.scale_n[row0];
+        if (SWIGLU) {
+            const float u = wave_sum(s1[r]) * e.scale_m[m] * e.scale_n[row0 + 16];
+            v = v / (1.0f + __expf(-v)) * u;
+        } else {
+            if (e.bias) v += e.bias[n];
+            v = act_apply(v, e.act);
+        }
+        if (lane == 0) {
+            if (e.resid) v += e.resid[(size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n];
+            if (OUT_F32)
+                reinterpret_cast<float*>(e.out)[(size_t)m * e.ldc + n] = v;
+            else
+                reinterpret_cast<bf16*>(e.out)[(size_t)m * e.ldc + n] = (bf16)v;
+        }
+    }
+}
+
+template <bool F, bool S, int MT, bool Q>
+int launch_fast_mt(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<F, S, MT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<F, S, MT, Q>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Tile<MT>::SMEM_BYTES);
         attr_set = true;
     }
     const int tiles = cdiv(M, Tile<MT>::BM) * (N / BN);
-    hipLaunchKernelGGL((gemm_nt_128<F, S, MT>), dim3(tiles), dim3(256), Tile<MT>::SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
+    hipLaunchKernelGGL((gemm_nt_128<F, S, MT, Q>), dim3(tiles), dim3(256), Tile<MT>::SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
@@ -283,55 +388,84 @@ inline bool prefer256(int M, int N, int K) {
     return c256 < c128;
 }
 
-template <bool F, bool S>
-int launch_fast(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
+template <bool F, bool S, bool Q>
+int launch_fast(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
     if (!S) {
         switch (pick_mt(M, N)) {
-            case 5: return launch_fast_mt<F, S, 5>(A, W, e, M, N, K, lda, ldw, st);
-            case 6: return launch_fast_mt<F, S, 6>(A, W, e, M, N, K, lda, ldw, st);
+            case 5: return launch_fast_mt<F, S, 5, Q>(A, W, e, M, N, K, lda, ldw, st);
+            case 6: return launch_fast_mt<F, S, 6, Q>(A, W, e, M, N, K, lda, ldw, st);
         }
     }
-    return launch_fast_mt<F, S, 4>(A, W, e, M, N, K, lda, ldw, st);
+    return launch_fast_mt<F, S, 4, Q>(A, W, e, M, N, K, lda, ldw, st);
 }
 
-template <bool F, bool S>
-int launch_any(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, int force, hipStream_t st) {
-    const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && (lda % 8 == 0) && (ldw % 8 == 0) &&
+template <bool F, bool S, bool Q>
+int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int force, hipStream_t st) {
+    constexpr int KE = Q ? 128 : BK;        // elements per K-tile; row pitches must keep rows 16-byte aligned
+    constexpr int LDA = Q ? 16 : 8;
+    const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && (lda % LDA == 0) && (ldw % LDA == 0) &&
                          ((uintptr_t)e.out % 16 == 0) && (e.ldc % 4 == 0) && (!e.bias || (uintptr_t)e.bias % 16 == 0) &&
-                         (!e.resid || ((uintptr_t)e.resid % 16 == 0 && e.ldr % 4 == 0));
-    const bool fast_ok = aligned && (N % BN == 0) && (K % BK == 0) && M >= 1;
-    const bool gemv_ok = aligned && (K % 8 == 0) && M <= 64 && (!S || N % 32 == 0);
+                         (!e.resid || ((uintptr_t)e.resid % 16 == 0 && e.ldr % 4 == 0)) &&
+                         (!Q || ((uintptr_t)e.scale_n % 16 == 0));
+    const bool fast_ok = aligned && (N % BN == 0) && (K % KE == 0) && M >= 1;
+    const bool gemv_ok = aligned && (K % (Q ? 16 : 8) == 0) && M <= 64 && (!S || N % 32 == 0);
     if (force == UFV_GEMM_FAST && !fast_ok) {
-        ufv_set_error("ufv_gemm: fast kernel needs N%%128==0, K%%64==0, 16-byte aligned operands (M=%d N=%d K=%d)", M, N, K);
+        ufv_set_error("ufv_gemm: fast kernel needs N%%128==0, K%%%d==0, 16-byte aligned operands (M=%d N=%d K=%d)", KE, M, N, K);
         return UFV_EUNSUPPORTED;
     }
     if ((force == UFV_GEMM_AUTO && gemv_ok) || force == UFV_GEMM_GEMV) {
         if (!gemv_ok) {
-            ufv_set_error("ufv_gemm: gemv kernel needs M<=64, K%%8==0 (M=%d N=%d K=%d)", M, N, K);
+            ufv_set_error("ufv_gemm: gemv kernel needs M<=64, K%%%d==0 (M=%d N=%d K=%d)", Q ? 16 : 8, M, N, K);
             return UFV_EUNSUPPORTED;
         }
         const int n_out = S ? N / 2 : N;
-        hipLaunchKernelGGL((gemv_nt<F, S, 8>), dim3(cdiv(n_out, 4), cdiv(M, 8)), dim3(256), 0, st, A, W, e, M, N, K, lda, ldw);
+        if constexpr (Q)
+            hipLaunchKernelGGL((gemv_nt_fp8<F, S, 8>), dim3(cdiv(n_out, 4), cdiv(M, 8)), dim3(256), 0, st, (const uint8_t*)A,
+                               (const uint8_t*)W, e, M, N, K, lda, ldw);
+        else
+            hipLaunchKernelGGL((gemv_nt<F, S, 8>), dim3(cdiv(n_out, 4), cdiv(M, 8)), dim3(256), 0, st, (const bf16*)A, (const bf16*)W,
+                               e, M, N, K, lda, ldw);
         UFV_CHECK_LAUNCH();
         return UFV_OK;
     }
     const bool big_ok = fast_ok && M >= 256;
     if (force == UFV_GEMM_FAST256 && !big_ok) {
-        ufv_set_error("ufv_gemm: 256-tile kernel needs M>=256, N%%128==0, K%%64==0 (M=%d N=%d K=%d)", M, N, K);
+        ufv_set_error("ufv_gemm: 256-tile kernel needs M>=256, N%%128==0, K%%%d==0 (M=%d N=%d K=%d)", KE, M, N, K);
         return UFV_EUNSUPPORTED;
     }
-    if (force == UFV_GEMM_FAST256 || (force == UFV_GEMM_AUTO && big_ok && prefer256(M, N, K)))
-        return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, st);
+    if (force == UFV_GEMM_FAST256 || (force == UFV_GEMM_AUTO && big_ok && prefer256(M, N, Q ? K / 2 : K)))
+        return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, st);
     if ((force == UFV_GEMM_AUTO && fast_ok && M > 64) || force == UFV_GEMM_FAST)
-        return launch_fast<F, S>(A, W, e, M, N, K, lda, ldw, st);
-    if (S && N % 32 != 0) {
-        ufv_set_error("ufv_gemm: SWIGLU needs N%%32==0");
-        return UFV_EINVAL;
+        return launch_fast<F, S, Q>(A, W, e, M, N, K, lda, ldw, st);
+    if constexpr (Q) {
+        ufv_set_error("ufv_gemm_fp8: needs N%%128==0 and K%%128==0 (or M<=64, K%%16==0) and 16-byte aligned rows (M=%d N=%d K=%d)", M, N, K);
+        return UFV_EUNSUPPORTED;
+    } else {
+        if (S && N % 32 != 0) {
+            ufv_set_error("ufv_gemm: SWIGLU needs N%%32==0");
+            return UFV_EINVAL;
+        }
+        const int n_out = S ? N / 2 : N;
+        hipLaunchKernelGGL((gemm_nt_generic<F, S>), dim3(cdiv(n_out, 64), M), dim3(64), 0, st, (const bf16*)A, (const bf16*)W, e, M, N, K,
+                           lda, ldw);
+        UFV_CHECK_LAUNCH();
+        return UFV_OK;
     }
-    const int n_out = S ? N / 2 : N;
-    hipLaunchKernelGGL((gemm_nt_generic<F, S>), dim3(cdiv(n_out, 64), M), dim3(64), 0, st, A, W, e, M, N, K, lda, ldw);
-    UFV_CHECK_LAUNCH();
-    return UFV_OK;
+}
+
+template <bool Q>
+int gemm_entry(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, void* C, int ldc, int out_f32,
+               int M, int N, int K, const float* bias, int act, const float* resid, int ldr, int resid_rows, int swiglu, int kernel,
+               void* stream) {
+    Epi e;
+    e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = resid_rows;
+    e.scale_m = a_scale; e.scale_n = w_scale;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (out_f32)
+        return swiglu ? launch_any<true, true, Q>(A, W, e, M, N, K, lda, ldw, kernel, st)
+                      : launch_any<true, false, Q>(A, W, e, M, N, K, lda, ldw, kernel, st);
+    return swiglu ? launch_any<false, true, Q>(A, W, e, M, N, K, lda, ldw, kernel, st)
+                  : launch_any<false, false, Q>(A, W, e, M, N, K, lda, ldw, kernel, st);
 }
 
 }  // namespace
@@ -341,14 +475,16 @@ extern "C" int ufv_gemm(const void* A, int lda, const void* W, int ldw, void* C,
                         void* stream) {
     UFV_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "ufv_gemm: bad arguments (M=%d N=%d K=%d)", M, N, K);
     UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemm: swiglu epilogue takes no bias/activation");
-    Epi e;
-    e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = resid_rows;
-    const bf16* a = reinterpret_cast<const bf16*>(A);
-    const bf16* w = reinterpret_cast<const bf16*>(W);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (out_f32)
-        return swiglu ? launch_any<true, true>(a, w, e, M, N, K, lda, ldw, kernel, st)
-                      : launch_any<true, false>(a, w, e, M, N, K, lda, ldw, kernel, st);
-    return swiglu ? launch_any<false, true>(a, w, e, M, N, K, lda, ldw, kernel, st)
-                  : launch_any<false, false>(a, w, e, M, N, K, lda, ldw, kernel, st);
+    return gemm_entry<false>(A, lda, nullptr, W, ldw, nullptr, C, ldc, out_f32, M, N, K, bias, act, resid, ldr, resid_rows, swiglu, kernel,
+                             stream);
+}
+
+extern "C" int ufv_gemm_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, void* C, int ldc,
+                            int out_f32, int M, int N, int K, const float* bias, int act, const float* resid, int ldr, int resid_rows,
+                            int swiglu, int kernel, void* stream) {
+    UFV_REQUIRE(A && W && C && a_scale && w_scale && M > 0 && N > 0 && K > 0, "ufv_gemm_fp8: bad arguments (M=%d N=%d K=%d)", M, N, K);
+    UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemm_fp8: swiglu epilogue takes no bias/activation");
+    UFV_REQUIRE(kernel != UFV_GEMM_GENERIC, "ufv_gemm_fp8: no generic kernel for fp8 operands");
+    return gemm_entry<true>(A, lda, a_scale, W, ldw, w_scale, C, ldc, out_f32, M, N, K, bias, act, resid, ldr, resid_rows, swiglu, kernel,
+                            stream);
 }

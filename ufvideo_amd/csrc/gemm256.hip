@@ -25,6 +25,11 @@ namespace {
 
 constexpr int SMEM256 = 131072;
 
+__device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {      // two 16-byte LDS chunks -> the 32-byte fp8 operand
+    const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // acc[nt][mt][j] = C[m0 + (mt>>2)*128 + wr*64 + (mt&3)*16 + frow][n0 + (nt>>1)*128 + wc*32 + (nt&1)*16 + fq*4 + j]
 template <bool OUT_F32, bool SWIGLU, int ACT>
 __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[4][8], const Epi& e, int M, int N, int m0, int n0, int wr, int wc,
@@ -59,17 +64,22 @@ __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[4][8], const Epi&
     }
 }
 
-template <bool OUT_F32, bool SWIGLU>
-__global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e, int M,
+// FP8: e4m3 operands, K-tile = 128 elements (the same 128-byte LDS rows and DMA pattern), 8 x v_mfma_f32_16x16x128_f8f6f4
+// per phase instead of 16 x 16x16x32_bf16; accumulators are scaled by scale_m[row] * scale_n[col] before the epilogue.
+template <bool OUT_F32, bool SWIGLU, bool FP8>
+__global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ Av, const void* __restrict__ Wv, Epi e, int M,
                                                        int N, int K, int lda, int ldw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = FP8 ? 1 : 2;
+    const char* A = reinterpret_cast<const char*>(Av);
+    const char* W = reinterpret_cast<const char*>(Wv);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
     const int tiles_m = (M + 255) / 256, tiles_n = (N + 255) / 256;
     const int nwg = tiles_m * tiles_n;
-    const int nk = K / 64;
+    const int nk = K * ES / 128;
     const int G = gridDim.x;                       // persistent: block b walks tiles b, b+G, ...
     // tile sequence position -> (tm, tn): within a round of G tiles give each XCD (launch id % 8) a contiguous run,
     // and order the sequence in groups of 8 row-tiles so that concurrent tiles share A/W panels in L2.
@@ -90,22 +100,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A
 
     // ---- LDS-DMA sources: half-tile `which` (0=A0 1=A1 2=B0 3=B1), two 8-row pieces per wave
     const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
-    const bf16* src[4][2];
+    const char* src[4][2];
     auto set_src = [&](int m0_, int n0_) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int r = h * 128 + (wave * 2 + i) * 8 + lrow;
-                src[h][i] = A + (size_t)min(m0_ + r, M - 1) * lda + lchunk * 8;
-                src[2 + h][i] = W + (size_t)min(n0_ + r, N - 1) * ldw + lchunk * 8;
+                src[h][i] = A + (size_t)min(m0_ + r, M - 1) * lda * ES + lchunk * 16;
+                src[2 + h][i] = W + (size_t)min(n0_ + r, N - 1) * ldw * ES + lchunk * 16;
             }
     };
     auto stage = [&](int d, int which, int kt) {
         if (kt < nk) {
             char* dst = smem + d * 65536 + which * 16384 + wave * 2048;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][0] + kt * 64), LDS_PTR(dst), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][1] + kt * 64), LDS_PTR(dst + 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][0] + kt * 128), LDS_PTR(dst), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][1] + kt * 128), LDS_PTR(dst + 1024), 16, 0, 0);
         }
     };
     auto prologue_loads = [&]() {      // K-tile 0 complete + A0/B1 of K-tile 1
@@ -116,7 +126,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int a_row_off = (wr * 64 + frow) * 128;     // + (mt&3)*2048 inside the half
     const int b_row_off = (wc * 32 + frow) * 128;     // + (nt&1)*2048 inside the half
-    const int coff0 = ((0 + fq) ^ fx) << 4, coff1 = ((4 + fq) ^ fx) << 4;
+    // bf16: k-step kk reads chunk 4*kk + fq;  fp8: the lane's 32 bytes are chunks 2*fq and 2*fq + 1
+    const int coff0 = ((FP8 ? 2 * fq : fq) ^ fx) << 4, coff1 = ((FP8 ? 2 * fq + 1 : 4 + fq) ^ fx) << 4;
 
     int m0, n0;
     bool have = tile_of(0, m0, n0);
@@ -149,11 +160,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
+    if constexpr (FP8) {                                                                                     \
+        _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                     \
+            _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                 \
+                acc[NTB + n_][MTB + m_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                  \
+                    cat8(bfr[n_][0], bfr[n_][1]), cat8(afr[m_][0], afr[m_][1]), acc[NTB + n_][MTB + m_], 0, 0, 0, 0, 0, 0); \
+    } else {                                                                                                 \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
         _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                                     \
             _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                                 \
                 acc[NTB + n_][MTB + m_] =                                                                    \
                     __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n_][kk], afr[m_][kk], acc[NTB + n_][MTB + m_], 0, 0, 0); \
+    }                                                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_barrier();
@@ -202,6 +220,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A
         bias3 = *reinterpret_cast<const f32x4*>(e.bias + nB + 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if constexpr (FP8) {     // de-quantise in place: acc *= scale_m[row] * scale_n[col] (loads retire before the DMA prologue)
+        f32x4 sn[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+            sn[nt] = *reinterpret_cast<const f32x4*>(e.scale_n + min(n0 + (nt >> 1) * 128, N - 128) + wc * 32 + (nt & 1) * 16 + fq * 4);
+        float sm[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) sm[mt] = e.scale_m[min(m0 + (mt >> 2) * 128 + wr * 64 + (mt & 3) * 16 + frow, M - 1)];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] *= sn[nt] * sm[mt];
+    }
     const int cm0 = m0, cn0 = n0;
     have = tile_of(round + 1, m0, n0);
     if (have) { set_src(m0, n0); prologue_loads(); }
@@ -212,11 +244,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const bf16* __restrict__ A
 
 }  // namespace
 
-template <bool F, bool S>
-static int launch256_t(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
+template <bool F, bool S, bool Q>
+static int launch256_t(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   SMEM256);
         attr_set = true;
     }
@@ -229,13 +261,20 @@ static int launch256_t(const bf16* A, const bf16* W, const Epi& e, int M, int N,
     }
     const int tiles = cdiv(M, 256) * cdiv(N, 256);
     const int grid = tiles < n_cu ? tiles : n_cu;          // persistent: one block per CU walks the tiles
-    hipLaunchKernelGGL((gemm_nt_256<F, S>), dim3(grid), dim3(512), SMEM256, st, A, W, e, M, N, K, lda, ldw);
+    hipLaunchKernelGGL((gemm_nt_256<F, S, Q>), dim3(grid), dim3(512), SMEM256, st, A, W, e, M, N, K, lda, ldw);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
 
-int ufv_launch_gemm256(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
-                       bool swiglu, hipStream_t st) {
-    if (out_f32) return swiglu ? launch256_t<true, true>(A, W, e, M, N, K, lda, ldw, st) : launch256_t<true, false>(A, W, e, M, N, K, lda, ldw, st);
-    return swiglu ? launch256_t<false, true>(A, W, e, M, N, K, lda, ldw, st) : launch256_t<false, false>(A, W, e, M, N, K, lda, ldw, st);
+template <bool Q>
+static int launch256_q(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32, bool swiglu,
+                       hipStream_t st) {
+    if (out_f32) return swiglu ? launch256_t<true, true, Q>(A, W, e, M, N, K, lda, ldw, st) : launch256_t<true, false, Q>(A, W, e, M, N, K, lda, ldw, st);
+    return swiglu ? launch256_t<false, true, Q>(A, W, e, M, N, K, lda, ldw, st) : launch256_t<false, false, Q>(A, W, e, M, N, K, lda, ldw, st);
+}
+
+int ufv_launch_gemm256(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
+                       bool swiglu, bool fp8, hipStream_t st) {
+    return fp8 ? launch256_q<true>(A, W, e, M, N, K, lda, ldw, out_f32, swiglu, st)
+               : launch256_q<false>(A, W, e, M, N, K, lda, ldw, out_f32, swiglu, st);
 }

@@ -8,7 +8,12 @@ struct Epi {
     void* out;             // bf16 or fp32
     int ldr, ldc, act;
     int resid_rows;        // >0: residual row = m % resid_rows (broadcast table, e.g. position embeddings)
+    const float* scale_m;  // fp8 operands only: per-row scale of A [M] and per-row scale of W [N]; acc *= scale_m[m] * scale_n[n]
+    const float* scale_n;
 };
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 template <bool OUT_F32, int ACT>
 __device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, float v0, float v1, float v2, float v3) {
@@ -58,5 +63,5 @@ __device__ __forceinline__ void epi_store4b(const Epi& e, int m, int n, float v0
     }
 }
 
-int ufv_launch_gemm256(const bf16* A, const bf16* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
-                       bool swiglu, hipStream_t st);
+int ufv_launch_gemm256(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
+                       bool swiglu, bool fp8, hipStream_t st);

@@ -37,9 +37,20 @@ class PackedModule(Holder):
     """Base for modules that keep reference-named parameters and derive packed kernel buffers from
     them on first use.  Moving / casting / loading the module invalidates the packed buffers."""
 
+    gemm_dtype = "bf16"          # "fp8": large GEMM weights are packed as e4m3 + per-channel scale (W8A8 path, config #5a)
+
     def __init__(self):
         super().__init__()
         self._packed = None
+
+    def gw(self, w):
+        """A GEMM weight [N, K] in this module's compute format: bf16, or `ops.Fp8Weight` when gemm_dtype == "fp8" and the
+        shape fits the fp8 MFMA tiles (N % 128 == 0, K % 128 == 0)."""
+        w = bf(w)
+        if self.gemm_dtype == "fp8" and w.is_cuda and w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0:
+            from .. import ops
+            return ops.Fp8Weight(w)
+        return w
 
     def _apply(self, fn, *a, **k):
         self._packed = None
@@ -92,3 +103,12 @@ def pad_cols(w, k):
 
 def round_up(x, m):
     return (x + m - 1) // m * m
+
+
+def set_gemm_dtype(root, mode):
+    """Switch every packed module under `root` between the bf16 and the W8A8 fp8 GEMM path (repacks lazily)."""
+    assert mode in ("bf16", "fp8")
+    for m in root.modules():
+        if isinstance(m, PackedModule):
+            m.gemm_dtype = mode
+            m._packed = None

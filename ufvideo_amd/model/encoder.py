@@ -102,11 +102,11 @@ class _VitBody(PackedModule):
             a = L.self_attn
             layers.append(dict(
                 ln1=(f32(L.layer_norm1.weight), f32(L.layer_norm1.bias)), ln2=(f32(L.layer_norm2.weight), f32(L.layer_norm2.bias)),
-                wqkv=bf(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
+                wqkv=self.gw(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
                 bqkv=f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)),
-                wo=bf(a.out_proj.weight), bo=f32(a.out_proj.bias),
-                w1=bf(pad_rows(L.mlp.fc1.weight, Ip)), b1=f32(pad_rows(L.mlp.fc1.bias, Ip)),
-                w2=bf(pad_cols(L.mlp.fc2.weight, Ip)), b2=f32(L.mlp.fc2.bias)))
+                wo=self.gw(a.out_proj.weight), bo=f32(a.out_proj.bias),
+                w1=self.gw(pad_rows(L.mlp.fc1.weight, Ip)), b1=f32(pad_rows(L.mlp.fc1.bias, Ip)),
+                w2=self.gw(pad_cols(L.mlp.fc2.weight, Ip)), b2=f32(L.mlp.fc2.bias)))
         pk["layers"] = layers
         return pk
 

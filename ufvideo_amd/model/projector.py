@@ -106,13 +106,13 @@ class STCConnector(PackedModule):
             b = st.get(f"b{i + 1}")
             C = b.conv1.conv.weight.shape[0]
             blk = dict(
-                w1=bf(b.conv1.conv.weight.reshape(C, -1)), n1=(f32(b.conv1.bn.weight), f32(b.conv1.bn.bias)),
+                w1=self.gw(b.conv1.conv.weight.reshape(C, -1)), n1=(f32(b.conv1.bn.weight), f32(b.conv1.bn.bias)),
                 w9=f32(b.conv2.conv.weight.reshape(C, 9).t()), n2=(f32(b.conv2.bn.weight), f32(b.conv2.bn.bias)),
                 se1=(bf(b.se.fc1.weight.reshape(b.se.fc1.weight.shape[0], C)), f32(b.se.fc1.bias)),
                 se2=(bf(b.se.fc2.weight.reshape(C, -1)), f32(b.se.fc2.bias)),
-                w3=bf(b.conv3.conv.weight.reshape(C, C)), n3=(f32(b.conv3.bn.weight), f32(b.conv3.bn.bias)), ds=None)
+                w3=self.gw(b.conv3.conv.weight.reshape(C, C)), n3=(f32(b.conv3.bn.weight), f32(b.conv3.bn.bias)), ds=None)
             if hasattr(b, "downsample"):
-                blk["ds"] = (bf(b.downsample.conv.weight.reshape(C, -1)), f32(b.downsample.bn.weight), f32(b.downsample.bn.bias))
+                blk["ds"] = (self.gw(b.downsample.conv.weight.reshape(C, -1)), f32(b.downsample.bn.weight), f32(b.downsample.bn.bias))
             blocks.append(blk)
         return blocks
 
@@ -121,9 +121,9 @@ class STCConnector(PackedModule):
         if self.depth:
             pk["s1"], pk["s2"] = self._pack_stage(self.s1), self._pack_stage(self.s2)
         w = self.sampler.get("0.weight")                       # [Co, Ci, kt, kh, kw] -> [Co, (kt kh kw Ci)]
-        pk["samp_w"] = bf(w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1))
+        pk["samp_w"] = self.gw(w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1))
         pk["samp_b"] = f32(self.sampler.get("0.bias"))
-        pk["readout"] = [(bf(self.readout.get(f"{2 * i}.weight")), f32(self.readout.get(f"{2 * i}.bias")))
+        pk["readout"] = [(self.gw(self.readout.get(f"{2 * i}.weight")), f32(self.readout.get(f"{2 * i}.bias")))
                          for i in range(self.mlp_depth)]
         return pk
 

@@ -149,6 +149,9 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
                 wqkv=bf(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
                 bqkv=f32(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)),
                 wo=bf(a.o_proj.weight), wgu=pack_swiglu(bf(m.gate_proj.weight), bf(m.up_proj.weight)), wd=bf(m.down_proj.weight)))
+            if self.gemm_dtype == "fp8":          # prefill GEMMs in W8A8; the bf16 copies stay for the one-call decode step
+                for k in ("wqkv", "wo", "wgu", "wd"):
+                    layers[-1][k + "8"] = self.gw(layers[-1][k])
         pk["layers"] = layers
         return pk
 
@@ -165,6 +168,8 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
         act = torch.empty((S, cfg.intermediate_size), device=dev, dtype=torch.bfloat16)
         Sk = pos0 + S
         for li, L in enumerate(pk["layers"]):
+            if "wqkv8" in L:
+                L = dict(L, wqkv=L["wqkv8"], wo=L["wo8"], wgu=L["wgu8"], wd=L["wd8"])
             kvb = cache.buf[li]
             ops.rmsnorm(x, L["ln1"], eps, out=h)
             ops.gemm(h, L["wqkv"], bias=L["bqkv"], out=qkv)
@@ -196,6 +201,13 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         self.put("lm_head.weight", init_tensor((config.vocab_size, config.hidden_size), "w", gen, std, device, dtype))
         self.generation_config = ModelOutput(eos_token_id=config.eos_token_id, pad_token_id=config.pad_token_id)
         self.requires_grad_(False)
+
+    def set_gemm_dtype(self, mode):
+        """"bf16" (default, the reference's precision) or "fp8": W8A8 e4m3 GEMMs for tower / projector / prefill (config #5a).
+        Call after the vision tower is loaded."""
+        from ._params import set_gemm_dtype
+        set_gemm_dtype(self, mode)
+        self.config.gemm_dtype = mode
 
     # ---- plumbing expected by the reference's callers ------------------------------------------------
     def get_model(self):

@@ -28,7 +28,12 @@ def _chk(t, dtype=None, name="tensor"):
 
 def gemm(a, w, bias=None, act=None, resid=None, resid_rows=0, out=None, out_dtype=torch.bfloat16, swiglu=False,
          kernel=GEMM_AUTO):
-    """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T).  a may be a row-strided view; w contiguous."""
+    """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T).  a may be a row-strided view; w contiguous.
+    w may be an `Fp8Weight`: then a is quantised per row and the fp8 MFMA path runs (same epilogues)."""
+    if isinstance(w, Fp8Weight):
+        aq, sa = quantize_fp8(a)
+        return gemm_fp8(aq, sa, w, bias=bias, act=act, resid=resid, resid_rows=resid_rows, out=out, out_dtype=out_dtype, swiglu=swiglu,
+                        kernel=kernel)
     _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w")
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1]
     M, K = a.shape
@@ -45,6 +50,59 @@ def gemm(a, w, bias=None, act=None, resid=None, resid_rows=0, out=None, out_dtyp
     _lib.call("ufv_gemm", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
               int(out.dtype == torch.float32), M, N, K, _ptr(bias), ACT[act], _ptr(resid), ldr, resid_rows, int(swiglu),
               kernel, _stream())
+    return out
+
+
+def quantize_fp8(x, out=None, scale=None):
+    """Row-wise e4m3 quantisation: x [M,K] bf16|f32 (any row pitch) -> (q uint8 [M,K], scale f32 [M]), x ~ q * scale[:, None]."""
+    _chk(x, name="x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    M, K = x.shape
+    q = out if out is not None else torch.empty((M, K), device=x.device, dtype=torch.uint8)
+    s = scale if scale is not None else torch.empty((M,), device=x.device, dtype=torch.float32)
+    _lib.call("ufv_quantize_fp8", x.data_ptr(), _DT[x.dtype], x.stride(0), q.data_ptr(), q.stride(0), s.data_ptr(), M, K, _stream())
+    return q, s
+
+
+def dequantize_fp8(q, scale):
+    M, K = q.shape
+    out = torch.empty((M, K), device=q.device, dtype=torch.float32)
+    _lib.call("ufv_dequantize_fp8", q.data_ptr(), q.stride(0), scale.data_ptr(), out.data_ptr(), out.stride(0), M, K, _stream())
+    return out
+
+
+class Fp8Weight:
+    """A weight matrix [N, K] held as e4m3 bytes + one fp32 scale per output channel.  Passing it to `gemm` in place of a
+    bf16 weight selects the W8A8 path: the activation is quantised per token on the fly."""
+
+    def __init__(self, w):
+        self.q, self.scale = quantize_fp8(w.contiguous())
+        self.shape = tuple(w.shape)
+        self.dtype = torch.uint8
+
+    def stride(self, i):
+        return self.q.stride(i)
+
+
+def gemm_fp8(aq, a_scale, w, bias=None, act=None, resid=None, resid_rows=0, out=None, out_dtype=torch.bfloat16, swiglu=False,
+             kernel=GEMM_AUTO):
+    """out = epilogue((aq @ w.q^T) * a_scale[:, None] * w.scale[None, :]); aq uint8 [M,K] e4m3, w Fp8Weight [N,K]."""
+    _chk(aq, torch.uint8, "aq"); _chk(a_scale, torch.float32, "a_scale")
+    M, K = aq.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and aq.stride(1) == 1
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((M, n_out), device=aq.device, dtype=out_dtype)
+    assert out.shape == (M, n_out) and out.stride(1) == 1
+    ldr = 0
+    if resid is not None:
+        _chk(resid, torch.float32, "resid"); ldr = resid.stride(0)
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+    _lib.call("ufv_gemm_fp8", aq.data_ptr(), aq.stride(0), a_scale.data_ptr(), w.q.data_ptr(), w.q.stride(0), w.scale.data_ptr(),
+              out.data_ptr(), out.stride(0), int(out.dtype == torch.float32), M, N, K, _ptr(bias), ACT[act], _ptr(resid), ldr, resid_rows,
+              int(swiglu), kernel, _stream())
     return out
 
 
