@@ -184,6 +184,15 @@ int ufv_gemm_fp8(const void* A, int lda, const float* a_scale, const void* W, in
                  int out_f32, int M, int N, int K, const float* bias, int act, const float* resid, int ldr, int resid_rows,
                  int swiglu, int kernel, void* stream);
 
+/* ---- training-loss forward values (no backward) ----
+ * loss[i] = logsumexp(logits[i,:]) - logits[i, labels[i]], 0 where labels[i] == ignore_index: the per-token terms of the
+ * causal-LM cross entropy inside HF Qwen2ForCausalLM.forward (used at videorefer_qwen2.py:198-215); labels already shifted. */
+int ufv_cross_entropy_rows(const float* logits, int64_t ld, const int64_t* labels, int M, int V, int64_t ignore_index, float* loss,
+                           void* stream);
+/* sums[n] = {sum bce_with_logits(pred, gt), sum sigmoid(pred)*gt, sum sigmoid(pred), sum gt} over the HW elements of mask n:
+ * the reductions of sigmoid_ce_loss / dice_loss (videorefer_qwen2.py:34-77). */
+int ufv_mask_loss_sums(const float* pred, const float* gt, int n_masks, int64_t HW, float* sums, void* stream);
+
 /* ---- SAM2 prompt/mask heads (sam2.py MaskDecoder.predict_masks :2094-2174, _forward_sam_heads :3276-3452) ---- */
 /* out[m,:] = a[m,:] + b[m % b_rows,:] (b may be NULL = plain convert); a/out f32|bf16, b f32.  The `queries + query_pe`
  * / `keys + key_pe` adds of TwoWayAttentionBlock (:1384-1412) and the no_mem_embed / no_mask_embed broadcasts. */

@@ -1039,3 +1039,53 @@ class fp8_linear_mode:
     def __exit__(self, *exc):
         globals()["F"] = self._saved
         return False
+
+
+# --------------------------------------------------------------------------------------
+# Training-loss forward (videorefer_qwen2.py:34-77 losses, :198-352 forward(inference=False)); forward values only
+# --------------------------------------------------------------------------------------
+def dice_loss(inputs: torch.Tensor, targets: torch.Tensor, num_masks: float, scale=1000, eps=1e-6):
+    """videorefer_qwen2.py:34-57."""
+    inputs = inputs.sigmoid().flatten(1, 2)
+    targets = targets.flatten(1, 2)
+    numerator = 2 * (inputs / scale * targets).sum(-1)
+    denominator = (inputs / scale).sum(-1) + (targets / scale).sum(-1)
+    loss = 1 - (numerator + eps) / (denominator + eps)
+    return loss.sum() / (num_masks + 1e-8)
+
+
+def sigmoid_ce_loss(inputs: torch.Tensor, targets: torch.Tensor, num_masks: float):
+    """videorefer_qwen2.py:60-76."""
+    loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    return loss.flatten(1, 2).mean(1).sum() / (num_masks + 1e-8)
+
+
+def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """HF Qwen2ForCausalLM loss: shift by one, mean cross entropy over labels != -100."""
+    return F.cross_entropy(logits[..., :-1, :].reshape(-1, logits.shape[-1]).float(), labels[..., 1:].reshape(-1), ignore_index=-100)
+
+
+def training_losses(sd: SD, cfg: dict, inputs_embeds, attention_mask, labels, seg_id: int, sam_sd: SD, sam_cfg: dict, images_sam,
+                    masks_list, label_list, weights=(1.0, 1.0, 1.0)):
+    """forward(inference=False) after the splice, batch 1 (the accelerated decoder's batch): CE on all positions, [SEG]
+    embeddings = text_hidden_fcs(last hidden state) at positions whose NEXT label is [SEG], each object queried on every
+    SAM frame (frame-major), best-IoU high-res mask -> bilinear to the label size -> BCE + DICE vs masks_list.
+    images_sam [T,3,S,S].  -> dict(loss, ce_loss, mask_bce_loss, mask_dice_loss, mask_loss)"""
+    w_ce, w_bce, w_dice = weights
+    out = qwen2_forward(sd, cfg, inputs_embeds, attention_mask, None, all_logits=True)
+    ce = causal_lm_loss(out["logits"], labels) * w_ce
+    m = labels[0] == seg_id
+    m = torch.cat([m[1:], torch.zeros(1, dtype=torch.bool)])
+    emb = text_hidden_fcs(sd, out["hidden_states"][-1][0])[m]                       # [n_obj, 256]
+    n_obj = emb.shape[0]
+    T = images_sam.shape[0]
+    bce = dice = torch.zeros(())
+    if n_obj > 0:
+        per_obj = [sam2_language_masks(sam_sd, sam_cfg, images_sam, emb[o].reshape(1, 1, -1).expand(T, 1, -1))["high_res_masks"] for o in range(n_obj)]
+        high = torch.cat(per_obj, dim=1).reshape(T * n_obj, 1, *images_sam.shape[-2:])            # frame-major, as the reference expands
+        pred = F.interpolate(high, size=tuple(label_list[0].shape), mode="bilinear", align_corners=False)[:, 0]
+        gt = masks_list[0].float()
+        n = gt.shape[0]
+        bce = w_bce * (sigmoid_ce_loss(pred, gt, n) * n) / (n + 1e-8)
+        dice = w_dice * (dice_loss(pred, gt, n) * n) / (n + 1e-8)
+    return dict(loss=ce + bce + dice, ce_loss=ce, mask_bce_loss=bce, mask_dice_loss=dice, mask_loss=bce + dice)

@@ -195,8 +195,8 @@ def test_end_to_end_tiny_vs_reference_golden():
     k0 = fo.past_key_values.buf[0][: fo.logits.shape[1], :32].float().view(-1, 2, 16).permute(1, 0, 2)[None]
     assert rel_err(k0.cpu(), t(a["fw_k0"])) < 3e-2
     assert rel_err(m.get_model().text_hidden_fcs[0](fo.hidden_states[-1]).cpu(), t(a["fcs_out"])) < 3e-2
-    with pytest.raises(NotImplementedError):
-        m(input_ids=ids, attention_mask=am, images=c["images"], images_sam=sam, inference=False)
+    with pytest.raises(ValueError):
+        m(input_ids=ids, attention_mask=am, images=c["images"], images_sam=sam, inference=False)      # training losses need labels
     # --- generate: greedy tokens bit-exact vs the reference
     gen = m.generate(ids, attention_mask=am, images=c["images"], masks=c["masks"], frame=c["frame"], ann_indices=c["ann"],
                      frame_nums=c["fn"], images_sam=sam, offset=[0, 1], masks_list=None, label_list=torch.zeros(56, 56),
@@ -311,3 +311,32 @@ def test_generate_seg_branches_vs_reference_golden():
     with pytest.raises(NotImplementedError):
         m2.generate(ids2, attention_mask=torch.ones_like(ids2), images=[(video, "video")], images_sam=sam, offset=[0, 1],
                     label_list=[torch.zeros(33, 47)], max_new_tokens=2)
+
+
+def test_training_losses_vs_reference_golden():
+    """forward(inference=False): CE + mask BCE + DICE values vs the reference's own forward (oracle/gen_fixtures_train.py)."""
+    a, _ = load_golden("train_tiny")
+    m, am_, w = tiny_model(sam2_trunk=dict(SAM_TINY, image_size=128), sam_seeds=a["sam_seeds"].tolist())
+    m.config.seg_token_id = 299
+    m.config.ce_loss_weight, m.config.bce_loss_weight, m.config.dice_loss_weight = a["loss_weights"].tolist()
+    sam = t(a["images_sam"]).to(DEV)
+    video = t(am_["video"]).to(DEV)
+    for name in ("two_obj", "one_obj", "no_seg"):
+        ids, labels, gt = t(a[name + "_ids"]).to(DEV), t(a[name + "_labels"]).to(DEV), t(a[name + "_gt"]).to(DEV)
+        hw = gt.shape[1:] if gt.shape[0] else (20, 30)
+        r = m(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels, images=[(video, "video")], images_sam=sam,
+              offset=torch.tensor([0, 1]), masks_list=[gt], label_list=[torch.zeros(*hw)], inference=False)
+        got = torch.stack([r[k].float().cpu() for k in ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss")])
+        ref = t(a[name + "_losses"]).float()
+        assert torch.allclose(got, ref, rtol=2e-2, atol=1e-3), (name, got.tolist(), ref.tolist())
+    # kernels alone vs torch: cross entropy rows with ignore_index, mask loss sums
+    g = torch.Generator().manual_seed(2)
+    lg = torch.randn(37, 1000, generator=g).to(DEV) * 3
+    lab = torch.randint(0, 1000, (37,), generator=g).to(DEV); lab[::5] = -100
+    ref = torch.nn.functional.cross_entropy(lg, lab, ignore_index=-100, reduction="none")
+    assert torch.allclose(ops.cross_entropy_rows(lg, lab), ref, atol=1e-5)
+    x = torch.randn(5, 33, 47, generator=g).to(DEV) * 4; tg = (torch.rand(5, 33, 47, generator=g) > 0.5).float().to(DEV)
+    sums = ops.mask_loss_sums(x, tg)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(x, tg, reduction="none").flatten(1).sum(1)
+    assert torch.allclose(sums[:, 0], bce, rtol=1e-5) and torch.allclose(sums[:, 1], (x.sigmoid() * tg).flatten(1).sum(1), rtol=1e-5)
+    assert torch.allclose(sums[:, 2], x.sigmoid().flatten(1).sum(1), rtol=1e-5) and torch.equal(sums[:, 3], tg.flatten(1).sum(1))

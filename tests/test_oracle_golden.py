@@ -240,3 +240,22 @@ def test_seg_branches_of_generate():
     assert rel_err(hl, t(a["prompt_hidden_last"])) < 1e-5
     pm, pl = O.seg_masks_prompt(w, a["prompt_ids"], [S - 3 + 0, 4], t(a["prompt_hidden_last"]), 299, sam, cfg, images_sam, (33, 47))
     assert rel_err(pl, t(a["prompt_logits"])) < 2e-4 and (pm.numpy() != a["prompt_masks"][0]).mean() < 1e-4
+
+
+def test_training_losses_vs_reference_forward():
+    """CE + mask BCE + DICE restatement vs the reference's forward(inference=False) (oracle/gen_fixtures_train.py)."""
+    a, _ = load_golden("train_tiny")
+    _, m, w, cfg, sam = _seg_setup()
+    tab, e1 = w["model.embed_tokens.weight"].float(), t(m["sp_vid_only_nolab_emb"])[0]
+    mm = e1[2:-3]                                               # the video tokens of the vid_only splice: [5, 6, <video>, 7, 8, 9]
+    images_sam = t(a["images_sam"])[0]
+    for name in ("two_obj", "one_obj", "no_seg"):
+        ids, labels = t(a[name + "_ids"])[0], t(a[name + "_labels"])
+        k = ids.tolist().index(-201)
+        emb = torch.cat([tab[ids[:k]], mm, tab[ids[k + 1:]]], 0)[None]
+        lab = torch.cat([labels[0, :k], torch.full((mm.shape[0],), -100), labels[0, k + 1:]])[None]
+        gt = t(a[name + "_gt"])
+        r = O.training_losses(w, TINY_LLM, emb, torch.ones(1, emb.shape[1], dtype=torch.long), lab, 299, sam, cfg, images_sam, [gt],
+                              [torch.zeros(gt.shape[1:]) if gt.shape[0] else torch.zeros(1, 1)], tuple(a["loss_weights"].tolist()))
+        got = torch.stack([r[k_].float() for k_ in ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss")])
+        assert torch.allclose(got, t(a[name + "_losses"]).float(), rtol=2e-5, atol=1e-6), (name, got, a[name + "_losses"])

@@ -653,6 +653,19 @@ class SAM2(nn.Module):
 
     get_sam2_embeddings_inference = get_sam2_embeddings
 
+    # ---- training-path entry points (ref :343-377, :408-447); forward values only ----------------------------------------------
+    def get_sam2_embeddings_train(self, images, expand_size=1, obj_num_list=None, BS=1, T=None):
+        """images [F,3,S,S] of ONE sample -> state; the per-object feature expansion of the reference (each frame's features
+        repeated once per object) is done lazily by `inject_language_embd_train`, which reuses the cached FPN tokens."""
+        return self.sam2_model.init_state(images)
+
+    @torch.no_grad()
+    def inject_language_embd_train(self, sam_states, language_embd, nf_nobj=None):
+        """language_embd [n_obj, C]: every object on every frame of the state, frame-major -> high-res mask logits
+        [F * n_obj, 1, S, S] (the reference's `high_res_masks`, index 4 of `_forward_sam_heads`)."""
+        F_ = sam_states["num_frames"]
+        return self.language_embd_inference(sam_states, [language_embd] * F_)
+
     @torch.no_grad()
     def _features(self, state, lo, hi):
         key = (lo, hi)

@@ -304,7 +304,8 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         # the reference dereferences images_sam unconditionally (videorefer_qwen2.py:155)
         batch_size, num_frames_sam = images_sam.shape[:2]
         if not inference:
-            raise NotImplementedError("training forward (CE + mask BCE/DICE, SURVEY §8 row a12) is not built yet")
+            return self._training_losses(input_ids, attention_mask, past_key_values, labels, images, masks, frame, ann_indices, frame_nums,
+                                         video_file, images_sam, offset, masks_list, label_list)
         if inputs_embeds is None:
             (input_ids, attention_mask, past_key_values, inputs_embeds, labels, _) = self.prepare_inputs_labels_for_multimodal(
                 input_ids, attention_mask, past_key_values, labels, images, masks, frame, ann_indices, frame_nums, video_file)
@@ -319,6 +320,75 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
                            hidden_states=tuple(h.unsqueeze(0) for h in hs) if hs is not None else None, attentions=None)
 
     __call__ = forward
+
+    @torch.no_grad()
+    def _training_losses(self, input_ids, attention_mask, past_key_values, labels, images, masks, frame, ann_indices, frame_nums,
+                         video_file, images_sam, offset, masks_list, label_list):
+        """Forward VALUES of the training objective (ref :198-352): ce_loss_weight * CE + bce_loss_weight * mask BCE +
+        dice_loss_weight * DICE, masks from `get_sam2_embeddings_train` / `inject_language_embd_train` (every object's [SEG]
+        embedding queried on each of the sample's SAM frames, frame-major).  No autograd graph is built: the backward pass
+        / optimizer step is outside this round; samples run through the decoder one at a time."""
+        cfg = self.config
+        B, T = images_sam.shape[:2]
+        if labels is None:
+            raise ValueError("forward(inference=False) computes the training losses and needs `labels`")
+        (input_ids, attention_mask, past_key_values, inputs_embeds, labels, _) = self.prepare_inputs_labels_for_multimodal(
+            input_ids, attention_mask, past_key_values, labels, images, masks, frame, ann_indices, frame_nums, video_file)
+        dev = inputs_embeds.device
+        offset = [int(o) for o in (offset.tolist() if torch.is_tensor(offset) else offset)]
+        assert B == len(offset) - 1
+        ce_sum = torch.zeros((), device=dev)
+        ce_cnt = 0
+        seg_embeds, seg_counts = [], []
+        fcs = self.get_model().text_hidden_fcs[0]
+        for b in range(B):
+            am = attention_mask[b:b + 1] if attention_mask is not None else None
+            logits, _, _, normed = self._decode_batch(inputs_embeds[b:b + 1], am, None, False, 0)
+            S = normed.shape[0]
+            lab = labels[b, :S].to(dev)
+            shifted = torch.cat([lab[1:], torch.full((1,), -100, dtype=lab.dtype, device=dev)]).contiguous()
+            ce_sum = ce_sum + ops.cross_entropy_rows(logits[0], shifted).sum()
+            ce_cnt += int((shifted != -100).sum().item())
+            seg = shifted == cfg.seg_token_id                                  # position p contributes when label p+1 is [SEG]
+            rows = torch.nonzero(seg).reshape(-1)
+            seg_counts.append(int(rows.numel()))
+            if rows.numel():
+                seg_embeds.append(fcs(normed[rows]))
+        ce = getattr(cfg, "ce_loss_weight", 1.0) * ce_sum / max(ce_cnt, 1)
+        pred_embeddings = torch.cat(seg_embeds, 0) if seg_embeds else torch.zeros((0, getattr(cfg, "sam_out_dim", 256)), device=dev)
+        cum = [0]
+        for c in seg_counts:
+            cum.append(cum[-1] + c)
+        seg_offset = [cum[o] for o in offset]
+        bce_tot = torch.zeros((), device=dev)
+        dice_tot = torch.zeros((), device=dev)
+        num_masks = 0
+        enc = self.get_model().mask_encoder
+        for i in range(len(seg_offset) - 1):
+            emb = pred_embeddings[seg_offset[i]:seg_offset[i + 1]]
+            gt = masks_list[i].to(dev).float().contiguous()
+            n_obj = emb.shape[0]
+            if n_obj == 0:                                                      # ref: zero embedding, prediction sliced to [0:0]
+                assert gt.shape[0] == 0, f"gt_mask.shape: {tuple(gt.shape)}, pred_mask.shape: (0, ...)"
+                continue
+            if enc is None:
+                raise NotImplementedError("the mask losses need the SAM2 head: build the model with config.sam2_trunk set")
+            hw = tuple(label_list[i].shape)
+            high = enc.inject_language_embd_train(enc.get_sam2_embeddings_train(images_sam[i]), emb)       # [T*n_obj, 1, S, S]
+            pred = ops.resize_bilinear(high.contiguous(), hw)[:, 0].contiguous()
+            assert gt.shape[0] == pred.shape[0], "gt_mask.shape: {}, pred_mask.shape: {}".format(tuple(gt.shape), tuple(pred.shape))
+            n = gt.shape[0]
+            sums = ops.mask_loss_sums(pred, gt)
+            HW = float(hw[0] * hw[1])
+            bce_tot = bce_tot + (sums[:, 0] / HW).sum() / (n + 1e-8) * n
+            num = 2 * (sums[:, 1] / 1000.0)
+            den = sums[:, 2] / 1000.0 + sums[:, 3] / 1000.0
+            dice_tot = dice_tot + (1 - (num + 1e-6) / (den + 1e-6)).sum() / (n + 1e-8) * n
+            num_masks += n
+        mask_bce = getattr(cfg, "bce_loss_weight", 1.0) * bce_tot / (num_masks + 1e-8)
+        mask_dice = getattr(cfg, "dice_loss_weight", 1.0) * dice_tot / (num_masks + 1e-8)
+        mask_loss = mask_bce + mask_dice
+        return {"loss": ce + mask_loss, "ce_loss": ce, "mask_bce_loss": mask_bce, "mask_dice_loss": mask_dice, "mask_loss": mask_loss}
 
     # ---- generate ---------------------------------------------------------------------------------------------
     @torch.no_grad()

@@ -303,6 +303,25 @@ def argmax_rows(x):
     return out
 
 
+def cross_entropy_rows(logits, labels, ignore_index=-100):
+    """per-row -log softmax(logits)[label] (0 where label == ignore_index); logits f32 [M, V], labels int64 [M]"""
+    _chk(logits, torch.float32, "logits"); _chk(labels, torch.int64, "labels")
+    M, V = logits.shape
+    out = torch.empty((M,), device=logits.device, dtype=torch.float32)
+    _lib.call("ufv_cross_entropy_rows", logits.data_ptr(), logits.stride(0), labels.data_ptr(), M, V, ignore_index, out.data_ptr(), _stream())
+    return out
+
+
+def mask_loss_sums(pred, gt):
+    """pred/gt f32 [n, H, W] -> f32 [n, 4] = (sum BCE-with-logits, sum sigmoid*gt, sum sigmoid, sum gt) per mask"""
+    _chk(pred, torch.float32, "pred"); _chk(gt, torch.float32, "gt")
+    assert pred.shape == gt.shape and pred.is_contiguous() and gt.is_contiguous()
+    n = pred.shape[0]
+    out = torch.zeros((n, 4), device=pred.device, dtype=torch.float32)
+    _lib.call("ufv_mask_loss_sums", pred.data_ptr(), gt.data_ptr(), n, pred[0].numel() if n else 1, out.data_ptr(), _stream())
+    return out
+
+
 def argmax(logits, out=None):
     _chk(logits, torch.float32, "logits")
     if out is None:
