@@ -210,8 +210,8 @@ def test_patchify(dt):
     assert out[:, 588:].abs().sum() == 0
 
 
-def test_dwconv_ln_silu_and_se_pieces():
-    F, H, W, C = 3, 6, 6, 256
+@pytest.mark.parametrize("F,H,W,C", [(3, 6, 6, 256), (2, 5, 7, 3584), (1, 24, 24, 896), (2, 3, 1, 64)])
+def test_dwconv_ln_silu_and_se_pieces(F, H, W, C):
     x = bf(g(F, H, W, C, seed=35))
     w = g(C, 1, 3, 3, seed=36, scale=0.3)
     lnw, lnb = 1 + 0.1 * g(C, seed=37), 0.1 * g(C, seed=38)

@@ -246,97 +246,159 @@ __global__ __launch_bounds__(256) void patchify_k(const void* px, bf16* out, int
 }
 
 // -------------------------------------------------------------------------------------------------
-// depthwise 3x3 (pad 1) + LayerNorm(C) + SiLU, NHWC.  One wave per pixel, 4 pixels per block.
+// depthwise 3x3 (pad 1) + LayerNorm(C) + SiLU, NHWC.  One block = 4 consecutive pixels of a row x all channels;
+// wave w owns a quarter of the 8-channel chunks, so every weight chunk is loaded once per 4 pixels and every input
+// column is loaded once for the 3 horizontal taps that use it; LayerNorm statistics are combined across the waves in LDS.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dwconv_ln_silu_k(const bf16* x, bf16* y, const float* w9, const float* lnw,
-                                                        const float* lnb, int F, int H, int W, int C, float eps) {
-    // one wave per pixel; lane owns 8-channel chunks lane + 64*i (16-byte loads), C <= 4096
-    constexpr int MAXC = 8;
-    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pix >= F * H * W) return;
-    const int px = pix % W, py = (pix / W) % H, f = pix / (W * H);
-    const int nc = C >> 3;
-    float v[MAXC][8];
+__global__ __launch_bounds__(256) void dwconv_ln_silu_k(const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w9,
+                                                        const float* __restrict__ lnw, const float* __restrict__ lnb, int F, int H, int W,
+                                                        int C, float eps) {
+    constexpr int PX = 4, MAXI = 2;                     // C <= 4096 -> <= 128 chunks per wave -> <= 2 per lane
+    __shared__ float red[2][4][PX];
+    const int nseg = (W + PX - 1) / PX;
+    const int seg = blockIdx.x % nseg, py = (blockIdx.x / nseg) % H, f = blockIdx.x / (nseg * H);
+    const int x0 = seg * PX, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nc = C >> 3, cpw = (nc + 3) >> 2;
+    int cidx[MAXI];
+    bool cok[MAXI];
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
+    for (int i = 0; i < MAXI; ++i) {
+        const int q = lane + 64 * i;
+        cok[i] = q < cpw && wave * cpw + q < nc;
+        cidx[i] = 8 * (wave * cpw + q);
+    }
+    float acc[MAXI][PX][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+    for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][p][j] = 0.f;
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
         const int yy = py + dy;
         if (yy < 0 || yy >= H) continue;
+        float wt[3][MAXI][8];
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int xx = px + dx;
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i)
+                if (cok[i]) {
+                    const float* wk = w9 + ((dy + 1) * 3 + dx) * C + cidx[i];
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(wk), b = *reinterpret_cast<const f32x4*>(wk + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { wt[dx][i][j] = a[j]; wt[dx][i][4 + j] = b[j]; }
+                }
+        const bf16* row = x + ((int64_t)(f * H + yy) * W) * C;
+#pragma unroll
+        for (int col = -1; col <= PX; ++col) {
+            const int xx = x0 + col;
             if (xx < 0 || xx >= W) continue;
-            const bf16* src = x + ((int64_t)(f * H + yy) * W + xx) * C;
-            const float* wk = w9 + ((dy + 1) * 3 + (dx + 1)) * C;
 #pragma unroll
-            for (int i = 0; i < MAXC; ++i)
-                if (lane + 64 * i < nc) {
-                    const int c = 8 * (lane + 64 * i);
-                    const bf16x8 xv = *reinterpret_cast<const bf16x8*>(src + c);
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wk + c), w1 = *reinterpret_cast<const f32x4*>(wk + c + 4);
+            for (int i = 0; i < MAXI; ++i)
+                if (cok[i]) {
+                    const bf16x8 xv = *reinterpret_cast<const bf16x8*>(row + (int64_t)xx * C + cidx[i]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[i][j] += (float)xv[j] * w0[j];
-                        v[i][4 + j] += (float)xv[4 + j] * w1[j];
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int p = col - (dx - 1);           // output pixel that sees this column through tap dx
+                        if (p >= 0 && p < PX)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[i][p][j] += (float)xv[j] * wt[dx][i][j];
                     }
                 }
         }
     }
-    // LayerNorm over C (two-pass in registers), then SiLU
-    float sum = 0.f;
+    // LayerNorm over C per pixel (mean, then centred variance), statistics combined across the 4 waves
+    float mean[PX], rstd[PX];
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-        if (lane + 64 * i < nc)
+    for (int p = 0; p < PX; ++p) {
+        float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += v[i][j];
-    const float mean = wave_sum(sum) / C;
-    float q = 0.f;
+        for (int i = 0; i < MAXI; ++i)
+            if (cok[i])
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-        if (lane + 64 * i < nc)
+                for (int j = 0; j < 8; ++j) s += acc[i][p][j];
+        s = wave_sum(s);
+        if (lane == 0) red[0][wave][p] = s;
+    }
+    __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d = v[i][j] - mean;
-                q += d * d;
-            }
-    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    for (int p = 0; p < PX; ++p) mean[p] = (red[0][0][p] + red[0][1][p] + red[0][2][p] + red[0][3][p]) / C;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-        if (lane + 64 * i < nc) {
-            const int c = 8 * (lane + 64 * i);
+    for (int p = 0; p < PX; ++p) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+            if (cok[i])
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = acc[i][p][j] - mean[p];
+                    q += d * d;
+                }
+        q = wave_sum(q);
+        if (lane == 0) red[1][wave][p] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PX; ++p) rstd[p] = rsqrtf((red[1][0][p] + red[1][1][p] + red[1][2][p] + red[1][3][p]) / C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+        if (cok[i]) {
+            const int c = cidx[i];
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnw + c), g1 = *reinterpret_cast<const f32x4*>(lnw + c + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(lnb + c), b1 = *reinterpret_cast<const f32x4*>(lnb + c + 4);
-            bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = (bf16)act_apply_t<ACT_SILU>((v[i][j] - mean) * rstd * g0[j] + b0[j]);
-                o[4 + j] = (bf16)act_apply_t<ACT_SILU>((v[i][4 + j] - mean) * rstd * g1[j] + b1[j]);
+            for (int p = 0; p < PX; ++p) {
+                if (x0 + p >= W) continue;
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = (bf16)act_apply_t<ACT_SILU>((acc[i][p][j] - mean[p]) * rstd[p] * g0[j] + b0[j]);
+                    o[4 + j] = (bf16)act_apply_t<ACT_SILU>((acc[i][p][4 + j] - mean[p]) * rstd[p] * g1[j] + b1[j]);
+                }
+                *reinterpret_cast<bf16x8*>(y + ((int64_t)(f * H + py) * W + x0 + p) * C + c) = o;
             }
-            *reinterpret_cast<bf16x8*>(y + (int64_t)pix * C + c) = o;
         }
 }
 
-// out[f, c] = mean_p x[f*P + p, c].  Block = 8 row groups x 64 lanes, lane owns 4 channels (256 channels / block);
-// row groups stride over the P rows and are combined through LDS.
-__global__ __launch_bounds__(512) void colmean_k(const bf16* x, bf16* out, int F, int P, int C) {
-    __shared__ f32x4 part[8][64];
+// out[f, c] = mean_p x[f*P + p, c].  Block = 8 row groups x 64 lanes, lane owns 8 channels (16-byte loads, 512 channels per
+// block); each row group walks its rows four at a time so that several loads are in flight; groups combine through LDS.
+__global__ __launch_bounds__(512) void colmean_k(const bf16* __restrict__ x, bf16* __restrict__ out, int F, int P, int C) {
+    __shared__ float part[8][64][8];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + lane) * 4, f = blockIdx.y;
-    f32x4 s = {0, 0, 0, 0};
+    const int c = (blockIdx.x * 64 + lane) * 8, f = blockIdx.y;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
     if (c < C) {
         const bf16* p = x + (int64_t)f * P * C + c;
-        for (int r = g; r < P; r += 8) s += load4<UFV_DT_BF16>(p, (int64_t)r * C);
+        int r = g;
+        for (; r + 24 < P; r += 32) {
+            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(p + (int64_t)r * C), v1 = *reinterpret_cast<const bf16x8*>(p + (int64_t)(r + 8) * C);
+            const bf16x8 v2 = *reinterpret_cast<const bf16x8*>(p + (int64_t)(r + 16) * C), v3 = *reinterpret_cast<const bf16x8*>(p + (int64_t)(r + 24) * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += ((float)v0[j] + (float)v1[j]) + ((float)v2[j] + (float)v3[j]);
+        }
+        for (; r < P; r += 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + (int64_t)r * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+        }
     }
-    part[g][lane] = s;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[g][lane][j] = s[j];
     __syncthreads();
     if (g == 0 && c < C) {
-#pragma unroll
-        for (int i = 1; i < 8; ++i) s += part[i][lane];
         const float inv = 1.0f / P;
-        store4<false>(out, (int64_t)f * C + c, f32x4{s[0] * inv, s[1] * inv, s[2] * inv, s[3] * inv});
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = s[j];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) t += part[i][lane][j];
+            o[j] = (bf16)(t * inv);
+        }
+        *reinterpret_cast<bf16x8*>(out + (int64_t)f * C + c) = o;
     }
 }
 
@@ -629,15 +691,15 @@ extern "C" int ufv_dwconv3x3_ln_silu(const void* x, void* y, const float* w9, co
                                      int W, int C, float eps, void* stream) {
     UFV_REQUIRE(x && y && w9 && lnw && lnb && F > 0, "ufv_dwconv3x3_ln_silu: bad arguments");
     UFV_REQUIRE(C % 8 == 0 && C <= 4096, "ufv_dwconv3x3_ln_silu: C=%d must be a multiple of 8 and <= 4096", C);
-    hipLaunchKernelGGL(dwconv_ln_silu_k, dim3(cdiv(F * H * W, 4)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F,
+    hipLaunchKernelGGL(dwconv_ln_silu_k, dim3(F * H * cdiv(W, 4)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F,
                        H, W, C, eps);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
 
 extern "C" int ufv_colmean(const void* x, void* out, int F, int P, int C, void* stream) {
-    UFV_REQUIRE(x && out && F > 0 && P > 0 && C % 4 == 0, "ufv_colmean: bad arguments");
-    hipLaunchKernelGGL(colmean_k, dim3(cdiv(C / 4, 64), F), dim3(512), 0, ST(stream), (const bf16*)x, (bf16*)out, F, P, C);
+    UFV_REQUIRE(x && out && F > 0 && P > 0 && C % 8 == 0, "ufv_colmean: C must be a multiple of 8");
+    hipLaunchKernelGGL(colmean_k, dim3(cdiv(C / 8, 64), F), dim3(512), 0, ST(stream), (const bf16*)x, (bf16*)out, F, P, C);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
