@@ -41,6 +41,7 @@ extern "C" {
 #define UFV_GEMM_GENERIC 2 /* one-thread-per-output kernel, any shape */
 #define UFV_GEMM_GEMV 3    /* weight-streaming kernel for M <= 64 */
 #define UFV_GEMM_FAST256 4 /* 256x256x64 8-wave ping-pong MFMA kernel (large M) */
+#define UFV_GEMM_STREAMK 5 /* the same kernel with stream-K work split: every CU gets the same number of K-tile iterations */
 
 /* dtype ids for inputs that may arrive in several formats */
 #define UFV_DT_BF16 0

@@ -324,3 +324,36 @@ def test_attention_decode(hd, Hq, Hkv, Sk, nsplit):
     o = ops.attention_decode(q.view(1, Hq * hd), kv, kv[:, Hkv * hd:], Hq, Hkv, Sk, hd, kv.stride(0), kv.stride(0), nsplit=nsplit)
     k = kv[:Sk, :Hkv * hd].view(1, Sk, Hkv, hd); v = kv[:Sk, Hkv * hd:].view(1, Sk, Hkv, hd)
     assert rel(o, attn_ref(q, k, v, True, Sk - 1)) < 1.2e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(2000, 1024, 4096), (2399, 3584, 18944), (2399, 4608, 3584), (18432, 1152, 1152), (515, 768, 8192),
+                                   (4096, 3456, 256), (300, 256, 2560)])
+def test_gemm_streamk_vs_tile_kernel(M, N, K):
+    """Stream-K work split of the 256-wide kernel: tiles are cut at arbitrary K-tile boundaries and summed through the fp32
+    workspace in a fixed order -> equal to the tile kernel up to fp32 summation order, and bit-reproducible run to run."""
+    a, w = bf(g(M, K, seed=61)), bf(g(N, K, seed=62, scale=0.05))
+    bias, resid = g(N, seed=63), g(M, N, seed=64)
+    ref = ops.gemm(a, w, bias=bias, act="gelu_tanh", resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST256)
+    outs = [ops.gemm(a, w, bias=bias, act="gelu_tanh", resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_STREAMK) for _ in range(4)]
+    assert rel(outs[0], ref) < 2e-6 * (K / 64) ** 0.5 + 1e-6
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    refb = ops.gemm(a, w, kernel=ops.GEMM_FAST256)
+    ob = ops.gemm(a, w, kernel=ops.GEMM_STREAMK)
+    assert rel(ob, refb) < 8e-3 and torch.equal(ob, ops.gemm(a, w, kernel=ops.GEMM_STREAMK))
+    # in-place fp32 residual stream (the decoder's o_proj / down_proj form)
+    x1, x2 = resid.clone(), resid.clone()
+    ops.gemm(a, w, resid=x1, out=x1, kernel=ops.GEMM_FAST256)
+    ops.gemm(a, w, resid=x2, out=x2, kernel=ops.GEMM_STREAMK)
+    assert rel(x2, x1) < 2e-6 * (K / 64) ** 0.5 + 1e-6
+
+
+def test_gemm_streamk_fp8_and_errors():
+    a, w = bf(g(2399, 3584, seed=65)), bf(g(1280, 3584, seed=66, scale=0.05))
+    W8 = ops.Fp8Weight(w)
+    aq, sa = ops.quantize_fp8(a)
+    ref = ops.gemm_fp8(aq, sa, W8, out_dtype=torch.float32, kernel=ops.GEMM_FAST256)
+    out = ops.gemm_fp8(aq, sa, W8, out_dtype=torch.float32, kernel=ops.GEMM_STREAMK)
+    assert rel(out, ref) < 2e-5
+    from ufvideo_amd import _lib
+    with pytest.raises(_lib.UfvError):
+        ops.gemm(a, bf(g(512, 3584, seed=67)), swiglu=True, kernel=ops.GEMM_STREAMK)

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libufv_hip.so")
 ACT = {None: 0, "none": 0, "gelu_pytorch_tanh": 1, "gelu_tanh": 1, "gelu": 2, "gelu_erf": 2, "silu": 3, "relu": 4,
        "quick_gelu": 5, "sigmoid": 6}
 DT_BF16, DT_F32, DT_F16 = 0, 1, 2
-GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, GEMM_GEMV, GEMM_FAST256 = 0, 1, 2, 3, 4
+GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, GEMM_GEMV, GEMM_FAST256, GEMM_STREAMK = 0, 1, 2, 3, 4, 5
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_int64
 

@@ -433,8 +433,13 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
         ufv_set_error("ufv_gemm: 256-tile kernel needs M>=256, N%%128==0, K%%%d==0 (M=%d N=%d K=%d)", KE, M, N, K);
         return UFV_EUNSUPPORTED;
     }
+    if (force == UFV_GEMM_STREAMK && !big_ok) {
+        ufv_set_error("ufv_gemm: stream-K kernel needs M>=256, N%%128==0, K%%%d==0 (M=%d N=%d K=%d)", KE, M, N, K);
+        return UFV_EUNSUPPORTED;
+    }
+    if (force == UFV_GEMM_STREAMK) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, true, st);
     if (force == UFV_GEMM_FAST256 || (force == UFV_GEMM_AUTO && big_ok && prefer256(M, N, Q ? K / 2 : K)))
-        return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, st);
+        return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, st);
     if ((force == UFV_GEMM_AUTO && fast_ok && M > 64) || force == UFV_GEMM_FAST)
         return launch_fast<F, S, Q>(A, W, e, M, N, K, lda, ldw, st);
     if constexpr (Q) {
@@ -459,7 +464,7 @@ int gemm_entry(const void* A, int lda, const float* a_scale, const void* W, int 
                void* stream) {
     Epi e;
     e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = resid_rows;
-    e.scale_m = a_scale; e.scale_n = w_scale;
+    e.scale_m = a_scale; e.scale_n = w_scale; e.dump_f32 = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (out_f32)
         return swiglu ? launch_any<true, true, Q>(A, W, e, M, N, K, lda, ldw, kernel, st)

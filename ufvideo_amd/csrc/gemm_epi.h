@@ -10,6 +10,7 @@ struct Epi {
     int resid_rows;        // >0: residual row = m % resid_rows (broadcast table, e.g. position embeddings)
     const float* scale_m;  // fp8 operands only: per-row scale of A [M] and per-row scale of W [N]; acc *= scale_m[m] * scale_n[n]
     const float* scale_n;
+    int dump_f32;          // stream-K only: store the raw accumulators as fp32 whatever the output type (partial tile dump)
 };
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -42,9 +43,19 @@ __device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, float v0,
 }
 
 
-// same as epi_store4 with the bias already in registers (ignored when e.bias is null)
-template <bool OUT_F32, int ACT>
+// same as epi_store4 with the bias already in registers (ignored when e.bias is null).  DUMP (stream-K kernels): when
+// e.dump_f32 is set the four values are stored untouched as fp32 -- the partial-tile dump reuses the epilogue's store code so
+// that the accumulators have a single consumer in the control flow (a second consumer block makes hipcc copy / spill them).
+template <bool OUT_F32, int ACT, bool DUMP = false>
 __device__ __forceinline__ void epi_store4b(const Epi& e, int m, int n, float v0, float v1, float v2, float v3, f32x4 b) {
+    if (DUMP && e.dump_f32) {
+        // system-scope (write-through) store: the partial tile is read by a block on another XCD, whose L2 is not coherent with
+        // ours; sc0 sc1 makes the line visible in memory when the store is acknowledged -- no L2 write-back fence needed.
+        f32x4 o = {v0, v1, v2, v3};
+        float* p = reinterpret_cast<float*>(e.out) + (size_t)m * e.ldc + n;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(o) : "memory");
+        return;
+    }
     float v[4] = {v0, v1, v2, v3};      // b = bias already in registers (zeros when there is none)
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = act_apply_t<ACT>(v[j] + b[j]);
@@ -64,4 +75,4 @@ __device__ __forceinline__ void epi_store4b(const Epi& e, int m, int n, float v0
 }
 
 int ufv_launch_gemm256(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
-                       bool swiglu, bool fp8, hipStream_t st);
+                       bool swiglu, bool fp8, bool streamk, hipStream_t st);

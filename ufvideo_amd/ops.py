@@ -5,7 +5,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import ACT, DT_BF16, DT_F32, DT_F16, GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, GEMM_GEMV, GEMM_FAST256  # noqa: F401
+from ._lib import ACT, DT_BF16, DT_F32, DT_F16, GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, GEMM_GEMV, GEMM_FAST256, GEMM_STREAMK  # noqa: F401
 
 _DT = {torch.bfloat16: DT_BF16, torch.float32: DT_F32, torch.float16: DT_F16}
 
