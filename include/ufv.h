@@ -176,8 +176,14 @@ int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* token_dev, in
                           float* hidden_out, int64_t* next_token_dev, void* stream);
 
 /* ---- W8A8 fp8 GEMM path (SURVEY §8f row 1 / BASELINE config #5a; not in the reference, which runs bf16/fp16) ----
- * OCP e4m3 operands with one fp32 scale per row: x[m,k] ~ q[m,k] * scale[m], scale = max|x[m,:]| / 448. */
+ * OCP e4m3 operands with one fp32 scale per row: x[m,k] ~ q[m,k] * scale[m], scale = max|x[m,:]| / 448,
+ * q = rne_e4m3(x * (1/scale)). */
 int ufv_quantize_fp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, float* scale, int M, int K, void* stream);
+/* ufv_layernorm / ufv_rmsnorm with the bf16 result quantised in the same pass (bit-identical to norm followed by
+ * ufv_quantize_fp8): q e4m3 [M, D], scale f32 [M]. */
+int ufv_layernorm_fp8(const void* x, int x_dtype, int ldx, void* q, int64_t ldq, float* scale, const float* w, const float* b, int M,
+                      int D, float eps, void* stream);
+int ufv_rmsnorm_fp8(const float* x, int ldx, void* q, int64_t ldq, float* scale, const float* w, int M, int D, float eps, void* stream);
 int ufv_dequantize_fp8(const void* q, int64_t ldq, const float* scale, float* out, int64_t ldo, int M, int K, void* stream);
 /* ufv_gemm with e4m3 A [M,K] (a_scale [M]) and W [N,K] (w_scale [N]):  C = epilogue((Aq Wq^T) * a_scale[m] * w_scale[n]).
  * v_mfma_f32_16x16x128_f8f6f4 tiles (N % 128 == 0, K % 128 == 0) or the fp8 GEMV (M <= 64, K % 16 == 0); same epilogues. */

@@ -995,11 +995,11 @@ def seg_masks_prompt(sd: SD, ids, mark, hidden_last, seg_id: int, sam_sd: SD, sa
 # the arithmetic the fp8 GEMM path must reproduce, include/ufv.h `ufv_quantize_fp8` / `ufv_gemm_fp8`)
 # --------------------------------------------------------------------------------------
 def quantize_fp8_rows(x: torch.Tensor):
-    """scale[m] = max|x[m]| / 448; q = round-to-nearest-even e4m3fn(x / scale) -> (dequantised values fp32, scale, codes uint8)."""
+    """scale[m] = max|x[m]| / 448; q = round-to-nearest-even e4m3fn(x * (1 / scale)) -> (dequantised values fp32, scale, codes uint8)."""
     x = x.float()
     amax = x.abs().amax(dim=1, keepdim=True)
     scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
-    q8 = (x / scale).to(torch.float8_e4m3fn)
+    q8 = (x * (1.0 / scale)).to(torch.float8_e4m3fn)
     return q8.float(), scale[:, 0], q8.view(torch.uint8)
 
 

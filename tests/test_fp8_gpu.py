@@ -32,6 +32,28 @@ def test_quantize_codes_bit_exact():
     assert torch.equal(q.cpu(), O.quantize_fp8_rows(big[:, 128:384].cpu())[2])
 
 
+def test_fused_norm_quant_equals_norm_then_quant():
+    g = torch.Generator().manual_seed(4)
+    for D in (1152, 3584, 64):
+        x = (torch.randn(77, D, generator=g) * 2).to(DEV)
+        w = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV); b = (0.1 * torch.randn(D, generator=g)).to(DEV)
+        qa = ops.layernorm(x, w, b, 1e-6, quant=True)
+        q, s = ops.quantize_fp8(ops.layernorm(x, w, b, 1e-6))
+        assert torch.equal(qa.q, q) and torch.equal(qa.scale, s)
+        qa = ops.layernorm(x.to(torch.bfloat16), w, b, 1e-6, quant=True)
+        q, s = ops.quantize_fp8(ops.layernorm(x.to(torch.bfloat16), w, b, 1e-6))
+        assert torch.equal(qa.q, q) and torch.equal(qa.scale, s)
+        qa = ops.rmsnorm(x, w, 1e-6, quant=True)
+        q, s = ops.quantize_fp8(ops.rmsnorm(x, w, 1e-6))
+        assert torch.equal(qa.q, q) and torch.equal(qa.scale, s)
+    # single-pass (K <= 8192) and two-pass (large K / f32) row quantisers agree with the restatement
+    for K in (8192, 18944):
+        xb = (torch.randn(9, K, generator=g) * 3).to(torch.bfloat16)
+        q, s = ops.quantize_fp8(xb.to(DEV))
+        _, sr, codes = O.quantize_fp8_rows(xb)
+        assert torch.equal(q.cpu(), codes) and torch.equal(s.cpu(), sr)
+
+
 @pytest.mark.parametrize("M,N,K,kernel", [(300, 256, 256, ops.GEMM_FAST), (300, 256, 256, ops.GEMM_FAST256), (1000, 384, 1152, ops.GEMM_AUTO),
                                           (515, 512, 128, ops.GEMM_FAST256), (7, 200, 272, ops.GEMM_GEMV), (64, 128, 3584, ops.GEMM_AUTO),
                                           (2399, 1280, 3584, ops.GEMM_FAST), (2399, 1280, 3584, ops.GEMM_FAST256)])

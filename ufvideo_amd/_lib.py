@@ -36,6 +36,8 @@ SIGNATURES = {
     "ufv_add_rows": [_p, _i, _l, _p, _l, _p, _i, _i, _p],
     "ufv_upsample2x_add": [_p, _p, _i, _i, _i, _i, _p],
     "ufv_quantize_fp8": [_p, _i, _l, _p, _l, _p, _i, _i, _p],
+    "ufv_layernorm_fp8": [_p, _i, _i, _p, _l, _p, _p, _p, _i, _i, _f, _p],
+    "ufv_rmsnorm_fp8": [_p, _i, _p, _l, _p, _p, _i, _i, _f, _p],
     "ufv_dequantize_fp8": [_p, _l, _p, _p, _l, _i, _i, _p],
     "ufv_gemm_fp8": [_p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p],
     "ufv_cross_entropy_rows": [_p, _l, _p, _i, _i, _l, _p, _p],

@@ -138,12 +138,15 @@ class _VitBody(PackedModule):
         ff = torch.empty((M, pk["Ip"]), device=x.device, dtype=torch.bfloat16)
         st = (S * 3 * D, 3 * D)
         for L in pk["layers"][:n_layers]:
-            ops.layernorm(x, L["ln1"][0], L["ln1"][1], cfg.layer_norm_eps, out=h)
-            ops.gemm(h, L["wqkv"], bias=L["bqkv"], out=qkv)
+            q8 = isinstance(L["wqkv"], ops.Fp8Weight)          # W8A8: the LayerNorms emit e4m3 + row scale directly
+            hq = (ops.layernorm(x, L["ln1"][0], L["ln1"][1], cfg.layer_norm_eps, quant=True) if q8
+                  else ops.layernorm(x, L["ln1"][0], L["ln1"][1], cfg.layer_norm_eps, out=h))
+            ops.gemm(hq, L["wqkv"], bias=L["bqkv"], out=qkv)
             ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], T, H, H, S, S, hd, st, st, st, out=o)
             ops.gemm(o, L["wo"], bias=L["bo"], resid=x, out=x)
-            ops.layernorm(x, L["ln2"][0], L["ln2"][1], cfg.layer_norm_eps, out=h)
-            ops.gemm(h, L["w1"], bias=L["b1"], act=cfg.hidden_act, out=ff)
+            hq = (ops.layernorm(x, L["ln2"][0], L["ln2"][1], cfg.layer_norm_eps, quant=True) if q8
+                  else ops.layernorm(x, L["ln2"][0], L["ln2"][1], cfg.layer_norm_eps, out=h))
+            ops.gemm(hq, L["w1"], bias=L["b1"], act=cfg.hidden_act, out=ff)
             ops.gemm(ff, L["w2"], bias=L["b2"], resid=x, out=x)
         return x, S
 

@@ -171,14 +171,15 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
             if "wqkv8" in L:
                 L = dict(L, wqkv=L["wqkv8"], wo=L["wo8"], wgu=L["wgu8"], wd=L["wd8"])
             kvb = cache.buf[li]
-            ops.rmsnorm(x, L["ln1"], eps, out=h)
-            ops.gemm(h, L["wqkv"], bias=L["bqkv"], out=qkv)
+            q8 = isinstance(L["wqkv"], ops.Fp8Weight)          # W8A8 prefill: the norms emit e4m3 + row scale directly
+            hq = ops.rmsnorm(x, L["ln1"], eps, quant=True) if q8 else ops.rmsnorm(x, L["ln1"], eps, out=h)
+            ops.gemm(hq, L["wqkv"], bias=L["bqkv"], out=qkv)
             ops.rope_kv(qkv, S, H, KV, hd, pk["inv_freq"], pos0, kvb)
             ops.attention(qkv, kvb, kvb[:, KV * hd:], 1, H, KV, S, Sk, hd, (0, qkv.stride(0)), (0, kvb.stride(0)),
                           (0, kvb.stride(0)), causal=True, q_pos0=pos0, out=o)
             ops.gemm(o, L["wo"], resid=x, out=x)
-            ops.rmsnorm(x, L["ln2"], eps, out=h)
-            ops.gemm(h, L["wgu"], swiglu=True, out=act)
+            hq = ops.rmsnorm(x, L["ln2"], eps, quant=True) if q8 else ops.rmsnorm(x, L["ln2"], eps, out=h)
+            ops.gemm(hq, L["wgu"], swiglu=True, out=act)
             ops.gemm(act, L["wd"], resid=x, out=x)
             if collect_hidden is not None and li < len(pk["layers"]) - 1:
                 collect_hidden.append(x.clone())

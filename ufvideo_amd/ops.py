@@ -31,7 +31,7 @@ def gemm(a, w, bias=None, act=None, resid=None, resid_rows=0, out=None, out_dtyp
     """out[M, N(/2)] = epilogue(a[M,K] @ w[N,K]^T).  a may be a row-strided view; w contiguous.
     w may be an `Fp8Weight`: then a is quantised per row and the fp8 MFMA path runs (same epilogues)."""
     if isinstance(w, Fp8Weight):
-        aq, sa = quantize_fp8(a)
+        aq, sa = (a.q, a.scale) if isinstance(a, QAct) else quantize_fp8(a)
         return gemm_fp8(aq, sa, w, bias=bias, act=act, resid=resid, resid_rows=resid_rows, out=out, out_dtype=out_dtype, swiglu=swiglu,
                         kernel=kernel)
     _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w")
@@ -71,6 +71,14 @@ def dequantize_fp8(q, scale):
     return out
 
 
+class QAct:
+    """A per-token-quantised activation: e4m3 codes [M, K] + fp32 row scales [M] (what `gemm` consumes with an Fp8Weight)."""
+
+    def __init__(self, q, scale):
+        self.q, self.scale = q, scale
+        self.shape = tuple(q.shape)
+
+
 class Fp8Weight:
     """A weight matrix [N, K] held as e4m3 bytes + one fp32 scale per output channel.  Passing it to `gemm` in place of a
     bf16 weight selects the W8A8 path: the activation is quantised per token on the fly."""
@@ -106,9 +114,17 @@ def gemm_fp8(aq, a_scale, w, bias=None, act=None, resid=None, resid_rows=0, out=
     return out
 
 
-def layernorm(x, w, b, eps, act=None, out=None, out_dtype=torch.bfloat16):
+def layernorm(x, w, b, eps, act=None, out=None, out_dtype=torch.bfloat16, quant=False):
+    """quant=True: the bf16 result is quantised in the same pass and returned as a QAct (input of an fp8 GEMM)."""
     _chk(x, name="x"); _chk(w, torch.float32, "w")
     M, D = x.shape
+    if quant:
+        assert act is None
+        q = torch.empty((M, D), device=x.device, dtype=torch.uint8)
+        s = torch.empty((M,), device=x.device, dtype=torch.float32)
+        _lib.call("ufv_layernorm_fp8", x.data_ptr(), _DT[x.dtype], x.stride(0), q.data_ptr(), q.stride(0), s.data_ptr(), w.data_ptr(),
+                  _ptr(b), M, D, float(eps), _stream())
+        return QAct(q, s)
     if out is None:
         out = torch.empty((M, D), device=x.device, dtype=out_dtype)
     _lib.call("ufv_layernorm", x.data_ptr(), _DT[x.dtype], x.stride(0), out.data_ptr(), int(out.dtype == torch.float32),
@@ -127,9 +143,15 @@ def ln_add_silu(a, wa, ba, b, wb=None, bb=None, eps=1e-5, out=None):
     return out
 
 
-def rmsnorm(x, w, eps, out=None, out_dtype=torch.bfloat16):
+def rmsnorm(x, w, eps, out=None, out_dtype=torch.bfloat16, quant=False):
     _chk(x, torch.float32, "x")
     M, D = x.shape
+    if quant:
+        q = torch.empty((M, D), device=x.device, dtype=torch.uint8)
+        s = torch.empty((M,), device=x.device, dtype=torch.float32)
+        _lib.call("ufv_rmsnorm_fp8", x.data_ptr(), x.stride(0), q.data_ptr(), q.stride(0), s.data_ptr(), w.data_ptr(), M, D, float(eps),
+                  _stream())
+        return QAct(q, s)
     if out is None:
         out = torch.empty((M, D), device=x.device, dtype=out_dtype)
     _lib.call("ufv_rmsnorm", x.data_ptr(), x.stride(0), out.data_ptr(), int(out.dtype == torch.float32), out.stride(0),
