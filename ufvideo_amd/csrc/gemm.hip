@@ -375,10 +375,12 @@ inline int pick_mt(int M, int N) {
 // rate at this K depth); rates fitted to tools/bench_kernels.py on MI355X: the persistent 256x256 ping-pong
 // kernel sustains ~1.2-1.3x the 128-wide kernel and hides its prologue/epilogue across tile seams, the 128-wide
 // one has the finer tile grid (2 blocks/CU, 128/160/192-row tiles) for small outputs.
-inline bool prefer256(int M, int N, int K) {
+inline bool prefer256(int M, int N, int K, bool out_f32) {
     const double nk = K / 64.0;
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    const double c256 = (double)((t256 + 255) / 256) * 65536.0 / (1.30 / (1.0 + 5.0 / nk));
+    // the persistent kernel's epilogue is a chip-wide store burst that nothing overlaps: ~5 K-tiles' worth for a bf16 tile,
+    // ~9 for an fp32 tile with an fp32 residual (measured with tools/gemm_exp.py)
+    const double c256 = (double)((t256 + 255) / 256) * 65536.0 / (1.30 / (1.0 + (out_f32 ? 9.0 : 5.0) / nk));
     double c128 = 1e30;
     for (int mt = 4; mt <= 6; ++mt) {
         const long t = (long)cdiv(M, 32 * mt) * (N / BN);
@@ -438,7 +440,7 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
         return UFV_EUNSUPPORTED;
     }
     if (force == UFV_GEMM_STREAMK) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, true, st);
-    if (force == UFV_GEMM_FAST256 || (force == UFV_GEMM_AUTO && big_ok && prefer256(M, N, Q ? K / 2 : K)))
+    if (force == UFV_GEMM_FAST256 || (force == UFV_GEMM_AUTO && big_ok && prefer256(M, N, Q ? K / 2 : K, F)))
         return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, st);
     if ((force == UFV_GEMM_AUTO && fast_ok && M > 64) || force == UFV_GEMM_FAST)
         return launch_fast<F, S, Q>(A, W, e, M, N, K, lda, ldw, st);
