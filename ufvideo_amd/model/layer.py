@@ -60,7 +60,7 @@ class MaskExtractor(PackedModule):
                 mask = F.pad(mask, ((m - w) // 2, (m - w) - (m - w) // 2, (m - _h) // 2, (m - _h) - (m - _h) // 2, 0, 0, 0, 0))
             ann_index = [i for index in ann_indices[idx] for i in index]
             if mask.shape[-2:] != (N, N):
-                mask = F.interpolate(mask, size=(N, N), mode="bilinear", align_corners=False)
+                mask = ops.resize_bilinear(mask.float().contiguous(), (N, N))      # F.interpolate(bilinear, align_corners=False), ref :139
             mbin = (mask[0] > 0).float().reshape(mask.shape[1], N * N).contiguous()
             frame_of = torch.tensor(ann_index, dtype=torch.int32, device=dev)
             raw = ops.mask_pool(feats.contiguous(), mbin, frame_of)          # [q, C] fp32
