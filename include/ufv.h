@@ -145,6 +145,13 @@ int ufv_argmax(const float* logits, int N, int64_t* out, void* stream);
 int ufv_preprocess_u8(const uint8_t* frames, void* out, int T, int H, int W, const float* mean3, const float* std3,
                       void* stream);
 
+/* Single-row GEMV of the decode step: y[N(/2)] = epilogue(h . W^T) with h = the bf16 row `a`, or -- when `x` (fp32 row) is
+ * given instead -- bf16(RMSNorm(x) * ln_w) computed in the kernel's prologue bit-identically to ufv_rmsnorm, which removes
+ * the separate norm launch (Qwen2RMSNorm + q/k/v or gate/up Linear, modeling_qwen2.py:35-48,150-172,238-254).
+ * Epilogue as ufv_gemm (bias -> act -> fp32 residual [N], or SwiGLU); K <= 32768, weights streamed once. */
+int ufv_gemv1(const void* a, const float* x, const float* ln_w, float eps, const void* W, int ldw, void* C, int out_f32, int N, int K,
+              const float* bias, int act, const float* resid, int swiglu, void* stream);
+
 /* ---- one-call greedy decode step (replaces HF GenerationMixin's per-token Qwen2ForCausalLM.forward under
  * videorefer_qwen2.py:414-426).  All pointers are device memory prepared by the caller (packed weights as for the
  * op-level calls: wqkv = [q|k|v] rows, wgu = gate/up rows interleaved in blocks of 16). */

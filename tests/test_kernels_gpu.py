@@ -357,3 +357,29 @@ def test_gemm_streamk_fp8_and_errors():
     from ufvideo_amd import _lib
     with pytest.raises(_lib.UfvError):
         ops.gemm(a, bf(g(512, 3584, seed=67)), swiglu=True, kernel=ops.GEMM_STREAMK)
+
+
+@pytest.mark.parametrize("N,K", [(4608, 3584), (3584, 18944), (300, 64), (151748, 3584)])
+def test_gemv1_fused_rmsnorm_bit_identical(N, K):
+    """Decode GEMV: fp32 row + fused RMSNorm == ufv_rmsnorm then the bf16-row GEMV, bit for bit; and both match the
+    batched GEMV kernel up to fp32 summation order."""
+    w = bf(g(N, K, seed=73, scale=0.05))
+    bias, resid = g(N, seed=74), g(N, seed=75)
+    if K > 4096:                                   # down_proj form: bf16 row in, no norm (ufv_rmsnorm covers D <= 4096)
+        h = bf(g(1, K, seed=71))
+        y = ops.gemv1(w, a=h[0], bias=bias, resid=resid, out_dtype=torch.float32)
+        ref = ops.gemm(h, w, bias=bias, resid=resid[None].contiguous(), out_dtype=torch.float32, kernel=ops.GEMM_GEMV)[0]
+        assert rel(y, ref) < 1e-5
+        return
+    x = g(1, K, seed=71) * 2
+    gw = 1 + 0.1 * g(K, seed=72)
+    h = ops.rmsnorm(x, gw, 1e-6)
+    y_sep = ops.gemv1(w, a=h[0], bias=bias, resid=resid, out_dtype=torch.float32)
+    y_fused = ops.gemv1(w, x=x[0].contiguous(), ln_w=gw, eps=1e-6, bias=bias, resid=resid, out_dtype=torch.float32)
+    assert torch.equal(y_sep, y_fused)
+    ref = ops.gemm(h, w, bias=bias, resid=resid[None].contiguous(), out_dtype=torch.float32, kernel=ops.GEMM_GEMV)[0]
+    assert rel(y_fused, ref) < 1e-5
+    if N % 32 == 0:
+        yb = ops.gemv1(w, x=x[0].contiguous(), ln_w=gw, eps=1e-6, swiglu=True)
+        refb = ops.gemm(h, w, swiglu=True, kernel=ops.GEMM_GEMV)[0]
+        assert rel(yb, refb) < 8e-3

@@ -345,6 +345,84 @@ __global__ __launch_bounds__(256) void gemv_nt_fp8(const uint8_t* __restrict__ A
     }
 }
 
+// ---- single-row GEMV for the decode step: y[N] = epilogue(h[K] . W[N,K]^T), h = the bf16 row `a`, or (RMS) the RMSNorm of
+//      an fp32 row computed in the prologue exactly as rmsnorm_k rounds it (so fusing the norm changes no bit).  h lives in
+//      LDS; a wave produces 4 outputs at once (4 or 8 weight rows in flight per lane: latency hidden, 4x fewer blocks).
+template <bool OUT_F32, bool SWIGLU, bool RMS>
+__global__ __launch_bounds__(256) void gemv1_nt(const bf16* __restrict__ a, const float* __restrict__ x, const float* __restrict__ g,
+                                                float eps, const bf16* __restrict__ W, Epi e, int N, int K, int ldw) {
+    extern __shared__ __attribute__((aligned(16))) char smem_v[];
+    bf16* hs = reinterpret_cast<bf16*>(smem_v);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (RMS) {
+        // every wave reduces the whole row with rmsnorm_k's own order (lane owns float4 chunks lane + 64 i, wave_sum), so
+        // r -- and with it every rounded h[k] = bf16(w * (x * r)) -- is the value the stand-alone kernel produces
+        float q = 0.f;
+        for (int c = lane; c < (K >> 2); c += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * c);
+            q += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        const float r = rsqrtf(wave_sum(q) / K + eps);
+        for (int k = tid * 4; k < K; k += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + k), w = *reinterpret_cast<const f32x4*>(g + k);
+            bf16x4 o = {(bf16)(w[0] * (v[0] * r)), (bf16)(w[1] * (v[1] * r)), (bf16)(w[2] * (v[2] * r)), (bf16)(w[3] * (v[3] * r))};
+            *reinterpret_cast<bf16x4*>(hs + k) = o;
+        }
+    } else {
+        for (int k = tid * 8; k < K; k += 2048) *reinterpret_cast<bf16x8*>(hs + k) = *reinterpret_cast<const bf16x8*>(a + k);
+    }
+    __syncthreads();
+    constexpr int NO = 4;                                     // outputs per wave
+    const int n_out = SWIGLU ? N / 2 : N;
+    const int n0 = (blockIdx.x * 4 + wave) * NO;
+    if (n0 >= n_out) return;
+    const bf16* wr[NO];
+    const bf16* wu[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const int n = min(n0 + j, n_out - 1);
+        const int row = SWIGLU ? (n / 16) * 32 + (n % 16) : n;
+        wr[j] = W + (size_t)row * ldw;
+        wu[j] = W + (size_t)(row + 16) * ldw;
+    }
+    float s0[NO], s1[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) s0[j] = s1[j] = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hs + k);
+        bf16x8 wv[NO], uv[NO];
+#pragma unroll
+        for (int j = 0; j < NO; ++j) {
+            wv[j] = *reinterpret_cast<const bf16x8*>(wr[j] + k);
+            if (SWIGLU) uv[j] = *reinterpret_cast<const bf16x8*>(wu[j] + k);
+        }
+#pragma unroll
+        for (int j = 0; j < NO; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s0[j] += (float)hv[i] * (float)wv[j][i];
+                if (SWIGLU) s1[j] += (float)hv[i] * (float)uv[j][i];
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+        const int n = n0 + j;
+        float v = wave_sum(s0[j]);
+        if (SWIGLU) {
+            const float u = wave_sum(s1[j]);
+            v = v / (1.0f + __expf(-v)) * u;
+        } else {
+            if (e.bias) v += e.bias[min(n, n_out - 1)];
+            v = act_apply(v, e.act);
+        }
+        if (lane == 0 && n < n_out) {
+            if (e.resid) v += e.resid[n];
+            if (OUT_F32) reinterpret_cast<float*>(e.out)[n] = v;
+            else reinterpret_cast<bf16*>(e.out)[n] = (bf16)v;
+        }
+    }
+}
+
 template <bool F, bool S, int MT, bool Q>
 int launch_fast_mt(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
     static bool attr_set = false;
@@ -494,4 +572,32 @@ extern "C" int ufv_gemm_fp8(const void* A, int lda, const float* a_scale, const 
     UFV_REQUIRE(kernel != UFV_GEMM_GENERIC, "ufv_gemm_fp8: no generic kernel for fp8 operands");
     return gemm_entry<true>(A, lda, a_scale, W, ldw, w_scale, C, ldc, out_f32, M, N, K, bias, act, resid, ldr, resid_rows, swiglu, kernel,
                             stream);
+}
+
+extern "C" int ufv_gemv1(const void* a, const float* x, const float* ln_w, float eps, const void* W, int ldw, void* C, int out_f32, int N,
+                         int K, const float* bias, int act, const float* resid, int swiglu, void* stream) {
+    UFV_REQUIRE(W && C && N > 0 && K > 0 && ((a != nullptr) != (x != nullptr)), "ufv_gemv1: give exactly one of a (bf16 row) / x (fp32 row)");
+    UFV_REQUIRE(!x || ln_w, "ufv_gemv1: the fp32 row form needs the RMSNorm weight");
+    UFV_REQUIRE(K % 8 == 0 && ldw % 8 == 0 && (size_t)K * 2 <= 64 * 1024 && (!swiglu || N % 32 == 0), "ufv_gemv1: K %% 8, K <= 32768 (K=%d)", K);
+    UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemv1: swiglu epilogue takes no bias/activation");
+    Epi e;
+    e.bias = bias; e.resid = resid; e.out = C; e.ldr = 0; e.ldc = 0; e.act = act; e.resid_rows = 0; e.scale_m = nullptr; e.scale_n = nullptr;
+    e.dump_f32 = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int n_out = swiglu ? N / 2 : N;
+    dim3 grid(cdiv(n_out, 16)), blk(256);
+    const size_t sm = (size_t)K * 2;
+    const bf16* ab = reinterpret_cast<const bf16*>(a);
+    const bf16* wb = reinterpret_cast<const bf16*>(W);
+#define G1(F_, S_, R_) hipLaunchKernelGGL((gemv1_nt<F_, S_, R_>), grid, blk, sm, st, ab, x, ln_w, eps, wb, e, N, K, ldw)
+    if (x) {
+        if (out_f32) { if (swiglu) G1(true, true, true); else G1(true, false, true); }
+        else { if (swiglu) G1(false, true, true); else G1(false, false, true); }
+    } else {
+        if (out_f32) { if (swiglu) G1(true, true, false); else G1(true, false, false); }
+        else { if (swiglu) G1(false, true, false); else G1(false, false, false); }
+    }
+#undef G1
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
 }

@@ -1,6 +1,6 @@
 // One greedy decode step of the Qwen2-style decoder as a single C call: embedding lookup of the previous token ->
-// N x {RMSNorm, fused QKV GEMV(+bias), RoPE + KV-cache append, split-key decode attention, o_proj(+residual), RMSNorm,
-// gate/up GEMV with SwiGLU, down(+residual)} -> final RMSNorm -> lm_head GEMV -> argmax.  Pure composition of the
+// N x {[RMSNorm+]fused QKV GEMV(+bias), RoPE + KV-cache append, split-key decode attention, o_proj(+residual),
+// [RMSNorm+]gate/up GEMV with SwiGLU, down(+residual)} -> final RMSNorm -> lm_head GEMV -> argmax.  Pure composition of the
 // entry points in include/ufv.h on one stream (no allocation, no synchronisation): it exists so that the host pays
 // one FFI call per token instead of ~340.
 #include "common.h"
@@ -49,20 +49,19 @@ extern "C" int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* to
     for (int l = 0; l < m->n_layers; ++l) {
         const ufv_qwen2_layer& L = m->layers[l];
         char* kv = reinterpret_cast<char*>(L.kv_cache);
-        UFV_TRY(ufv_rmsnorm(x, D, h, 0, D, L.ln1, 1, D, m->eps, stream));
-        UFV_TRY(ufv_gemm(h, D, L.wqkv, D, qkv, qkv_n, 0, 1, qkv_n, D, L.bqkv, UFV_ACT_NONE, nullptr, 0, 0, 0, UFV_GEMM_GEMV, stream));
+        // RMSNorm is fused into the GEMV that consumes it (bit-identical h, one launch less per norm)
+        UFV_TRY(ufv_gemv1(nullptr, x, L.ln1, m->eps, L.wqkv, D, qkv, 0, qkv_n, D, L.bqkv, UFV_ACT_NONE, nullptr, 0, stream));
         UFV_TRY(ufv_rope_kv(qkv, qkv_n, 1, H, KV, hd, m->inv_freq, pos, kv, m->ldkv, stream));
         UFV_TRY(ufv_attention_decode(qkv, 0, kv, 0, m->ldkv, kv + 2 * (size_t)KV * hd, 0, m->ldkv, o, 0, 1, H, KV, pos + 1, hd, scale,
                                      aws, m->attn_splits, stream));
-        UFV_TRY(ufv_gemm(o, H * hd, L.wo, H * hd, x, D, 1, 1, D, H * hd, nullptr, UFV_ACT_NONE, x, D, 0, 0, UFV_GEMM_GEMV, stream));
-        UFV_TRY(ufv_rmsnorm(x, D, h, 0, D, L.ln2, 1, D, m->eps, stream));
-        UFV_TRY(ufv_gemm(h, D, L.wgu, D, act, I, 0, 1, 2 * I, D, nullptr, UFV_ACT_NONE, nullptr, 0, 0, 1, UFV_GEMM_GEMV, stream));
-        UFV_TRY(ufv_gemm(act, I, L.wd, I, x, D, 1, 1, D, I, nullptr, UFV_ACT_NONE, x, D, 0, 0, UFV_GEMM_GEMV, stream));
+        UFV_TRY(ufv_gemv1(o, nullptr, nullptr, 0.f, L.wo, H * hd, x, 1, D, H * hd, nullptr, UFV_ACT_NONE, x, 0, stream));
+        UFV_TRY(ufv_gemv1(nullptr, x, L.ln2, m->eps, L.wgu, D, act, 0, 2 * I, D, nullptr, UFV_ACT_NONE, nullptr, 1, stream));
+        UFV_TRY(ufv_gemv1(act, nullptr, nullptr, 0.f, L.wd, I, x, 1, D, I, nullptr, UFV_ACT_NONE, x, 0, stream));
     }
     UFV_TRY(ufv_rmsnorm(x, D, normed, 1, D, m->norm, 1, D, m->eps, stream));
     if (hidden_out) UFV_TRY(ufv_convert(normed, UFV_DT_F32, hidden_out, UFV_DT_F32, D, stream));
     UFV_TRY(ufv_convert(normed, UFV_DT_F32, h, UFV_DT_BF16, D, stream));
-    UFV_TRY(ufv_gemm(h, D, m->lm_head, D, logits, m->vocab, 1, 1, m->vocab, D, nullptr, UFV_ACT_NONE, nullptr, 0, 0, 0, UFV_GEMM_GEMV, stream));
+    UFV_TRY(ufv_gemv1(h, nullptr, nullptr, 0.f, m->lm_head, D, logits, 1, m->vocab, D, nullptr, UFV_ACT_NONE, nullptr, 0, stream));
     UFV_TRY(ufv_argmax(logits, m->vocab, next_token_dev, stream));
     return UFV_OK;
 }

@@ -53,6 +53,17 @@ def gemm(a, w, bias=None, act=None, resid=None, resid_rows=0, out=None, out_dtyp
     return out
 
 
+def gemv1(w, a=None, x=None, ln_w=None, eps=1e-6, bias=None, act=None, resid=None, swiglu=False, out=None, out_dtype=torch.bfloat16):
+    """One-row GEMV (decode): a bf16 [K] row, or x fp32 [K] + RMSNorm weight (norm fused into the kernel).  -> [N(/2)]"""
+    N, K = w.shape
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((n_out,), device=w.device, dtype=out_dtype)
+    _lib.call("ufv_gemv1", _ptr(a), _ptr(x), _ptr(ln_w), float(eps), w.data_ptr(), w.stride(0), out.data_ptr(), int(out.dtype == torch.float32),
+              N, K, _ptr(bias), ACT[act], _ptr(resid), int(swiglu), _stream())
+    return out
+
+
 def quantize_fp8(x, out=None, scale=None):
     """Row-wise e4m3 quantisation: x [M,K] bf16|f32 (any row pitch) -> (q uint8 [M,K], scale f32 [M]), x ~ q * scale[:, None]."""
     _chk(x, name="x")
