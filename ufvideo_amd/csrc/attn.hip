@@ -83,8 +83,18 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 ? 3 : 2)) void attn_fwd_mfma(Att
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
-    const int qt = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;   // heavy causal tiles first
-    const int hq = blockIdx.y, b = blockIdx.z, hkv = hq / (a.Hq / a.Hkv);
+    int qt = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
+    if (CAUSAL) {
+        // Causal work per block grows with its q-tile: hand the blocks out globally heaviest first (all heads' last q-tiles,
+        // then the next ones, ...) so that the light blocks fill the slots the heavy ones free up.  (Pairing heavy with light
+        // blocks per CU on top of this order measured no further gain.)
+        const int nqt = gridDim.x, per = a.Hq * a.B;
+        const int i = blockIdx.x + nqt * (blockIdx.y + a.Hq * blockIdx.z);
+        qt = nqt - 1 - i / per;
+        const int g = i % per;
+        hq = g % a.Hq; b = g / a.Hq;
+    }
+    const int hkv = hq / (a.Hq / a.Hkv);
     const int qblk0 = qt * 32 * NW, q0 = qblk0 + wave * 32;
     const int qi = q0 + l31;                                                       // this lane's query row
 
