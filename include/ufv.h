@@ -148,9 +148,11 @@ int ufv_preprocess_u8(const uint8_t* frames, void* out, int T, int H, int W, con
 /* Single-row GEMV of the decode step: y[N(/2)] = epilogue(h . W^T) with h = the bf16 row `a`, or -- when `x` (fp32 row) is
  * given instead -- bf16(RMSNorm(x) * ln_w) computed in the kernel's prologue bit-identically to ufv_rmsnorm, which removes
  * the separate norm launch (Qwen2RMSNorm + q/k/v or gate/up Linear, modeling_qwen2.py:35-48,150-172,238-254).
- * Epilogue as ufv_gemm (bias -> act -> fp32 residual [N], or SwiGLU); K <= 32768, weights streamed once. */
-int ufv_gemv1(const void* a, const float* x, const float* ln_w, float eps, const void* W, int ldw, void* C, int out_f32, int N, int K,
-              const float* bias, int act, const float* resid, int swiglu, void* stream);
+ * Epilogue as ufv_gemm (bias -> act -> fp32 residual [N], or SwiGLU); K <= 21845, weights streamed once.
+ * w_scale != NULL: W holds e4m3 bytes with one scale per row and the row h is quantised in the prologue exactly as
+ * ufv_quantize_fp8 would (W8A8, the decode side of config #5a). */
+int ufv_gemv1(const void* a, const float* x, const float* ln_w, float eps, const void* W, int ldw, const float* w_scale, void* C,
+              int out_f32, int N, int K, const float* bias, int act, const float* resid, int swiglu, void* stream);
 
 /* ---- one-call greedy decode step (replaces HF GenerationMixin's per-token Qwen2ForCausalLM.forward under
  * videorefer_qwen2.py:414-426).  All pointers are device memory prepared by the caller (packed weights as for the
@@ -164,6 +166,8 @@ typedef struct {
     const float* ln1;   /* f32 [d] input_layernorm */
     const float* ln2;   /* f32 [d] post_attention_layernorm */
     void* kv_cache;     /* bf16 [max_len, ldkv]: row = [Hkv*hd k | Hkv*hd v] */
+    /* optional W8A8 decode (all four NULL = bf16): e4m3 weights in the same layouts + one fp32 scale per weight row */
+    const void* wqkv8; const float* sqkv; const void* wo8; const float* so; const void* wgu8; const float* sgu; const void* wd8; const float* sd;
 } ufv_qwen2_layer;
 
 typedef struct {

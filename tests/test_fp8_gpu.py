@@ -143,3 +143,31 @@ def test_fulldim_siglip_fp8_vs_restatement():
     with O.fp8_linear_mode():
         ref = O.siglip_tower(sd, vit, x)
     assert rms_rel(y8, ref) < rms_rel(y8, y16) < 0.15, (rms_rel(y8, ref), rms_rel(y8, y16))
+
+
+def test_gemv1_fp8_and_decode_step_fp8():
+    """W8A8 decode: the one-row GEMV quantises its input row in the kernel exactly like ufv_quantize_fp8, so it must agree with
+    the batched fp8 GEMV on pre-quantised input; the one-call decode step in fp8 mode must agree with the layer loop."""
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
+    g = torch.Generator().manual_seed(21)
+    for N, K, sw in ((4608, 3584, False), (3584, 18944, False), (1024, 3584, True)):
+        w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+        h = torch.randn(1, K, generator=g).to(torch.bfloat16).to(DEV)
+        W8 = ops.Fp8Weight(w)
+        ref = ops.gemm(h, W8, swiglu=sw, out_dtype=torch.float32)[0]                    # quantize_fp8 + gemv_nt_fp8
+        got = ops.gemv1(W8, a=h[0], swiglu=sw, out_dtype=torch.float32)
+        assert rel_err(got.cpu(), ref.cpu()) < 1e-5
+    cfg = dict(vocab_size=512, hidden_size=3584, intermediate_size=18944, num_hidden_layers=2, num_attention_heads=28,
+               num_key_value_heads=4, rope_theta=1e6, rms_norm_eps=1e-6)
+    sd = O.make_qwen2_weights(cfg, seed=12)
+    m = VideoReferQwen2ForCausalLM(VideoReferQwen2Config(**cfg, train_mask_decoder=True))
+    m.load_state_dict(sd, strict=True); m = m.to(DEV)
+    m.set_gemm_dtype("fp8")
+    x = (torch.randn(1, 100, 3584, generator=g) * 0.5).to(DEV)
+    out = m._greedy(x, None, max_new_tokens=3, eos_token_id=None)                       # prefill + 2 one-call decode steps (fp8 weights)
+    toks = out["sequences"][0].tolist()
+    table = sd["model.embed_tokens.weight"].to(DEV)
+    full = torch.cat([x[0], table[toks[:-1]].float()], 0)[None]
+    _, _, _, normed = m._decode_batch(full, None, None, False, 1)                       # the same positions through the layer loop
+    # two W8A8 evaluations of the same token decorrelate through e4m3 rounding (see the layer test above): statistical bound only
+    assert rms_rel(out["hidden_last"][-1].cpu(), normed[-1:].cpu()) < 0.2 and len(toks) == 3

@@ -1,10 +1,14 @@
-"""Diagnostic: greedy decode latency (ms/token) after a config-#2 prefill, full UFVideo-7B dims, synthetic weights."""
+"""Diagnostic: greedy decode latency (ms/token) after a config-#2 prefill, full UFVideo-7B dims, synthetic weights.
+`--fp8`: W8A8 mode (e4m3 weights streamed by the decode step too)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 model = bench.build_model(dev)
+fp8 = "--fp8" in sys.argv
+if fp8:
+    model.set_gemm_dtype("fp8")
 video, ids, am = bench.synthetic_inputs(dev)
 with torch.no_grad():
     _, am2, _, emb, _, _ = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, [(video, "video")], None, None, None, None)
@@ -17,4 +21,5 @@ with torch.no_grad():
     out8 = model._greedy(emb, am2, max_new_tokens=8, eos_token_id=None); torch.cuda.synchronize(); t8 = time.perf_counter() - t0
     t0 = time.perf_counter()
     out72 = model._greedy(emb, am2, max_new_tokens=72, eos_token_id=None); torch.cuda.synchronize(); t72 = time.perf_counter() - t0
-    print(f"decode: {(t72 - t8) / 64 * 1e3:.2f} ms/token  (weights 15.2 GB bf16 -> {(15.2e9 / ((t72 - t8) / 64)) / 1e12:.2f} TB/s effective)")
+    gb = 7.6 + 1.09 if fp8 else 15.2
+    print(f"decode ({'fp8' if fp8 else 'bf16'} weights): {(t72 - t8) / 64 * 1e3:.2f} ms/token  (weights {gb:.1f} GB -> {(gb * 1e9 / ((t72 - t8) / 64)) / 1e12:.2f} TB/s effective)")

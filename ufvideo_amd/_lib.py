@@ -42,7 +42,7 @@ SIGNATURES = {
     "ufv_gemm_fp8": [_p, _i, _p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p],
     "ufv_cross_entropy_rows": [_p, _l, _p, _i, _i, _l, _p, _p],
     "ufv_mask_loss_sums": [_p, _p, _i, _l, _p, _p],
-    "ufv_gemv1": [_p, _p, _p, _f, _p, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p],
+    "ufv_gemv1": [_p, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p],
     "ufv_add_bcast": [_p, _i, _l, _p, _l, _i, _p, _i, _l, _l, _i, _p],
     "ufv_sam_mask_head": [_p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _p],
     "ufv_resize_bilinear": [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _p],
@@ -53,7 +53,8 @@ SIGNATURES = {
 
 
 class Qwen2Layer(C.Structure):
-    _fields_ = [("wqkv", _p), ("bqkv", _p), ("wo", _p), ("wgu", _p), ("wd", _p), ("ln1", _p), ("ln2", _p), ("kv_cache", _p)]
+    _fields_ = [("wqkv", _p), ("bqkv", _p), ("wo", _p), ("wgu", _p), ("wd", _p), ("ln1", _p), ("ln2", _p), ("kv_cache", _p),
+                ("wqkv8", _p), ("sqkv", _p), ("wo8", _p), ("so", _p), ("wgu8", _p), ("sgu", _p), ("wd8", _p), ("sd", _p)]
 
 
 class Qwen2Model(C.Structure):

@@ -348,11 +348,13 @@ __global__ __launch_bounds__(256) void gemv_nt_fp8(const uint8_t* __restrict__ A
 // ---- single-row GEMV for the decode step: y[N] = epilogue(h[K] . W[N,K]^T), h = the bf16 row `a`, or (RMS) the RMSNorm of
 //      an fp32 row computed in the prologue exactly as rmsnorm_k rounds it (so fusing the norm changes no bit).  h lives in
 //      LDS; a wave produces 4 outputs at once (4 or 8 weight rows in flight per lane: latency hidden, 4x fewer blocks).
-template <bool OUT_F32, bool SWIGLU, bool RMS>
+template <bool OUT_F32, bool SWIGLU, bool RMS, bool W8>
 __global__ __launch_bounds__(256) void gemv1_nt(const bf16* __restrict__ a, const float* __restrict__ x, const float* __restrict__ g,
-                                                float eps, const bf16* __restrict__ W, Epi e, int N, int K, int ldw) {
+                                                float eps, const void* __restrict__ Wv, const float* __restrict__ w_scale, Epi e, int N,
+                                                int K, int ldw) {
     extern __shared__ __attribute__((aligned(16))) char smem_v[];
     bf16* hs = reinterpret_cast<bf16*>(smem_v);
+    __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (RMS) {
         // every wave reduces the whole row with rmsnorm_k's own order (lane owns float4 chunks lane + 64 i, wave_sum), so
@@ -372,44 +374,107 @@ __global__ __launch_bounds__(256) void gemv1_nt(const bf16* __restrict__ a, cons
         for (int k = tid * 8; k < K; k += 2048) *reinterpret_cast<bf16x8*>(hs + k) = *reinterpret_cast<const bf16x8*>(a + k);
     }
     __syncthreads();
+    // W8: quantise the row exactly as ufv_quantize_fp8 does (scale = amax/448, q = rne_e4m3(h * (1/scale))); codes behind hs
+    uint8_t* hq = reinterpret_cast<uint8_t*>(smem_v) + (size_t)K * 2;
+    float a_scale = 1.f;
+    if (W8) {
+        float amax = 0.f;
+        for (int k = tid; k < K; k += 256) amax = fmaxf(amax, fabsf((float)hs[k]));
+        amax = wave_max(amax);
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        a_scale = amax > 0.f ? amax / 448.0f : 1.0f;
+        const float inv = 1.0f / a_scale;
+        for (int k = tid * 4; k < K; k += 1024) {
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32((float)hs[k] * inv, (float)hs[k + 1] * inv, w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32((float)hs[k + 2] * inv, (float)hs[k + 3] * inv, w, true);
+            *reinterpret_cast<int*>(hq + k) = w;
+        }
+        __syncthreads();
+    }
     constexpr int NO = 4;                                     // outputs per wave
+    constexpr int ES = W8 ? 1 : 2;
+    const char* W = reinterpret_cast<const char*>(Wv);
     const int n_out = SWIGLU ? N / 2 : N;
     const int n0 = (blockIdx.x * 4 + wave) * NO;
     if (n0 >= n_out) return;
-    const bf16* wr[NO];
-    const bf16* wu[NO];
+    const char* wr[NO];
+    const char* wu[NO];
+    int rows[NO];
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
         const int n = min(n0 + j, n_out - 1);
-        const int row = SWIGLU ? (n / 16) * 32 + (n % 16) : n;
-        wr[j] = W + (size_t)row * ldw;
-        wu[j] = W + (size_t)(row + 16) * ldw;
+        rows[j] = SWIGLU ? (n / 16) * 32 + (n % 16) : n;
+        wr[j] = W + (size_t)rows[j] * ldw * ES;
+        wu[j] = W + (size_t)(rows[j] + 16) * ldw * ES;
     }
     float s0[NO], s1[NO];
 #pragma unroll
     for (int j = 0; j < NO; ++j) s0[j] = s1[j] = 0.f;
-    for (int k = lane * 8; k < K; k += 512) {
-        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hs + k);
-        bf16x8 wv[NO], uv[NO];
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 p0[NO], p1[NO];                                     // fp8 path: packed partial sums (v_cvt_pk_f32_fp8 + v_pk_fma_f32)
 #pragma unroll
-        for (int j = 0; j < NO; ++j) {
-            wv[j] = *reinterpret_cast<const bf16x8*>(wr[j] + k);
-            if (SWIGLU) uv[j] = *reinterpret_cast<const bf16x8*>(wu[j] + k);
+    for (int j = 0; j < NO; ++j) p0[j] = p1[j] = f32x2{0.f, 0.f};
+    if constexpr (W8) {
+        auto unpack = [](const i32x4 v, f32x2 (&f)[8]) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                f[2 * d + 0] = __builtin_amdgcn_cvt_pk_f32_fp8(v[d], false);
+                f[2 * d + 1] = __builtin_amdgcn_cvt_pk_f32_fp8(v[d], true);
+            }
+        };
+        for (int k = lane * 16; k < K; k += 1024) {
+            f32x2 hv[8];
+            unpack(*reinterpret_cast<const i32x4*>(hq + k), hv);
+            i32x4 wv[NO], uv[NO];
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                wv[j] = *reinterpret_cast<const i32x4*>(wr[j] + k);
+                if (SWIGLU) uv[j] = *reinterpret_cast<const i32x4*>(wu[j] + k);
+            }
+#pragma unroll
+            for (int j = 0; j < NO; ++j) {
+                f32x2 wf[8];
+                unpack(wv[j], wf);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) p0[j] = __builtin_elementwise_fma(hv[i], wf[i], p0[j]);
+                if (SWIGLU) {
+                    unpack(uv[j], wf);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) p1[j] = __builtin_elementwise_fma(hv[i], wf[i], p1[j]);
+                }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < NO; ++j)
+        for (int j = 0; j < NO; ++j) { s0[j] = p0[j][0] + p0[j][1]; s1[j] = p1[j][0] + p1[j][1]; }
+    } else {
+        for (int k = lane * 8; k < K; k += 512) {
+            const bf16x8 hv = *reinterpret_cast<const bf16x8*>(hs + k);
+            bf16x8 wv[NO], uv[NO];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s0[j] += (float)hv[i] * (float)wv[j][i];
-                if (SWIGLU) s1[j] += (float)hv[i] * (float)uv[j][i];
+            for (int j = 0; j < NO; ++j) {
+                wv[j] = *reinterpret_cast<const bf16x8*>(wr[j] + (size_t)k * 2);
+                if (SWIGLU) uv[j] = *reinterpret_cast<const bf16x8*>(wu[j] + (size_t)k * 2);
             }
+#pragma unroll
+            for (int j = 0; j < NO; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s0[j] += (float)hv[i] * (float)wv[j][i];
+                    if (SWIGLU) s1[j] += (float)hv[i] * (float)uv[j][i];
+                }
+        }
     }
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
         const int n = n0 + j;
         float v = wave_sum(s0[j]);
+        if (W8) v *= a_scale * w_scale[rows[j]];
         if (SWIGLU) {
-            const float u = wave_sum(s1[j]);
+            float u = wave_sum(s1[j]);
+            if (W8) u *= a_scale * w_scale[rows[j] + 16];
             v = v / (1.0f + __expf(-v)) * u;
         } else {
             if (e.bias) v += e.bias[min(n, n_out - 1)];
@@ -574,11 +639,12 @@ extern "C" int ufv_gemm_fp8(const void* A, int lda, const float* a_scale, const 
                             stream);
 }
 
-extern "C" int ufv_gemv1(const void* a, const float* x, const float* ln_w, float eps, const void* W, int ldw, void* C, int out_f32, int N,
-                         int K, const float* bias, int act, const float* resid, int swiglu, void* stream) {
+extern "C" int ufv_gemv1(const void* a, const float* x, const float* ln_w, float eps, const void* W, int ldw, const float* w_scale,
+                         void* C, int out_f32, int N, int K, const float* bias, int act, const float* resid, int swiglu, void* stream) {
     UFV_REQUIRE(W && C && N > 0 && K > 0 && ((a != nullptr) != (x != nullptr)), "ufv_gemv1: give exactly one of a (bf16 row) / x (fp32 row)");
     UFV_REQUIRE(!x || ln_w, "ufv_gemv1: the fp32 row form needs the RMSNorm weight");
-    UFV_REQUIRE(K % 8 == 0 && ldw % 8 == 0 && (size_t)K * 2 <= 64 * 1024 && (!swiglu || N % 32 == 0), "ufv_gemv1: K %% 8, K <= 32768 (K=%d)", K);
+    UFV_REQUIRE(K % (w_scale ? 16 : 8) == 0 && ldw % (w_scale ? 16 : 8) == 0 && (size_t)K * 3 <= 64 * 1024 && (!swiglu || N % 32 == 0),
+                "ufv_gemv1: K %% 8 (16 for fp8 weights), K <= 21845 (K=%d)", K);
     UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemv1: swiglu epilogue takes no bias/activation");
     Epi e;
     e.bias = bias; e.resid = resid; e.out = C; e.ldr = 0; e.ldc = 0; e.act = act; e.resid_rows = 0; e.scale_m = nullptr; e.scale_n = nullptr;
@@ -586,17 +652,18 @@ extern "C" int ufv_gemv1(const void* a, const float* x, const float* ln_w, float
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int n_out = swiglu ? N / 2 : N;
     dim3 grid(cdiv(n_out, 16)), blk(256);
-    const size_t sm = (size_t)K * 2;
+    const size_t sm = (size_t)K * (w_scale ? 3 : 2);
     const bf16* ab = reinterpret_cast<const bf16*>(a);
-    const bf16* wb = reinterpret_cast<const bf16*>(W);
-#define G1(F_, S_, R_) hipLaunchKernelGGL((gemv1_nt<F_, S_, R_>), grid, blk, sm, st, ab, x, ln_w, eps, wb, e, N, K, ldw)
+#define G1(F_, S_, R_, Q_) hipLaunchKernelGGL((gemv1_nt<F_, S_, R_, Q_>), grid, blk, sm, st, ab, x, ln_w, eps, W, w_scale, e, N, K, ldw)
+#define G1Q(F_, S_, R_) do { if (w_scale) G1(F_, S_, R_, true); else G1(F_, S_, R_, false); } while (0)
     if (x) {
-        if (out_f32) { if (swiglu) G1(true, true, true); else G1(true, false, true); }
-        else { if (swiglu) G1(false, true, true); else G1(false, false, true); }
+        if (out_f32) { if (swiglu) G1Q(true, true, true); else G1Q(true, false, true); }
+        else { if (swiglu) G1Q(false, true, true); else G1Q(false, false, true); }
     } else {
-        if (out_f32) { if (swiglu) G1(true, true, false); else G1(true, false, false); }
-        else { if (swiglu) G1(false, true, false); else G1(false, false, false); }
+        if (out_f32) { if (swiglu) G1Q(true, true, false); else G1Q(true, false, false); }
+        else { if (swiglu) G1Q(false, true, false); else G1Q(false, false, false); }
     }
+#undef G1Q
 #undef G1
     UFV_CHECK_LAUNCH();
     return UFV_OK;

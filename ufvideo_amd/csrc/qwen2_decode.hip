@@ -50,18 +50,23 @@ extern "C" int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* to
         const ufv_qwen2_layer& L = m->layers[l];
         char* kv = reinterpret_cast<char*>(L.kv_cache);
         // RMSNorm is fused into the GEMV that consumes it (bit-identical h, one launch less per norm)
-        UFV_TRY(ufv_gemv1(nullptr, x, L.ln1, m->eps, L.wqkv, D, qkv, 0, qkv_n, D, L.bqkv, UFV_ACT_NONE, nullptr, 0, stream));
+        const bool q8 = L.wqkv8 && L.wo8 && L.wgu8 && L.wd8;      // W8A8 decode: e4m3 weights, rows quantised inside the GEMV
+        UFV_TRY(ufv_gemv1(nullptr, x, L.ln1, m->eps, q8 ? L.wqkv8 : L.wqkv, D, q8 ? L.sqkv : nullptr, qkv, 0, qkv_n, D, L.bqkv, UFV_ACT_NONE,
+                          nullptr, 0, stream));
         UFV_TRY(ufv_rope_kv(qkv, qkv_n, 1, H, KV, hd, m->inv_freq, pos, kv, m->ldkv, stream));
         UFV_TRY(ufv_attention_decode(qkv, 0, kv, 0, m->ldkv, kv + 2 * (size_t)KV * hd, 0, m->ldkv, o, 0, 1, H, KV, pos + 1, hd, scale,
                                      aws, m->attn_splits, stream));
-        UFV_TRY(ufv_gemv1(o, nullptr, nullptr, 0.f, L.wo, H * hd, x, 1, D, H * hd, nullptr, UFV_ACT_NONE, x, 0, stream));
-        UFV_TRY(ufv_gemv1(nullptr, x, L.ln2, m->eps, L.wgu, D, act, 0, 2 * I, D, nullptr, UFV_ACT_NONE, nullptr, 1, stream));
-        UFV_TRY(ufv_gemv1(act, nullptr, nullptr, 0.f, L.wd, I, x, 1, D, I, nullptr, UFV_ACT_NONE, x, 0, stream));
+        UFV_TRY(ufv_gemv1(o, nullptr, nullptr, 0.f, q8 ? L.wo8 : L.wo, H * hd, q8 ? L.so : nullptr, x, 1, D, H * hd, nullptr, UFV_ACT_NONE, x, 0,
+                          stream));
+        UFV_TRY(ufv_gemv1(nullptr, x, L.ln2, m->eps, q8 ? L.wgu8 : L.wgu, D, q8 ? L.sgu : nullptr, act, 0, 2 * I, D, nullptr, UFV_ACT_NONE,
+                          nullptr, 1, stream));
+        UFV_TRY(ufv_gemv1(act, nullptr, nullptr, 0.f, q8 ? L.wd8 : L.wd, I, q8 ? L.sd : nullptr, x, 1, D, I, nullptr, UFV_ACT_NONE, x, 0,
+                          stream));
     }
     UFV_TRY(ufv_rmsnorm(x, D, normed, 1, D, m->norm, 1, D, m->eps, stream));
     if (hidden_out) UFV_TRY(ufv_convert(normed, UFV_DT_F32, hidden_out, UFV_DT_F32, D, stream));
     UFV_TRY(ufv_convert(normed, UFV_DT_F32, h, UFV_DT_BF16, D, stream));
-    UFV_TRY(ufv_gemv1(h, nullptr, nullptr, 0.f, m->lm_head, D, logits, 1, m->vocab, D, nullptr, UFV_ACT_NONE, nullptr, 0, stream));
+    UFV_TRY(ufv_gemv1(h, nullptr, nullptr, 0.f, m->lm_head, D, nullptr, logits, 1, m->vocab, D, nullptr, UFV_ACT_NONE, nullptr, 0, stream));
     UFV_TRY(ufv_argmax(logits, m->vocab, next_token_dev, stream));
     return UFV_OK;
 }

@@ -499,8 +499,12 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         L = cfg.num_hidden_layers
         layers = (_lib.Qwen2Layer * L)()
         for i, w in enumerate(pk["layers"]):
+            q8 = []
+            for k in ("wqkv8", "wo8", "wgu8", "wd8"):                  # fp8 mode: the decode step streams the e4m3 weights too
+                fw = w.get(k)
+                q8 += [fw.q.data_ptr(), fw.scale.data_ptr()] if fw is not None else [None, None]
             layers[i] = _lib.Qwen2Layer(w["wqkv"].data_ptr(), w["bqkv"].data_ptr(), w["wo"].data_ptr(), w["wgu"].data_ptr(),
-                                        w["wd"].data_ptr(), w["ln1"].data_ptr(), w["ln2"].data_ptr(), cache.buf[i].data_ptr())
+                                        w["wd"].data_ptr(), w["ln1"].data_ptr(), w["ln2"].data_ptr(), cache.buf[i].data_ptr(), *q8)
         m = _lib.Qwen2Model(n_layers=L, d=cfg.hidden_size, n_q=cfg.num_attention_heads, n_kv=cfg.num_key_value_heads, hd=cfg.head_dim,
                             d_ff=cfg.intermediate_size, vocab=head["V"], ldkv=cache.buf[0].stride(0), max_len=cache.max_len,
                             attn_splits=16, eps=cfg.rms_norm_eps, inv_freq=pk["inv_freq"].data_ptr(), norm=pk["norm"].data_ptr(),

@@ -54,12 +54,18 @@ def gemm(a, w, bias=None, act=None, resid=None, resid_rows=0, out=None, out_dtyp
 
 
 def gemv1(w, a=None, x=None, ln_w=None, eps=1e-6, bias=None, act=None, resid=None, swiglu=False, out=None, out_dtype=torch.bfloat16):
-    """One-row GEMV (decode): a bf16 [K] row, or x fp32 [K] + RMSNorm weight (norm fused into the kernel).  -> [N(/2)]"""
+    """One-row GEMV (decode): a bf16 [K] row, or x fp32 [K] + RMSNorm weight (norm fused into the kernel).  w bf16 [N,K] or
+    an Fp8Weight (then the row is quantised in the kernel: W8A8).  -> [N(/2)]"""
     N, K = w.shape
     n_out = N // 2 if swiglu else N
+    dev = (a if a is not None else x).device
     if out is None:
-        out = torch.empty((n_out,), device=w.device, dtype=out_dtype)
-    _lib.call("ufv_gemv1", _ptr(a), _ptr(x), _ptr(ln_w), float(eps), w.data_ptr(), w.stride(0), out.data_ptr(), int(out.dtype == torch.float32),
+        out = torch.empty((n_out,), device=dev, dtype=out_dtype)
+    if isinstance(w, Fp8Weight):
+        wp, ldw, ws = w.q.data_ptr(), w.q.stride(0), w.scale.data_ptr()
+    else:
+        wp, ldw, ws = w.data_ptr(), w.stride(0), None
+    _lib.call("ufv_gemv1", _ptr(a), _ptr(x), _ptr(ln_w), float(eps), wp, ldw, ws, out.data_ptr(), int(out.dtype == torch.float32),
               N, K, _ptr(bias), ACT[act], _ptr(resid), int(swiglu), _stream())
     return out
 
