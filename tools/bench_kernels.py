@@ -49,6 +49,9 @@ if not only or "attn" in only:
     f3 = lambda: ops.attention(qkv, qkv[:, H * hd:], qkv[:, 2 * H * hd:], T, H, H, S, S, hd, (S * 3 * H * hd, 3 * H * hd),
                                (S * 3 * H * hd, 3 * H * hd), (S * 3 * H * hd, 3 * H * hd), out=o, kernel=4)
     ms = timeit(f3); print(f"vit_attn (6-wave dma variant) {ms:8.3f} ms  {4.0 * T * H * S * S * hd / ms / 1e9:7.1f} TF/s")
+    f6 = lambda: ops.attention(qkv, qkv[:, H * hd:], qkv[:, 2 * H * hd:], T, H, H, S, S, hd, (S * 3 * H * hd, 3 * H * hd),
+                               (S * 3 * H * hd, 3 * H * hd), (S * 3 * H * hd, 3 * H * hd), out=o, kernel=6)
+    ms = timeit(f6); print(f"vit_attn (9-wave lockstep, no ping-pong) {ms:8.3f} ms  {4.0 * T * H * S * S * hd / ms / 1e9:7.1f} TF/s")
     S, Hq, Hkv, hd = 2399, 28, 4, 128
     q = rnd(S, Hq * hd); kv = rnd(S, 2 * Hkv * hd)
     o = torch.empty(S, Hq * hd, device=dev, dtype=torch.bfloat16)

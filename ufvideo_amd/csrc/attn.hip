@@ -269,13 +269,18 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 ? 3 : 2)) void attn_fwd_mfma(Att
 // pitch (HD*2 bytes = odd number of 16-B slots -> conflict-free ds_read_b128 K fragments); the zero padding of
 // the QK^T contraction (72 -> 80) lives in the Q fragment, so the K "pad" chunk may alias the next row.
 // ---------------------------------------------------------------------------------------------------------
-template <int HD, int NW, bool CAUSAL>
+// PP (ping-pong): the waves of a SIMD come from two groups that run half a tile apart -- a second barrier splits every tile
+// step into [QK^T MFMA, first half of the softmax] and [second half of the softmax, PV MFMA], and group 1 starts one barrier
+// late, so one group's MFMAs overlap the other group's exp/convert VALU work instead of all waves alternating in lockstep
+// between the two units.  Needs a 4-stage K/V ring (the late group still reads tile t-1 when tile t+2 is prefetched).
+template <int HD, int NW, bool CAUSAL, bool PP>
 __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(AttnArgs a) {
     constexpr int KS = (HD + 15) / 16, DT = (HD + 31) / 32;
     constexpr int PK = HD * 2, PV = HD * 2;                 // natural row pitch
     constexpr int TILEB = 64 * PK, NI = TILEB / 1024;       // bytes / 1-KiB DMA pieces per operand tile
     static_assert(TILEB % 1024 == 0 && (HD % 8) == 0 && ((HD / 8) & 1) == 1, "row must be an odd number of 16-B chunks");
     constexpr int STG = 2 * TILEB + 256;                    // [K tile][16 B zeros + pad][V tile][tail pad]
+    constexpr int NST = PP ? 4 : 3;                         // ring stages
     constexpr int VOFF = TILEB + 128;
     constexpr int NPW = (2 * NI + NW - 1) / NW;             // DMA pieces per wave per tile (max)
     constexpr int NPW_MIN = (2 * NI) / NW;
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
         }
     };
     // zero the 16 bytes after every K tile (read as the d>=HD tail of the last key row)
-    if (tid < 3 * 4) reinterpret_cast<float*>(smem + (tid >> 2) * STG + TILEB)[tid & 3] = 0.f;
+    if (tid < NST * 4) reinterpret_cast<float*>(smem + (tid >> 2) * STG + TILEB)[tid & 3] = 0.f;
 
     f32x16 oacc[DT];
 #pragma unroll
@@ -363,9 +368,11 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    const bool grp1 = PP && ((wave >> 2) & 1);                // waves 4..7: one barrier behind (SIMD s holds waves s, s+4, s+8)
+    if (grp1) __builtin_amdgcn_s_barrier();
     int st = 0;
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 2 < ntiles) dma_tile(st == 0 ? 2 : st - 1, t + 2);       // ring slot (t+2)%3 == (st+2)%3
+        if (t + 2 < ntiles) dma_tile(st + 2 >= NST ? st + 2 - NST : st + 2, t + 2);       // ring slot (t+2) % NST
         const char* kb = smem + st * STG;
         const char* vb = kb + VOFF;
         const int kbase_idx = t * 64;
@@ -420,17 +427,27 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
         // ---- P = exp2(s*scale*log2e - m): one FMA + one v_exp per element; masked keys give exp2(-inf) = 0
         const float msub = (m_run == -INFINITY) ? 0.f : m_run;
         float psum = 0.f;
+        bf16x8 pf[4];                 // P^T as B operand: k-step sp of half hh uses registers 8sp..8sp+7
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -msub));
-            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -msub));
-            psum += s0[r] + s1[r];
+            psum += s0[r];
         }
-        l_run += psum;
-        // ---- P^T as B operand: k-step sp of half hh uses registers 8sp..8sp+7
-        bf16x8 pf[4];
         pf[0] = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
         pf[1] = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
+        if constexpr (PP) {           // half-step seam: the other group is entering its MFMA-heavy half
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW_MIN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -msub));
+            psum += s1[r];
+        }
+        l_run += psum;
         pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
         pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
         // ---- O^T[d][q] += sum_key V[key][d] P[key][q]; V^T fragments via transposed LDS reads
@@ -458,8 +475,9 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
         if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW_MIN) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        st = (st == 2) ? 0 : st + 1;
+        st = (st == NST - 1) ? 0 : st + 1;
     }
+    if (PP && !grp1) __builtin_amdgcn_s_barrier();           // balance the stagger barrier
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
@@ -693,21 +711,21 @@ int launch_mfma(const AttnArgs& a, int causal, hipStream_t st) {
     return UFV_OK;
 }
 
-template <int HD, int NW>
+template <int HD, int NW, bool PP>
 int launch_mfma_dma(const AttnArgs& a, int causal, hipStream_t st) {
-    constexpr int smem = 3 * (2 * 64 * HD * 2 + 256);
+    constexpr int smem = (PP ? 4 : 3) * (2 * 64 * HD * 2 + 256);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_dma<HD, NW, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_dma<HD, NW, true, PP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_dma<HD, NW, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_dma<HD, NW, false, PP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     const int nqt = cdiv(a.Sq, 32 * NW), groups = a.Hq * a.B, gper = (groups + 7) / 8;
     dim3 grid(8 * gper * nqt);
-    if (causal) hipLaunchKernelGGL((attn_fwd_mfma_dma<HD, NW, true>), grid, dim3(NW * 64), smem, st, a);
-    else hipLaunchKernelGGL((attn_fwd_mfma_dma<HD, NW, false>), grid, dim3(NW * 64), smem, st, a);
+    if (causal) hipLaunchKernelGGL((attn_fwd_mfma_dma<HD, NW, true, PP>), grid, dim3(NW * 64), smem, st, a);
+    else hipLaunchKernelGGL((attn_fwd_mfma_dma<HD, NW, false, PP>), grid, dim3(NW * 64), smem, st, a);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
@@ -733,13 +751,14 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
     }
-    if (kernel == 1 || kernel == 3 || kernel == 4 || (kernel == 0 && mfma_ok && Sq >= 16)) {
+    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || (kernel == 0 && mfma_ok && Sq >= 16)) {
         const bool six = (Sq % 192 == 0) && (Sq % 128 != 0);     // e.g. 576 ViT tokens: 3 blocks of 6 waves, no idle wave
         switch (hd) {
             case 64: return launch_mfma<64, 4>(a, causal, st);
             case 72: if (kernel == 3) return launch_mfma<72, 4>(a, causal, st);      // register-staged variant (diagnostic)
-                     if (Sq % 288 == 0 && kernel != 4) return launch_mfma_dma<72, 9>(a, causal, st);   // 576 ViT tokens = 2 blocks of 9 waves
-                     return six ? launch_mfma_dma<72, 6>(a, causal, st) : launch_mfma_dma<72, 4>(a, causal, st);
+                     if (Sq % 288 == 0 && kernel == 6) return launch_mfma_dma<72, 9, false>(a, causal, st);   // lockstep variant (diagnostic)
+                     if (Sq % 288 == 0 && kernel != 4) return launch_mfma_dma<72, 9, true>(a, causal, st);     // 576 ViT tokens = 2 blocks of 9 waves
+                     return six ? launch_mfma_dma<72, 6, false>(a, causal, st) : launch_mfma_dma<72, 4, false>(a, causal, st);
             case 80: return launch_mfma<80, 4>(a, causal, st);
             case 96: return launch_mfma<96, 4>(a, causal, st);
             case 128: return launch_mfma<128, 4>(a, causal, st);
