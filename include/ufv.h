@@ -154,6 +154,14 @@ int ufv_preprocess_u8(const uint8_t* frames, void* out, int T, int H, int W, con
 int ufv_gemv1(const void* a, const float* x, const float* ln_w, float eps, const void* W, int ldw, const float* w_scale, void* C,
               int out_f32, int N, int K, const float* bias, int act, const float* resid, int swiglu, void* stream);
 
+/* Resize step of the frame batching (mm_utils.py:269-295 -> HF SiglipImageProcessor -> PIL Image.resize(BICUBIC)): Pillow's
+ * 8-bit separable resample reproduced bit for bit on uint8 HWC frames [T,H,W,3] -> [T,Ho,Wo,3].  bounds_* int32 [out,2] = (first
+ * input index, tap count), coeff_* int32 [out, ksize] fixed point 2^22 (host: ufvideo_amd.mm_utils.pil_resize_coeffs);
+ * tmp = [T,H,Wo,3] scratch when both passes run. */
+int ufv_resize_bicubic_u8(const uint8_t* frames, uint8_t* tmp, uint8_t* out, int T, int H, int W, int Ho, int Wo,
+                          const int32_t* bounds_x, const int32_t* coeff_x, int ksize_x, const int32_t* bounds_y, const int32_t* coeff_y,
+                          int ksize_y, void* stream);
+
 /* ---- one-call greedy decode step (replaces HF GenerationMixin's per-token Qwen2ForCausalLM.forward under
  * videorefer_qwen2.py:414-426).  All pointers are device memory prepared by the caller (packed weights as for the
  * op-level calls: wqkv = [q|k|v] rows, wgu = gate/up rows interleaved in blocks of 16). */

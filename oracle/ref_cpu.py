@@ -1089,3 +1089,74 @@ def training_losses(sd: SD, cfg: dict, inputs_embeds, attention_mask, labels, se
         bce = w_bce * (sigmoid_ce_loss(pred, gt, n) * n) / (n + 1e-8)
         dice = w_dice * (dice_loss(pred, gt, n) * n) / (n + 1e-8)
     return dict(loss=ce + bce + dice, ce_loss=ce, mask_bce_loss=bce, mask_dice_loss=dice, mask_loss=bce + dice)
+
+
+# --------------------------------------------------------------------------------------
+# Pillow's 8-bit bicubic resize (Image.resize(resample=BICUBIC) under HF SiglipImageProcessor, reference mm_utils.py:269-295):
+# restated from the published algorithm of Pillow's Resample.c (precompute_coeffs / normalize_coeffs_8bpc /
+# ImagingResampleHorizontal_8bpc / ...Vertical_8bpc); the GPU frame-batching path must match it bit for bit.
+# --------------------------------------------------------------------------------------
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_bicubic(x: float) -> float:
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resize_coeffs(in_size: int, out_size: int):
+    """-> (bounds int32 [out, 2] = (first input index, tap count), coeffs int32 [out, ksize] fixed point 2^22)"""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_pil_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(0.5 + k * (1 << PIL_PRECISION_BITS)) if k >= 0 else int(-0.5 + k * (1 << PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def pil_resize_bicubic_u8(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """img uint8 [H, W, C] -> uint8 [out_h, out_w, C]: horizontal pass, round/clip to uint8, vertical pass, round/clip."""
+    H, W, C = img.shape
+    x = img.astype(np.int64)
+    if W != out_w:
+        b, k = pil_resize_coeffs(W, out_w)
+        tmp = np.empty((H, out_w, C), dtype=np.int64)
+        for xo in range(out_w):
+            x0, n = b[xo]
+            acc = (x[:, x0:x0 + n, :] * k[xo, :n].astype(np.int64)[None, :, None]).sum(1) + (1 << (PIL_PRECISION_BITS - 1))
+            tmp[:, xo, :] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+        x = tmp
+    if H != out_h:
+        b, k = pil_resize_coeffs(H, out_h)
+        out = np.empty((out_h, x.shape[1], C), dtype=np.int64)
+        for yo in range(out_h):
+            y0, n = b[yo]
+            acc = (x[y0:y0 + n] * k[yo, :n].astype(np.int64)[:, None, None]).sum(0) + (1 << (PIL_PRECISION_BITS - 1))
+            out[yo] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255)
+        x = out
+    return x.astype(np.uint8)

@@ -153,3 +153,19 @@ def test_ops_fail_loudly_without_gpu_tensors():
         pytest.skip("GPU present")
     with pytest.raises(_lib.UfvError):
         ops.gemm(torch.zeros(4, 8, dtype=torch.bfloat16), torch.zeros(4, 8, dtype=torch.bfloat16))
+
+
+def test_pil_bicubic_restatement_and_coefficients_match_pillow():
+    """The restated Pillow 8-bit bicubic resample (oracle) and the product's coefficient tables against PIL itself."""
+    from PIL import Image
+    from oracle import ref_cpu as O
+    from ufvideo_amd.mm_utils import pil_resize_coeffs
+    rng = np.random.default_rng(3)
+    for H, W, S in [(360, 640, 336), (224, 224, 336), (96, 54, 56), (35, 50, 56), (56, 56, 56)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((S, S), resample=Image.BICUBIC))
+        assert np.array_equal(O.pil_resize_bicubic_u8(img, S, S), ref), (H, W, S)
+        for n_in in (H, W):
+            b1, k1 = pil_resize_coeffs(n_in, S)
+            b2, k2 = O.pil_resize_coeffs(n_in, S)
+            assert np.array_equal(b1, b2) and np.array_equal(k1, k2)

@@ -383,3 +383,29 @@ def test_gemv1_fused_rmsnorm_bit_identical(N, K):
         yb = ops.gemv1(w, x=x[0].contiguous(), ln_w=gw, eps=1e-6, swiglu=True)
         refb = ops.gemm(h, w, swiglu=True, kernel=ops.GEMM_GEMV)[0]
         assert rel(yb, refb) < 8e-3
+
+
+def test_device_frame_batching_matches_pillow_bit_for_bit():
+    """u8 HWC frames -> Pillow-exact bicubic resize on the GPU -> normalise/layout; resize output equals PIL's byte for byte."""
+    import numpy as np
+    from PIL import Image
+    from ufvideo_amd.mm_utils import UfvImageProcessor
+    rng = np.random.default_rng(5)
+    for T, H, W, S in [(3, 360, 640, 336), (2, 224, 224, 336), (2, 100, 37, 56), (1, 480, 270, 384), (2, 56, 56, 56), (1, 56, 90, 56)]:
+        fr = rng.integers(0, 256, (T, H, W, 3), dtype=np.uint8)
+        ref = np.stack([np.asarray(Image.fromarray(f).resize((S, S), resample=Image.BICUBIC)) for f in fr])
+        got = ops.resize_bicubic_u8(torch.from_numpy(fr).to(DEV), S, S)
+        assert torch.equal(got.cpu(), torch.from_numpy(ref)), (T, H, W, S)
+        proc = UfvImageProcessor(size=S)
+        want = proc.preprocess(list(fr))["pixel_values"]                       # the reference-style CPU path (PIL + float32)
+        dev = proc.preprocess_device(fr, device=DEV)
+        assert dev.shape == want.shape and dev.dtype == torch.bfloat16
+        assert (dev.float().cpu() - want).abs().max() <= 2 ** -7              # bf16 rounding of values in [-1, 1]
+    # process_video(device=...): same frames through the opt-in device path vs the reference-style CPU path
+    from ufvideo_amd.mm_utils import process_video
+    frames = rng.integers(0, 256, (5, 90, 160, 3), dtype=np.uint8)
+    proc = UfvImageProcessor(size=56)
+    v_cpu, f_cpu, h, w, _ = process_video(frames, proc, aspect_ratio="pad", num_frames=4, frame_idx=[1, 3])
+    v_dev, f_dev, h2, w2, _ = process_video(frames, proc, aspect_ratio="pad", num_frames=4, frame_idx=[1, 3], device=DEV)
+    assert (h, w) == (h2, w2) and v_dev.is_cuda and v_dev.shape == v_cpu.shape and f_dev.shape == f_cpu.shape
+    assert (v_dev.float().cpu() - v_cpu).abs().max() <= 2 ** -7 and (f_dev.float().cpu() - f_cpu).abs().max() <= 2 ** -7

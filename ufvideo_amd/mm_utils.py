@@ -46,6 +46,44 @@ def frame_sample(duration, mode="uniform", num_frames=None, fps=None):
     raise ImportError(f"Unsupported frame sampling mode: {mode}")
 
 
+def _pil_bicubic(x):
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resize_coeffs(in_size, out_size, precision_bits=22):
+    """Coefficient tables of Pillow's 8-bit bicubic resample for one axis (the algorithm of Pillow's Resample.c:
+    precompute_coeffs + normalize_coeffs_8bpc, in the same double-precision operation order).  -> (bounds int32 [out, 2] =
+    (first input index, tap count), coeffs int32 [out, ksize], fixed point 2^22) for `ufv_resize_bicubic_u8`."""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    one = float(1 << precision_bits)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [_pil_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(0.5 + k * one) if k >= 0 else int(-0.5 + k * one)
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
 class UfvImageProcessor:
     """Stand-in for the HF SiglipImageProcessor the reference obtains from the tower
     (encoder.py:120): bicubic PIL resize -> x/255 -> (x-mean)/std -> float32 NCHW."""
@@ -85,6 +123,18 @@ class UfvImageProcessor:
 
     __call__ = preprocess
 
+    def preprocess_device(self, frames_u8, device="cuda"):
+        """Device-side frame batching: uint8 HWC frames [T,H,W,3] (numpy or tensor, all one size) -> bf16 NCHW [T,3,S,S] on the
+        GPU: Pillow-exact bicubic resize (`ufv_resize_bicubic_u8`) + normalise / layout (`ufv_preprocess_u8`).  The uint8 image
+        after the resize is bit-identical to `resize_u8`; the final values are `preprocess`'s float32 values within bf16 rounding."""
+        from . import ops
+        t = torch.as_tensor(np.ascontiguousarray(frames_u8) if isinstance(frames_u8, np.ndarray) else frames_u8)
+        t = t.to(device=device, dtype=torch.uint8).contiguous()
+        S = self.size["height"]
+        if tuple(t.shape[1:3]) != (S, S):
+            t = ops.resize_bicubic_u8(t, S, S)
+        return ops.preprocess_u8(t, self.image_mean, self.image_std)
+
 
 def _to_pil_list(video_path, frame_idx):
     """The already-decoded input forms of process_video (ref mm_utils.py:230-267)."""
@@ -105,8 +155,9 @@ def _to_pil_list(video_path, frame_idx):
     return video, frames
 
 
-def process_video(video_path, processor, s=None, e=None, aspect_ratio="pad", num_frames=NUM_FRAMES, frame_idx=None):
-    """-> (video [T,3,S,S] f32, frame_data [n,3,S,S] | None, height, width, frames_list)  (ref mm_utils.py:161-295)"""
+def process_video(video_path, processor, s=None, e=None, aspect_ratio="pad", num_frames=NUM_FRAMES, frame_idx=None, device=None):
+    """-> (video [T,3,S,S] f32, frame_data [n,3,S,S] | None, height, width, frames_list)  (ref mm_utils.py:161-295).
+    `device` (not in the reference): resize + normalise on that GPU instead of PIL/numpy -> bf16 device tensors."""
     if isinstance(video_path, str):
         if s is not None and e is not None:
             s = max(s, 0.0); e = max(e, 0.0)
@@ -152,6 +203,9 @@ def process_video(video_path, processor, s=None, e=None, aspect_ratio="pad", num
         if aspect_ratio == "pad":
             bg = tuple(int(x * 255) for x in processor.image_mean)
             imgs = [expand2square(im, bg) for im in imgs]
+        if device is not None and len({im.size for im in imgs}) == 1 and hasattr(processor, "preprocess_device"):
+            # opt-in device-side frame batching: one H2D copy of the uint8 frames, Pillow-exact resize + normalise on the GPU
+            return processor.preprocess_device(np.stack([np.asarray(im.convert("RGB"), dtype=np.uint8) for im in imgs]), device=device)
         return processor.preprocess(imgs, return_tensors="pt")["pixel_values"]
 
     video = prep(video_data)

@@ -380,6 +380,31 @@ def preprocess_u8(frames, mean, std):
     return out
 
 
+_RESIZE_TABLES = {}
+
+
+def resize_bicubic_u8(frames, out_h, out_w):
+    """frames u8 [T,H,W,3] on device -> u8 [T,out_h,out_w,3], bit-identical to PIL Image.resize((out_w, out_h), BICUBIC)."""
+    from .mm_utils import pil_resize_coeffs
+    _chk(frames, torch.uint8, "frames"); assert frames.is_contiguous() and frames.dim() == 4 and frames.shape[3] == 3
+    T, H, W, _ = frames.shape
+    dev = frames.device
+
+    def tables(n_in, n_out):
+        key = (n_in, n_out, str(dev))
+        if key not in _RESIZE_TABLES:
+            b, k = pil_resize_coeffs(n_in, n_out)
+            _RESIZE_TABLES[key] = (torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev), k.shape[1])
+        return _RESIZE_TABLES[key]
+    bx, kx, nx = tables(W, out_w) if W != out_w else (None, None, 0)
+    by, ky, ny = tables(H, out_h) if H != out_h else (None, None, 0)
+    out = torch.empty((T, out_h, out_w, 3), device=dev, dtype=torch.uint8)
+    tmp = torch.empty((T, H, out_w, 3), device=dev, dtype=torch.uint8) if (W != out_w and H != out_h) else None
+    _lib.call("ufv_resize_bicubic_u8", frames.data_ptr(), _ptr(tmp), out.data_ptr(), T, H, W, out_h, out_w, _ptr(bx), _ptr(kx), nx,
+              _ptr(by), _ptr(ky), ny, _stream())
+    return out
+
+
 def convert(src, dtype):
     _chk(src, name="src")
     if src.dtype == dtype:
