@@ -601,8 +601,8 @@ __global__ __launch_bounds__(256) void attn_generic(AttnArgs a, int causal) {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     float* qv = reinterpret_cast<float*>(smem_g);            // [hd]
     float* red = qv + a.hd;                                  // [16]
-    float* part = red + 16;                                  // [4][hd]
-    float* sc = part + 4 * a.hd;                             // [nk]
+    float* part = red + 16;                                  // [key groups][hd]: max(4 * hd, 256) floats
+    float* sc = part + max(4 * a.hd, 256);                   // [nk]
     const int qi = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, hkv = hq / (a.Hq / a.Hkv);
     const int tid = threadIdx.x;
     const int nk = causal ? min(a.Sk, a.q_pos0 + qi + 1) : a.Sk;
@@ -633,7 +633,23 @@ __global__ __launch_bounds__(256) void attn_generic(AttnArgs a, int causal) {
     }
     sum = block_sum(sum, red);
     __syncthreads();
-    // output: 4 key groups x 64 lanes over d
+    // output: G = 256 / hd key groups (at least 4 x 64 lanes for hd >= 64), thread (g, d) sums keys g, g+G, ...
+    if (a.hd <= 64) {
+        const int G = 256 / a.hd, g = tid / a.hd, d = tid - g * a.hd;
+        if (g < G) {
+            float acc = 0.f;
+            for (int j = g; j < nk; j += G) acc += sc[j] * (float)vb[(int64_t)j * a.v_ss + d];
+            part[g * a.hd + d] = acc;
+        }
+        __syncthreads();
+        bf16* op = a.o + b * a.o_bs + (int64_t)qi * a.o_ss + hq * a.hd;
+        if (tid < a.hd) {
+            float t = 0.f;
+            for (int gg = 0; gg < G; ++gg) t += part[gg * a.hd + tid];
+            op[tid] = (bf16)(t / sum);
+        }
+        return;
+    }
     const int g = tid >> 6, ln = tid & 63;
     for (int d = ln; d < a.hd; d += 64) {
         float acc = 0.f;
@@ -777,7 +793,7 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         UFV_CHECK_LAUNCH();
         return UFV_OK;
     }
-    const size_t smem = sizeof(float) * ((size_t)hd * 5 + 16 + Sk);
+    const size_t smem = sizeof(float) * ((size_t)hd + 16 + (4 * hd > 256 ? 4 * hd : 256) + Sk);
     UFV_REQUIRE(smem <= 64 * 1024, "ufv_attention: generic kernel supports Sk <= ~16000 (Sk=%d hd=%d)", Sk, hd);
     hipLaunchKernelGGL(attn_generic, dim3(Sq, Hq, B), dim3(256), smem, st, a, causal);
     UFV_CHECK_LAUNCH();

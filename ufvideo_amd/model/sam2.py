@@ -114,6 +114,15 @@ class Hiera(PackedModule):
         self.channel_list = ([self.schedule[i]["dim_out"] for i in self.stage_ends[::-1]] if return_interm_layers
                              else [self.schedule[-1]["dim_out"]])
         self._idx_cache = {}
+        self._zbufs = {}
+
+    def _zbuf(self, name, shape, device, dtype=torch.bfloat16):
+        """Channel-padded scratch whose pad columns must read zero: allocated (zeroed) once per shape and reused -- kernels only
+        ever write the valid columns, and everything runs on one stream, so the pads stay zero and no per-block memset is needed."""
+        key = (name, tuple(shape), str(device), dtype)
+        if key not in self._zbufs:
+            self._zbufs[key] = torch.zeros(shape, device=device, dtype=dtype)
+        return self._zbufs[key]
 
     # ---- packing -----------------------------------------------------------------------------------------------
     def _pack(self):
@@ -171,7 +180,7 @@ class Hiera(PackedModule):
         dp, dop = w["dp"], w["dop"]
         dev = x.device
         N = B * H * W
-        xn = torch.zeros((N, dp), device=dev, dtype=torch.bfloat16) if dp != d else torch.empty((N, dp), device=dev, dtype=torch.bfloat16)
+        xn = self._zbuf("xn", (N, dp), dev) if dp != d else torch.empty((N, dp), device=dev, dtype=torch.bfloat16)
         ops.layernorm(x[:, :d] if dp != d else x, w["n1"][0], w["n1"][1], 1e-6, out=xn[:, :d] if dp != d else xn)
         Ho, Wo = (H // 2, W // 2) if qs else (H, W)
         if w["proj"] is not None:                       # dim change: shortcut = pool(proj(norm1(x)))
@@ -190,10 +199,10 @@ class Hiera(PackedModule):
         qkv = ops.gemm(xw, w["wqkv"], bias=w["bqkv"])     # [Bw*Sk, 3*dop]  (q | k | v, each padded to dop)
         q, Sq, ldq = qkv, Sk, 3 * dop
         if qs:
-            q = ops.maxpool2x2(qkv, Bw, gh, gw, do, out=torch.zeros((Bw * (gh // 2) * (gw // 2), dop), device=dev, dtype=torch.bfloat16))
+            q = ops.maxpool2x2(qkv, Bw, gh, gw, do, out=self._zbuf("q", (Bw * (gh // 2) * (gw // 2), dop), dev))
             Sq, ldq = (gh // 2) * (gw // 2), dop
         hd = do // heads
-        o = torch.zeros((Bw * Sq, dop), device=dev, dtype=torch.bfloat16) if dop != do else None
+        o = self._zbuf("o", (Bw * Sq, dop), dev) if dop != do else None
         o = ops.attention(q, qkv[:, dop:], qkv[:, 2 * dop:], Bw, heads, heads, Sq, Sk, hd, (Sq * ldq, ldq), (Sk * 3 * dop, 3 * dop),
                           (Sk * 3 * dop, 3 * dop), out=o)
         y = ops.gemm(o, w["wo"], bias=w["bo"])            # [Bw*Sq, dop] in window order
@@ -205,7 +214,7 @@ class Hiera(PackedModule):
         else:
             ops.add_rows(y, x, None)
         # MLP
-        h2 = torch.zeros((x.shape[0], dop), device=dev, dtype=torch.bfloat16) if dop != do else torch.empty((x.shape[0], dop), device=dev, dtype=torch.bfloat16)
+        h2 = self._zbuf("h2", (x.shape[0], dop), dev) if dop != do else torch.empty((x.shape[0], dop), device=dev, dtype=torch.bfloat16)
         ops.layernorm(x[:, :do] if dop != do else x, w["n2"][0], w["n2"][1], 1e-6, out=h2[:, :do] if dop != do else h2)
         f = ops.gemm(h2, w["w1"], bias=w["b1"], act="gelu")
         ops.gemm(f, w["w2"], bias=w["b2"], resid=x, out=x)
