@@ -89,35 +89,63 @@ __global__ __launch_bounds__(256) void layernorm_k(const void* x, int ldx, void*
         }
 }
 
+// rows stay in registers as bf16 (16-byte loads, 8 channels per chunk): half the registers of an fp32 copy, so more waves are
+// resident to hide the three HBM streams (a, b in; out)
+__device__ __forceinline__ void ln_stats8(const bf16x8* x, int nc, int lane, int D, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nc)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)x[i][j];
+    mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nc)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)x[i][j] - mean;
+                q += d * d;
+            }
+    rstd = rsqrtf(wave_sum(q) / D + eps);
+}
+
 __global__ __launch_bounds__(256) void ln_add_silu_k(const bf16* a, const float* wa, const float* ba, const bf16* b,
                                                      const float* wb, const float* bb, bf16* out, int M, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
-    const int nv = D >> 2;
-    f32x4 va[MAXV], vb[MAXV];
+    const int nc = D >> 3;
+    bf16x8 va[8], vb[8];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (lane + 64 * i < nv) {
-            va[i] = load4<UFV_DT_BF16>(a, (int64_t)row * D + 4 * (lane + 64 * i));
-            vb[i] = load4<UFV_DT_BF16>(b, (int64_t)row * D + 4 * (lane + 64 * i));
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nc) {
+            va[i] = *reinterpret_cast<const bf16x8*>(a + (int64_t)row * D + 8 * (lane + 64 * i));
+            vb[i] = *reinterpret_cast<const bf16x8*>(b + (int64_t)row * D + 8 * (lane + 64 * i));
         }
     float ma, ra, mb = 0.f, rb = 1.f;
-    ln_stats(va, nv, lane, D, eps, ma, ra);
-    if (wb) ln_stats(vb, nv, lane, D, eps, mb, rb);
+    ln_stats8(va, nc, lane, D, eps, ma, ra);
+    if (wb) ln_stats8(vb, nc, lane, D, eps, mb, rb);
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-        if (lane + 64 * i < nv) {
-            const int c = 4 * (lane + 64 * i);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wa + c), b1 = *reinterpret_cast<const f32x4*>(ba + c);
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = (va[i][j] - ma) * ra * w1[j] + b1[j];
-                float s = vb[i][j];
-                if (wb) s = (s - mb) * rb * wb[c + j] + bb[c + j];
-                o[j] = act_apply(t + s, ACT_SILU);
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nc) {
+            const int c = 8 * (lane + 64 * i);
+            float w1[8], b1[8], w2[8], b2[8];
+            *reinterpret_cast<f32x4*>(w1) = *reinterpret_cast<const f32x4*>(wa + c); *reinterpret_cast<f32x4*>(w1 + 4) = *reinterpret_cast<const f32x4*>(wa + c + 4);
+            *reinterpret_cast<f32x4*>(b1) = *reinterpret_cast<const f32x4*>(ba + c); *reinterpret_cast<f32x4*>(b1 + 4) = *reinterpret_cast<const f32x4*>(ba + c + 4);
+            if (wb) {
+                *reinterpret_cast<f32x4*>(w2) = *reinterpret_cast<const f32x4*>(wb + c); *reinterpret_cast<f32x4*>(w2 + 4) = *reinterpret_cast<const f32x4*>(wb + c + 4);
+                *reinterpret_cast<f32x4*>(b2) = *reinterpret_cast<const f32x4*>(bb + c); *reinterpret_cast<f32x4*>(b2 + 4) = *reinterpret_cast<const f32x4*>(bb + c + 4);
             }
-            store4<false>(out, (int64_t)row * D + c, o);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = ((float)va[i][j] - ma) * ra * w1[j] + b1[j];
+                float s = (float)vb[i][j];
+                if (wb) s = (s - mb) * rb * w2[j] + b2[j];
+                o[j] = (bf16)act_apply_t<ACT_SILU>(t + s);
+            }
+            *reinterpret_cast<bf16x8*>(out + (int64_t)row * D + c) = o;
         }
 }
 
@@ -642,7 +670,7 @@ extern "C" int ufv_layernorm(const void* x, int x_dtype, int ldx, void* y, int y
 extern "C" int ufv_ln_add_silu(const void* a, const float* wa, const float* ba, const void* b, const float* wb, const float* bb,
                                void* out, int M, int D, float eps, void* stream) {
     UFV_REQUIRE(a && wa && ba && b && out && M > 0, "ufv_ln_add_silu: bad arguments");
-    UFV_REQUIRE(D % 4 == 0 && D <= 4 * 64 * MAXV, "ufv_ln_add_silu: D=%d unsupported", D);
+    UFV_REQUIRE(D % 8 == 0 && D <= 4096, "ufv_ln_add_silu: D=%d must be a multiple of 8 and <= 4096", D);
     hipLaunchKernelGGL(ln_add_silu_k, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), (const bf16*)a, wa, ba, (const bf16*)b, wb, bb,
                        (bf16*)out, M, D, eps);
     UFV_CHECK_LAUNCH();
