@@ -64,27 +64,45 @@ __device__ __forceinline__ void ln_stats(const f32x4* x, int nv, int lane, int D
     rstd = rsqrtf(wave_sum(q) / D + eps);
 }
 
-template <int XDT, bool YF32>
+// NV = float4 chunks per lane (row length <= 256 * NV); ACT is a compile-time activation id or -1 = runtime `act`
+template <int XDT, bool YF32, int NV, int ACT>
 __global__ __launch_bounds__(256) void layernorm_k(const void* x, int ldx, void* y, int ldy, const float* w, const float* b,
                                                    int M, int D, float eps, int act) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const int nv = D >> 2;
-    f32x4 v[MAXV];
+    f32x4 v[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
+    for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < nv) v[i] = load4<XDT>(x, (int64_t)row * ldx + 4 * (lane + 64 * i));
-    float mean, rstd;
-    ln_stats(v, nv, lane, D, eps, mean, rstd);
+    // statistics: two-pass in registers, like torch
+    float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nv) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nv)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                q += d * d;
+            }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < nv) {
             const int c = 4 * (lane + 64 * i);
             const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
             const f32x4 bb = b ? *reinterpret_cast<const f32x4*>(b + c) : f32x4{0, 0, 0, 0};
             f32x4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = act_apply((v[i][j] - mean) * rstd * ww[j] + bb[j], act);
+            for (int j = 0; j < 4; ++j) {
+                const float t = (v[i][j] - mean) * rstd * ww[j] + bb[j];
+                o[j] = ACT >= 0 ? act_apply_t<(ACT >= 0 ? ACT : 0)>(t) : act_apply(t, act);
+            }
             store4<YF32>(y, (int64_t)row * ldy + c, o);
         }
 }
@@ -658,10 +676,17 @@ extern "C" int ufv_layernorm(const void* x, int x_dtype, int ldx, void* y, int y
     UFV_REQUIRE(x && y && w && M > 0 && D > 0, "ufv_layernorm: bad arguments");
     UFV_REQUIRE(D % 4 == 0 && D <= 4 * 64 * MAXV && ldx % 4 == 0 && ldy % 4 == 0, "ufv_layernorm: D=%d must be a multiple of 4 and <= %d", D, 4 * 64 * MAXV);
     dim3 g(cdiv(M, 4)), blk(256);
-#define LN_LAUNCH(XD, YF) hipLaunchKernelGGL((layernorm_k<XD, YF>), g, blk, 0, ST(stream), x, ldx, y, ldy, w, b, M, D, eps, act)
+#define LN_LAUNCH2(XD, YF, NV_, ACT_) hipLaunchKernelGGL((layernorm_k<XD, YF, NV_, ACT_>), g, blk, 0, ST(stream), x, ldx, y, ldy, w, b, M, D, eps, act)
+#define LN_LAUNCH(XD, YF)                                                         \
+    do {                                                                          \
+        if (act == ACT_NONE && D <= 1280) LN_LAUNCH2(XD, YF, 5, ACT_NONE);        \
+        else if (act == ACT_NONE) LN_LAUNCH2(XD, YF, MAXV, ACT_NONE);             \
+        else LN_LAUNCH2(XD, YF, MAXV, -1);                                        \
+    } while (0)
     if (x_dtype == UFV_DT_F32) { if (y_f32) LN_LAUNCH(UFV_DT_F32, true); else LN_LAUNCH(UFV_DT_F32, false); }
     else if (x_dtype == UFV_DT_BF16) { if (y_f32) LN_LAUNCH(UFV_DT_BF16, true); else LN_LAUNCH(UFV_DT_BF16, false); }
     else { ufv_set_error("ufv_layernorm: unsupported input dtype %d", x_dtype); return UFV_EINVAL; }
+#undef LN_LAUNCH2
 #undef LN_LAUNCH
     UFV_CHECK_LAUNCH();
     return UFV_OK;
