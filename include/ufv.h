@@ -112,6 +112,9 @@ int ufv_colmean(const void* x, void* out, int F, int P, int C, void* stream);
 /* x[f*P + p, c] *= gate[f, c]   (SE excite; bf16 in place) */
 int ufv_scale_channels(void* x, const void* gate, int F, int P, int C, void* stream);
 
+/* nn.AvgPool3d(k) + nn.SiLU sampler of STPConnector / SpatialPool (projector.py:218-222,247-250): x bf16 [T,H,W,C] token-major
+ * -> bf16 [T/kt, H/kh, W/kw, C] (floor, no padding). */
+int ufv_avgpool3d_silu(const void* x, void* out, int T, int H, int W, int C, int kt, int kh, int kw, void* stream);
 /* Conv3d patch gather (kernel = stride = (kt,kh,kw), zero padding `pad` on all three dims):
  * x bf16 [T,H,W,C] -> out bf16 [To*Ho*Wo, kt*kh*kw*C], k = ((dt*kh+dh)*kw+dw)*C + c (projector.py:164-172,229-237) */
 int ufv_conv3d_gather(const void* x, void* out, int T, int H, int W, int C, int kt, int kh, int kw, int pad, void* stream);

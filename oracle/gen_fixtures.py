@@ -242,6 +242,20 @@ def fx_projector():
     yo3 = O.stc_connector(sd3, x2, downsample=(2, 2, 2), padding=1, depth=0)
     print("   stc(depth0,pad1) rel err", close(yo3, y3, what="stc depth0"), tuple(y3.shape))
     out.update({"stc_x": x2, "stc_y": y3}); out.update({k.replace("w::", "w::stc."): v for k, v in sd_np(sd3).items()})
+    # AvgPool3d samplers: spatial_pool (1,2,2) and stp_connector (2,2,2), depth 0 (projector.py:218-222,247-250)
+    m5 = RP.SpatialPool(Cfg2()).eval()
+    y5 = m5(x)
+    sd5 = dict(m5.state_dict())
+    yo5 = O.stc_connector(sd5, x, downsample=(1, 2, 2), depth=0, avgpool=True)
+    print("   spatial_pool rel err", close(yo5, y5, what="spatial_pool"), tuple(y5.shape))
+    out.update({"sp_x": x, "sp_y": y5}); out.update({k.replace("w::", "w::sp."): v for k, v in sd_np(sd5).items()})
+    m6 = RP.STPConnector(Cfg2(), depth=0).eval()
+    x6 = torch.randn(2, 5, 49, 32)                          # odd sizes: AvgPool3d floors (5,7,7) -> (2,3,3)
+    y6 = m6(x6)
+    sd6 = dict(m6.state_dict())
+    yo6 = O.stc_connector(sd6, x6, downsample=(2, 2, 2), depth=0, avgpool=True)
+    print("   stp(depth0) rel err", close(yo6, y6, what="stp depth0"), tuple(y6.shape))
+    out.update({"stp_x": x6, "stp_y": y6}); out.update({k.replace("w::", "w::stp."): v for k, v in sd_np(sd6).items()})
     # mlp2x_gelu
     class Cfg3:
         mm_hidden_size = 16

@@ -185,9 +185,10 @@ def regstage(sd: SD, p: str, x: torch.Tensor, depth: int, eps: float = 1e-5) -> 
 
 
 def stc_connector(sd: SD, x: torch.Tensor, prefix: str = "", downsample=(2, 2, 2), padding: int = 0,
-                  depth: int = 4, mlp_depth: int = 2, ln_eps: float = 1e-5) -> torch.Tensor:
+                  depth: int = 4, mlp_depth: int = 2, ln_eps: float = 1e-5, avgpool: bool = False) -> torch.Tensor:
     """STCConnector.forward (projector.py:189-215).  v35 = padding 0, depth 4 (:225-238);
-    'spatial_conv' = downsample (1,2,2), padding 1, depth 0 (:241-244)."""
+    'spatial_conv' = downsample (1,2,2), padding 1, depth 0 (:241-244); avgpool=True = the STPConnector / SpatialPool
+    sampler nn.AvgPool3d(downsample) + SiLU (:218-222, :247-250)."""
     p = prefix
     b, t, n, d = x.shape
     hw = int(n ** 0.5)
@@ -196,8 +197,11 @@ def stc_connector(sd: SD, x: torch.Tensor, prefix: str = "", downsample=(2, 2, 2
         x = regstage(sd, p + "s1.", x, depth, ln_eps)
     C = x.shape[1]
     x = x.view(b, t, C, hw, hw).permute(0, 2, 1, 3, 4)                              # b d t h w
-    x = F.conv3d(x, _g(sd, p, "sampler.0.weight"), _g(sd, p, "sampler.0.bias"),
-                 stride=downsample, padding=padding)
+    if avgpool:
+        x = F.avg_pool3d(x, tuple(downsample))
+    else:
+        x = F.conv3d(x, _g(sd, p, "sampler.0.weight"), _g(sd, p, "sampler.0.bias"),
+                     stride=downsample, padding=padding)
     x = F.silu(x)
     nt, nh, nw = x.shape[2:]
     x = x.permute(0, 2, 1, 3, 4).reshape(b * nt, C, nh, nw)

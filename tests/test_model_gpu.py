@@ -113,6 +113,15 @@ def test_projector_variants_vs_reference_golden():
     m = STCConnectorV35(Cfg(), depth=0); m.load_state_dict(_sub(w, "v35.")); m = m.to(DEV)
     y = m(t(a["v35_x"]).to(DEV))
     assert y.shape == a["v35_y"].shape and rel_err(y.cpu(), t(a["v35_y"])) < 1e-2
+    from ufvideo_amd.model.projector import STPConnector, SpatialPool        # AvgPool3d samplers (odd sizes floor)
+    for m, pre, xk, yk in ((SpatialPool(Cfg()), "sp.", "sp_x", "sp_y"), (STPConnector(Cfg(), depth=0), "stp.", "stp_x", "stp_y")):
+        m.load_state_dict(_sub(w, pre)); m = m.to(DEV)
+        y = m(t(a[xk]).to(DEV))
+        assert y.shape == a[yk].shape and rel_err(y.cpu(), t(a[yk])) < 1e-2, pre
+
+    class CfgP(Cfg):
+        mm_projector_type = "spatial_pool"
+    assert type(build_vision_projector(CfgP())).__name__ == "SpatialPool"
 
     class Cfg3:
         mm_hidden_size = 16

@@ -75,6 +75,9 @@ def test_projector_variants():
     assert rel_err(O.stc_connector(_sub(w, "v35."), t(a["v35_x"]), downsample=(2, 2, 2), padding=0, depth=0), t(a["v35_y"])) < TOL
     assert rel_err(O.stc_connector(_sub(w, "stc."), t(a["stc_x"]), downsample=(2, 2, 2), padding=1, depth=0), t(a["stc_y"])) < TOL
     assert a["sc_y"].shape == (1, 54, 32)        # SURVEY §2.3-C token-count probe
+    for pre, ds in (("sp", (1, 2, 2)), ("stp", (2, 2, 2))):          # AvgPool3d samplers: spatial_pool / stp_connector (odd sizes floor)
+        y = O.stc_connector(_sub(w, pre + "."), t(a[pre + "_x"]), downsample=ds, depth=0, avgpool=True)
+        assert y.shape == a[pre + "_y"].shape and rel_err(y, t(a[pre + "_y"])) < TOL, pre
 
 
 def test_regstage_shapes_and_token_rule():

@@ -44,6 +44,7 @@ SIGNATURES = {
     "ufv_mask_loss_sums": [_p, _p, _i, _l, _p, _p],
     "ufv_gemv1": [_p, _p, _p, _f, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p, _i, _p],
     "ufv_resize_bicubic_u8": [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p],
+    "ufv_avgpool3d_silu": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ufv_add_bcast": [_p, _i, _l, _p, _l, _i, _p, _i, _l, _l, _i, _p],
     "ufv_sam_mask_head": [_p, _l, _p, _l, _p, _p, _i, _i, _i, _i, _i, _p],
     "ufv_resize_bilinear": [_p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _p],

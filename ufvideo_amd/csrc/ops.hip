@@ -462,6 +462,31 @@ __global__ __launch_bounds__(256) void scale_channels_k(bf16* x, const bf16* gat
     }
 }
 
+// AvgPool3d(k = stride = (kt,kh,kw), no padding, floor) + SiLU over token-major x [T,H,W,C] (STP / spatial_pool sampler)
+__global__ __launch_bounds__(256) void avgpool3d_silu_k(const bf16* x, bf16* out, int T, int H, int W, int C, int kt, int kh, int kw,
+                                                        int To, int Ho, int Wo) {
+    const int cv = C / 8;
+    const int64_t total = (int64_t)To * Ho * Wo * cv;
+    const float inv = 1.0f / (kt * kh * kw);
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(id % cv) * 8;
+        const int64_t p = id / cv;
+        const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), to = (int)(p / ((int64_t)Wo * Ho));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int dt = 0; dt < kt; ++dt)
+            for (int dh = 0; dh < kh; ++dh)
+                for (int dw = 0; dw < kw; ++dw) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)(to * kt + dt) * H + ho * kh + dh) * W + wo * kw + dw) * C + c);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+                }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)act_apply_t<ACT_SILU>(acc[j] * inv);
+        *reinterpret_cast<bf16x8*>(out + p * C + c) = o;
+    }
+}
+
 // Conv3d gather: out row (to,ho,wo), col ((dt*kh+dh)*kw+dw)*C + c
 __global__ __launch_bounds__(256) void conv3d_gather_k(const bf16* x, bf16* out, int T, int H, int W, int C, int kt, int kh,
                                                        int kw, int pad, int To, int Ho, int Wo) {
@@ -773,6 +798,16 @@ extern "C" int ufv_conv3d_gather(const void* x, void* out, int T, int H, int W, 
     const int64_t total = (int64_t)To * Ho * Wo * kt * kh * kw * (C / 8);
     hipLaunchKernelGGL(conv3d_gather_k, dim3(grid_for(total)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)out, T, H, W, C, kt,
                        kh, kw, pad, To, Ho, Wo);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_avgpool3d_silu(const void* x, void* out, int T, int H, int W, int C, int kt, int kh, int kw, void* stream) {
+    UFV_REQUIRE(x && out && C % 8 == 0 && kt > 0 && kh > 0 && kw > 0, "ufv_avgpool3d_silu: C must be a multiple of 8");
+    const int To = T / kt, Ho = H / kh, Wo = W / kw;
+    UFV_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "ufv_avgpool3d_silu: empty output");
+    hipLaunchKernelGGL(avgpool3d_silu_k, dim3(grid_for((int64_t)To * Ho * Wo * (C / 8))), dim3(256), 0, ST(stream), (const bf16*)x,
+                       (bf16*)out, T, H, W, C, kt, kh, kw, To, Ho, Wo);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }

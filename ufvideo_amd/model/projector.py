@@ -79,6 +79,7 @@ def _regstage_params(h, prefix, depth, cin, cout, mk):
 class STCConnector(PackedModule):
     """ref projector.py:133-215 (base: Conv3d padding 1)."""
     PADDING = 1
+    AVGPOOL = False          # STP / spatial_pool: nn.AvgPool3d(downsample) + SiLU instead of the Conv3d sampler
 
     def __init__(self, config, downsample=(2, 2, 2), depth=4, mlp_depth=2, device=None, dtype=torch.bfloat16, seed=1,
                  std=0.02, ln_eps=1e-5):
@@ -92,7 +93,8 @@ class STCConnector(PackedModule):
         if depth:
             self.s1 = Holder(); _regstage_params(self.s1, "", depth, cin, hid, mk)
         self.sampler = Holder()
-        self.sampler.put("0.weight", mk((hid, hid, *self.downsample))); self.sampler.put("0.bias", mk((hid,), "zero"))
+        if not self.AVGPOOL:
+            self.sampler.put("0.weight", mk((hid, hid, *self.downsample))); self.sampler.put("0.bias", mk((hid,), "zero"))
         if depth:
             self.s2 = Holder(); _regstage_params(self.s2, "", depth, hid, hid, mk)
         self.readout = Holder()
@@ -120,9 +122,10 @@ class STCConnector(PackedModule):
         pk = {}
         if self.depth:
             pk["s1"], pk["s2"] = self._pack_stage(self.s1), self._pack_stage(self.s2)
-        w = self.sampler.get("0.weight")                       # [Co, Ci, kt, kh, kw] -> [Co, (kt kh kw Ci)]
-        pk["samp_w"] = self.gw(w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1))
-        pk["samp_b"] = f32(self.sampler.get("0.bias"))
+        if not self.AVGPOOL:
+            w = self.sampler.get("0.weight")                   # [Co, Ci, kt, kh, kw] -> [Co, (kt kh kw Ci)]
+            pk["samp_w"] = self.gw(w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1))
+            pk["samp_b"] = f32(self.sampler.get("0.bias"))
         pk["readout"] = [(self.gw(self.readout.get(f"{2 * i}.weight")), f32(self.readout.get(f"{2 * i}.bias")))
                          for i in range(self.mlp_depth)]
         return pk
@@ -151,8 +154,11 @@ class STCConnector(PackedModule):
             for blk in pk["s1"]:
                 h = self._block(h, blk, t, hw, hw)
         C = h.shape[1]
-        A, (To, Ho, Wo) = ops.conv3d_gather(h, t, hw, hw, C, self.downsample, self.PADDING)
-        h = ops.gemm(A, pk["samp_w"], bias=pk["samp_b"], act="silu")
+        if self.AVGPOOL:
+            h, (To, Ho, Wo) = ops.avgpool3d_silu(h.contiguous(), t, hw, hw, C, self.downsample)
+        else:
+            A, (To, Ho, Wo) = ops.conv3d_gather(h, t, hw, hw, C, self.downsample, self.PADDING)
+            h = ops.gemm(A, pk["samp_w"], bias=pk["samp_b"], act="silu")
         if self.depth:
             for blk in pk["s2"]:
                 h = self._block(h, blk, To, Ho, Wo)
@@ -178,6 +184,11 @@ class STCConnectorV35(STCConnector):
     PADDING = 0
 
 
+class STPConnector(STCConnector):
+    """ref projector.py:218-222: the Conv3d sampler replaced by AvgPool3d(downsample) + SiLU."""
+    AVGPOOL = True
+
+
 class SpatialConv(STCConnector):
     """ref projector.py:241-244: depth 0, downsample (1,2,2), padding 1."""
 
@@ -200,6 +211,15 @@ def build_vision_projector(config, delay_load=False, **kwargs):
         return SpatialConv(config, **kwargs)
     if kind == "identity":
         return IdentityMap()
-    if kind in ("stp_connector", "spatial_pool"):
-        raise NotImplementedError(f"projector type {kind} (AvgPool3d sampler) is outside the accelerated hot path")
+    if kind == "stp_connector":
+        return STPConnector(config, **kwargs)
+    if kind == "spatial_pool":
+        return SpatialPool(config, **kwargs)
     raise ValueError(f"Unknown projector type: {kind}")
+
+
+class SpatialPool(STPConnector):
+    """ref projector.py:247-250: depth 0, downsample (1,2,2), AvgPool3d sampler."""
+
+    def __init__(self, config, downsample=(1, 2, 2), depth=0, mlp_depth=2, **kw):
+        super().__init__(config, downsample=downsample, depth=depth, mlp_depth=mlp_depth, **kw)

@@ -243,6 +243,15 @@ def conv3d_gather(x, T, H, W, C, k, pad):
     return out, (To, Ho, Wo)
 
 
+def avgpool3d_silu(x, T, H, W, C, k):
+    """x bf16 [T*H*W, C] token-major -> (bf16 [To*Ho*Wo, C], (To, Ho, Wo)): AvgPool3d(k) + SiLU"""
+    _chk(x, torch.bfloat16, "x"); assert x.is_contiguous()
+    To, Ho, Wo = T // k[0], H // k[1], W // k[2]
+    out = torch.empty((To * Ho * Wo, C), device=x.device, dtype=torch.bfloat16)
+    _lib.call("ufv_avgpool3d_silu", x.data_ptr(), out.data_ptr(), T, H, W, C, k[0], k[1], k[2], _stream())
+    return out, (To, Ho, Wo)
+
+
 def gather_rows(src, src_idx, dst, dst_idx, n=None):
     D = src.shape[-1]
     if n is None:
