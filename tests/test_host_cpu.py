@@ -169,3 +169,50 @@ def test_pil_bicubic_restatement_and_coefficients_match_pillow():
             b1, k1 = pil_resize_coeffs(n_in, S)
             b2, k2 = O.pil_resize_coeffs(n_in, S)
             assert np.array_equal(b1, b2) and np.array_equal(k1, k2)
+
+
+def test_ann_to_mask_rle_and_photo_grid():
+    """COCO RLE decode (no pycocotools in the image: checked with an independent encoder written here from the format
+    description) and create_photo_grid / process_image(image_grid=True) shapes."""
+    rng = np.random.default_rng(7)
+
+    def encode_runs(mask):                                   # column-major runs, first run counts zeros
+        flat = mask.T.reshape(-1)
+        runs, cur, n = [], 0, 0
+        for v in flat:
+            if v == cur:
+                n += 1
+            else:
+                runs.append(n); cur, n = v, 1
+        runs.append(n)
+        return runs
+
+    def to_string(runs):                                     # pycocotools rleToString
+        out = []
+        for i, r in enumerate(runs):
+            x = r - runs[i - 2] if i > 2 else r
+            more = True
+            while more:
+                c = x & 0x1F
+                x >>= 5
+                more = not ((x == 0 and not (c & 0x10)) or (x == -1 and (c & 0x10)))
+                if more:
+                    c |= 0x20
+                out.append(chr(c + 48))
+        return "".join(out)
+
+    for h, w in ((7, 5), (40, 33), (1, 9)):
+        m = (rng.random((h, w)) > 0.6).astype(np.uint8)
+        runs = encode_runs(m)
+        assert np.array_equal(MU.annToMask({"counts": runs, "size": [h, w]}), m)
+        assert np.array_equal(MU.annToMask({"counts": to_string(runs), "size": [h, w]}), m)
+        assert np.array_equal(MU.annToMask({"counts": to_string(runs).encode(), "size": [h, w]}), m)
+    with pytest.raises(NotImplementedError):
+        MU.annToMask([[0, 0, 4, 0, 4, 4]], 8, 8)
+    fr = rng.integers(0, 256, (5, 6, 4, 3), dtype=np.uint8)
+    g = MU.create_photo_grid(fr)
+    assert g.shape == (18, 8, 3) and np.array_equal(g[6:12, 4:8], fr[3]) and g[12:, 4:].sum() == 0
+    from PIL import Image
+    proc = MU.UfvImageProcessor(size=56)
+    imgs, hh, ww, fl = MU.process_image(Image.fromarray(fr[0]), proc, num_frames=4, image_grid=True)
+    assert imgs.shape == (2, 3, 56, 56) and (hh, ww) == (12, 8) and len(fl) == 4

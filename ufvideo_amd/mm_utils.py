@@ -16,6 +16,83 @@ from PIL import Image
 from .constants import NUM_FRAMES, NUM_FRAMES_PER_SECOND, MODAL_INDEX_MAP, DEFAULT_IMAGE_TOKEN
 
 
+def _rle_counts_from_string(s):
+    """COCO compressed-RLE string -> run lengths (the published LEB128-like coding of pycocotools' rleFrString: 5 data bits
+    + continuation bit per character offset by 48, sign-extended, runs after the second stored as a difference to counts[i-2])."""
+    if isinstance(s, bytes):
+        s = s.decode("ascii")
+    cnts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(s[p]) - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    return cnts
+
+
+def annToMask(mask_ann, h=None, w=None):
+    """COCO segmentation -> uint8 [h, w] mask (ref mm_utils.py:22-33, which calls pycocotools).  RLE inputs (uncompressed
+    counts list or compressed counts string) are decoded natively: runs alternate 0/1 starting with 0 in column-major order.
+    Polygon lists need pycocotools' rasteriser and are delegated to it when it is installed."""
+    if isinstance(mask_ann, list):
+        try:
+            from pycocotools import mask as maskUtils
+        except ImportError as ex:
+            raise NotImplementedError("polygon annotations need pycocotools (frPyObjects); RLE annotations are decoded natively") from ex
+        return maskUtils.decode(maskUtils.merge(maskUtils.frPyObjects(mask_ann, h, w)))
+    counts = mask_ann["counts"]
+    hh, ww = mask_ann.get("size", (h, w))
+    runs = list(counts) if isinstance(counts, (list, tuple)) else _rle_counts_from_string(counts)
+    flat = np.zeros(hh * ww, dtype=np.uint8)
+    pos, val = 0, 0
+    for r in runs:
+        if val:
+            flat[pos:pos + r] = 1
+        pos += r
+        val ^= 1
+    return flat.reshape(ww, hh).T.copy()                     # column-major (Fortran) order
+
+
+def load_image_from_base64(image):
+    import base64
+    from io import BytesIO
+    return Image.open(BytesIO(base64.b64decode(image)))
+
+
+def create_photo_grid(arr, rows=None, cols=None):
+    """[t, h, w, c] frames (array / list of arrays / list of PIL) -> one [rows*h, cols*w, c] grid image (ref mm_utils.py:57-104)."""
+    if isinstance(arr, list):
+        if isinstance(arr[0], Image.Image):
+            arr = np.stack([np.array(img) for img in arr])
+        elif isinstance(arr[0], np.ndarray):
+            arr = np.stack(arr)
+        else:
+            raise ValueError("Invalid input type. Expected list of Images or numpy arrays.")
+    t, h, w, c = arr.shape
+    if rows is None and cols is None:
+        rows = math.ceil(math.sqrt(t))
+        cols = math.ceil(t / rows)
+    elif rows is None:
+        rows = math.ceil(t / cols)
+    elif cols is None:
+        cols = math.ceil(t / rows)
+    if rows * cols < t:
+        raise ValueError(f"Not enough grid cells ({rows}x{cols}) to hold all images ({t}).")
+    grid = np.zeros((h * rows, w * cols, c), dtype=arr.dtype)
+    for i in range(t):
+        r, cc = i // cols, i % cols
+        grid[r * h:(r + 1) * h, cc * w:(cc + 1) * w, :] = arr[i]
+    return grid
+
+
 def chunk_list(input_list, chunk_size):
     return [input_list[i:i + chunk_size] for i in range(0, len(input_list), chunk_size)]
 
@@ -218,14 +295,17 @@ def process_image(image_path, processor, aspect_ratio="pad", num_frames=NUM_FRAM
     """-> (images, height, width, frame_list)  (ref mm_utils.py:107-131)"""
     image = Image.open(image_path).convert("RGB") if isinstance(image_path, str) else image_path.convert("RGB")
     if image_grid:
-        raise NotImplementedError("image_grid is not on the hot path")
-    arr = np.array(image)
-    frame_list = [arr for _ in range(4)]
-    height, width = arr.shape[:2]
-    im = Image.fromarray(arr)
+        pg = np.stack([np.array(image)] * num_frames)
+        g = math.ceil(math.sqrt(num_frames))
+        images = [create_photo_grid(pg, g, g), np.array(image)]
+    else:
+        images = [np.array(image)]
+    frame_list = [images[0] for _ in range(4)]
+    height, width = images[0].shape[:2]
+    images = [Image.fromarray(f) for f in images]
     if aspect_ratio == "pad":
-        im = expand2square(im, tuple(int(x * 255) for x in processor.image_mean))
-    images = processor.preprocess([im], return_tensors="pt")["pixel_values"]
+        images = [expand2square(im, tuple(int(x * 255) for x in processor.image_mean)) for im in images]
+    images = processor.preprocess(images, return_tensors="pt")["pixel_values"]
     return images, height, width, frame_list
 
 
