@@ -52,6 +52,19 @@ __device__ __forceinline__ void tr_read8(unsigned addr, bf16x4 (&v)[8]) {
         : "memory");
 }
 
+// ds_read_b128 from inline asm: hipcc makes an ordinary LDS load wait vmcnt(0) while LDS-DMA writes are in flight (it
+// cannot prove the ring stages disjoint), which drains the K/V prefetch every tile.  The caller counts lgkmcnt by hand.
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait2(bf16x8& a, bf16x8& b) {      // ties the fragments to the wait so their MFMAs stay behind it
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 struct AttnArgs {
     const bf16 *q, *k, *v;
     bf16* o;
@@ -319,6 +332,10 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // Q in registers before any DMA is in flight
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // ... and hipcc's own scoreboard must see them consumed here:
+    // it does not understand the asm wait above, and with LDS-DMA issued in between it would otherwise put a vmcnt(0) in
+    // front of the first MFMA of EVERY iteration (draining the K/V prefetch ring each tile)
     int kmax = a.Sk;
     if (CAUSAL) kmax = min(a.Sk, a.q_pos0 + min(qblk0 + 32 * NW, a.Sq));
     const int ntiles = (kmax + 63) / 64;
@@ -380,12 +397,30 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kb + k_off + ks * 32);
-            const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kb + 32 * PK + k_off + ks * 32);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
+        {
+            static_assert(KS == 5, "hand-counted lgkmcnt schedule below is written for 5 k-steps (head_dim 72)");
+            const unsigned kaddr = (unsigned)(uintptr_t)LDS_PTR(kb + k_off);
+            bf16x8 kf[KS][2];
+            kf[0][0] = lds_read128<0 * 32>(kaddr); kf[0][1] = lds_read128<32 * PK + 0 * 32>(kaddr);
+            kf[1][0] = lds_read128<1 * 32>(kaddr); kf[1][1] = lds_read128<32 * PK + 1 * 32>(kaddr);
+            kf[2][0] = lds_read128<2 * 32>(kaddr); kf[2][1] = lds_read128<32 * PK + 2 * 32>(kaddr);
+            kf[3][0] = lds_read128<3 * 32>(kaddr); kf[3][1] = lds_read128<32 * PK + 3 * 32>(kaddr);
+            kf[4][0] = lds_read128<4 * 32>(kaddr); kf[4][1] = lds_read128<32 * PK + 4 * 32>(kaddr);
+            lgkm_wait2<8>(kf[0][0], kf[0][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][0], qf[0], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][1], qf[0], s1, 0, 0, 0);
+            lgkm_wait2<6>(kf[1][0], kf[1][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][0], qf[1], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][1], qf[1], s1, 0, 0, 0);
+            lgkm_wait2<4>(kf[2][0], kf[2][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2][0], qf[2], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2][1], qf[2], s1, 0, 0, 0);
+            lgkm_wait2<2>(kf[3][0], kf[3][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[3][0], qf[3], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[3][1], qf[3], s1, 0, 0, 0);
+            lgkm_wait2<0>(kf[4][0], kf[4][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4][0], qf[4], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4][1], qf[4], s1, 0, 0, 0);
         }
         // ---- V^T fragments for the first two d-tiles: issued now (K fragment reads have been consumed by the MFMAs
         //      above, so the LDS queue holds nothing else) and landing under the softmax arithmetic below.
