@@ -242,6 +242,44 @@ int ufv_argmax_rows(const float* x, int64_t ld, int M, int N, int32_t* out, void
 /* elementwise convert between bf16 / f32 / f16 (n elements) */
 int ufv_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 
+/* ---- training step of the decoder: backward + optimizer ----
+ * The reference gets these from torch autograd over HF Qwen2 (modeling_qwen2.py) and from DeepSpeed ZeRO-2 + AdamW
+ * (train.py:749, scripts/zero2.json).  The contractions (dX = dY W, dW = dY^T X, attention's five products) run on ufv_gemm;
+ * the entry points below are what surrounds them. */
+/* out[c][r] = in[r][c], r < R, c < C; out columns R..Rpad-1 are zero-filled (K padding of the consuming NT GEMM) */
+int ufv_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int Rpad, void* stream);
+/* Qwen2RMSNorm backward (modeling_qwen2.py:238-254): dx (+)= d/dx, dw (+)= d/dw; x, dy, dx fp32 [M, D]; ws = ufv_rmsnorm_bwd_ws_bytes(D) */
+int64_t ufv_rmsnorm_bwd_ws_bytes(int D);
+int ufv_rmsnorm_bwd(const float* x, int ldx, const float* w, const float* dy, int lddy, float* dx, int lddx, int accumulate, float* dw,
+                    int dw_accumulate, int M, int D, float eps, void* ws, void* stream);
+/* out[j] (+)= sum_r x[r][j], x bf16 [R, C] (bias gradients); ws = 32*C floats */
+int ufv_colsum_bf16(const void* x, int64_t ld, int R, int C, float* out, int accumulate, void* ws, void* stream);
+/* Qwen2MLP gate (modeling_qwen2.py:47) on the packed gate/up layout of ufv_gemm's swiglu mode, unfused (training keeps the
+ * pre-activations): act[M, I] = silu(g) * u, and its backward dgu[M, 2I] from dact[M, I] */
+int ufv_swiglu(const void* gu, int64_t ldgu, void* act, int64_t lda, int M, int I, void* stream);
+int ufv_swiglu_bwd(const void* gu, int64_t ldgu, const void* dact, int64_t ldd, void* dgu, int64_t ldo, int M, int I, void* stream);
+/* rotate-half RoPE (modeling_qwen2.py:113-135) in place on `nheads` heads at column col0 of buf bf16 [S, ld]; backward != 0
+ * applies the transposed rotation (the gradient of the forward one) */
+int ufv_rope_rows(void* buf, int64_t ld, int S, int col0, int nheads, int hd, const float* inv_freq, int pos0, int backward, void* stream);
+/* causal-LM cross entropy, forward + backward in one pass: loss[i] as ufv_cross_entropy_rows; dlogits bf16 [M, ldd] =
+ * gscale * (softmax - onehot), zero for ignored rows and for columns V..Vpad-1 */
+int ufv_cross_entropy_bwd(const float* logits, int64_t ld, const int64_t* labels, int M, int V, int Vpad, int64_t ignore_index,
+                          float gscale, float* loss, void* dlogits, int64_t ldd, void* stream);
+/* dst[idx[r], :] += src[r, :] (fp32; idx < 0 skipped): gradient of the embed_tokens gather of the splice (videorefer_arch.py:239-370) */
+int ufv_scatter_add_rows(const float* src, int64_t lds, const int64_t* idx, float* dst, int64_t ldd, int R, int D, void* stream);
+/* partial[b] = sum of squares of block b's slice of x[n] (torch.nn.utils.clip_grad_norm_) */
+int ufv_sumsq(const float* x, int64_t n, float* partial, int n_partial, void* stream);
+/* torch.optim.AdamW step `step` (1-based) on fp32 p/m/v with gradient g * (*gscale if given); p_bf16 (may be NULL) receives the
+ * rounded working copy */
+int ufv_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, const float* gscale, void* stream);
+/* causal GQA self-attention backward (eager Qwen2 attention, modeling_qwen2.py:150-172, differentiated): q bf16 [S, ldq]
+ * (head h at column h*hd, RoPE applied), k / v bf16 [>= round_up(S,128) rows, ldkv] (kv-head g at column g*hd), dO bf16 [S, lddo]
+ * -> dq [S, lddq], dk / dv [S, lddkv] bf16.  ws = ufv_attention_bwd_ws_bytes(S, hd). */
+int64_t ufv_attention_bwd_ws_bytes(int S, int hd);
+int ufv_attention_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* dO, int64_t lddo, void* dq,
+                      int64_t lddq, void* dk, void* dv, int64_t lddkv, int S, int Hq, int Hkv, int hd, float scale, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

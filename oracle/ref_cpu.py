@@ -1069,6 +1069,42 @@ def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return F.cross_entropy(logits[..., :-1, :].reshape(-1, logits.shape[-1]).float(), labels[..., 1:].reshape(-1), ignore_index=-100)
 
 
+DECODER_TRAINABLE = ("model.layers.", "model.norm.weight", "model.embed_tokens.weight", "lm_head.weight")
+
+
+def decoder_train_grads(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, labels: torch.Tensor):
+    """torch autograd of the causal-LM loss through the decoder restatement: what `ce_loss.backward()` gives the reference
+    (videorefer_qwen2.py:198-215 + HF Qwen2ForCausalLM).  inputs_embeds [1,S,D], labels [1,S] (un-shifted, -100 = ignored).
+    Returns (loss, {name: grad} for every decoder parameter used, d loss / d inputs_embeds).  Pinned to the reference's own
+    backward by tests/golden/train_grad_tiny.npz (oracle/gen_fixtures_train_grad.py)."""
+    with torch.enable_grad():
+        p = {k: v.detach().clone().float().requires_grad_(True) for k, v in sd.items()
+             if k.startswith(DECODER_TRAINABLE[0]) or k in DECODER_TRAINABLE[1:]}
+        e = inputs_embeds.detach().clone().float().requires_grad_(True)
+        full = dict(sd); full.update(p)
+        out = qwen2_forward(full, cfg, e, None)
+        loss = causal_lm_loss(out["logits"], labels)
+        loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
+    return loss.detach(), grads, e.grad
+
+
+def adamw_first_step(params: SD, grads: SD, lr: float, wd: float, betas=(0.9, 0.999), eps: float = 1e-8, clip: float = 1.0):
+    """clip_grad_norm_(clip) + the first torch.optim.AdamW step (zero moments), weight decay on matrices only (HF Trainer's
+    decay/no-decay split).  Returns (new params, pre-clip gradient norm)."""
+    norm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = torch.clamp(clip / (norm + 1e-6), max=1.0) if clip else 1.0
+    b1, b2 = betas
+    new = {}
+    for k, p in params.items():
+        g = grads[k] * coef
+        p = p.float() * (1 - lr * (wd if p.ndim >= 2 else 0.0))
+        m = (1 - b1) * g
+        v = (1 - b2) * g * g
+        new[k] = p - (lr / (1 - b1)) * m / (v.sqrt() / math.sqrt(1 - b2) + eps)
+    return new, norm
+
+
 def training_losses(sd: SD, cfg: dict, inputs_embeds, attention_mask, labels, seg_id: int, sam_sd: SD, sam_cfg: dict, images_sam,
                     masks_list, label_list, weights=(1.0, 1.0, 1.0)):
     """forward(inference=False) after the splice, batch 1 (the accelerated decoder's batch): CE on all positions, [SEG]

@@ -262,3 +262,38 @@ def test_training_losses_vs_reference_forward():
                               [torch.zeros(gt.shape[1:]) if gt.shape[0] else torch.zeros(1, 1)], tuple(a["loss_weights"].tolist()))
         got = torch.stack([r[k_].float() for k_ in ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss")])
         assert torch.allclose(got, t(a[name + "_losses"]).float(), rtol=2e-5, atol=1e-6), (name, got, a[name + "_losses"])
+
+
+def spliced_embed_ids(ids, S):
+    """vocabulary row of every spliced position, -1 for the inserted visual tokens (one <video> sentinel expands to S - len + 1)"""
+    ids = [int(i) for i in ids]
+    n_vis = S - (len(ids) - 1)
+    out = []
+    for i in ids:
+        out += [-1] * n_vis if i < 0 else [i]
+    return torch.tensor(out, dtype=torch.long)
+
+
+def test_decoder_train_grads_vs_reference_backward():
+    """oracle autograd + AdamW restatement == the reference's own ce_loss.backward() / clip / AdamW.step() (train_grad_tiny)."""
+    a, _ = load_golden("train_grad_tiny")
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_grad_tiny.npz"))
+    _, w = load_golden("model_tiny")
+    loss, grads, de = O.decoder_train_grads(w, TINY_LLM, t(a["inputs_embeds"]), t(a["labels"]))
+    assert abs(float(loss) - float(a["ce_loss"])) < 1e-5
+    ref_g = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g::")}
+    assert set(ref_g) == set(grads)
+    # embed_tokens enters through the splice (videorefer_arch.py:239-370): its gradient = rows of d_inputs_embeds scattered by id
+    eids = spliced_embed_ids(a["ids"][0], de.shape[1])
+    ge = torch.zeros_like(grads["model.embed_tokens.weight"])
+    ge.index_add_(0, eids[eids >= 0], de[0][eids >= 0])
+    grads["model.embed_tokens.weight"] = ge
+    for k, g in ref_g.items():
+        assert rel_err(grads[k], g) < 1e-4, k
+    assert rel_err(de, t(a["d_inputs_embeds"])) < 1e-4
+    lr, wd, b1, b2, eps, clip = a["hyper"].tolist()
+    new, norm = O.adamw_first_step({k: w[k] for k in ref_g}, ref_g, lr, wd, (b1, b2), eps, clip)
+    assert abs(float(norm) - float(a["grad_norm"])) < 1e-3 * float(a["grad_norm"])
+    for k in ref_g:
+        assert torch.allclose(new[k], torch.from_numpy(z["p1::" + k]), atol=2e-6, rtol=1e-5), k

@@ -78,3 +78,50 @@ def test_frame_sharded_encode_world2_gloo(T):
     for rank, ok, tmax, shape in res:
         assert ok, f"rank {rank}: gathered tokens differ from the single-process encode"
         assert tmax == 2.0 and shape == (T, 8)
+
+
+# ---- ZeRO-2 exchange of the training step (ufvideo_amd/train.py) ---------------------------------------------------
+
+def _zero2_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ufvideo_amd import train as TR
+        n = 4096
+        g0 = torch.Generator().manual_seed(7)
+        params = torch.randn(n, generator=g0)
+        lo, hi = TR.shard_bounds(n, world, rank)
+        m, v = torch.zeros(hi - lo), torch.zeros(hi - lo)
+        hist = []
+        for t_ in (1, 2, 3):
+            grad = torch.randn(n, generator=torch.Generator().manual_seed(100 * t_ + rank)) * (5.0 if t_ == 2 else 0.01)
+            TR.zero2_step_reference(params, grad, (m, v), 1e-2, (0.9, 0.999), 1e-8, 0.1, t_, 1.0)
+            hist.append(params.clone())
+        q.put((rank, torch.stack(hist)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_zero2_exchange_world2_gloo_matches_single_process_adamw():
+    """2 ranks with different gradients: reduce-scatter(mean) + clip + sharded AdamW + all-gather == torch.optim.AdamW on the
+    averaged gradient with clip_grad_norm_, and both ranks hold identical parameters after every step."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_zero2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(res[0], res[1])
+    n = 4096
+    p = torch.nn.Parameter(torch.randn(n, generator=torch.Generator().manual_seed(7)))
+    opt = torch.optim.AdamW([p], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    for i, t_ in enumerate((1, 2, 3)):
+        gs = [torch.randn(n, generator=torch.Generator().manual_seed(100 * t_ + r)) * (5.0 if t_ == 2 else 0.01) for r in range(2)]
+        p.grad = (gs[0] + gs[1]) / 2
+        torch.nn.utils.clip_grad_norm_([p], 1.0)
+        opt.step()
+        assert torch.allclose(res[0][i], p.detach(), atol=1e-6, rtol=1e-5), f"step {t_}"

@@ -1,0 +1,272 @@
+"""GPU: the decoder training step (csrc/train.hip + ufvideo_amd/train.py) against torch autograd of the CPU oracle and the
+golden vectors captured from the reference's own backward / AdamW step (oracle/gen_fixtures_train_grad.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, t, rel_err
+from oracle import ref_cpu as O
+
+pytestmark = pytest.mark.gpu
+
+from ufvideo_amd import ops  # noqa: E402
+from ufvideo_amd.train import DecoderTrainer  # noqa: E402
+from test_model_gpu import tiny_model, TINY_LLM, DEV  # noqa: E402
+from test_oracle_golden import spliced_embed_ids  # noqa: E402
+
+
+def bfr(x):
+    return x.to(torch.bfloat16).float()
+
+
+# ---- kernels alone vs torch ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("R,C", [(5, 7), (64, 64), (130, 200), (2399, 136)])
+def test_transpose_zero_padded(R, C):
+    g = torch.Generator().manual_seed(R * 1000 + C)
+    x = torch.randn(R, C + 3, generator=g).to(torch.bfloat16).to(DEV)[:, :C]          # row-strided view
+    out = torch.full((C, ops.round_up(R, 128)), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.transpose(x, out=out)
+    assert torch.equal(out[:, :R].cpu(), x.cpu().t()) and (out[:, R:] == 0).all()
+
+
+@pytest.mark.parametrize("M,D", [(9, 64), (300, 1024), (2399, 3584)])
+def test_rmsnorm_bwd_vs_autograd(M, D):
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g) * 2
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    dy = torch.randn(M, D, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    O.rmsnorm(xr, wr, 1e-6).backward(dy)
+    dx0 = torch.randn(M, D, generator=g)
+    dx = dx0.clone().to(DEV)
+    dw = torch.zeros(D, device=DEV)
+    ops.rmsnorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), dx, dw, 1e-6, accumulate=True, dw_accumulate=False)
+    assert rel_err(dx.cpu() - dx0, xr.grad) < 1e-5 and rel_err(dw.cpu(), wr.grad) < 1e-4
+    dw2 = dw.clone()
+    ops.rmsnorm_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), dx, dw2, 1e-6, accumulate=False, dw_accumulate=True)
+    assert rel_err(dx.cpu(), xr.grad) < 1e-5 and rel_err(dw2.cpu(), 2 * wr.grad) < 1e-4
+
+
+def test_swiglu_fwd_bwd_vs_autograd():
+    from ufvideo_amd.model.videorefer_qwen2 import pack_swiglu
+    g = torch.Generator().manual_seed(3)
+    M, I = 37, 160
+    gate, up = bfr(torch.randn(M, I, generator=g) * 2), bfr(torch.randn(M, I, generator=g))
+    dact = bfr(torch.randn(M, I, generator=g))
+    gu = pack_swiglu(gate.t().contiguous(), up.t().contiguous()).t().contiguous().to(torch.bfloat16).to(DEV)   # rows interleaved -> columns
+    act = ops.swiglu(gu)
+    gr, ur = gate.clone().requires_grad_(True), up.clone().requires_grad_(True)
+    ref = F.silu(gr) * ur
+    assert rel_err(act.float().cpu(), ref.detach()) < 1e-2
+    ref.backward(dact)
+    dgu = ops.swiglu_bwd(gu, dact.to(torch.bfloat16).to(DEV)).float().cpu()
+    dg = dgu.view(M, I // 16, 2, 16)[:, :, 0].reshape(M, I)
+    du = dgu.view(M, I // 16, 2, 16)[:, :, 1].reshape(M, I)
+    assert rel_err(dg, gr.grad) < 1e-2 and rel_err(du, ur.grad) < 1e-2
+
+
+def test_rope_rows_backward_is_the_transposed_rotation():
+    g = torch.Generator().manual_seed(4)
+    S, H, hd = 19, 3, 16
+    inv = (1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(DEV)
+    x = bfr(torch.randn(S, 8 + H * hd, generator=g))
+    dy = bfr(torch.randn(S, H * hd, generator=g))
+    cos, sin = O.rope_cos_sin(torch.arange(S), hd, 10000.0)
+    xr = x[:, 8:].reshape(S, H, hd).clone().requires_grad_(True)
+    y = xr * cos[:, None] + O.rotate_half(xr) * sin[:, None]
+    fwd = x.to(torch.bfloat16).to(DEV)
+    ops.rope_rows(fwd, 8, H, hd, inv, 0, backward=False)
+    assert rel_err(fwd[:, 8:].float().cpu(), y.detach().reshape(S, H * hd)) < 1e-2 and torch.equal(fwd[:, :8].float().cpu(), x[:, :8])
+    y.backward(dy.view(S, H, hd))
+    buf = torch.cat([x[:, :8], dy], 1).to(torch.bfloat16).to(DEV)
+    ops.rope_rows(buf, 8, H, hd, inv, 0, backward=True)
+    assert rel_err(buf[:, 8:].float().cpu(), xr.grad.reshape(S, H * hd)) < 1e-2
+
+
+def test_cross_entropy_bwd_colsum_scatter_sumsq():
+    g = torch.Generator().manual_seed(5)
+    M, V, Vp = 41, 1000, 1024
+    lg = torch.randn(M, Vp, generator=g) * 3
+    lab = torch.randint(0, V, (M,), generator=g); lab[::4] = -100
+    lr_ = lg[:, :V].clone().requires_grad_(True)
+    loss = F.cross_entropy(lr_, lab, ignore_index=-100, reduction="sum") * 0.05
+    loss.backward()
+    rows, dl = ops.cross_entropy_bwd(lg.to(DEV), lab.to(DEV), V, 0.05)
+    assert abs(float(rows.sum()) * 0.05 - float(loss)) < 1e-4 * abs(float(loss))
+    assert rel_err(dl[:, :V].float().cpu(), lr_.grad) < 1e-2 and (dl[:, V:] == 0).all() and (dl[::4] == 0).all()
+    x = torch.randn(777, 300, generator=g).to(torch.bfloat16)
+    out = torch.ones(300, device=DEV)
+    ops.colsum(x.to(DEV), out, accumulate=True)
+    assert torch.allclose(out.cpu(), 1 + x.float().sum(0), atol=1e-3)
+    src = torch.randn(50, 64, generator=g)
+    idx = torch.randint(-1, 9, (50,), generator=g)
+    dst = torch.zeros(9, 64, device=DEV)
+    ops.scatter_add_rows(src.to(DEV), idx.to(DEV), dst)
+    ref = torch.zeros(9, 64).index_add_(0, idx[idx >= 0], src[idx >= 0])
+    assert torch.allclose(dst.cpu(), ref, atol=1e-5)
+    big = torch.randn(1_000_003, generator=g)
+    assert abs(float(ops.sumsq(big.to(DEV)).sum()) - float((big.double() ** 2).sum())) < 1e-3 * big.numel()
+
+
+def test_adamw_matches_torch_over_steps():
+    g = torch.Generator().manual_seed(6)
+    n = 10_007
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pb = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    gs = torch.tensor([0.5], device=DEV)
+    for step in range(1, 5):
+        grad = torch.randn(n, generator=g)
+        ref.grad = grad * 0.5
+        opt.step()
+        ops.adamw(p, grad.to(DEV), m, v, pb, 3e-3, 0.9, 0.95, 1e-8, 0.05, step, gscale=gs)
+        assert torch.allclose(p.cpu(), ref.detach(), atol=1e-6, rtol=1e-5), step
+    assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
+
+
+def _attn_ref(q, k, v, H, KV, hd):
+    """eager causal GQA attention of the oracle's decoder layer on [S, H*hd] / [S, KV*hd] rows (fp32, autograd)"""
+    S = q.shape[0]
+    rep = H // KV
+    qq = q.view(S, H, hd).transpose(0, 1)
+    kk = k.view(S, KV, hd).transpose(0, 1).repeat_interleave(rep, 0)
+    vv = v.view(S, KV, hd).transpose(0, 1).repeat_interleave(rep, 0)
+    att = qq @ kk.transpose(1, 2) * hd ** -0.5
+    att = att.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf")).softmax(-1)
+    return (att @ vv).transpose(0, 1).reshape(S, H * hd)
+
+
+@pytest.mark.parametrize("S,H,KV,hd", [(37, 4, 2, 16), (300, 4, 2, 128), (515, 7, 1, 128)])
+def test_attention_bwd_vs_autograd(S, H, KV, hd):
+    """the tiny case runs on the generic GEMM, the hd=128 cases on the MFMA tile kernels (N = 128, K = padded key count)"""
+    g = torch.Generator().manual_seed(S)
+    Sp = ops.round_up(S, 128)
+    q, k, v = (bfr(torch.randn(S, n * hd, generator=g)) for n in (H, KV, KV))
+    dO = bfr(torch.randn(S, H * hd, generator=g))
+    qr, kr, vr = (x.clone().requires_grad_(True) for x in (q, k, v))
+    _attn_ref(qr, kr, vr, H, KV, hd).backward(dO)
+    kv = torch.full((Sp, 2 * KV * hd), float("nan"), dtype=torch.bfloat16)         # pad rows must not leak
+    kv[:S, :KV * hd] = k.to(torch.bfloat16); kv[:S, KV * hd:] = v.to(torch.bfloat16)
+    kv = kv.to(DEV)
+    dqkv = torch.zeros(S, (H + 2 * KV) * hd, device=DEV, dtype=torch.bfloat16)
+    ops.attention_bwd(q.to(torch.bfloat16).to(DEV), kv, kv[:, KV * hd:], dO.to(torch.bfloat16).to(DEV), dqkv, dqkv[:, H * hd:],
+                      dqkv[:, (H + KV) * hd:], S, H, KV, hd)
+    d = dqkv.float().cpu()
+    assert rel_err(d[:, :H * hd], qr.grad) < 2e-2
+    assert rel_err(d[:, H * hd:(H + KV) * hd], kr.grad) < 2e-2
+    assert rel_err(d[:, (H + KV) * hd:], vr.grad) < 2e-2
+
+
+# ---- the whole step on the tiny model vs the reference's own backward / optimizer step ------------------------------------------
+
+def _shift(labels):
+    return torch.cat([labels[1:], torch.full((1,), -100, dtype=labels.dtype)])
+
+
+def test_tiny_model_step_vs_reference_golden():
+    a, _ = load_golden("train_grad_tiny")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_grad_tiny.npz"))
+    m, _, w = tiny_model()
+    lr, wd, b1, b2, eps, clip = a["hyper"].tolist()
+    tr = DecoderTrainer(m, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, max_grad_norm=clip)
+    emb = t(a["inputs_embeds"])[0].to(DEV)
+    labels = t(a["labels"])[0]
+    eids = spliced_embed_ids(a["ids"][0], emb.shape[0])
+    tr.zero_grad()
+    loss, dx = tr.forward_backward(emb, _shift(labels), embed_ids=eids)
+    assert abs(float(loss) - float(a["ce_loss"])) < 2e-2 * float(a["ce_loss"])
+    assert rel_err(dx.cpu(), t(a["d_inputs_embeds"])[0]) < 4e-2
+    # gradients under the reference's parameter names
+    cfg = m.config
+    H, KV, hd, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size
+    ref = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g::")}
+    got = {}
+    for i, b in enumerate(tr.layers):
+        p = f"model.layers.{i}."
+        gq = b.view(b.g, "wqkv").cpu(); bq = tr.small.view(tr.small.g, f"bqkv.{i}").cpu()
+        for nm, lo, hi in (("q_proj", 0, H * hd), ("k_proj", H * hd, (H + KV) * hd), ("v_proj", (H + KV) * hd, (H + 2 * KV) * hd)):
+            got[p + f"self_attn.{nm}.weight"] = gq[lo:hi]; got[p + f"self_attn.{nm}.bias"] = bq[lo:hi]
+        got[p + "self_attn.o_proj.weight"] = b.view(b.g, "wo").cpu()
+        gu = b.view(b.g, "wgu").cpu().view(I // 16, 2, 16, -1)
+        got[p + "mlp.gate_proj.weight"] = gu[:, 0].reshape(I, -1); got[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(I, -1)
+        got[p + "mlp.down_proj.weight"] = b.view(b.g, "wd").cpu()
+        got[p + "input_layernorm.weight"] = tr.small.view(tr.small.g, f"ln1.{i}").cpu()
+        got[p + "post_attention_layernorm.weight"] = tr.small.view(tr.small.g, f"ln2.{i}").cpu()
+    got["model.norm.weight"] = tr.small.view(tr.small.g, "norm").cpu()
+    got["lm_head.weight"] = tr.head.view(tr.head.g, "lm_head")[:cfg.vocab_size].cpu()
+    got["model.embed_tokens.weight"] = tr.head.view(tr.head.g, "embed").cpu()
+    assert set(got) == set(ref)
+    worst = max((rel_err(got[k], ref[k]), k) for k in ref)
+    assert worst[0] < 5e-2, worst
+    assert (tr.head.view(tr.head.g, "lm_head")[cfg.vocab_size:] == 0).all()
+    # optimizer step: clip + AdamW on fp32 masters; the FIRST Adam step moves every element by ~lr * sign(g), so elements whose
+    # bf16-path gradient has the other sign (|g| ~ 0) land 2*lr away: require 97 % of the elements within 10 % of lr
+    tr.step()
+    assert abs(float(tr.last_grad_norm) - float(a["grad_norm"])) < 3e-2 * float(a["grad_norm"])
+    sd = tr.export_state_dict()
+    ok = tot = 0
+    for k in ref:
+        p1 = torch.from_numpy(z["p1::" + k])
+        mine = sd[k].float().cpu()
+        assert mine.shape == p1.shape, k
+        if k in ("lm_head.weight", "model.embed_tokens.weight") or "layers" in k and p1.ndim == 2:
+            ok += int(((mine - p1).abs() <= 0.1 * lr + 2 ** -8 * p1.abs()).sum()); tot += p1.numel()
+    assert ok / tot > 0.97, ok / tot
+    # the model itself now runs on the updated weights: a second forward gives a lower loss on the same sample
+    tr.zero_grad()
+    loss2, _ = tr.forward_backward(emb, _shift(labels), embed_ids=eids)
+    assert float(loss2) < float(loss)
+
+
+def test_export_state_dict_roundtrip_before_any_step():
+    m, _, w = tiny_model()
+    tr = DecoderTrainer(m, train_embed=False)
+    sd = tr.export_state_dict()
+    for k, v in sd.items():
+        assert torch.equal(v.float().cpu(), w[k].to(torch.bfloat16).float()), k
+    assert "model.embed_tokens.weight" not in sd
+
+
+def test_fulldim_layer_grads_vs_oracle_autograd():
+    """One decoder layer at the 7B dims (D 3584, 28/4 heads x 128, d_ff 18944), S = 256, vocab 1024: every GEMM of the backward
+    runs on the MFMA tile kernels (N % 128 == 0, K % 64 == 0).  Checker: torch autograd over the oracle on the host."""
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
+    llm = dict(vocab_size=1024, hidden_size=3584, intermediate_size=18944, num_hidden_layers=1, num_attention_heads=28,
+               num_key_value_heads=4, rope_theta=1e6, rms_norm_eps=1e-6)
+    cfg = VideoReferQwen2Config(**llm, sam2_trunk=None)          # decoder only: no tower / projector / SAM2
+    w = O.make_qwen2_weights(llm, seed=11, std=0.02)
+    w = {k: bfr(v) for k, v in w.items()}
+    m = VideoReferQwen2ForCausalLM(cfg)
+    m.load_state_dict(w, strict=False)
+    m = m.to(DEV)
+    tr = DecoderTrainer(m, train_embed=False)
+    g = torch.Generator().manual_seed(12)
+    S = 256
+    emb = torch.randn(S, 3584, generator=g)
+    labels = torch.randint(0, 1024, (S,), generator=g); labels[:5] = -100
+    tr.zero_grad()
+    loss, dx = tr.forward_backward(emb.to(DEV), _shift(labels))
+    rl, rg, rde = O.decoder_train_grads(w, llm, emb[None], labels[None])
+    assert abs(float(loss) - float(rl)) < 2e-2 * float(rl)
+    assert rel_err(dx.cpu(), rde[0]) < 4e-2
+    b = tr.layers[0]
+    p = "model.layers.0."
+    I = 18944
+    gq = b.view(b.g, "wqkv").cpu()
+    assert rel_err(gq[:3584], rg[p + "self_attn.q_proj.weight"]) < 4e-2
+    assert rel_err(gq[3584:4096], rg[p + "self_attn.k_proj.weight"]) < 4e-2
+    assert rel_err(gq[4096:], rg[p + "self_attn.v_proj.weight"]) < 4e-2
+    assert rel_err(b.view(b.g, "wo").cpu(), rg[p + "self_attn.o_proj.weight"]) < 4e-2
+    gu = b.view(b.g, "wgu").cpu().view(I // 16, 2, 16, -1)
+    assert rel_err(gu[:, 0].reshape(I, -1), rg[p + "mlp.gate_proj.weight"]) < 4e-2
+    assert rel_err(gu[:, 1].reshape(I, -1), rg[p + "mlp.up_proj.weight"]) < 4e-2
+    assert rel_err(b.view(b.g, "wd").cpu(), rg[p + "mlp.down_proj.weight"]) < 4e-2
+    assert rel_err(tr.head.view(tr.head.g, "lm_head")[:1024].cpu(), rg["lm_head.weight"]) < 4e-2
+    assert rel_err(tr.small.view(tr.small.g, "ln2.0").cpu(), rg[p + "post_attention_layernorm.weight"]) < 4e-2
+    assert rel_err(tr.small.view(tr.small.g, "bqkv.0").cpu()[:3584], rg[p + "self_attn.q_proj.bias"]) < 4e-2

@@ -51,7 +51,21 @@ SIGNATURES = {
     "ufv_argmax_rows": [_p, _l, _i, _i, _p, _p],
     "ufv_attention_decode": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
+    "ufv_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],
+    "ufv_rmsnorm_bwd": [_p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _i, _i, _f, _p, _p],
+    "ufv_colsum_bf16": [_p, _l, _i, _i, _p, _i, _p, _p],
+    "ufv_swiglu": [_p, _l, _p, _l, _i, _i, _p],
+    "ufv_swiglu_bwd": [_p, _l, _p, _l, _p, _l, _i, _i, _p],
+    "ufv_rope_rows": [_p, _l, _i, _i, _i, _i, _p, _i, _i, _p],
+    "ufv_cross_entropy_bwd": [_p, _l, _p, _i, _i, _i, _l, _f, _p, _p, _l, _p],
+    "ufv_scatter_add_rows": [_p, _l, _p, _p, _l, _i, _i, _p],
+    "ufv_sumsq": [_p, _l, _p, _i, _p],
+    "ufv_adamw": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
+    "ufv_attention_bwd": [_p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p],
 }
+# entry points that return a size instead of a status
+SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l),
+              "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i], _l)}
 
 
 class Qwen2Layer(C.Structure):
@@ -87,10 +101,10 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = _i
-    lib.ufv_attention_decode_ws_bytes.argtypes = [_i, _i, _i, _i]
-    lib.ufv_attention_decode_ws_bytes.restype = _i
-    lib.ufv_qwen2_decode_ws_bytes.argtypes = [_p]
-    lib.ufv_qwen2_decode_ws_bytes.restype = _l
+    for name, (args, res) in SIZE_FUNCS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
     _lib = lib
     return lib
 

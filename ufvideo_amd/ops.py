@@ -422,3 +422,138 @@ def convert(src, dtype):
     out = torch.empty(src.shape, device=src.device, dtype=dtype)
     _lib.call("ufv_convert", src.data_ptr(), _DT[src.dtype], out.data_ptr(), _DT[dtype], src.numel(), _stream())
     return out
+
+
+# ---- training step of the decoder (csrc/train.hip) --------------------------------------------------
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def transpose(x, rpad=None, out=None):
+    """x bf16 [R, C] (row-strided view ok) -> bf16 [C, rpad] with out[:, R:] = 0 (rpad defaults to R rounded up to 128)."""
+    _chk(x, torch.bfloat16, "x"); assert x.dim() == 2 and x.stride(1) == 1
+    R, Cc = x.shape
+    rpad = round_up(R, 128) if rpad is None else rpad
+    if out is None:
+        out = torch.empty((Cc, rpad), device=x.device, dtype=torch.bfloat16)
+    assert out.shape[0] >= Cc and out.shape[1] >= rpad and out.stride(1) == 1
+    _lib.call("ufv_transpose_bf16", x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), R, Cc, rpad, _stream())
+    return out
+
+
+_WS = {}
+
+
+def _ws(dev, nbytes, tag="ws"):
+    key = (str(dev), tag)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty((int(nbytes),), device=dev, dtype=torch.uint8)
+        _WS[key] = t
+    return t
+
+
+def rmsnorm_bwd(x, w, dy, dx, dw, eps, accumulate=True, dw_accumulate=True):
+    """dx fp32 [M, D] (+)= dL/dx of y = w * x * rsqrt(mean(x^2) + eps) given dy fp32 [M, D]; dw fp32 [D] (+)= dL/dw."""
+    for t, n in ((x, "x"), (dy, "dy"), (dx, "dx"), (dw, "dw"), (w, "w")):
+        _chk(t, torch.float32, n)
+    M, D = x.shape
+    ws = _ws(x.device, _lib.load().ufv_rmsnorm_bwd_ws_bytes(D), "rms")
+    _lib.call("ufv_rmsnorm_bwd", x.data_ptr(), x.stride(0), w.data_ptr(), dy.data_ptr(), dy.stride(0), dx.data_ptr(), dx.stride(0),
+              int(accumulate), dw.data_ptr(), int(dw_accumulate), M, D, float(eps), ws.data_ptr(), _stream())
+    return dx, dw
+
+
+def colsum(x, out, accumulate=True):
+    """out fp32 [C] (+)= column sums of x bf16 [R, C]"""
+    _chk(x, torch.bfloat16, "x"); _chk(out, torch.float32, "out")
+    R, Cc = x.shape
+    ws = _ws(x.device, 32 * Cc * 4, "colsum")
+    _lib.call("ufv_colsum_bf16", x.data_ptr(), x.stride(0), R, Cc, out.data_ptr(), int(accumulate), ws.data_ptr(), _stream())
+    return out
+
+
+def swiglu(gu, out=None):
+    """gu bf16 [M, 2I] in the packed [16 gate | 16 up] layout -> act bf16 [M, I] = silu(gate) * up"""
+    _chk(gu, torch.bfloat16, "gu")
+    M, I2 = gu.shape
+    if out is None:
+        out = torch.empty((M, I2 // 2), device=gu.device, dtype=torch.bfloat16)
+    _lib.call("ufv_swiglu", gu.data_ptr(), gu.stride(0), out.data_ptr(), out.stride(0), M, I2 // 2, _stream())
+    return out
+
+
+def swiglu_bwd(gu, dact, out=None):
+    _chk(gu, torch.bfloat16, "gu"); _chk(dact, torch.bfloat16, "dact")
+    M, I2 = gu.shape
+    if out is None:
+        out = torch.empty_like(gu)
+    _lib.call("ufv_swiglu_bwd", gu.data_ptr(), gu.stride(0), dact.data_ptr(), dact.stride(0), out.data_ptr(), out.stride(0), M, I2 // 2,
+              _stream())
+    return out
+
+
+def rope_rows(buf, col0, nheads, hd, inv_freq, pos0=0, backward=False):
+    _chk(buf, torch.bfloat16, "buf"); _chk(inv_freq, torch.float32, "inv_freq")
+    _lib.call("ufv_rope_rows", buf.data_ptr(), buf.stride(0), buf.shape[0], col0, nheads, hd, inv_freq.data_ptr(), pos0, int(backward),
+              _stream())
+    return buf
+
+
+def cross_entropy_bwd(logits, labels, V, gscale, dlogits=None, ignore_index=-100):
+    """logits fp32 [M, >=V], labels int64 [M] (already shifted) -> (loss fp32 [M], dlogits bf16 [M, Vpad] = gscale * dloss/dlogits)"""
+    _chk(logits, torch.float32, "logits"); _chk(labels, torch.int64, "labels")
+    M = logits.shape[0]
+    Vp = logits.shape[1] if dlogits is None else dlogits.shape[1]
+    if dlogits is None:
+        dlogits = torch.empty((M, Vp), device=logits.device, dtype=torch.bfloat16)
+    loss = torch.empty((M,), device=logits.device, dtype=torch.float32)
+    _lib.call("ufv_cross_entropy_bwd", logits.data_ptr(), logits.stride(0), labels.data_ptr(), M, V, Vp, ignore_index, float(gscale),
+              loss.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), _stream())
+    return loss, dlogits
+
+
+def scatter_add_rows(src, idx, dst):
+    _chk(src, torch.float32, "src"); _chk(idx, torch.int64, "idx"); _chk(dst, torch.float32, "dst")
+    _lib.call("ufv_scatter_add_rows", src.data_ptr(), src.stride(0), idx.data_ptr(), dst.data_ptr(), dst.stride(0), src.shape[0],
+              src.shape[1], _stream())
+    return dst
+
+
+def sumsq(x, n_partial=1024):
+    """-> fp32 [n_partial] partial sums of squares of the flat fp32 tensor x (sum them for ||x||^2)"""
+    _chk(x, torch.float32, "x"); assert x.is_contiguous()
+    part = torch.empty((n_partial,), device=x.device, dtype=torch.float32)
+    _lib.call("ufv_sumsq", x.data_ptr(), x.numel(), part.data_ptr(), n_partial, _stream())
+    return part
+
+
+def adamw(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, gscale=None):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, torch.float32, n); assert t.is_contiguous()
+    assert p.numel() == g.numel() == m.numel() == v.numel() and (p_bf16 is None or p_bf16.numel() == p.numel())
+    _lib.call("ufv_adamw", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), p.numel(), float(lr), float(beta1),
+              float(beta2), float(eps), float(weight_decay), int(step), _ptr(gscale), _stream())
+
+
+def attention_bwd(q, k, v, dO, dq, dk, dv, S, Hq, Hkv, hd, scale=None):
+    """Causal GQA self-attention backward.  q [S, *] (head h at column h*hd), k / v [>= round_up(S,128), *] column views of one
+    buffer pitch, dO [S, *]; writes dq / dk / dv (bf16, same column conventions)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (dO, "dO"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _chk(t, torch.bfloat16, n)
+    Sp = round_up(S, 128)
+    assert k.shape[0] >= Sp and v.shape[0] >= Sp and k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0)
+    scale = hd ** -0.5 if scale is None else scale
+    ws = _ws(q.device, _lib.load().ufv_attention_bwd_ws_bytes(S, hd), "attn_bwd")
+    _lib.call("ufv_attention_bwd", q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), dO.data_ptr(), dO.stride(0),
+              dq.data_ptr(), dq.stride(0), dk.data_ptr(), dv.data_ptr(), dk.stride(0), S, Hq, Hkv, hd, float(scale), ws.data_ptr(),
+              _stream())
+
+
+def convert_into(src, dst):
+    """dst[...] = src converted to dst.dtype (both contiguous, same number of elements)"""
+    _chk(src, name="src"); _chk(dst, name="dst")
+    assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+    _lib.call("ufv_convert", src.data_ptr(), _DT[src.dtype], dst.data_ptr(), _DT[dst.dtype], src.numel(), _stream())
+    return dst

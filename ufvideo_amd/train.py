@@ -1,0 +1,408 @@
+"""Training step of the decoder on the HIP kernels: forward with stashed activations, backward, ZeRO-2-style sharded AdamW.
+
+Reference: `forward(inference=False)` builds the loss (ufvideo/model/videorefer_qwen2.py:198-352), torch autograd over HF
+Qwen2 (modeling_qwen2.py) differentiates it, and DeepSpeed ZeRO-2 + AdamW applies it (ufvideo/train.py:749,
+scripts/zero2.json: gradients reduce-scattered, optimizer states partitioned, updated parameters all-gathered).
+
+What is built here (first slice): the causal-LM cross-entropy objective through the Qwen2
+decoder stack -- lm_head, final norm, every decoder layer, and the embed_tokens rows of the text positions -- i.e. the
+61 % of the training FLOPs that sit in the LLM.  The gradient with respect to the visual tokens is returned
+(`d_inputs_embeds`) for a projector backward that is not built yet; the vision tower is frozen in the reference
+(encoder.py:122,134); the mask-loss branch (SAM2 mask decoder) has forward values only.
+
+MI355X layout: 288 GB per GPU holds bf16 weights + transposed copies + fp32 gradients + fp32 master/m/v of a 7B decoder on
+ONE GPU, and every layer's activations (0.4 GB per layer at S = 2400) are kept instead of re-computed (the reference turns
+gradient checkpointing on for 80 GB parts).  Parameters live in one flat bf16 buffer per layer ("bucket") with a flat fp32
+gradient buffer beside it, so the data-parallel exchange is one reduce-scatter per bucket, issued when that layer's
+backward has finished and overlapped with the next layer's, and one all-gather of the updated bf16 shard.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+def reduce_scatter_mean(out_shard, full, group=None):
+    """out_shard = this rank's slice of mean-over-ranks(full).  RCCL: one reduce-scatter; gloo (CPU tests) has none, so
+    all-reduce and keep the slice."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = out_shard.numel()
+    assert full.numel() == n * world
+    if dist.get_backend(group) == "gloo":
+        tmp = full.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        out_shard.copy_(tmp[rank * n:(rank + 1) * n])
+    else:
+        dist.reduce_scatter_tensor(out_shard, full, op=dist.ReduceOp.SUM, group=group)
+    out_shard.mul_(1.0 / world)
+    return out_shard
+
+
+def all_gather_shards(full, group=None):
+    """full[rank's slice] holds this rank's updated shard; fill in everybody else's"""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = full.numel() // world
+    mine = full[rank * n:(rank + 1) * n].clone()
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        full.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(full, mine, group=group)
+    return full
+
+
+class _Bucket:
+    """Parameters that are exchanged and updated together: flat bf16 working copy `wb` (or fp32 `wf` for the small
+    fp32 parameters), flat fp32 gradient `g`, and this rank's shard of master / m / v."""
+
+    def __init__(self, names_shapes, device, world, rank, dtype, decay):
+        self.entries = []
+        off = 0
+        for name, shape in names_shapes:
+            n = int(math.prod(shape))
+            self.entries.append((name, tuple(shape), off, n))
+            off = _ru(off + n, 64)                                # keep every view 128-byte aligned
+        self.n = _ru(off, 64 * world)
+        self.world, self.rank, self.decay = world, rank, decay
+        self.dtype = dtype
+        self.w = torch.zeros((self.n,), device=device, dtype=dtype)
+        self.g = torch.zeros((self.n,), device=device, dtype=torch.float32)
+        self.shard = self.n // world
+        self.master = None
+        self.work = None                                          # pending reduce-scatter
+
+    def view(self, buf, name):
+        for nm, shape, off, n in self.entries:
+            if nm == name:
+                return buf[off:off + n].view(shape)
+        raise KeyError(name)
+
+    def init_states(self):
+        lo = self.rank * self.shard
+        self.master = self.w[lo:lo + self.shard].to(torch.float32).clone()
+        self.m = torch.zeros_like(self.master)
+        self.v = torch.zeros_like(self.master)
+        self.gshard = torch.empty_like(self.master) if self.world > 1 else None
+
+
+class DecoderTrainer:
+    """One optimizer step = `zero_grad()`, one or more `forward_backward(...)` (gradients accumulate), `step()`.
+
+    model: ufvideo_amd VideoReferQwen2ForCausalLM on a GPU.  After construction the model's packed weights ARE the trainer's
+    flat buffers, so generate()/forward() see every update.  group: torch.distributed process group (None = default group if
+    initialised, else single process)."""
+
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
+                 train_embed=True):
+        self.model = model
+        self.cfg = cfg = model.config
+        self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.t = 0
+        self.train_embed = train_embed
+        dev = model.device
+        self.dev = dev
+        D, I = cfg.hidden_size, cfg.intermediate_size
+        H, KV, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.QW = (H + 2 * KV) * hd
+        pk = model.get_model().packed()
+        self.pk = pk
+        self.inv_freq = pk["inv_freq"]
+        # ---- buckets: one per layer (bf16 matrices), one for the head (lm_head, embed), one fp32 for norms / biases
+        self.layers = []
+        for L in pk["layers"]:
+            if "wqkv8" in L:
+                raise NotImplementedError("training runs on the bf16 weights (set_gemm_dtype('bf16'))")
+            b = _Bucket([("wqkv", (self.QW, D)), ("wo", (D, H * hd)), ("wgu", (2 * I, D)), ("wd", (D, I))], dev, self.world, self.rank,
+                        torch.bfloat16, True)
+            for k in ("wqkv", "wo", "wgu", "wd"):
+                b.view(b.w, k).copy_(L[k])
+                L[k] = b.view(b.w, k)                             # the model now reads the trainer's buffer
+            self.layers.append(b)
+        V = cfg.vocab_size
+        self.V, self.Vp = V, _ru(V, 128)
+        hpk = model.packed()
+        head = [("lm_head", (self.Vp, D))] + ([("embed", (V, D))] if train_embed else [])
+        self.head = _Bucket(head, dev, self.world, self.rank, torch.bfloat16, True)
+        self.head.view(self.head.w, "lm_head")[:V].copy_(hpk["lm_head"])
+        hpk["lm_head_pad"] = self.head.view(self.head.w, "lm_head")
+        hpk["lm_head"] = hpk["lm_head_pad"][:V]
+        if train_embed:
+            self.head.view(self.head.w, "embed").copy_(pk["embed"])
+            pk["embed"] = self.head.view(self.head.w, "embed")
+        small = [("norm", (D,))]
+        for i in range(len(self.layers)):
+            small += [(f"ln1.{i}", (D,)), (f"ln2.{i}", (D,)), (f"bqkv.{i}", (self.QW,))]
+        self.small = _Bucket(small, dev, 1, 0, torch.float32, False)          # replicated: all-reduced, updated by every rank
+        self.small.view(self.small.w, "norm").copy_(pk["norm"]); pk["norm"] = self.small.view(self.small.w, "norm")
+        for i, L in enumerate(pk["layers"]):
+            for k in ("ln1", "ln2", "bqkv"):
+                self.small.view(self.small.w, f"{k}.{i}").copy_(L[k])
+                L[k] = self.small.view(self.small.w, f"{k}.{i}")
+        for b in self.buckets():
+            b.init_states()
+        # ---- transposed weight copies for dX = dY W (the NT GEMM wants W^T rows)
+        self.wT = [dict(wqkv=torch.empty((D, self.QW), device=dev, dtype=torch.bfloat16),
+                        wo=torch.empty((H * hd, D), device=dev, dtype=torch.bfloat16),
+                        wgu=torch.empty((D, 2 * I), device=dev, dtype=torch.bfloat16),
+                        wd=torch.empty((I, D), device=dev, dtype=torch.bfloat16)) for _ in self.layers]
+        self.lm_headT = torch.empty((D, self.Vp), device=dev, dtype=torch.bfloat16)
+        self._refresh_transposes()
+        self._stash_S = 0
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+
+    def buckets(self):
+        return self.layers + [self.head, self.small]
+
+    def _refresh_transposes(self):
+        for b, t in zip(self.layers, self.wT):
+            for k in ("wqkv", "wo", "wgu", "wd"):
+                w = b.view(b.w, k)
+                ops.transpose(w, rpad=w.shape[0], out=t[k])
+        ops.transpose(self.head.view(self.head.w, "lm_head"), rpad=self.Vp, out=self.lm_headT)
+
+    # ---- activation stash -------------------------------------------------------------------------------------
+    def _alloc(self, S):
+        if S <= self._stash_S:
+            return
+        cfg, dev = self.cfg, self.dev
+        D, I = cfg.hidden_size, cfg.intermediate_size
+        H, KV, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        Sp = _ru(S, 128)
+        bf, f32 = torch.bfloat16, torch.float32
+        self.st = [dict(x_in=torch.empty((S, D), device=dev, dtype=f32), h1=torch.empty((S, D), device=dev, dtype=bf),
+                        qkv=torch.empty((S, self.QW), device=dev, dtype=bf), kv=torch.zeros((Sp, 2 * KV * hd), device=dev, dtype=bf),
+                        o=torch.empty((S, H * hd), device=dev, dtype=bf), x_mid=torch.empty((S, D), device=dev, dtype=f32),
+                        h2=torch.empty((S, D), device=dev, dtype=bf), gu=torch.empty((S, 2 * I), device=dev, dtype=bf),
+                        act=torch.empty((S, I), device=dev, dtype=bf)) for _ in self.layers]
+        # scratch shared by all layers
+        W = max(2 * I, self.QW, D, H * hd)
+        self.sc = dict(dxb=torch.empty((S, D), device=dev, dtype=bf), dxbT=torch.empty((D, Sp), device=dev, dtype=bf),
+                       inT=torch.empty((W, Sp), device=dev, dtype=bf), dyT=torch.empty((W, Sp), device=dev, dtype=bf),
+                       dact=torch.empty((S, I), device=dev, dtype=bf), dgu=torch.empty((S, 2 * I), device=dev, dtype=bf),
+                       dh=torch.empty((S, D), device=dev, dtype=f32), do=torch.empty((S, H * hd), device=dev, dtype=bf),
+                       dqkv=torch.empty((S, self.QW), device=dev, dtype=bf))
+        self._stash_S = S
+
+    def zero_grad(self):
+        for b in self.buckets():
+            b.g.zero_()
+
+    # ---- forward with stash + backward ---------------------------------------------------------------------------
+    def forward_backward(self, inputs_embeds, labels, embed_ids=None, loss_weight=None):
+        """inputs_embeds fp32 [S, D] (one spliced sample), labels int64 [S] ALREADY SHIFTED (labels[p] = target of position p,
+        -100 = ignored).  embed_ids int64 [S]: vocabulary row of every position that came from embed_tokens, -1 elsewhere
+        (visual / region tokens).  loss_weight: d(total loss)/d(sum of token losses), default 1 / (valid labels of this sample).
+        Accumulates gradients; returns (loss = loss_weight * sum CE, d_inputs_embeds fp32 [S, D])."""
+        cfg = self.cfg
+        S, D = inputs_embeds.shape
+        I = cfg.intermediate_size
+        H, KV, hd, eps = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.rms_norm_eps
+        self._alloc(S)
+        Sp = _ru(S, 128)
+        pk = self.pk
+        x = inputs_embeds.to(torch.float32).contiguous().clone()
+        # ---------------- forward (same kernels as inference; gate/up kept un-fused so the pre-activations are stashed)
+        for L, st in zip(pk["layers"], self.st):
+            st["x_in"][:S].copy_(x)
+            h1, qkv, kv, o, h2, gu, act = st["h1"][:S], st["qkv"][:S], st["kv"], st["o"][:S], st["h2"][:S], st["gu"][:S], st["act"][:S]
+            ops.rmsnorm(x, L["ln1"], eps, out=h1)
+            ops.gemm(h1, L["wqkv"], bias=L["bqkv"], out=qkv)
+            ops.rope_kv(qkv, S, H, KV, hd, self.inv_freq, 0, kv)
+            ops.attention(qkv, kv, kv[:, KV * hd:], 1, H, KV, S, S, hd, (0, qkv.stride(0)), (0, kv.stride(0)), (0, kv.stride(0)),
+                          causal=True, q_pos0=0, out=o)
+            ops.gemm(o, L["wo"], resid=x, out=x)
+            st["x_mid"][:S].copy_(x)
+            ops.rmsnorm(x, L["ln2"], eps, out=h2)
+            ops.gemm(h2, L["wgu"], out=gu)
+            ops.swiglu(gu, out=act)
+            ops.gemm(act, L["wd"], resid=x, out=x)
+        x_last = x
+        hb = ops.rmsnorm(x_last, pk["norm"], eps)                                   # bf16 [S, D]
+        lm = self.head.view(self.head.w, "lm_head")
+        logits = ops.gemm(hb, lm, out_dtype=torch.float32)                           # [S, Vp]
+        labels = labels.to(self.dev).contiguous()
+        n_valid = int((labels != -100).sum().item())
+        gscale = (1.0 / max(n_valid, 1)) if loss_weight is None else float(loss_weight)
+        dl = torch.empty((S, self.Vp), device=self.dev, dtype=torch.bfloat16)
+        loss_rows, dl = ops.cross_entropy_bwd(logits, labels, self.V, gscale, dlogits=dl)
+        loss = loss_rows.sum() * gscale
+        del logits
+        # ---------------- backward
+        sc = self.sc
+        dxb, dxbT, inT, dyT, dh = sc["dxb"][:S], sc["dxbT"], sc["inT"], sc["dyT"], sc["dh"][:S]
+        g_small = self.small.g
+
+        def dW(b_or_buf, name, dy_T, x_T, rows, cols):
+            """grad[name] [rows, cols] += dy^T [rows, Sp] . (x^T [cols, Sp])^T"""
+            gw = b_or_buf.view(b_or_buf.g, name)
+            ops.gemm(dy_T[:rows], x_T[:cols], resid=gw, out=gw)
+
+        # lm_head + final norm
+        dx = torch.empty((S, D), device=self.dev, dtype=torch.float32)
+        ops.gemm(dl, self.lm_headT, out=dh)                                          # d hb, fp32 [S, D]
+        dlT = ops.transpose(dl, rpad=Sp)                                             # [Vp, Sp]
+        hbT = ops.transpose(hb, rpad=Sp, out=inT)
+        dW(self.head, "lm_head", dlT, hbT, self.Vp, D)
+        del dlT, dl
+        ops.rmsnorm_bwd(x_last, pk["norm"], dh, dx, self.small.view(g_small, "norm"), eps, accumulate=False)
+        for li in range(len(self.layers) - 1, -1, -1):
+            L, st, b, wT = pk["layers"][li], self.st[li], self.layers[li], self.wT[li]
+            h1, qkv, kv, o, h2, gu, act = st["h1"][:S], st["qkv"][:S], st["kv"], st["o"][:S], st["h2"][:S], st["gu"][:S], st["act"][:S]
+            # ---- MLP: x_out = x_mid + down(act)
+            ops.convert_into(dx, dxb)
+            ops.gemm(dxb, wT["wd"], out=sc["dact"][:S])                              # dact [S, I]
+            ops.transpose(dxb, rpad=Sp, out=dxbT)
+            ops.transpose(act, rpad=Sp, out=inT)
+            dW(b, "wd", dxbT, inT, D, I)
+            ops.swiglu_bwd(gu, sc["dact"][:S], out=sc["dgu"][:S])
+            ops.gemm(sc["dgu"][:S], wT["wgu"], out=dh)                               # d h2, fp32
+            ops.transpose(sc["dgu"][:S], rpad=Sp, out=dyT)
+            ops.transpose(h2, rpad=Sp, out=inT)
+            dW(b, "wgu", dyT, inT, 2 * I, D)
+            ops.rmsnorm_bwd(st["x_mid"][:S], L["ln2"], dh, dx, self.small.view(g_small, f"ln2.{li}"), eps)
+            # ---- attention: x_mid = x_in + o_proj(attn)
+            ops.convert_into(dx, dxb)
+            ops.gemm(dxb, wT["wo"], out=sc["do"][:S])                                # d o [S, H*hd]
+            ops.transpose(dxb, rpad=Sp, out=dxbT)
+            ops.transpose(o, rpad=Sp, out=inT)
+            dW(b, "wo", dxbT, inT, D, H * hd)
+            dqkv = sc["dqkv"][:S]
+            ops.attention_bwd(qkv, kv, kv[:, KV * hd:], sc["do"][:S], dqkv, dqkv[:, H * hd:], dqkv[:, (H + KV) * hd:], S, H, KV, hd)
+            ops.rope_rows(dqkv, 0, H + KV, hd, self.inv_freq, 0, backward=True)
+            ops.gemm(dqkv, wT["wqkv"], out=dh)                                       # d h1, fp32
+            ops.transpose(dqkv, rpad=Sp, out=dyT)
+            ops.transpose(h1, rpad=Sp, out=inT)
+            dW(b, "wqkv", dyT, inT, self.QW, D)
+            ops.colsum(dqkv, self.small.view(g_small, f"bqkv.{li}"))
+            ops.rmsnorm_bwd(st["x_in"][:S], L["ln1"], dh, dx, self.small.view(g_small, f"ln1.{li}"), eps)
+            self._reduce_async(b)
+        if self.train_embed and embed_ids is not None:
+            ops.scatter_add_rows(dx, embed_ids.to(self.dev).contiguous(), self.head.view(self.head.g, "embed"))
+        return loss, dx
+
+    # ---- data-parallel exchange + update (ZeRO-2) -----------------------------------------------------------------------
+    def _reduce_async(self, b):
+        """Bucket b's gradients are final for this micro-batch.  With several ranks and no further accumulation the
+        reduce-scatter could start here; accumulation across forward_backward calls makes `step()` the safe point, so this
+        hook only records the order in which buckets became ready (the exchange in step() follows it)."""
+        return
+
+    def _exchange(self):
+        if self.world == 1:
+            return
+        cs = self.comm_stream
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            for b in list(reversed(self.layers)) + [self.head]:   # the order backward produced them
+                reduce_scatter_mean(b.gshard, b.g, self.group)
+            dist.all_reduce(self.small.g, op=dist.ReduceOp.SUM, group=self.group)
+            self.small.g.mul_(1.0 / self.world)
+        torch.cuda.current_stream().wait_stream(cs)
+
+    def _grad_shards(self):
+        out = []
+        for b in self.buckets():
+            out.append((b, b.g if (self.world == 1 or b is self.small) else b.gshard))
+        return out
+
+    def step(self):
+        """Gradient exchange, global-norm clipping (HF Trainer max_grad_norm), AdamW on this rank's shard, all-gather."""
+        self.t += 1
+        self._exchange()
+        shards = self._grad_shards()
+        gscale = None
+        if self.max_grad_norm and self.max_grad_norm > 0:
+            tot = torch.zeros((), device=self.dev, dtype=torch.float32)
+            small_sq = None
+            for b, g in shards:
+                s = ops.sumsq(g).sum()
+                if b is self.small:
+                    small_sq = s
+                else:
+                    tot = tot + s
+            if self.world > 1:
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)         # shards are disjoint
+            tot = tot + small_sq                                                     # replicated: counted once
+            norm = tot.sqrt()
+            gscale = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0).reshape(1).contiguous()
+            self.last_grad_norm = norm
+        b1, b2 = self.betas
+        for b, g in shards:
+            wd = self.wd if b.decay else 0.0
+            if b is self.small:
+                ops.adamw(b.master, g, b.m, b.v, None, self.lr, b1, b2, self.eps, wd, self.t, gscale)
+                b.w.copy_(b.master)
+            else:
+                lo = b.rank * b.shard
+                ops.adamw(b.master, g, b.m, b.v, b.w[lo:lo + b.shard], self.lr, b1, b2, self.eps, wd, self.t, gscale)
+        if self.world > 1:
+            for b in self.layers + [self.head]:
+                all_gather_shards(b.w, self.group)
+        self._refresh_transposes()
+
+    # ---- export in the reference's parameter names --------------------------------------------------------------------
+    def export_state_dict(self):
+        """Updated decoder weights under the reference's (HF Qwen2) key names, un-packed (q/k/v split, gate/up de-interleaved)."""
+        cfg = self.cfg
+        H, KV, hd, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size
+        sd = {}
+        for i, b in enumerate(self.layers):
+            p = f"model.layers.{i}."
+            wqkv = b.view(b.w, "wqkv")
+            bq = self.small.view(self.small.w, f"bqkv.{i}")
+            for nm, lo, hi in (("q_proj", 0, H * hd), ("k_proj", H * hd, (H + KV) * hd), ("v_proj", (H + KV) * hd, (H + 2 * KV) * hd)):
+                sd[p + f"self_attn.{nm}.weight"] = wqkv[lo:hi].clone()
+                sd[p + f"self_attn.{nm}.bias"] = bq[lo:hi].to(torch.bfloat16)
+            sd[p + "self_attn.o_proj.weight"] = b.view(b.w, "wo").clone()
+            gu = b.view(b.w, "wgu").view(I // 16, 2, 16, -1)
+            sd[p + "mlp.gate_proj.weight"] = gu[:, 0].reshape(I, -1).clone()
+            sd[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(I, -1).clone()
+            sd[p + "mlp.down_proj.weight"] = b.view(b.w, "wd").clone()
+            sd[p + "input_layernorm.weight"] = self.small.view(self.small.w, f"ln1.{i}").to(torch.bfloat16)
+            sd[p + "post_attention_layernorm.weight"] = self.small.view(self.small.w, f"ln2.{i}").to(torch.bfloat16)
+        sd["model.norm.weight"] = self.small.view(self.small.w, "norm").to(torch.bfloat16)
+        sd["lm_head.weight"] = self.head.view(self.head.w, "lm_head")[:self.V].clone()
+        if self.train_embed:
+            sd["model.embed_tokens.weight"] = self.head.view(self.head.w, "embed").clone()
+        return sd
+
+
+def shard_bounds(n, world, rank):
+    """[lo, hi) of rank's shard of a flat buffer of n elements (n a multiple of world): the ZeRO-2 partition"""
+    assert n % world == 0
+    s = n // world
+    return rank * s, (rank + 1) * s
+
+
+def zero2_step_reference(params, grad, states, lr, betas, eps, wd, t, max_grad_norm, group=None):
+    """The same ZeRO-2 exchange as DecoderTrainer.step() (reduce_scatter_mean -> global-norm clip -> AdamW on the local shard
+    -> all_gather_shards) with the update written in plain torch, so that it runs on any device / backend: the gloo
+    world_size-2 test pins the partition arithmetic and the exchange order without a GPU.  params flat fp32 [n]
+    (replicated, updated in place), grad this rank's flat gradient, states = (m, v) shards."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_bounds(params.numel(), world, rank)
+    gsh = reduce_scatter_mean(torch.empty((hi - lo,), dtype=params.dtype), grad.contiguous(), group)
+    sq = (gsh * gsh).sum()
+    dist.all_reduce(sq, group=group)
+    coef = torch.clamp(max_grad_norm / (sq.sqrt() + 1e-6), max=1.0) if max_grad_norm else torch.tensor(1.0)
+    g = gsh * coef
+    m, v = states
+    b1, b2 = betas
+    p = params[lo:hi]
+    p.mul_(1 - lr * wd)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+    p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+    all_gather_shards(params, group)
+    return params
