@@ -275,8 +275,11 @@ int ufv_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_
               float weight_decay, int step, const float* gscale, void* stream);
 /* causal GQA self-attention backward (eager Qwen2 attention, modeling_qwen2.py:150-172, differentiated): q bf16 [S, ldq]
  * (head h at column h*hd, RoPE applied), k / v bf16 [>= round_up(S,128) rows, ldkv] (kv-head g at column g*hd), dO bf16 [S, lddo]
- * -> dq [S, lddq], dk / dv [S, lddkv] bf16.  ws = ufv_attention_bwd_ws_bytes(S, hd). */
-int64_t ufv_attention_bwd_ws_bytes(int S, int hd);
+ * -> dq [S, lddq], dk / dv [S, lddkv] bf16.  ws = ufv_attention_bwd_ws_bytes(S, Hq, Hkv, hd). */
+int64_t ufv_attention_bwd_ws_bytes(int S, int Hq, int Hkv, int hd);
+/* C[M,N] fp32 (initialised by the caller) += A[M,K] * W[N,K]^T, K split over nsplit blocks per output tile with fp32 atomic
+ * accumulation (thin outputs over a long K: dV = P^T dO, dK = dS^T Q) */
+int ufv_gemm_splitk_acc(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, int nsplit, void* stream);
 int ufv_attention_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* dO, int64_t lddo, void* dq,
                       int64_t lddq, void* dk, void* dv, int64_t lddkv, int S, int Hq, int Hkv, int hd, float scale, void* ws, void* stream);
 

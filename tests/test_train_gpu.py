@@ -270,3 +270,15 @@ def test_fulldim_layer_grads_vs_oracle_autograd():
     assert rel_err(tr.head.view(tr.head.g, "lm_head")[:1024].cpu(), rg["lm_head.weight"]) < 4e-2
     assert rel_err(tr.small.view(tr.small.g, "ln2.0").cpu(), rg[p + "post_attention_layernorm.weight"]) < 4e-2
     assert rel_err(tr.small.view(tr.small.g, "bqkv.0").cpu()[:3584], rg[p + "self_attn.q_proj.bias"]) < 4e-2
+
+
+@pytest.mark.parametrize("M,N,K,ns", [(2399, 128, 16896, 16), (300, 256, 1024, 4), (37, 16, 72, 4)])
+def test_gemm_splitk_acc_vs_torch(M, N, K, ns):
+    """C += A W^T with K split over blocks (fp32 atomics); the last case falls back to the residual-input kernels"""
+    g = torch.Generator().manual_seed(M + K)
+    a, w = bfr(torch.randn(M, K, generator=g)), bfr(torch.randn(N, K, generator=g))
+    c0 = torch.randn(M, N, generator=g)
+    out = c0.clone().to(DEV)
+    ops.gemm_splitk_acc(a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), out, ns)
+    ref = c0.double() + a.double() @ w.double().t()
+    assert rel_err(out.cpu().double(), ref) < 1e-5

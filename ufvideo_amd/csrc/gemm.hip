@@ -125,13 +125,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const void* __restrict__ A
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int a_off = (wm * (BM / 2) + frow) * 128, b_off = BM * BK * 2 + (wn * 64 + frow) * 128;
 
-    const int nk = K * ES / 128;
-    stage(0, 0);
+    int nk = K * ES / 128, t0 = 0;
+    // split-K (only the fp32-output 192-row instantiation carries it; training's thin "reduce over tokens" products):
+    // blockIdx.y takes K-tiles [t0, nk) of its slice and ADDS its partial tile to C with fp32 atomics.
+    constexpr bool CAN_SPLIT = OUT_F32 && !SWIGLU && MT == 6 && !FP8;
+    if constexpr (CAN_SPLIT) {
+        if (e.ksplit > 1) {
+            const int per = (nk + e.ksplit - 1) / e.ksplit;
+            t0 = blockIdx.y * per;
+            nk = min(nk, t0 + per);
+            if (t0 >= nk) return;
+        }
+    }
+    stage(0, t0 * 128);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * 128);
-        const char* sb = smem + (t & 1) * STAGE_BYTES;
+    for (int t = t0; t < nk; ++t) {
+        if (t + 1 < nk) stage((t + 1 - t0) & 1, (t + 1) * 128);
+        const char* sb = smem + ((t - t0) & 1) * STAGE_BYTES;
         if constexpr (FP8) {
             // lane (row r, k-group g) feeds bytes 32g..32g+31 of its row = 16-byte chunks 2g and 2g+1
             const int c0 = ((2 * fq) ^ fx) << 4, c1 = ((2 * fq + 1) ^ fx) << 4;
@@ -185,6 +196,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const void* __restrict__ A
         }
     }
 
+    if constexpr (CAN_SPLIT) {
+        if (e.ksplit > 1) {
+            float* C = reinterpret_cast<float*>(e.out);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m0 + wm * (16 * MT) + mt * 16 + frow;
+                if (m < M) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            unsafeAtomicAdd(C + (size_t)m * e.ldc + n0 + wn * 64 + nt * 16 + fq * 4 + j, acc[nt][mt][j]);
+                }
+            }
+            return;
+        }
+    }
     // ---- epilogue (activation resolved once so the body stays unrolled)
     UFV_ACT_SWITCH(e.act, (epilogue128<OUT_F32, SWIGLU, MT, ACT_>(acc, e, M, m0, n0, wm, wn, frow, fq)))
 }
@@ -609,7 +637,7 @@ int gemm_entry(const void* A, int lda, const float* a_scale, const void* W, int 
                void* stream) {
     Epi e;
     e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = resid_rows;
-    e.scale_m = a_scale; e.scale_n = w_scale; e.dump_f32 = 0;
+    e.scale_m = a_scale; e.scale_n = w_scale; e.dump_f32 = 0; e.ksplit = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (out_f32)
         return swiglu ? launch_any<true, true, Q>(A, W, e, M, N, K, lda, ldw, kernel, st)
@@ -627,6 +655,33 @@ extern "C" int ufv_gemm(const void* A, int lda, const void* W, int ldw, void* C,
     UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemm: swiglu epilogue takes no bias/activation");
     return gemm_entry<false>(A, lda, nullptr, W, ldw, nullptr, C, ldc, out_f32, M, N, K, bias, act, resid, ldr, resid_rows, swiglu, kernel,
                              stream);
+}
+
+// C[M,N] (fp32, already initialised) += A[M,K] * W[N,K]^T with the K range split over `nsplit` blocks per output tile and
+// fp32 atomic accumulation: for products whose output is small and whose K is long (attention backward's dV = P^T dO,
+// dK = dS^T Q: 2399 x 128 outputs over K = 7 x 2399), where whole-K tiles would occupy 13 of the 256 CUs.
+extern "C" int ufv_gemm_splitk_acc(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, int nsplit,
+                                   void* stream) {
+    UFV_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && nsplit >= 1, "ufv_gemm_splitk_acc: bad arguments (M=%d N=%d K=%d)", M, N, K);
+    const bool ok = ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && (lda % 8 == 0) && (ldw % 8 == 0) && (N % BN == 0) && (K % BK == 0) &&
+                    ((uintptr_t)C % 16 == 0) && (ldc % 4 == 0);
+    Epi e;
+    e.bias = nullptr; e.resid = C; e.out = C; e.ldr = ldc; e.ldc = ldc; e.act = ACT_NONE; e.resid_rows = 0;
+    e.scale_m = nullptr; e.scale_n = nullptr; e.dump_f32 = 0; e.ksplit = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!ok || nsplit == 1)                 // small / unaligned shapes: the ordinary kernels with the fp32 residual input
+        return launch_any<true, false, false>(A, W, e, M, N, K, lda, ldw, UFV_GEMM_AUTO, st);
+    e.resid = nullptr; e.ksplit = nsplit;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<true, false, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  Tile<6>::SMEM_BYTES);
+        attr_set = true;
+    }
+    const int tiles = cdiv(M, Tile<6>::BM) * (N / BN);
+    hipLaunchKernelGGL((gemm_nt_128<true, false, 6, false>), dim3(tiles, nsplit), dim3(256), Tile<6>::SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
 }
 
 extern "C" int ufv_gemm_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, void* C, int ldc,
@@ -648,7 +703,7 @@ extern "C" int ufv_gemv1(const void* a, const float* x, const float* ln_w, float
     UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemv1: swiglu epilogue takes no bias/activation");
     Epi e;
     e.bias = bias; e.resid = resid; e.out = C; e.ldr = 0; e.ldc = 0; e.act = act; e.resid_rows = 0; e.scale_m = nullptr; e.scale_n = nullptr;
-    e.dump_f32 = 0;
+    e.dump_f32 = 0; e.ksplit = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int n_out = swiglu ? N / 2 : N;
     dim3 grid(cdiv(n_out, 16)), blk(256);

@@ -11,6 +11,7 @@ struct Epi {
     const float* scale_m;  // fp8 operands only: per-row scale of A [M] and per-row scale of W [N]; acc *= scale_m[m] * scale_n[n]
     const float* scale_n;
     int dump_f32;          // stream-K only: store the raw accumulators as fp32 whatever the output type (partial tile dump)
+    int ksplit;            // > 1: split-K launch (gridDim.y = ksplit), partial tiles are added to the fp32 output atomically
 };
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;

@@ -193,17 +193,17 @@ __global__ __launch_bounds__(256) void rope_rows_k(bf16* buf, int64_t ld, int S,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Attention backward, softmax part, one block per query row i (causal: keys j <= q_pos0 + i, j < Sk):
+// Attention backward, softmax part, one block per stacked query row i (causal: keys j <= i / rep, j < Sk):
 //   p_j = softmax_j(scale * sc_ij);  delta = sum_j p_j dp_ij;  ds_ij = scale * p_j * (dp_ij - delta)
 // writes P (bf16, the operand of dV = P^T dO) and dS (bf16, the operand of dQ = dS K and dK = dS^T Q); every column up to
 // ldp (the padded key count) is written, masked ones as exact zeros.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_softmax_bwd_k(const float* __restrict__ sc, const float* __restrict__ dp, int64_t ld,
                                                           bf16* __restrict__ P, bf16* __restrict__ dS, int64_t ldp, int Sk, int Skpad,
-                                                          float scale, int causal, int q_pos0) {
+                                                          float scale, int rep) {
     __shared__ float red[16];
     const int i = blockIdx.x, tid = threadIdx.x;
-    const int nvalid = causal ? min(Sk, q_pos0 + i + 1) : Sk;
+    const int nvalid = min(Sk, i / rep + 1);                      // row i = query position i / rep (rep stacked heads per position)
     const float* s = sc + (int64_t)i * ld;
     const float* d = dp + (int64_t)i * ld;
     float mx = -INFINITY;
@@ -421,24 +421,49 @@ extern "C" int ufv_adamw(float* p, const float* g, float* m, float* v, void* p_b
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Causal self-attention backward (GQA), materialised per head on the MFMA GEMMs (HF Qwen2Attention eager math,
-// modeling_qwen2.py:150-172, differentiated):  for q-head h of kv-group g
-//   sc = q_h k_g^T, dp = do_h v_g^T                         (fp32 [S, Sp])
-//   P, dS = softmax backward (attn_softmax_bwd_k)           (bf16 [S, Sp])
-//   dq_h = dS k_g;  dv_g += P^T do_h;  dk_g += dS^T q_h     (the group sums accumulate in fp32 through the GEMM's residual input)
-// Sp = S rounded up to 128 (the fast GEMMs' N / K granularity); q/k/v/do must have at least Sp readable rows.
+// Causal self-attention backward (GQA), materialised on the MFMA GEMMs (HF Qwen2Attention eager math,
+// modeling_qwen2.py:150-172, differentiated).  The `rep` = Hq/Hkv query heads of kv-group g are processed TOGETHER:
+// their rows are gathered into Qg / dOg [S*rep, hd] (row s*rep + j = token s of head g*rep + j), so that
+//   sc = Qg k_g^T, dp = dOg v_g^T                            (fp32 [S*rep, Sp], one GEMM each)
+//   P, dS = softmax backward, query position = row / rep     (bf16 [S*rep, Sp])
+//   dQg = dS k_g                                             (one GEMM, scattered back to the head columns)
+//   dv_g = P^T dOg,  dk_g = dS^T Qg                          (K = S*rep: split-K GEMMs with fp32 atomic accumulation)
+// Sp = S rounded up to 128 (the fast GEMMs' N / K granularity); k / v must have at least Sp readable rows.
 // ---------------------------------------------------------------------------------------------------------
 static inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-extern "C" int64_t ufv_attention_bwd_ws_bytes(int S, int hd) {
-    const int64_t Sp = rup(S, 128), hp = rup(hd, 8);
+namespace {
+// dst[r][c] = src[(r / rep)][ (r % rep) * C + c ]  (gather = 1: head columns -> stacked rows) or the inverse scatter
+__global__ __launch_bounds__(256) void head_rows_k(const bf16* __restrict__ src, int64_t lds, bf16* __restrict__ dst, int64_t ldd, int S,
+                                                   int rep, int C, int gather) {
+    const int cpr = C >> 3;
+    const int64_t total = (int64_t)S * rep * cpr;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int ch = id % cpr;
+        const int64_t r = id / cpr;
+        const int s = r / rep, j = r % rep;
+        if (gather)
+            *reinterpret_cast<bf16x8*>(dst + r * ldd + ch * 8) = *reinterpret_cast<const bf16x8*>(src + (int64_t)s * lds + j * C + ch * 8);
+        else
+            *reinterpret_cast<bf16x8*>(dst + (int64_t)s * ldd + j * C + ch * 8) = *reinterpret_cast<const bf16x8*>(src + r * lds + ch * 8);
+    }
+}
+}  // namespace
+
+extern "C" int ufv_gemm_splitk_acc(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, int nsplit,
+                                   void* stream);
+
+extern "C" int64_t ufv_attention_bwd_ws_bytes(int S, int Hq, int Hkv, int hd) {
+    const int64_t rep = Hq / (Hkv > 0 ? Hkv : 1), M = (int64_t)S * rep, Sp = rup(S, 128), Mp = rup(M, 128);
     int64_t b = 0;
-    b += 2 * (int64_t)S * Sp * 4;        // sc, dp
-    b += 2 * (int64_t)S * Sp * 2;        // P, dS
-    b += 2 * Sp * Sp * 2;                // P^T, dS^T
-    b += 4 * hp * Sp * 2;                // k^T, q^T, do^T (+1 spare)
-    b += 2 * Sp * hp * 4;                // dk, dv accumulators
-    return b + 4096;
+    b += 2 * M * Sp * 4;                 // sc, dp
+    b += 2 * M * Sp * 2;                 // P, dS
+    b += 2 * Sp * Mp * 2;                // P^T, dS^T
+    b += (int64_t)hd * Sp * 2;           // k^T
+    b += 3 * M * hd * 2;                 // Qg, dOg, dQg
+    b += 2 * (int64_t)hd * Mp * 2;       // Qg^T, dOg^T
+    b += 2 * Sp * hd * 4;                // dk, dv accumulators
+    return b + 16 * 256 + 4096;
 }
 
 extern "C" int ufv_attention_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* dO, int64_t lddo,
@@ -446,49 +471,58 @@ extern "C" int ufv_attention_bwd(const void* q, int64_t ldq, const void* k, cons
                                  void* ws, void* stream) {
     UFV_REQUIRE(q && k && v && dO && dq && dk && dv && ws && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && hd > 0 && hd % 8 == 0,
                 "ufv_attention_bwd: bad arguments (S=%d Hq=%d Hkv=%d hd=%d)", S, Hq, Hkv, hd);
+    const int rep = Hq / Hkv;
     const int Sp = (int)rup(S, 128);
+    const int64_t M64 = (int64_t)S * rep;
+    UFV_REQUIRE(M64 < (1 << 30), "ufv_attention_bwd: S * heads-per-group too large");
+    const int M = (int)M64, Mp = (int)rup(M, 128);
     char* w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     auto take = [&](int64_t bytes) { char* p = w; w += rup(bytes, 256); return p; };
-    float* sc = (float*)take((int64_t)S * Sp * 4);
-    float* dp = (float*)take((int64_t)S * Sp * 4);
-    bf16* P = (bf16*)take((int64_t)S * Sp * 2);
-    bf16* dS = (bf16*)take((int64_t)S * Sp * 2);
-    bf16* PT = (bf16*)take((int64_t)Sp * Sp * 2);
-    bf16* dST = (bf16*)take((int64_t)Sp * Sp * 2);
+    float* sc = (float*)take((int64_t)M * Sp * 4);
+    float* dp = (float*)take((int64_t)M * Sp * 4);
+    bf16* P = (bf16*)take((int64_t)M * Sp * 2);
+    bf16* dS = (bf16*)take((int64_t)M * Sp * 2);
+    bf16* PT = (bf16*)take((int64_t)Sp * Mp * 2);
+    bf16* dST = (bf16*)take((int64_t)Sp * Mp * 2);
     bf16* kT = (bf16*)take((int64_t)hd * Sp * 2);
-    bf16* qT = (bf16*)take((int64_t)hd * Sp * 2);
-    bf16* doT = (bf16*)take((int64_t)hd * Sp * 2);
+    bf16* Qg = (bf16*)take((int64_t)M * hd * 2);
+    bf16* dOg = (bf16*)take((int64_t)M * hd * 2);
+    bf16* dQg = (bf16*)take((int64_t)M * hd * 2);
+    bf16* QgT = (bf16*)take((int64_t)hd * Mp * 2);
+    bf16* dOgT = (bf16*)take((int64_t)hd * Mp * 2);
     float* dka = (float*)take((int64_t)Sp * hd * 4);
     float* dva = (float*)take((int64_t)Sp * hd * 4);
     const bf16* qb = (const bf16*)q; const bf16* kb = (const bf16*)k; const bf16* vb = (const bf16*)v; const bf16* dob = (const bf16*)dO;
-    const int rep = Hq / Hkv;
+    // K of the two split products = M: give every output tile ~16 K-tiles' worth of work per block
+    const int nsplit = Mp / 64 >= 64 ? 16 : (Mp / 64 >= 16 ? 4 : 1);
+    hipStream_t st = ST(stream);
     int rc;
 #define TRY(call) do { rc = (call); if (rc != UFV_OK) return rc; } while (0)
     for (int g = 0; g < Hkv; ++g) {
         const bf16* kg = kb + (int64_t)g * hd;
         const bf16* vg = vb + (int64_t)g * hd;
-        TRY(ufv_transpose_bf16(kg, ldkv, kT, Sp, S, hd, Sp, stream));
-        for (int r = 0; r < rep; ++r) {
-            const int h = g * rep + r;
-            const bf16* qh = qb + (int64_t)h * hd;
-            const bf16* doh = dob + (int64_t)h * hd;
-            TRY(ufv_gemm(qh, (int)ldq, kg, (int)ldkv, sc, Sp, 1, S, Sp, hd, nullptr, 0, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
-            TRY(ufv_gemm(doh, (int)lddo, vg, (int)ldkv, dp, Sp, 1, S, Sp, hd, nullptr, 0, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
-            hipLaunchKernelGGL(attn_softmax_bwd_k, dim3(S), dim3(256), 0, ST(stream), sc, dp, (int64_t)Sp, P, dS, (int64_t)Sp, S, Sp, scale, 1, 0);
-            UFV_CHECK_LAUNCH();
-            TRY(ufv_gemm(dS, Sp, kT, Sp, (bf16*)dq + (int64_t)h * hd, (int)lddq, 0, S, hd, Sp, nullptr, 0, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
-            TRY(ufv_transpose_bf16(P, Sp, PT, Sp, S, S, Sp, stream));
-            TRY(ufv_transpose_bf16(dS, Sp, dST, Sp, S, S, Sp, stream));
-            TRY(ufv_transpose_bf16(qh, ldq, qT, Sp, S, hd, Sp, stream));
-            TRY(ufv_transpose_bf16(doh, lddo, doT, Sp, S, hd, Sp, stream));
-            const float* rk = r ? dka : nullptr;
-            const float* rv = r ? dva : nullptr;
-            TRY(ufv_gemm(PT, Sp, doT, Sp, dva, hd, 1, S, hd, Sp, nullptr, 0, rv, hd, 0, 0, UFV_GEMM_AUTO, stream));
-            TRY(ufv_gemm(dST, Sp, qT, Sp, dka, hd, 1, S, hd, Sp, nullptr, 0, rk, hd, 0, 0, UFV_GEMM_AUTO, stream));
-        }
-        hipLaunchKernelGGL(cvt_rows_k, dim3(grid_for((int64_t)S * hd)), dim3(256), 0, ST(stream), dka, (int64_t)hd, (bf16*)dk + (int64_t)g * hd, lddkv, S, hd);
+        hipLaunchKernelGGL(head_rows_k, dim3(grid_for((int64_t)M * hd / 8)), dim3(256), 0, st, qb + (int64_t)g * rep * hd, ldq, Qg, (int64_t)hd, S, rep, hd, 1);
         UFV_CHECK_LAUNCH();
-        hipLaunchKernelGGL(cvt_rows_k, dim3(grid_for((int64_t)S * hd)), dim3(256), 0, ST(stream), dva, (int64_t)hd, (bf16*)dv + (int64_t)g * hd, lddkv, S, hd);
+        hipLaunchKernelGGL(head_rows_k, dim3(grid_for((int64_t)M * hd / 8)), dim3(256), 0, st, dob + (int64_t)g * rep * hd, lddo, dOg, (int64_t)hd, S, rep, hd, 1);
+        UFV_CHECK_LAUNCH();
+        TRY(ufv_transpose_bf16(kg, ldkv, kT, Sp, S, hd, Sp, stream));
+        TRY(ufv_gemm(Qg, hd, kg, (int)ldkv, sc, Sp, 1, M, Sp, hd, nullptr, 0, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+        TRY(ufv_gemm(dOg, hd, vg, (int)ldkv, dp, Sp, 1, M, Sp, hd, nullptr, 0, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+        hipLaunchKernelGGL(attn_softmax_bwd_k, dim3(M), dim3(256), 0, st, sc, dp, (int64_t)Sp, P, dS, (int64_t)Sp, S, Sp, scale, rep);
+        UFV_CHECK_LAUNCH();
+        TRY(ufv_gemm(dS, Sp, kT, Sp, dQg, hd, 0, M, hd, Sp, nullptr, 0, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+        hipLaunchKernelGGL(head_rows_k, dim3(grid_for((int64_t)M * hd / 8)), dim3(256), 0, st, dQg, (int64_t)hd, (bf16*)dq + (int64_t)g * rep * hd, lddq, S, rep, hd, 0);
+        UFV_CHECK_LAUNCH();
+        TRY(ufv_transpose_bf16(P, Sp, PT, Mp, M, S, Mp, stream));
+        TRY(ufv_transpose_bf16(dS, Sp, dST, Mp, M, S, Mp, stream));
+        TRY(ufv_transpose_bf16(Qg, hd, QgT, Mp, M, hd, Mp, stream));
+        TRY(ufv_transpose_bf16(dOg, hd, dOgT, Mp, M, hd, Mp, stream));
+        if (hipMemsetAsync(dka, 0, (size_t)Sp * hd * 4 * 2, st) != hipSuccess) { ufv_set_error("ufv_attention_bwd: memset failed"); return UFV_EHIP; }
+        TRY(ufv_gemm_splitk_acc(PT, Mp, dOgT, Mp, dva, hd, S, hd, Mp, nsplit, stream));
+        TRY(ufv_gemm_splitk_acc(dST, Mp, QgT, Mp, dka, hd, S, hd, Mp, nsplit, stream));
+        hipLaunchKernelGGL(cvt_rows_k, dim3(grid_for((int64_t)S * hd)), dim3(256), 0, st, dka, (int64_t)hd, (bf16*)dk + (int64_t)g * hd, lddkv, S, hd);
+        UFV_CHECK_LAUNCH();
+        hipLaunchKernelGGL(cvt_rows_k, dim3(grid_for((int64_t)S * hd)), dim3(256), 0, st, dva, (int64_t)hd, (bf16*)dv + (int64_t)g * hd, lddkv, S, hd);
         UFV_CHECK_LAUNCH();
     }
 #undef TRY

@@ -545,7 +545,7 @@ def attention_bwd(q, k, v, dO, dq, dk, dv, S, Hq, Hkv, hd, scale=None):
     Sp = round_up(S, 128)
     assert k.shape[0] >= Sp and v.shape[0] >= Sp and k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0)
     scale = hd ** -0.5 if scale is None else scale
-    ws = _ws(q.device, _lib.load().ufv_attention_bwd_ws_bytes(S, hd), "attn_bwd")
+    ws = _ws(q.device, _lib.load().ufv_attention_bwd_ws_bytes(S, Hq, Hkv, hd), "attn_bwd")
     _lib.call("ufv_attention_bwd", q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), dO.data_ptr(), dO.stride(0),
               dq.data_ptr(), dq.stride(0), dk.data_ptr(), dv.data_ptr(), dk.stride(0), S, Hq, Hkv, hd, float(scale), ws.data_ptr(),
               _stream())
@@ -557,3 +557,14 @@ def convert_into(src, dst):
     assert src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
     _lib.call("ufv_convert", src.data_ptr(), _DT[src.dtype], dst.data_ptr(), _DT[dst.dtype], src.numel(), _stream())
     return dst
+
+
+def gemm_splitk_acc(a, w, out, nsplit):
+    """out fp32 [M, N] += a [M, K] @ w [N, K]^T with the K range split over `nsplit` blocks per tile (fp32 atomics)"""
+    _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w"); _chk(out, torch.float32, "out")
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and out.shape == (M, N) and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    _lib.call("ufv_gemm_splitk_acc", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+              nsplit, _stream())
+    return out
