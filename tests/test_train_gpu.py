@@ -282,3 +282,28 @@ def test_gemm_splitk_acc_vs_torch(M, N, K, ns):
     ops.gemm_splitk_acc(a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), out, ns)
     ref = c0.double() + a.double() @ w.double().t()
     assert rel_err(out.cpu().double(), ref) < 1e-5
+
+
+def test_gradient_accumulation_equals_sum_of_micro_batches():
+    """two forward_backward() calls in one window: the first overwrites the matrix gradients, the second accumulates"""
+    a, _ = load_golden("train_grad_tiny")
+    m, _, _ = tiny_model()
+    tr = DecoderTrainer(m)
+    emb = t(a["inputs_embeds"])[0].to(DEV)
+    labels = _shift(t(a["labels"])[0])
+    eids = spliced_embed_ids(a["ids"][0], emb.shape[0])
+    for b in tr.layers:
+        b.g.fill_(123.0)                                   # stale values from an earlier step must not survive
+    tr.zero_grad()
+    tr.forward_backward(emb, labels, embed_ids=eids)
+    g1 = [b.g.clone() for b in tr.buckets()]
+    tr.forward_backward(emb * 0.5, labels, embed_ids=eids)
+    g12 = [b.g.clone() for b in tr.buckets()]
+    tr.zero_grad()
+    tr.forward_backward(emb * 0.5, labels, embed_ids=eids)
+    g2 = [b.g.clone() for b in tr.buckets()]
+    for x1, x12, x2, b in zip(g1, g12, g2, tr.buckets()):
+        views = [n for n, *_ in b.entries]
+        for n in views:
+            s_ = b.view(x1, n) + b.view(x2, n)
+            assert torch.allclose(b.view(x12, n), s_, rtol=1e-4, atol=1e-6 * float(s_.abs().max() + 1)), n

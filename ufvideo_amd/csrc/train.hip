@@ -43,6 +43,39 @@ __global__ __launch_bounds__(256) void transpose_bf16_k(const bf16* __restrict__
     }
 }
 
+// Same transpose with 16-byte global accesses (rows 16-byte aligned, C and Rpad multiples of 8): a wave reads 8 rows x 128 B and
+// writes 8 rows x 128 B; the 64x64 tile sits in LDS as 32-bit words (2 columns each) at an odd word pitch.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+__global__ __launch_bounds__(256) void transpose_bf16_v8_k(const bf16* __restrict__ in, int64_t ldi, bf16* __restrict__ out, int64_t ldo,
+                                                           int R, int C, int Rpad) {
+    __shared__ uint32_t tile[64][33];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int hi = threadIdx.x >> 3, lo = threadIdx.x & 7;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = hi + 32 * p, c = c0 + 8 * lo;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < R && c < C) v = *reinterpret_cast<const u32x4*>(in + (int64_t)(r0 + r) * ldi + c);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tile[r][4 * lo + w] = v[w];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = hi + 32 * p, r = r0 + 8 * lo;
+        if (c0 + c < C && r < Rpad) {
+            const int sh = (c & 1) * 16;
+            uint32_t o[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t a = (tile[8 * lo + 2 * w][c >> 1] >> sh) & 0xffffu, b = (tile[8 * lo + 2 * w + 1][c >> 1] >> sh) & 0xffffu;
+                o[w] = a | (b << 16);
+            }
+            *reinterpret_cast<u32x4*>(out + (int64_t)(c0 + c) * ldo + r) = u32x4{o[0], o[1], o[2], o[3]};
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // RMSNorm backward.  y = w * (x * r), r = rsqrt(mean(x^2) + eps)  (modeling_qwen2.py:238-254)
 //   dx[row] (+)= r * (w*dy) - x * r^3/D * sum_j(w_j dy_j x_j);   dw_part[wave][j] = sum over this wave's rows of dy_j x_j r
@@ -289,11 +322,19 @@ __global__ __launch_bounds__(256) void scatter_add_rows_k(const float* __restric
     }
 }
 
-// part[b] = sum of squares of this block's grid-stride slice (gradient-norm clipping: torch.nn.utils.clip_grad_norm_)
+// part[b] = sum of squares of this block's grid-stride slice (gradient-norm clipping: torch.nn.utils.clip_grad_norm_);
+// x is 16-byte aligned, 4 floats per lane per step, scalar tail
 __global__ __launch_bounds__(256) void sumsq_k(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
     __shared__ float red[16];
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i] * x[i];
+    const int64_t n4 = n >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = x4[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += x[i] * x[i];
     s = block_sum(s, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
@@ -323,8 +364,13 @@ __global__ __launch_bounds__(256) void adamw_k(float* __restrict__ p, const floa
 
 extern "C" int ufv_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int Rpad, void* stream) {
     UFV_REQUIRE(in && out && R > 0 && C > 0 && Rpad >= R && ldo >= Rpad && ldi >= C, "ufv_transpose_bf16: bad arguments (R=%d C=%d Rpad=%d)", R, C, Rpad);
-    hipLaunchKernelGGL(transpose_bf16_k, dim3(cdiv(Rpad, 64), cdiv(C, 64)), dim3(256), 0, ST(stream), (const bf16*)in, ldi, (bf16*)out, ldo,
-                       R, C, Rpad);
+    const bool vec = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ldi % 8 == 0 && ldo % 8 == 0 && C % 8 == 0 && Rpad % 8 == 0;
+    if (vec)
+        hipLaunchKernelGGL(transpose_bf16_v8_k, dim3(cdiv(Rpad, 64), cdiv(C, 64)), dim3(256), 0, ST(stream), (const bf16*)in, ldi, (bf16*)out,
+                           ldo, R, C, Rpad);
+    else
+        hipLaunchKernelGGL(transpose_bf16_k, dim3(cdiv(Rpad, 64), cdiv(C, 64)), dim3(256), 0, ST(stream), (const bf16*)in, ldi, (bf16*)out, ldo,
+                           R, C, Rpad);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
@@ -403,7 +449,7 @@ extern "C" int ufv_scatter_add_rows(const float* src, int64_t lds, const int64_t
 }
 
 extern "C" int ufv_sumsq(const float* x, int64_t n, float* partial, int n_partial, void* stream) {
-    UFV_REQUIRE(x && partial && n > 0 && n_partial > 0 && n_partial <= 16384, "ufv_sumsq: bad arguments");
+    UFV_REQUIRE(x && partial && n > 0 && n_partial > 0 && n_partial <= 16384 && (uintptr_t)x % 16 == 0, "ufv_sumsq: bad arguments (x must be 16-byte aligned)");
     hipLaunchKernelGGL(sumsq_k, dim3(n_partial), dim3(256), 0, ST(stream), x, n, partial);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
