@@ -307,3 +307,27 @@ def test_gradient_accumulation_equals_sum_of_micro_batches():
         for n in views:
             s_ = b.view(x1, n) + b.view(x2, n)
             assert torch.allclose(b.view(x12, n), s_, rtol=1e-4, atol=1e-6 * float(s_.abs().max() + 1)), n
+
+
+def test_train_step_on_the_collator_batch_contract():
+    """train_step(**batch) with the reference collator's keys: loss = the reference's ce_loss on the same sample (our tower +
+    projector feed the splice), and repeated steps on the sample drive it down."""
+    a, am_ = load_golden("train_grad_tiny")
+    m, arrs, _ = tiny_model()
+    tr = DecoderTrainer(m, lr=1e-3, weight_decay=0.01)
+    ids, labels = t(a["ids"]).to(DEV), t(a["labels_in"]).to(DEV)
+    video = t(arrs["video"]).to(DEV)
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids), images=[(video, "video")], images_sam=None,
+                 offset=[0, 1], masks_list=None, label_list=None)
+    r1 = tr.train_step(**batch)
+    assert abs(float(r1["loss"]) - float(a["ce_loss"])) < 2e-2 * float(a["ce_loss"])
+    assert abs(float(r1["grad_norm"]) - float(a["grad_norm"])) < 5e-2 * float(a["grad_norm"])
+    r2 = tr.train_step(**batch)
+    r3 = tr.train_step(**batch)
+    assert float(r3["loss"]) < float(r2["loss"]) < float(r1["loss"])
+    # a batch of two samples of different length: loss is the token-weighted mean of the per-sample losses
+    ids2 = torch.cat([ids, ids], 0); ids2[1, -3:] = 0
+    am2 = torch.ones_like(ids2); am2[1, -3:] = 0
+    lab2 = torch.cat([labels, labels], 0); lab2[1, -3:] = -100
+    r = tr.train_step(input_ids=ids2, labels=lab2, attention_mask=am2, images=[(video, "video"), (video, "video")])
+    assert torch.isfinite(r["loss"]) and float(r["grad_norm"]) > 0

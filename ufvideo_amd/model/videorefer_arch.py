@@ -278,6 +278,12 @@ class VideoReferMetaForCausalLM(ABC):
             ops.gather_rows(mm_features.view(n_mm * tok, D), i64(m_src), embeds, i64(m_dst))
         if r_src:
             ops.gather_rows(mask_feats, i64(r_src), embeds, i64(r_dst))
+        # vocabulary row of every spliced position that came from embed_tokens (-1 elsewhere): the scatter map of the
+        # embedding gradient in ufvideo_amd.train
+        eids = torch.full((B * S,), -1, dtype=torch.int64)
+        if t_src:
+            eids[torch.tensor(t_dst, dtype=torch.int64)] = torch.tensor(t_src, dtype=torch.int64)
+        self._last_embed_ids = eids.view(B, S)
         return None, new_mask, past_key_values, embeds.view(B, S, D), new_labels, plan.mark
 
     def initialize_MM_tokenizer(self, tokenizer):

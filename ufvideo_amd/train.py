@@ -298,6 +298,37 @@ class DecoderTrainer:
             ops.scatter_add_rows(dx, embed_ids.to(self.dev).contiguous(), self.head.view(self.head.g, "embed"))
         return loss, dx
 
+    def train_step(self, input_ids=None, labels=None, attention_mask=None, images=None, masks=None, frame=None, ann_indices=None,
+                   frame_nums=None, video_file=None, **_unused):
+        """One optimizer step on a collated batch with the keys the reference's collator produces (train.py:706-732; SURVEY
+        §3.5): splice (tower + projector + region encoder run forward-only: they are outside this slice's trainable set),
+        causal-LM loss averaged over the batch's supervised tokens (HF Qwen2ForCausalLM), backward, exchange, AdamW.
+        Returns {"loss", "ce_loss", "grad_norm"}."""
+        m = self.model
+        with torch.no_grad():
+            (_, am, _, embeds, new_labels, _) = m.prepare_inputs_labels_for_multimodal(input_ids, attention_mask, None, labels, images, masks,
+                                                                                      frame, ann_indices, frame_nums, video_file)
+        if embeds is None:
+            raise ValueError("train_step needs multimodal inputs (images=...) as the reference's training batches have")
+        eids = m._last_embed_ids
+        B, S, _ = embeds.shape
+        shifted, lens = [], []
+        for b in range(B):
+            n = int(am[b].sum().item()) if am is not None else S
+            lab = new_labels[b, :n].to("cpu")
+            shifted.append(torch.cat([lab[1:], torch.full((1,), -100, dtype=lab.dtype)]))
+            lens.append(n)
+        n_valid = sum(int((s_ != -100).sum()) for s_ in shifted)
+        w = 1.0 / max(n_valid, 1)
+        self.zero_grad()
+        loss = torch.zeros((), device=self.dev)
+        for b in range(B):
+            l_b, _ = self.forward_backward(embeds[b, :lens[b]], shifted[b], embed_ids=eids[b, :lens[b]], loss_weight=w)
+            loss = loss + l_b
+        self.step()
+        ce = getattr(self.cfg, "ce_loss_weight", 1.0) * loss
+        return {"loss": ce, "ce_loss": ce, "grad_norm": getattr(self, "last_grad_norm", None)}
+
     # ---- data-parallel exchange + update (ZeRO-2) -----------------------------------------------------------------------
     def _reduce_async(self, b):
         """Bucket b's gradients are final for this micro-batch.  With several ranks and no further accumulation the
