@@ -54,7 +54,7 @@ def main():
     for it in range(args.warmup + args.steps):
         sync(); t0 = time.perf_counter()
         tr.zero_grad()
-        loss, _ = tr.forward_backward(emb, labels, embed_ids=eids)
+        loss, _ = tr.forward_backward(emb, labels, embed_ids=eids, last=True)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         tr.step()
         sync(); t2 = time.perf_counter()

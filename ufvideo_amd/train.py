@@ -159,6 +159,7 @@ class DecoderTrainer:
         self._refresh_transposes()
         self._stash_S = 0
         self._fresh = True
+        self._last_micro = False
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
 
     def buckets(self):
@@ -204,11 +205,14 @@ class DecoderTrainer:
         self._fresh = True
 
     # ---- forward with stash + backward ---------------------------------------------------------------------------
-    def forward_backward(self, inputs_embeds, labels, embed_ids=None, loss_weight=None):
+    def forward_backward(self, inputs_embeds, labels, embed_ids=None, loss_weight=None, last=False):
         """inputs_embeds fp32 [S, D] (one spliced sample), labels int64 [S] ALREADY SHIFTED (labels[p] = target of position p,
         -100 = ignored).  embed_ids int64 [S]: vocabulary row of every position that came from embed_tokens, -1 elsewhere
         (visual / region tokens).  loss_weight: d(total loss)/d(sum of token losses), default 1 / (valid labels of this sample).
+        last=True: no further micro-batch follows before step(), so every layer's gradient bucket is handed to the exchange
+        as soon as that layer's backward is done (overlapped reduce-scatter).
         Accumulates gradients; returns (loss = loss_weight * sum CE, d_inputs_embeds fp32 [S, D])."""
+        self._last_micro = bool(last)
         cfg = self.cfg
         S, D = inputs_embeds.shape
         I = cfg.intermediate_size
@@ -323,7 +327,7 @@ class DecoderTrainer:
         self.zero_grad()
         loss = torch.zeros((), device=self.dev)
         for b in range(B):
-            l_b, _ = self.forward_backward(embeds[b, :lens[b]], shifted[b], embed_ids=eids[b, :lens[b]], loss_weight=w)
+            l_b, _ = self.forward_backward(embeds[b, :lens[b]], shifted[b], embed_ids=eids[b, :lens[b]], loss_weight=w, last=(b == B - 1))
             loss = loss + l_b
         self.step()
         ce = getattr(self.cfg, "ce_loss_weight", 1.0) * loss
@@ -331,10 +335,16 @@ class DecoderTrainer:
 
     # ---- data-parallel exchange + update (ZeRO-2) -----------------------------------------------------------------------
     def _reduce_async(self, b):
-        """Bucket b's gradients are final for this micro-batch.  With several ranks and no further accumulation the
-        reduce-scatter could start here; accumulation across forward_backward calls makes `step()` the safe point, so this
-        hook only records the order in which buckets became ready (the exchange in step() follows it)."""
-        return
+        """Bucket b's gradients are final once its layer's backward has run in the LAST micro-batch of the window: start its
+        reduce-scatter on the side stream so that it overlaps the backward of the earlier layers."""
+        if self.world == 1 or not self._last_micro:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            reduce_scatter_mean(b.gshard, b.g, self.group)
+        b.reduced = True
 
     def _exchange(self):
         if self.world == 1:
@@ -343,7 +353,9 @@ class DecoderTrainer:
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):
             for b in list(reversed(self.layers)) + [self.head]:   # the order backward produced them
-                reduce_scatter_mean(b.gshard, b.g, self.group)
+                if not getattr(b, "reduced", False):              # not already started by _reduce_async
+                    reduce_scatter_mean(b.gshard, b.g, self.group)
+                b.reduced = False
             dist.all_reduce(self.small.g, op=dist.ReduceOp.SUM, group=self.group)
             self.small.g.mul_(1.0 / self.world)
         torch.cuda.current_stream().wait_stream(cs)
