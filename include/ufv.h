@@ -277,9 +277,10 @@ int ufv_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_
  * (head h at column h*hd, RoPE applied), k / v bf16 [>= round_up(S,128) rows, ldkv] (kv-head g at column g*hd), dO bf16 [S, lddo]
  * -> dq [S, lddq], dk / dv [S, lddkv] bf16.  ws = ufv_attention_bwd_ws_bytes(S, Hq, Hkv, hd). */
 int64_t ufv_attention_bwd_ws_bytes(int S, int Hq, int Hkv, int hd);
-/* C[M,N] fp32 (initialised by the caller) += A[M,K] * W[N,K]^T, K split over nsplit blocks per output tile with fp32 atomic
- * accumulation (thin outputs over a long K: dV = P^T dO, dK = dS^T Q) */
-int ufv_gemm_splitk_acc(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, int nsplit, void* stream);
+/* C[M,N] (+)= A[M,K] * W[N,K]^T with K split over up to nsplit blocks per output tile (thin outputs over a long K: dV = P^T dO,
+ * dK = dS^T Q); partial tiles go to ws (fp32 [nsplit][M][N]) and are summed in order; C fp32 (optionally accumulated) or bf16 */
+int ufv_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int out_f32, int accumulate, int M, int N, int K,
+                    int nsplit, void* ws, void* stream);
 int ufv_attention_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* dO, int64_t lddo, void* dq,
                       int64_t lddq, void* dk, void* dv, int64_t lddkv, int S, int Hq, int Hkv, int hd, float scale, void* ws, void* stream);
 

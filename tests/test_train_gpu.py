@@ -272,16 +272,22 @@ def test_fulldim_layer_grads_vs_oracle_autograd():
     assert rel_err(tr.small.view(tr.small.g, "bqkv.0").cpu()[:3584], rg[p + "self_attn.q_proj.bias"]) < 4e-2
 
 
-@pytest.mark.parametrize("M,N,K,ns", [(2399, 128, 16896, 16), (300, 256, 1024, 4), (37, 16, 72, 4)])
-def test_gemm_splitk_acc_vs_torch(M, N, K, ns):
-    """C += A W^T with K split over blocks (fp32 atomics); the last case falls back to the residual-input kernels"""
+@pytest.mark.parametrize("M,N,K,ns", [(2399, 128, 16896, 16), (300, 256, 1024, 4), (300, 128, 1088, 16), (37, 16, 72, 4)])
+def test_gemm_splitk_vs_torch(M, N, K, ns):
+    """C (+)= A W^T with K split over blocks (partials + ordered sum); the last case falls back to one ordinary GEMM"""
     g = torch.Generator().manual_seed(M + K)
     a, w = bfr(torch.randn(M, K, generator=g)), bfr(torch.randn(N, K, generator=g))
     c0 = torch.randn(M, N, generator=g)
+    ad, wd = a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV)
+    prod = a.double() @ w.double().t()
     out = c0.clone().to(DEV)
-    ops.gemm_splitk_acc(a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), out, ns)
-    ref = c0.double() + a.double() @ w.double().t()
-    assert rel_err(out.cpu().double(), ref) < 1e-5
+    ops.gemm_splitk(ad, wd, out, ns, accumulate=True)
+    assert rel_err(out.cpu().double(), c0.double() + prod) < 1e-5
+    ops.gemm_splitk(ad, wd, out, ns)
+    assert rel_err(out.cpu().double(), prod) < 1e-5
+    ob = torch.empty(M, N + 8, device=DEV, dtype=torch.bfloat16)[:, :N]
+    ops.gemm_splitk(ad, wd, ob, ns)
+    assert rel_err(ob.float().cpu().double(), prod) < 1e-2
 
 
 def test_gradient_accumulation_equals_sum_of_micro_batches():

@@ -61,7 +61,7 @@ SIGNATURES = {
     "ufv_scatter_add_rows": [_p, _l, _p, _p, _l, _i, _i, _p],
     "ufv_sumsq": [_p, _l, _p, _i, _p],
     "ufv_adamw": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
-    "ufv_gemm_splitk_acc": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    "ufv_gemm_splitk": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p],
     "ufv_attention_bwd": [_p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p],
 }
 # entry points that return a size instead of a status

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const void* __restrict__ A
 
     int nk = K * ES / 128, t0 = 0;
     // split-K (only the fp32-output 192-row instantiation carries it; training's thin "reduce over tokens" products):
-    // blockIdx.y takes K-tiles [t0, nk) of its slice and ADDS its partial tile to C with fp32 atomics.
+    // blockIdx.y takes K-tiles [t0, nk) of its slice and stores its partial tile to slice blockIdx.y of a workspace.
     constexpr bool CAN_SPLIT = OUT_F32 && !SWIGLU && MT == 6 && !FP8;
     if constexpr (CAN_SPLIT) {
         if (e.ksplit > 1) {
@@ -197,19 +197,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const void* __restrict__ A
     }
 
     if constexpr (CAN_SPLIT) {
-        if (e.ksplit > 1) {
-            float* C = reinterpret_cast<float*>(e.out);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = m0 + wm * (16 * MT) + mt * 16 + frow;
-                if (m < M) {
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            unsafeAtomicAdd(C + (size_t)m * e.ldc + n0 + wn * 64 + nt * 16 + fq * 4 + j, acc[nt][mt][j]);
-                }
-            }
+        if (e.ksplit > 1) {       // partial tile of K-slice blockIdx.y -> slice blockIdx.y of the fp32 workspace [ksplit][M][ldc]
+            Epi pe = e;
+            pe.out = reinterpret_cast<float*>(e.out) + (size_t)blockIdx.y * M * e.ldc;
+            epilogue128<OUT_F32, SWIGLU, MT, ACT_NONE>(acc, pe, M, m0, n0, wm, wn, frow, fq);
             return;
         }
     }
@@ -657,29 +648,63 @@ extern "C" int ufv_gemm(const void* A, int lda, const void* W, int ldw, void* C,
                              stream);
 }
 
-// C[M,N] (fp32, already initialised) += A[M,K] * W[N,K]^T with the K range split over `nsplit` blocks per output tile and
-// fp32 atomic accumulation: for products whose output is small and whose K is long (attention backward's dV = P^T dO,
-// dK = dS^T Q: 2399 x 128 outputs over K = 7 x 2399), where whole-K tiles would occupy 13 of the 256 CUs.
-extern "C" int ufv_gemm_splitk_acc(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, int nsplit,
-                                   void* stream) {
-    UFV_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && nsplit >= 1, "ufv_gemm_splitk_acc: bad arguments (M=%d N=%d K=%d)", M, N, K);
-    const bool ok = ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && (lda % 8 == 0) && (ldw % 8 == 0) && (N % BN == 0) && (K % BK == 0) &&
-                    ((uintptr_t)C % 16 == 0) && (ldc % 4 == 0);
+// C[M,N] (+)= A[M,K] * W[N,K]^T with the K range split over up to `nsplit` blocks per output tile: for products whose output
+// is small and whose K is long (attention backward's dV = P^T dO, dK = dS^T Q: 2399 x 128 outputs over K = 7 x 2399), where
+// whole-K tiles would occupy 13 of the 256 CUs.  Partial tiles go to the fp32 workspace [nsplit][M][N] with plain stores
+// and are summed in slice order by a second kernel (deterministic; device-scope fp32 atomics measured 4x slower: they are
+// served memory-side because the XCDs' L2s are not coherent).
+namespace {
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void sum_partials_k(const float* __restrict__ part, int nsplit, int M, int N, void* __restrict__ out, int ldc,
+                                                      int accumulate) {
+    const int64_t total = (int64_t)M * N / 4;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int m = (id * 4) / N, n = (id * 4) % N;
+        f32x4 s = *reinterpret_cast<const f32x4*>(part + (size_t)m * N + n);
+        for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(part + ((size_t)k * M + m) * N + n);
+        if (OUT_F32) {
+            float* o = reinterpret_cast<float*>(out) + (size_t)m * ldc + n;
+            if (accumulate) s += *reinterpret_cast<const f32x4*>(o);
+            *reinterpret_cast<f32x4*>(o) = s;
+        } else {
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(out) + (size_t)m * ldc + n) = bf16x4{(bf16)s[0], (bf16)s[1], (bf16)s[2], (bf16)s[3]};
+        }
+    }
+}
+}  // namespace
+
+extern "C" int ufv_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int out_f32, int accumulate, int M, int N,
+                               int K, int nsplit, void* ws, void* stream) {
+    UFV_REQUIRE(A && W && C && ws && M > 0 && N > 0 && K > 0 && nsplit >= 1, "ufv_gemm_splitk: bad arguments (M=%d N=%d K=%d)", M, N, K);
+    UFV_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && (uintptr_t)C % 16 == 0 && (uintptr_t)ws % 16 == 0 && !(accumulate && !out_f32),
+                "ufv_gemm_splitk: N, ldc multiples of 4, 16-byte aligned C / ws, accumulation only into fp32 (N=%d ldc=%d)", N, ldc);
+    const bool ok = ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && (lda % 8 == 0) && (ldw % 8 == 0) && (N % BN == 0) && (K % BK == 0);
     Epi e;
-    e.bias = nullptr; e.resid = C; e.out = C; e.ldr = ldc; e.ldc = ldc; e.act = ACT_NONE; e.resid_rows = 0;
+    e.bias = nullptr; e.resid = nullptr; e.out = ws; e.ldr = 0; e.ldc = N; e.act = ACT_NONE; e.resid_rows = 0;
     e.scale_m = nullptr; e.scale_n = nullptr; e.dump_f32 = 0; e.ksplit = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!ok || nsplit == 1)                 // small / unaligned shapes: the ordinary kernels with the fp32 residual input
-        return launch_any<true, false, false>(A, W, e, M, N, K, lda, ldw, UFV_GEMM_AUTO, st);
-    e.resid = nullptr; e.ksplit = nsplit;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<true, false, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  Tile<6>::SMEM_BYTES);
-        attr_set = true;
+    int splits = 1;
+    if (!ok || nsplit == 1) {               // small / unaligned shapes: one ordinary GEMM into slice 0
+        const int rc = launch_any<true, false, false>(A, W, e, M, N, K, lda, ldw, UFV_GEMM_AUTO, st);
+        if (rc != UFV_OK) return rc;
+    } else {
+        const int nk = K / BK, per = cdiv(nk, nsplit);
+        splits = cdiv(nk, per);                                    // no empty slice
+        e.ksplit = splits > 1 ? splits : 0;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<true, false, 6, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, Tile<6>::SMEM_BYTES);
+            attr_set = true;
+        }
+        const int tiles = cdiv(M, Tile<6>::BM) * (N / BN);
+        hipLaunchKernelGGL((gemm_nt_128<true, false, 6, false>), dim3(tiles, splits), dim3(256), Tile<6>::SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
+        UFV_CHECK_LAUNCH();
     }
-    const int tiles = cdiv(M, Tile<6>::BM) * (N / BN);
-    hipLaunchKernelGGL((gemm_nt_128<true, false, 6, false>), dim3(tiles, nsplit), dim3(256), Tile<6>::SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
+    const int64_t total = (int64_t)M * N / 4;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (out_f32) hipLaunchKernelGGL((sum_partials_k<true>), dim3(grid), dim3(256), 0, st, (const float*)ws, splits, M, N, C, ldc, accumulate);
+    else hipLaunchKernelGGL((sum_partials_k<false>), dim3(grid), dim3(256), 0, st, (const float*)ws, splits, M, N, C, ldc, 0);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }

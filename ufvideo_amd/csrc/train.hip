@@ -496,8 +496,6 @@ __global__ __launch_bounds__(256) void head_rows_k(const bf16* __restrict__ src,
 }
 }  // namespace
 
-extern "C" int ufv_gemm_splitk_acc(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, int nsplit,
-                                   void* stream);
 
 extern "C" int64_t ufv_attention_bwd_ws_bytes(int S, int Hq, int Hkv, int hd) {
     const int64_t rep = Hq / (Hkv > 0 ? Hkv : 1), M = (int64_t)S * rep, Sp = rup(S, 128), Mp = rup(M, 128);
@@ -508,7 +506,7 @@ extern "C" int64_t ufv_attention_bwd_ws_bytes(int S, int Hq, int Hkv, int hd) {
     b += (int64_t)hd * Sp * 2;           // k^T
     b += 3 * M * hd * 2;                 // Qg, dOg, dQg
     b += 2 * (int64_t)hd * Mp * 2;       // Qg^T, dOg^T
-    b += 2 * Sp * hd * 4;                // dk, dv accumulators
+    b += 16 * Sp * hd * 4;               // split-K partial tiles (up to 16 slices)
     return b + 16 * 256 + 4096;
 }
 
@@ -536,8 +534,7 @@ extern "C" int ufv_attention_bwd(const void* q, int64_t ldq, const void* k, cons
     bf16* dQg = (bf16*)take((int64_t)M * hd * 2);
     bf16* QgT = (bf16*)take((int64_t)hd * Mp * 2);
     bf16* dOgT = (bf16*)take((int64_t)hd * Mp * 2);
-    float* dka = (float*)take((int64_t)Sp * hd * 4);
-    float* dva = (float*)take((int64_t)Sp * hd * 4);
+    float* part = (float*)take((int64_t)16 * Sp * hd * 4);
     const bf16* qb = (const bf16*)q; const bf16* kb = (const bf16*)k; const bf16* vb = (const bf16*)v; const bf16* dob = (const bf16*)dO;
     // K of the two split products = M: give every output tile ~16 K-tiles' worth of work per block
     const int nsplit = Mp / 64 >= 64 ? 16 : (Mp / 64 >= 16 ? 4 : 1);
@@ -559,17 +556,12 @@ extern "C" int ufv_attention_bwd(const void* q, int64_t ldq, const void* k, cons
         TRY(ufv_gemm(dS, Sp, kT, Sp, dQg, hd, 0, M, hd, Sp, nullptr, 0, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
         hipLaunchKernelGGL(head_rows_k, dim3(grid_for((int64_t)M * hd / 8)), dim3(256), 0, st, dQg, (int64_t)hd, (bf16*)dq + (int64_t)g * rep * hd, lddq, S, rep, hd, 0);
         UFV_CHECK_LAUNCH();
-        TRY(ufv_transpose_bf16(P, Sp, PT, Mp, M, S, Mp, stream));
-        TRY(ufv_transpose_bf16(dS, Sp, dST, Mp, M, S, Mp, stream));
+        TRY(ufv_transpose_bf16(P, Sp, PT, Mp, M, Sp, Mp, stream));         // all Sp columns (the pad columns are zeros): 16-byte path
+        TRY(ufv_transpose_bf16(dS, Sp, dST, Mp, M, Sp, Mp, stream));
         TRY(ufv_transpose_bf16(Qg, hd, QgT, Mp, M, hd, Mp, stream));
         TRY(ufv_transpose_bf16(dOg, hd, dOgT, Mp, M, hd, Mp, stream));
-        if (hipMemsetAsync(dka, 0, (size_t)Sp * hd * 4 * 2, st) != hipSuccess) { ufv_set_error("ufv_attention_bwd: memset failed"); return UFV_EHIP; }
-        TRY(ufv_gemm_splitk_acc(PT, Mp, dOgT, Mp, dva, hd, S, hd, Mp, nsplit, stream));
-        TRY(ufv_gemm_splitk_acc(dST, Mp, QgT, Mp, dka, hd, S, hd, Mp, nsplit, stream));
-        hipLaunchKernelGGL(cvt_rows_k, dim3(grid_for((int64_t)S * hd)), dim3(256), 0, st, dka, (int64_t)hd, (bf16*)dk + (int64_t)g * hd, lddkv, S, hd);
-        UFV_CHECK_LAUNCH();
-        hipLaunchKernelGGL(cvt_rows_k, dim3(grid_for((int64_t)S * hd)), dim3(256), 0, st, dva, (int64_t)hd, (bf16*)dv + (int64_t)g * hd, lddkv, S, hd);
-        UFV_CHECK_LAUNCH();
+        TRY(ufv_gemm_splitk(PT, Mp, dOgT, Mp, (bf16*)dv + (int64_t)g * hd, (int)lddkv, 0, 0, S, hd, Mp, nsplit, part, stream));
+        TRY(ufv_gemm_splitk(dST, Mp, QgT, Mp, (bf16*)dk + (int64_t)g * hd, (int)lddkv, 0, 0, S, hd, Mp, nsplit, part, stream));
     }
 #undef TRY
     return UFV_OK;

@@ -559,12 +559,14 @@ def convert_into(src, dst):
     return dst
 
 
-def gemm_splitk_acc(a, w, out, nsplit):
-    """out fp32 [M, N] += a [M, K] @ w [N, K]^T with the K range split over `nsplit` blocks per tile (fp32 atomics)"""
-    _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w"); _chk(out, torch.float32, "out")
+def gemm_splitk(a, w, out, nsplit, accumulate=False):
+    """out [M, N] (+)= a [M, K] @ w [N, K]^T with the K range split over up to `nsplit` blocks per tile; out fp32 (accumulate
+    allowed) or bf16"""
+    _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w"); _chk(out, name="out")
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and out.shape == (M, N) and a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
-    _lib.call("ufv_gemm_splitk_acc", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0), M, N, K,
-              nsplit, _stream())
+    ws = _ws(a.device, nsplit * M * N * 4, "splitk")
+    _lib.call("ufv_gemm_splitk", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
+              int(out.dtype == torch.float32), int(accumulate), M, N, K, nsplit, ws.data_ptr(), _stream())
     return out
