@@ -533,6 +533,262 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Head-pair variant of the LDS-DMA kernel (diagnostic, kernel ids 7 / 8).  With 168 VGPRs a CU holds 3 waves per SIMD, i.e. ONE
+// 9-wave block of the kernel above (3/2/2/2 waves per SIMD, 4 sequential rounds per CU, each exposing ~8 us of Q / first-tile
+// latency).  Here a block is 2*NW = 12 waves = 3 per SIMD: two heads of one image side by side (each half with its own K/V ring),
+// every wave walking Sq / (32*NW) = 3 query blocks in turn, so the launch is one round of 256 blocks with balanced SIMDs.
+// Measured (MI355X, 32 x 16 x 576 x 72): 118.6 us lockstep / 104.9 us ping-pong against 94.9 us for the 9-wave blocks: a tile
+// step of 12 waves takes 3.2 / 2.7 us against 1.9 us for 9 -- the CU retires ~4.6 wave-tiles per us whatever the arrangement
+// (QK^T MFMA, softmax VALU and PV MFMA of co-resident waves largely serialise), so filling the idle SIMD slots buys nothing
+// and the three drained pass seams cost more than the four block prologues they replace.  Kept as a tested variant.
+// ---------------------------------------------------------------------------------------------------------
+template <int HD, int NW, bool PP>
+__global__ __launch_bounds__(2 * NW * 64, 1) void attn_fwd_pair(AttnArgs a) {
+    constexpr bool CAUSAL = false;
+    constexpr int KS = (HD + 15) / 16, DT = (HD + 31) / 32;
+    constexpr int PK = HD * 2, PV = HD * 2;                 // natural row pitch
+    constexpr int TILEB = 64 * PK, NI = TILEB / 1024;       // bytes / 1-KiB DMA pieces per operand tile
+    static_assert(TILEB % 1024 == 0 && (HD % 8) == 0 && ((HD / 8) & 1) == 1, "row must be an odd number of 16-B chunks");
+    constexpr int STG = 2 * TILEB + 256;                    // [K tile][16 B zeros + pad][V tile][tail pad]
+    constexpr int NST = PP ? 4 : 3;                         // ring stages
+    constexpr int VOFF = TILEB + 128;
+    constexpr int NPW = (2 * NI + NW - 1) / NW;             // DMA pieces per wave per tile (max)
+    constexpr int NPW_MIN = (2 * NI) / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    // block = one (batch, head PAIR); waves 0..NW-1 work on the even head, NW..2NW-1 on the odd one, each half with its own
+    // K/V ring.  1-D grid; consecutive launch ids go to different XCDs: XCD x takes a contiguous run of pairs.
+    const int half = wave >= NW ? 1 : 0;
+    const int w = wave - half * NW;                              // wave index inside its half
+    char* smem = smem_all + half * (NST * STG);
+    int hq, b;
+    {
+        const int id = blockIdx.x, x = id & 7, slot = id >> 3;
+        const int groups = (a.Hq >> 1) * a.B;
+        const int gper = (groups + 7) >> 3;
+        const int g = x * gper + slot;
+        if (g >= groups || slot >= gper) return;
+        hq = 2 * (g % (a.Hq >> 1)) + half; b = g / (a.Hq >> 1);
+    }
+    const int hkv = hq / (a.Hq / a.Hkv);
+    const int npass = a.Sq / (32 * NW);                          // the launcher guarantees Sq % (32 * NW) == 0
+    const int kmax = a.Sk;
+    const int ntiles = (kmax + 63) / 64;
+    const bf16* kbase = a.k + b * a.k_bs + hkv * HD;
+    const bf16* vbase = a.v + b * a.v_bs + hkv * HD;
+    // this wave's DMA pieces: piece j = w + i*NW, j < 2*NI; op = j / NI (0 K, 1 V); lane -> (row, chunk)
+    int p_row[NPW], p_chunk[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int j = w + i * NW, jj = j % NI;
+        const int c16 = jj * 64 + lane;
+        p_row[i] = c16 / (HD / 8);
+        p_chunk[i] = c16 % (HD / 8);
+    }
+    auto dma_tile = [&](int stage, int tile) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int j = w + i * NW;
+            if (j < 2 * NI) {
+                const bool isv = j >= NI;
+                const int jj = j - (isv ? NI : 0);
+                const int row = min(tile * 64 + p_row[i], a.Sk - 1);
+                const bf16* src = (isv ? vbase + (int64_t)row * a.v_ss : kbase + (int64_t)row * a.k_ss) + p_chunk[i] * 8;
+                char* dst = smem + stage * STG + (isv ? VOFF : 0) + jj * 1024;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst), 16, 0, 0);
+            }
+        }
+    };
+    // zero the 16 bytes after every K tile (read as the d>=HD tail of the last key row)
+    if (w == 0 && lane < NST * 4) reinterpret_cast<float*>(smem + (lane >> 2) * STG + TILEB)[lane & 3] = 0.f;
+    const float sl2 = a.scale * 1.4426950408889634f;
+    constexpr float RESCALE_THR = 6.0f;
+    const int k_off = l31 * PK + h * 16;
+    const int v_off = (4 * h + ((lane & 15) >> 2)) * PV + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const bool grp1 = PP && ((wave >> 2) & 1);                // waves 4..7: one barrier behind (SIMD s holds waves s, s+4, s+8)
+
+    for (int pass = 0; pass < npass; ++pass) {
+    const int q0 = (pass * NW + w) * 32;
+    const int qi = q0 + l31;
+    bf16x8 qf[KS];
+    {
+        const bf16* qp = a.q + b * a.q_bs + (int64_t)min(qi, a.Sq - 1) * a.q_ss + hq * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + h * 8;
+            if (d0 < HD) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + d0);
+            else qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // Q in registers before any DMA is in flight
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // ... and hipcc's own scoreboard must see them consumed here:
+    // it does not understand the asm wait above, and with LDS-DMA issued in between it would otherwise put a vmcnt(0) in
+    // front of the first MFMA of EVERY iteration (draining the K/V prefetch ring each tile)
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    dma_tile(0, 0);
+    if (ntiles > 1) dma_tile(1, 1);
+    if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW_MIN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp1) __builtin_amdgcn_s_barrier();
+    int st = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 2 < ntiles) dma_tile(st + 2 >= NST ? st + 2 - NST : st + 2, t + 2);       // ring slot (t+2) % NST
+        const char* kb = smem + st * STG;
+        const char* vb = kb + VOFF;
+        const int kbase_idx = t * 64;
+        // ---- S^T[key][q] for 64 keys: two 32x32 tiles
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        {
+            static_assert(KS == 5, "hand-counted lgkmcnt schedule below is written for 5 k-steps (head_dim 72)");
+            const unsigned kaddr = (unsigned)(uintptr_t)LDS_PTR(kb + k_off);
+            bf16x8 kf[KS][2];
+            kf[0][0] = lds_read128<0 * 32>(kaddr); kf[0][1] = lds_read128<32 * PK + 0 * 32>(kaddr);
+            kf[1][0] = lds_read128<1 * 32>(kaddr); kf[1][1] = lds_read128<32 * PK + 1 * 32>(kaddr);
+            kf[2][0] = lds_read128<2 * 32>(kaddr); kf[2][1] = lds_read128<32 * PK + 2 * 32>(kaddr);
+            kf[3][0] = lds_read128<3 * 32>(kaddr); kf[3][1] = lds_read128<32 * PK + 3 * 32>(kaddr);
+            kf[4][0] = lds_read128<4 * 32>(kaddr); kf[4][1] = lds_read128<32 * PK + 4 * 32>(kaddr);
+            lgkm_wait2<8>(kf[0][0], kf[0][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][0], qf[0], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0][1], qf[0], s1, 0, 0, 0);
+            lgkm_wait2<6>(kf[1][0], kf[1][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][0], qf[1], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1][1], qf[1], s1, 0, 0, 0);
+            lgkm_wait2<4>(kf[2][0], kf[2][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2][0], qf[2], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2][1], qf[2], s1, 0, 0, 0);
+            lgkm_wait2<2>(kf[3][0], kf[3][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[3][0], qf[3], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[3][1], qf[3], s1, 0, 0, 0);
+            lgkm_wait2<0>(kf[4][0], kf[4][1]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4][0], qf[4], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[4][1], qf[4], s1, 0, 0, 0);
+        }
+        // ---- V^T fragments for the first two d-tiles: issued now (K fragment reads have been consumed by the MFMAs
+        //      above, so the LDS queue holds nothing else) and landing under the softmax arithmetic below.
+        const unsigned vaddr = (unsigned)(uintptr_t)LDS_PTR(vb + v_off);
+        bf16x4 vr[2][8];                                                // two register sets, d-tile dt uses set dt&1
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tr_read8<PV, 0>(vaddr, vr[0]);
+        if (DT > 1) tr_read8<PV, 64>(vaddr, vr[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- masking only where a tile can contain invalid keys (sequence end / causal diagonal): wave-uniform
+        bool need_mask = kbase_idx + 64 > a.Sk;
+        if (CAUSAL) need_mask = need_mask || (kbase_idx + 63 > a.q_pos0 + q0);
+        if (need_mask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kj = kbase_idx + (r & 3) + 8 * (r >> 2) + 4 * h;
+                bool ok0 = kj < a.Sk, ok1 = kj + 32 < a.Sk;
+                if (CAUSAL) { ok0 = ok0 && (kj <= a.q_pos0 + qi); ok1 = ok1 && (kj + 32 <= a.q_pos0 + qi); }
+                s0[r] = ok0 ? s0[r] : -INFINITY;
+                s1[r] = ok1 ? s1[r] : -INFINITY;
+            }
+        }
+        // ---- row max (raw scores), lane pair exchange, deferred rescale
+        float tmax = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = max3f(tmax, s0[r], s1[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+        if (__any(tmax > m_run + RESCALE_THR)) {
+            const float mnew = fmaxf(m_run, tmax);
+            const float alpha = (mnew == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - mnew);   // exp2(-inf) = 0 on the first tile
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = mnew;
+        }
+        // ---- P = exp2(s*scale*log2e - m): one FMA + one v_exp per element; masked keys give exp2(-inf) = 0
+        const float msub = (m_run == -INFINITY) ? 0.f : m_run;
+        float psum = 0.f;
+        bf16x8 pf[4];                 // P^T as B operand: k-step sp of half hh uses registers 8sp..8sp+7
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -msub));
+            psum += s0[r];
+        }
+        pf[0] = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
+        pf[1] = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
+        if constexpr (PP) {           // half-step seam: the other group is entering its MFMA-heavy half
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW_MIN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -msub));
+            psum += s1[r];
+        }
+        l_run += psum;
+        pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
+        pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
+        // ---- O^T[d][q] += sum_key V[key][d] P[key][q]; V^T fragments via transposed LDS reads
+        {
+            static_assert(DT <= 4, "V fragment register sets");
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                if (dt + 1 < DT) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // set dt landed, set dt+1 in flight
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {       // c = hh*2 + sp : 16-key chunk
+                    const bf16x8 vf = __builtin_shufflevector(vr[dt & 1][2 * c], vr[dt & 1][2 * c + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], oacc[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (dt + 2 < DT) {                   // refill this set for d-tile dt+2 (its MFMAs above have issued)
+                    if (dt == 0) tr_read8<PV, 128>(vaddr, vr[0]);
+                    else tr_read8<PV, 192>(vaddr, vr[1]);
+                }
+            }
+        }
+        // tile t+1 must have landed (every wave waits for its own pieces, then the barrier publishes them);
+        // tile t+2 stays in flight across the barrier.
+        if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW_MIN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        st = (st == NST - 1) ? 0 : st + 1;
+    }
+    if (PP && !grp1) __builtin_amdgcn_s_barrier();           // balance the stagger barrier
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qi < a.Sq) {
+        bf16* op = a.o + b * a.o_bs + (int64_t)qi * a.o_ss + hq * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = dt * 32 + g4 * 8 + h * 4;
+                if (d0 < HD) {
+                    bf16x4 ov = {(bf16)(oacc[dt][g4 * 4 + 0] * inv), (bf16)(oacc[dt][g4 * 4 + 1] * inv),
+                                 (bf16)(oacc[dt][g4 * 4 + 2] * inv), (bf16)(oacc[dt][g4 * 4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(op + d0) = ov;
+                }
+            }
+    }
+    }   // pass
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Decode attention (Sq == 1): HBM/L2-bound streaming of the KV cache.  Keys are split over blocks (flash-decoding):
 // grid (nsplit, Hq, B); a wave reads 64/CPR keys per 16-byte load instruction (CPR = hd/8 lanes per key row),
 // scores go to LDS, each block writes an un-normalised partial (max, sum, o[hd]); attn_decode_combine merges them.
@@ -781,6 +1037,20 @@ int launch_mfma_dma(const AttnArgs& a, int causal, hipStream_t st) {
     return UFV_OK;
 }
 
+template <int HD, int NW, bool PP>
+int launch_pair(const AttnArgs& a, hipStream_t st) {
+    constexpr int smem = 2 * (PP ? 4 : 3) * (2 * 64 * HD * 2 + 256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pair<HD, NW, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    const int groups = (a.Hq / 2) * a.B, gper = (groups + 7) / 8;
+    hipLaunchKernelGGL((attn_fwd_pair<HD, NW, PP>), dim3(8 * gper), dim3(2 * NW * 64), smem, st, a);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
 }  // namespace
 
 extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const void* k, int64_t k_bs, int64_t k_ss,
@@ -802,13 +1072,16 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
     }
-    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || (kernel == 0 && mfma_ok && Sq >= 16)) {
+    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || (kernel == 0 && mfma_ok && Sq >= 16)) {
         const bool six = (Sq % 192 == 0) && (Sq % 128 != 0);     // e.g. 576 ViT tokens: 3 blocks of 6 waves, no idle wave
         switch (hd) {
             case 64: return launch_mfma<64, 4>(a, causal, st);
             case 72: if (kernel == 3) return launch_mfma<72, 4>(a, causal, st);      // register-staged variant (diagnostic)
+                     // head-pair variants (diagnostic: measured 10-25 % slower than the 9-wave blocks)
+                     if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 7) return launch_pair<72, 6, false>(a, st);
+                     if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 8) return launch_pair<72, 6, true>(a, st);
                      if (Sq % 288 == 0 && kernel == 6) return launch_mfma_dma<72, 9, false>(a, causal, st);   // lockstep variant (diagnostic)
-                     if (Sq % 288 == 0 && kernel != 4) return launch_mfma_dma<72, 9, true>(a, causal, st);     // 576 ViT tokens = 2 blocks of 9 waves
+                     if (Sq % 288 == 0 && kernel != 4) return launch_mfma_dma<72, 9, true>(a, causal, st);     // 2 blocks of 9 waves (kernel 9: the former default)
                      return six ? launch_mfma_dma<72, 6, false>(a, causal, st) : launch_mfma_dma<72, 4, false>(a, causal, st);
             case 80: return launch_mfma<80, 4>(a, causal, st);
             case 96: return launch_mfma<96, 4>(a, causal, st);
