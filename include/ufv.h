@@ -96,6 +96,11 @@ int ufv_attention_decode(const void* q, int64_t q_bs, const void* k, int64_t k_b
  * (cache row = [Hkv*hd k | Hkv*hd v]).  angle = (pos0+s) * inv_freq[i] in fp32. */
 int ufv_rope_kv(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0, void* kv_cache,
                 int ldkv, void* stream);
+/* the same with cos / sin of all S positions precomputed once per forward pass (table fp32 [S, hd]: cos | sin per row, row s =
+ * position pos0+s; bit-identical to ufv_rope_kv): every layer re-uses the table instead of 16 sincos per thread */
+int ufv_rope_table(const float* inv_freq, int pos0, int S, int hd, float* table, void* stream);
+int ufv_rope_kv_table(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* table, int pos0, void* kv_cache, int ldkv,
+                      void* stream);
 
 /* Conv2d(k=s=P, valid) as im2col: pixels [T,C,H,W] (dtype id) -> bf16 [T*(H/P)*(W/P), Kpad],
  * k = c*P*P + py*P + px, zero-filled to Kpad (modeling_siglip.py:124-130,178-179). */

@@ -409,3 +409,15 @@ def test_device_frame_batching_matches_pillow_bit_for_bit():
     v_dev, f_dev, h2, w2, _ = process_video(frames, proc, aspect_ratio="pad", num_frames=4, frame_idx=[1, 3], device=DEV)
     assert (h, w) == (h2, w2) and v_dev.is_cuda and v_dev.shape == v_cpu.shape and f_dev.shape == f_cpu.shape
     assert (v_dev.float().cpu() - v_cpu).abs().max() <= 2 ** -7 and (f_dev.float().cpu() - f_cpu).abs().max() <= 2 ** -7
+
+
+def test_rope_table_form_is_bit_identical():
+    g = torch.Generator().manual_seed(77)
+    S, Hq, Hkv, hd, pos0 = 333, 6, 2, 128, 17
+    inv = (1.0 / (1e6 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(DEV)
+    qkv = torch.randn(S, (Hq + 2 * Hkv) * hd, generator=g).to(torch.bfloat16).to(DEV)
+    a, b = qkv.clone(), qkv.clone()
+    ka = torch.zeros(pos0 + S, 2 * Hkv * hd, device=DEV, dtype=torch.bfloat16); kb = ka.clone()
+    ops.rope_kv(a, S, Hq, Hkv, hd, inv, pos0, ka)
+    ops.rope_kv(b, S, Hq, Hkv, hd, inv, pos0, kb, table=ops.rope_table(inv, pos0, S, hd))
+    assert torch.equal(a, b) and torch.equal(ka, kb)

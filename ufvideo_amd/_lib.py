@@ -21,6 +21,8 @@ SIGNATURES = {
     "ufv_rmsnorm": [_p, _i, _p, _i, _i, _p, _i, _i, _f, _p],
     "ufv_attention": [_p, _l, _l, _p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _p],
     "ufv_rope_kv": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
+    "ufv_rope_table": [_p, _i, _i, _i, _p, _p],
+    "ufv_rope_kv_table": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
     "ufv_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ufv_dwconv3x3_ln_silu": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ufv_colmean": [_p, _p, _i, _i, _i, _p],

@@ -234,6 +234,57 @@ __global__ __launch_bounds__(256) void rope_kv_k(bf16* qkv, int ldqkv, int S, in
     }
 }
 
+// cos / sin of every (position, frequency) once per forward pass: tab[s][i] = cos((pos0+s) * inv_freq[i]), tab[s][half+i] = sin(..)
+// (the same cosf / sinf as rope_kv_k, so the table form is bit-identical); every layer and every head re-uses it.
+__global__ __launch_bounds__(256) void rope_table_k(const float* inv_freq, int pos0, int S, int half, float* tab) {
+    const int64_t total = (int64_t)S * half;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int i = id % half, s = id / half;
+        const float ang = (float)(pos0 + s) * inv_freq[i];
+        tab[(int64_t)s * 2 * half + i] = cosf(ang);
+        tab[(int64_t)s * 2 * half + half + i] = sinf(ang);
+    }
+}
+
+// rope_kv_k with the angles' cos / sin read from the table (16-byte loads) instead of 16 transcendentals per thread
+__global__ __launch_bounds__(256) void rope_kv_tab_k(bf16* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* __restrict__ tab, int pos0,
+                                                     bf16* kv, int ldkv) {
+    const int half = hd >> 1, cpr = half >> 3;
+    const int H = Hq + 2 * Hkv;
+    const int64_t total = (int64_t)S * H * cpr;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = id % cpr;
+        const int hh = (id / cpr) % H;
+        const int s = id / ((int64_t)cpr * H);
+        bf16* row = qkv + (int64_t)s * ldqkv;
+        const int i0 = ch * 8;
+        if (hh < Hq + Hkv) {
+            bf16* p = row + hh * hd;
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p + i0), b2 = *reinterpret_cast<const bf16x8*>(p + half + i0);
+            const float* tr = tab + (int64_t)s * hd;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(tr + i0), c1 = *reinterpret_cast<const f32x4*>(tr + i0 + 4);
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(tr + half + i0), s1 = *reinterpret_cast<const f32x4*>(tr + half + i0 + 4);
+            bf16x8 y1, y2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float c = j < 4 ? c0[j & 3] : c1[j & 3], sn = j < 4 ? s0[j & 3] : s1[j & 3];
+                const float x1 = (float)a[j], x2 = (float)b2[j];
+                y1[j] = (bf16)(x1 * c - x2 * sn);
+                y2[j] = (bf16)(x2 * c + x1 * sn);
+            }
+            bf16* d = (hh < Hq) ? p : kv + (int64_t)(pos0 + s) * ldkv + (hh - Hq) * hd;
+            *reinterpret_cast<bf16x8*>(d + i0) = y1;
+            *reinterpret_cast<bf16x8*>(d + half + i0) = y2;
+        } else {
+            const int hv = hh - Hq - Hkv;
+            const bf16* p = row + (Hq + Hkv) * hd + hv * hd;
+            bf16* d = kv + (int64_t)(pos0 + s) * ldkv + Hkv * hd + hv * hd;
+            *reinterpret_cast<bf16x8*>(d + i0) = *reinterpret_cast<const bf16x8*>(p + i0);
+            *reinterpret_cast<bf16x8*>(d + half + i0) = *reinterpret_cast<const bf16x8*>(p + half + i0);
+        }
+    }
+}
+
 __global__ void rope_kv_scalar_k(bf16* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0, bf16* kv,
                                  int ldkv) {
     const int half = hd >> 1;
@@ -750,6 +801,25 @@ extern "C" int ufv_rope_kv(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd,
         hipLaunchKernelGGL(rope_kv_scalar_k, dim3(grid_for(total)), dim3(256), 0, ST(stream), (bf16*)qkv, ldqkv, S, Hq, Hkv, hd, inv_freq,
                            pos0, (bf16*)kv_cache, ldkv);
     }
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_rope_table(const float* inv_freq, int pos0, int S, int hd, float* table, void* stream) {
+    UFV_REQUIRE(inv_freq && table && S > 0 && hd % 2 == 0, "ufv_rope_table: bad arguments");
+    hipLaunchKernelGGL(rope_table_k, dim3(grid_for((int64_t)S * (hd / 2))), dim3(256), 0, ST(stream), inv_freq, pos0, S, hd / 2, table);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_rope_kv_table(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* table, int pos0, void* kv_cache,
+                                 int ldkv, void* stream) {
+    UFV_REQUIRE(qkv && table && kv_cache && S > 0, "ufv_rope_kv_table: bad arguments");
+    UFV_REQUIRE((hd % 16 == 0) && (ldqkv % 8 == 0) && (ldkv % 8 == 0) && ((uintptr_t)qkv % 16 == 0) && ((uintptr_t)kv_cache % 16 == 0) &&
+                ((uintptr_t)table % 16 == 0), "ufv_rope_kv_table: needs hd %% 16 == 0 and 16-byte aligned rows (hd=%d)", hd);
+    const int64_t total = (int64_t)S * (Hq + 2 * Hkv) * (hd / 16);
+    hipLaunchKernelGGL(rope_kv_tab_k, dim3(grid_for(total)), dim3(256), 0, ST(stream), (bf16*)qkv, ldqkv, S, Hq, Hkv, hd, table, pos0,
+                       (bf16*)kv_cache, ldkv);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }

@@ -167,6 +167,7 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
         o = torch.empty((S, H * hd), device=dev, dtype=torch.bfloat16)
         act = torch.empty((S, cfg.intermediate_size), device=dev, dtype=torch.bfloat16)
         Sk = pos0 + S
+        rope_tab = ops.rope_table(pk["inv_freq"], pos0, S, hd) if S > 1 and hd % 16 == 0 else None
         for li, L in enumerate(pk["layers"]):
             if "wqkv8" in L:
                 L = dict(L, wqkv=L["wqkv8"], wo=L["wo8"], wgu=L["wgu8"], wd=L["wd8"])
@@ -174,7 +175,7 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
             q8 = isinstance(L["wqkv"], ops.Fp8Weight)          # W8A8 prefill: the norms emit e4m3 + row scale directly
             hq = ops.rmsnorm(x, L["ln1"], eps, quant=True) if q8 else ops.rmsnorm(x, L["ln1"], eps, out=h)
             ops.gemm(hq, L["wqkv"], bias=L["bqkv"], out=qkv)
-            ops.rope_kv(qkv, S, H, KV, hd, pk["inv_freq"], pos0, kvb)
+            ops.rope_kv(qkv, S, H, KV, hd, pk["inv_freq"], pos0, kvb, table=rope_tab)
             ops.attention(qkv, kvb, kvb[:, KV * hd:], 1, H, KV, S, Sk, hd, (0, qkv.stride(0)), (0, kvb.stride(0)),
                           (0, kvb.stride(0)), causal=True, q_pos0=pos0, out=o)
             ops.gemm(o, L["wo"], resid=x, out=x)

@@ -201,7 +201,20 @@ def attention_decode(q, k, v, Hq, Hkv, Sk, hd, k_ss, v_ss, scale=None, nsplit=16
     return out
 
 
-def rope_kv(qkv, S, Hq, Hkv, hd, inv_freq, pos0, kv_cache):
+def rope_table(inv_freq, pos0, S, hd):
+    """fp32 [S, hd]: cos | sin of (pos0+s) * inv_freq, computed once per forward pass and shared by all layers"""
+    _chk(inv_freq, torch.float32, "inv_freq")
+    tab = torch.empty((S, hd), device=inv_freq.device, dtype=torch.float32)
+    _lib.call("ufv_rope_table", inv_freq.data_ptr(), pos0, S, hd, tab.data_ptr(), _stream())
+    return tab
+
+
+def rope_kv(qkv, S, Hq, Hkv, hd, inv_freq, pos0, kv_cache, table=None):
+    if table is not None and hd % 16 == 0:
+        _chk(qkv, torch.bfloat16, "qkv"); _chk(kv_cache, torch.bfloat16, "kv_cache"); _chk(table, torch.float32, "table")
+        _lib.call("ufv_rope_kv_table", qkv.data_ptr(), qkv.stride(0), S, Hq, Hkv, hd, table.data_ptr(), pos0, kv_cache.data_ptr(),
+                  kv_cache.stride(0), _stream())
+        return
     _chk(qkv, torch.bfloat16, "qkv"); _chk(kv_cache, torch.bfloat16, "kv_cache"); _chk(inv_freq, torch.float32, "inv_freq")
     _lib.call("ufv_rope_kv", qkv.data_ptr(), qkv.stride(0), S, Hq, Hkv, hd, inv_freq.data_ptr(), pos0, kv_cache.data_ptr(),
               kv_cache.stride(0), _stream())

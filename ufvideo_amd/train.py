@@ -221,13 +221,14 @@ class DecoderTrainer:
         Sp = _ru(S, 128)
         pk = self.pk
         x = inputs_embeds.to(torch.float32).contiguous().clone()
+        rope_tab = ops.rope_table(self.inv_freq, 0, S, hd) if hd % 16 == 0 else None
         # ---------------- forward (same kernels as inference; gate/up kept un-fused so the pre-activations are stashed)
         for L, st in zip(pk["layers"], self.st):
             st["x_in"][:S].copy_(x)
             h1, qkv, kv, o, h2, gu, act = st["h1"][:S], st["qkv"][:S], st["kv"], st["o"][:S], st["h2"][:S], st["gu"][:S], st["act"][:S]
             ops.rmsnorm(x, L["ln1"], eps, out=h1)
             ops.gemm(h1, L["wqkv"], bias=L["bqkv"], out=qkv)
-            ops.rope_kv(qkv, S, H, KV, hd, self.inv_freq, 0, kv)
+            ops.rope_kv(qkv, S, H, KV, hd, self.inv_freq, 0, kv, table=rope_tab)
             ops.attention(qkv, kv, kv[:, KV * hd:], 1, H, KV, S, S, hd, (0, qkv.stride(0)), (0, kv.stride(0)), (0, kv.stride(0)),
                           causal=True, q_pos0=0, out=o)
             ops.gemm(o, L["wo"], resid=x, out=x)
