@@ -244,6 +244,13 @@ int ufv_resize_bilinear(const float* src, const int32_t* sel, int planes_per, in
 /* out[m] = argmax_j x[m, j], j < N (torch.argmax tie-breaking) */
 int ufv_argmax_rows(const float* x, int64_t ld, int M, int N, int32_t* out, void* stream);
 
+/* generate(do_sample=True) (ufvideo/__init__.py:113-127 -> HF TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper +
+ * multinomial): for each of the M rows of logits f32 [M, ld], out[m] = a token drawn from softmax(logits / temperature)
+ * restricted to the top_k (0 = off) most likely tokens and then to the smallest set reaching mass top_p; u[m] in [0,1) is the
+ * caller's uniform variate (inverse CDF in vocabulary order).  kept_out (optional, f32 [M,2]) = {kept mass / top-k mass, cut-off logit}. */
+int ufv_sample_top_p(const float* logits, int64_t ld, int M, int V, float temperature, int top_k, float top_p, const float* u, int64_t* out,
+                     float* kept_out, void* stream);
+
 /* elementwise convert between bf16 / f32 / f16 (n elements) */
 int ufv_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 

@@ -1069,6 +1069,31 @@ def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return F.cross_entropy(logits[..., :-1, :].reshape(-1, logits.shape[-1]).float(), labels[..., 1:].reshape(-1), ignore_index=-100)
 
 
+def sampling_distribution(logits: torch.Tensor, temperature: float, top_k: int, top_p: float) -> torch.Tensor:
+    """Probabilities HF's sampling chain draws from (GenerationMixin with the kwargs the reference forwards,
+    ufvideo/__init__.py:113-127): TemperatureLogitsWarper -> TopKLogitsWarper (top_k > 0) -> TopPLogitsWarper (top_p < 1)
+    -> softmax.  logits [V] fp32.  Pinned against transformers' own warpers in tests/test_oracle_golden.py."""
+    x = logits.float() / temperature
+    if top_k and top_k > 0:
+        k = min(top_k, x.numel())
+        x = x.masked_fill(x < torch.topk(x, k)[0][-1], float("-inf"))
+    if top_p < 1.0:
+        sl, si = torch.sort(x, descending=False)
+        cum = sl.softmax(-1).cumsum(-1)
+        rem = cum <= (1 - top_p)
+        rem[-1:] = False
+        x = x.masked_fill(torch.zeros_like(rem).scatter(0, si, rem), float("-inf"))
+    return x.softmax(-1)
+
+
+def sample_inverse_cdf(probs: torch.Tensor, u: float) -> int:
+    """first index (vocabulary order) whose running mass exceeds u * total"""
+    c = probs.double().cumsum(0)
+    idx = int(torch.searchsorted(c, torch.tensor(u * float(c[-1]), dtype=torch.float64), right=True))
+    nz = torch.nonzero(probs > 0).reshape(-1)
+    return min(idx, int(nz[-1]))
+
+
 DECODER_TRAINABLE = ("model.layers.", "model.norm.weight", "model.embed_tokens.weight", "lm_head.weight")
 
 

@@ -421,3 +421,27 @@ def test_rope_table_form_is_bit_identical():
     ops.rope_kv(a, S, Hq, Hkv, hd, inv, pos0, ka)
     ops.rope_kv(b, S, Hq, Hkv, hd, inv, pos0, kb, table=ops.rope_table(inv, pos0, S, hd))
     assert torch.equal(a, b) and torch.equal(ka, kb)
+
+
+@pytest.mark.parametrize("V,T,k,p", [(1000, 0.2, 50, 0.9), (151748, 0.7, 0, 0.8), (5000, 1.3, 20, 1.0), (300, 0.2, 0, 0.9), (4096, 1.0, 1, 0.5)])
+def test_sample_top_p_vs_oracle_distribution(V, T, k, p):
+    """kept set (count above the cut-off, kept mass) exact vs the oracle's HF-warper restatement; draws by inverse CDF follow it"""
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(V + k)
+    lg = torch.randn(V, generator=g) * 3
+    ref = O.sampling_distribution(lg, T, k, p)
+    ref_k = O.sampling_distribution(lg, T, k, 1.0)
+    n = 4096
+    u = torch.rand(n, generator=g)
+    u[0], u[1] = 0.0, 1.0 - 2 ** -24
+    rows = lg.to(DEV)[None].expand(n, V).contiguous()
+    kept = torch.zeros(n, 2, device=DEV)
+    toks = ops.sample_top_p(rows, T, k, p, u.to(DEV), kept=kept).cpu()
+    kept = kept.cpu()
+    assert int((lg >= kept[0, 1]).sum()) == int((ref > 0).sum())                       # the cut-off keeps exactly HF's set
+    assert abs(float(kept[0, 0]) - float(ref_k[ref > 0].sum())) < 1e-4
+    assert bool((ref[toks] > 0).all())
+    exp_tok = torch.tensor([O.sample_inverse_cdf(ref, float(x)) for x in u[:256]])
+    assert (toks[:256] == exp_tok).float().mean() > 0.98                                 # fp32 vs fp64 running sums at bin edges
+    emp = torch.bincount(toks, minlength=V).float() / n
+    assert 0.5 * float((emp - ref).abs().sum()) < 0.05 + 0.5 * float((ref > 0).sum()) / n

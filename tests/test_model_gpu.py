@@ -349,3 +349,23 @@ def test_training_losses_vs_reference_golden():
     bce = torch.nn.functional.binary_cross_entropy_with_logits(x, tg, reduction="none").flatten(1).sum(1)
     assert torch.allclose(sums[:, 0], bce, rtol=1e-5) and torch.allclose(sums[:, 1], (x.sigmoid() * tg).flatten(1).sum(1), rtol=1e-5)
     assert torch.allclose(sums[:, 2], x.sigmoid().flatten(1).sum(1), rtol=1e-5) and torch.equal(sums[:, 3], tg.flatten(1).sum(1))
+
+
+def test_generate_do_sample_reproducible_and_top_k1_is_greedy():
+    """mm_infer's sampling kwargs (ref ufvideo/__init__.py:113-127): seeded runs repeat; top_k = 1 leaves only the argmax"""
+    m, a, _ = tiny_model()
+    video = t(a["video"]).to(DEV)
+    ids = torch.tensor([[5, 6, -201, 7, 8, 9]], device=DEV)
+    kw = dict(attention_mask=torch.ones_like(ids), images=[(video, "video")], images_sam=torch.zeros(1, 4, 3, 8, 8, device=DEV), offset=[0, 1],
+              label_list=torch.zeros(56, 56), max_new_tokens=6, eos_token_id=298, pad_token_id=0)
+    greedy = m.generate(ids, **kw)["output"].cpu()
+    k1 = m.generate(ids, do_sample=True, temperature=0.7, top_p=0.9, top_k=1, **kw)["output"].cpu()
+    assert torch.equal(greedy, k1)
+    torch.manual_seed(123); s1 = m.generate(ids, do_sample=True, temperature=1.5, top_p=0.95, **kw)["output"].cpu()
+    torch.manual_seed(123); s2 = m.generate(ids, do_sample=True, temperature=1.5, top_p=0.95, **kw)["output"].cpu()
+    assert torch.equal(s1, s2) and int(s1.max()) < m.config.vocab_size and int(s1.min()) >= 0
+    outs = set()
+    for seed in range(8):
+        torch.manual_seed(seed)
+        outs.add(tuple(m.generate(ids, do_sample=True, temperature=3.0, top_p=1.0, top_k=0, **kw)["output"].cpu().flatten().tolist()))
+    assert len(outs) > 1                                                                   # hot sampling actually varies

@@ -297,3 +297,20 @@ def test_decoder_train_grads_vs_reference_backward():
     assert abs(float(norm) - float(a["grad_norm"])) < 1e-3 * float(a["grad_norm"])
     for k in ref_g:
         assert torch.allclose(new[k], torch.from_numpy(z["p1::" + k]), atol=2e-6, rtol=1e-5), k
+
+
+def test_sampling_distribution_vs_transformers_warpers():
+    """the oracle's temperature / top-k / top-p restatement == transformers' own LogitsWarpers (the chain HF generate() builds
+    from the kwargs the reference forwards)"""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    g = torch.Generator().manual_seed(9)
+    for V, T, k, p in ((1000, 0.2, 50, 0.9), (5000, 0.7, 0, 0.8), (300, 1.3, 20, 1.0), (300, 0.2, 0, 0.9)):
+        lg = torch.randn(1, V, generator=g) * 3
+        x = TemperatureLogitsWarper(T)(None, lg.clone())
+        if k:
+            x = TopKLogitsWarper(k)(None, x)
+        if p < 1.0:
+            x = TopPLogitsWarper(p)(None, x)
+        ref = x.softmax(-1)[0]
+        got = O.sampling_distribution(lg[0], T, k, p)
+        assert torch.equal(got > 0, ref > 0) and torch.allclose(got, ref, atol=1e-7)

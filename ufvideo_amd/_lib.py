@@ -53,6 +53,7 @@ SIGNATURES = {
     "ufv_argmax_rows": [_p, _l, _i, _i, _p, _p],
     "ufv_attention_decode": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
+    "ufv_sample_top_p": [_p, _l, _i, _i, _f, _i, _f, _p, _p, _p, _p],
     "ufv_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],
     "ufv_rmsnorm_bwd": [_p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _i, _i, _f, _p, _p],
     "ufv_colsum_bf16": [_p, _l, _i, _i, _p, _i, _p, _p],

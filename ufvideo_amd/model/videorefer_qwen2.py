@@ -458,10 +458,16 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         return masks > 0                                                                   # == sigmoid(masks) > 0.5
 
     def _greedy(self, inputs_embeds, attention_mask, max_new_tokens=20, eos_token_id=None, stopping_criteria=None,
-                do_sample=False, pad_token_id=None, use_cache=True, **unused):
-        """HF greedy search from inputs_embeds (batch 1): returns only the new tokens; EOS included."""
-        if do_sample:
-            raise NotImplementedError("sampling is outside the accelerated path; the reference's default is greedy")
+                do_sample=False, pad_token_id=None, use_cache=True, temperature=1.0, top_p=1.0, top_k=None, generator=None, **unused):
+        """HF greedy search -- or, with do_sample=True, HF's sampling chain temperature -> top_k -> top_p -> multinomial
+        (`ufv_sample_top_p`; the uniform variates come from torch's host generator, so `torch.manual_seed` makes a run
+        reproducible; HF draws with torch.multinomial on the device, so individual draws differ from the reference's while the
+        distribution is the same) -- from inputs_embeds (batch 1): returns only the new tokens; EOS included."""
+        sample = bool(do_sample) and temperature is not None and temperature > 0
+        if sample:
+            top_k = self.generation_config.get("top_k", 50) if top_k is None else top_k      # HF GenerationConfig default
+            top_p = 1.0 if top_p is None else float(top_p)
+            uni = torch.rand((max_new_tokens,), generator=generator).to(inputs_embeds.device)
         eos = eos_token_id if eos_token_id is not None else self.generation_config.eos_token_id
         eos = set(eos) if isinstance(eos, (list, tuple)) else ({eos} if eos is not None else set())
         dev = inputs_embeds.device
@@ -474,7 +480,10 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         tokens = []
         tok = torch.empty((1,), device=dev, dtype=torch.int64)
         nxt = torch.empty((1,), device=dev, dtype=torch.int64)
-        ops.argmax(logits.view(-1), out=tok)
+        if sample:
+            ops.sample_top_p(logits.view(1, -1), temperature, top_k or 0, top_p, uni[0:1], out=tok)
+        else:
+            ops.argmax(logits.view(-1), out=tok)
         step = self._decode_step_ctx(cache)
         for i in range(max_new_tokens):
             t = int(tok.item())                                   # the only host<->device sync per token
@@ -491,6 +500,8 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
                       torch.cuda.current_stream().cuda_stream)
             cache.len += 1
             hidden_steps.append(hid)
+            if sample:                                            # the step's own argmax is ignored: draw from its logits instead
+                ops.sample_top_p(step["logits"].view(1, -1), temperature, top_k or 0, top_p, uni[i + 1:i + 2], out=nxt)
             tok, nxt = nxt, tok
         return {"sequences": torch.tensor([tokens], dtype=torch.long, device=dev), "hidden_last": hidden_steps, "cache": cache}
 

@@ -583,3 +583,15 @@ def gemm_splitk(a, w, out, nsplit, accumulate=False):
     _lib.call("ufv_gemm_splitk", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), out.stride(0),
               int(out.dtype == torch.float32), int(accumulate), M, N, K, nsplit, ws.data_ptr(), _stream())
     return out
+
+
+def sample_top_p(logits, temperature, top_k, top_p, u, out=None, kept=None):
+    """logits fp32 [M, V] (or [V]) -> int64 [M] tokens drawn after temperature / top-k / top-p filtering; u fp32 [M] uniforms in [0,1)"""
+    _chk(logits, torch.float32, "logits"); _chk(u, torch.float32, "u")
+    lg = logits.view(1, -1) if logits.dim() == 1 else logits
+    M, V = lg.shape
+    if out is None:
+        out = torch.empty((M,), device=lg.device, dtype=torch.int64)
+    _lib.call("ufv_sample_top_p", lg.data_ptr(), lg.stride(0), M, V, float(temperature), int(top_k), float(top_p), u.data_ptr(),
+              out.data_ptr(), _ptr(kept), _stream())
+    return out
