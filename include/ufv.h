@@ -244,6 +244,29 @@ int ufv_resize_bilinear(const float* src, const int32_t* sel, int planes_per, in
 /* out[m] = argmax_j x[m, j], j < N (torch.argmax tie-breaking) */
 int ufv_argmax_rows(const float* x, int64_t ld, int M, int N, int32_t* out, void* stream);
 
+/* ---- projector backward (ufvideo/model/projector.py:133-238 under torch autograd; timm RegStage bottlenecks) ---- */
+/* out = act(pre) and dpre = dout * act'(pre) on flat bf16 arrays (n % 8 == 0): the un-fused activations of the training forward */
+int ufv_act(const void* pre, void* out, int64_t n, int act, void* stream);
+int ufv_act_bwd(const void* pre, const void* dout, void* dpre, int64_t n, int act, void* stream);
+int ufv_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* row LayerNorm (+ optional activation) backward: x, dout, dx bf16 [M, C]; dw, db fp32 [C] are ADDED to; ws = ufv_layernorm_bwd_ws_bytes(C) */
+int64_t ufv_layernorm_bwd_ws_bytes(int C);
+int ufv_layernorm_bwd(const void* x, int64_t ldx, const float* w, const float* b, const void* dout, int64_t ldd, void* dx, int64_t lddx,
+                      float* dw, float* db, int M, int C, float eps, int act, void* ws, void* stream);
+/* g = dout * silu'(LN_a(z) + (LN_b(s) or s when wb == NULL)): the gradient entering both branches of a bottleneck's output */
+int ufv_ln_add_silu_g(const void* z, const float* wa, const float* ba, const void* s, const float* wb, const float* bb, const void* dout,
+                      void* g, int M, int C, float eps, void* stream);
+/* depthwise 3x3 conv, padding 1, token-major NHWC bf16, w9 fp32 [9, C]; flip = 1: taps mirrored = gradient with respect to the input */
+int ufv_dwconv3x3(const void* x, void* y, const float* w9, int F, int H, int W, int C, int flip, void* stream);
+/* dw9[tap][c] += sum over pixels of dy * shifted x; ws = ufv_dwconv3x3_dw_ws_bytes(C) */
+int64_t ufv_dwconv3x3_dw_ws_bytes(int C);
+int ufv_dwconv3x3_dw(const void* x, const void* dy, float* dw9, int F, int H, int W, int C, void* ws, void* stream);
+/* out[f][c] = sum_p a[f,p,c] * b[f,p,c] (SE gate gradient); out[f,p,c] = a[f,p,c] * g[f,c] + s[f,c] * k (s may be NULL) */
+int ufv_prod_colsum(const void* a, const void* b, int F, int P, int C, float* out, void* stream);
+int ufv_scale_add_bcast(const void* a, const void* g, const float* s, float k, void* out, int F, int P, int C, void* stream);
+/* inverse of ufv_conv3d_gather for padding 0 / stride = kernel: dx [T*H*W, C] from dA [To*Ho*Wo, kt*kh*kw*C] */
+int ufv_conv3d_scatter(const void* dA, void* dx, int T, int H, int W, int C, int kt, int kh, int kw, void* stream);
+
 /* generate(do_sample=True) (ufvideo/__init__.py:113-127 -> HF TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper +
  * multinomial): for each of the M rows of logits f32 [M, ld], out[m] = a token drawn from softmax(logits / temperature)
  * restricted to the top_k (0 = off) most likely tokens and then to the smallest set reaching mass top_p; u[m] in [0,1) is the

@@ -337,3 +337,40 @@ def test_train_step_on_the_collator_batch_contract():
     lab2 = torch.cat([labels, labels], 0); lab2[1, -3:] = -100
     r = tr.train_step(input_ids=ids2, labels=lab2, attention_mask=am2, images=[(video, "video"), (video, "video")])
     assert torch.isfinite(r["loss"]) and float(r["grad_norm"]) > 0
+
+
+# ---- projector backward ------------------------------------------------------------------------------------------------------
+
+class _PCfg:
+    def __init__(self, cin, hid):
+        self.mm_hidden_size, self.hidden_size = cin, hid
+
+
+@pytest.mark.parametrize("cin,hid,t,hw,depth", [(64, 64, 4, 4, 4), (128, 256, 4, 8, 2), (64, 64, 2, 6, 0)])
+def test_projector_grad_vs_oracle_autograd(cin, hid, t, hw, depth):
+    """every parameter gradient and the input gradient of the STC connector (v35: Conv3d 2x2x2 / padding 0) against torch autograd
+    over the oracle restatement; the middle case runs its 1x1 convs on the MFMA tile kernels"""
+    from ufvideo_amd.model.projector import STCConnectorV35
+    from ufvideo_amd.train_projector import ProjectorGrad
+    sd = O.make_stc_weights(cin, hid, seed=31, depth=depth)
+    sd = {k: bfr(v * (3.0 if v.ndim >= 2 else 1.0)) for k, v in sd.items()}
+    pj = STCConnectorV35(_PCfg(cin, hid), depth=depth)
+    pj.load_state_dict(sd)
+    pj = pj.to(DEV)
+    g_ = torch.Generator().manual_seed(32)
+    x = bfr(torch.randn(t * hw * hw, cin, generator=g_))
+    n_out = (t // 2) * (hw // 2) ** 2
+    dout = torch.randn(n_out, hid, generator=g_)
+    with torch.enable_grad():
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        y = O.stc_connector(p, xr.view(1, t, hw * hw, cin), downsample=(2, 2, 2), padding=0, depth=depth)
+        y[0].backward(dout)
+    pg = ProjectorGrad(pj)
+    out = pg.forward(x.to(DEV), t, hw)
+    assert rel_err(out.cpu(), y[0].detach()) < 3e-2
+    grads, dx = pg.backward(dout.to(DEV))
+    assert set(grads) == set(sd), set(sd) ^ set(grads)
+    worst = max((rel_err(grads[k].cpu().reshape(p[k].shape), p[k].grad), k) for k in sd)
+    assert worst[0] < 6e-2, worst
+    assert rel_err(dx.float().cpu(), xr.grad) < 6e-2

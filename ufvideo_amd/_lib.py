@@ -53,6 +53,16 @@ SIGNATURES = {
     "ufv_argmax_rows": [_p, _l, _i, _i, _p, _p],
     "ufv_attention_decode": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
+    "ufv_act": [_p, _p, _l, _i, _p],
+    "ufv_act_bwd": [_p, _p, _p, _l, _i, _p],
+    "ufv_add_bf16": [_p, _p, _p, _l, _p],
+    "ufv_layernorm_bwd": [_p, _l, _p, _p, _p, _l, _p, _l, _p, _p, _i, _i, _f, _i, _p, _p],
+    "ufv_ln_add_silu_g": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "ufv_dwconv3x3": [_p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "ufv_dwconv3x3_dw": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
+    "ufv_prod_colsum": [_p, _p, _i, _i, _i, _p, _p],
+    "ufv_scale_add_bcast": [_p, _p, _p, _f, _p, _i, _i, _i, _p],
+    "ufv_conv3d_scatter": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ufv_sample_top_p": [_p, _l, _i, _i, _f, _i, _f, _p, _p, _p, _p],
     "ufv_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],
     "ufv_rmsnorm_bwd": [_p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _i, _i, _f, _p, _p],
@@ -69,7 +79,8 @@ SIGNATURES = {
 }
 # entry points that return a size instead of a status
 SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l),
-              "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l)}
+              "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l),
+              "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l)}
 
 
 class Qwen2Layer(C.Structure):

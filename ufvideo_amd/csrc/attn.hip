@@ -1072,7 +1072,7 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
     }
-    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || (kernel == 0 && mfma_ok && Sq >= 16)) {
+    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || kernel == 10 || (kernel == 0 && mfma_ok && Sq >= 16)) {
         const bool six = (Sq % 192 == 0) && (Sq % 128 != 0);     // e.g. 576 ViT tokens: 3 blocks of 6 waves, no idle wave
         switch (hd) {
             case 64: return launch_mfma<64, 4>(a, causal, st);
@@ -1081,6 +1081,7 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 7) return launch_pair<72, 6, false>(a, st);
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 8) return launch_pair<72, 6, true>(a, st);
                      if (Sq % 288 == 0 && kernel == 6) return launch_mfma_dma<72, 9, false>(a, causal, st);   // lockstep variant (diagnostic)
+                     if (six && kernel == 10) return launch_mfma_dma<72, 6, true>(a, causal, st);               // 6-wave blocks, ping-pong, 2 blocks / CU (diagnostic)
                      if (Sq % 288 == 0 && kernel != 4) return launch_mfma_dma<72, 9, true>(a, causal, st);     // 2 blocks of 9 waves (kernel 9: the former default)
                      return six ? launch_mfma_dma<72, 6, false>(a, causal, st) : launch_mfma_dma<72, 4, false>(a, causal, st);
             case 80: return launch_mfma<80, 4>(a, causal, st);

@@ -1,0 +1,441 @@
+// Backward kernels of the multimodal projector (STC connector: timm RegStage bottlenecks + Conv3d sampler + readout MLP;
+// reference ufvideo/model/projector.py:133-238, differentiated by torch autograd in the reference's training step).
+// Token-major bf16 activations [pixels, C] as in the forward path; the 1x1 convolutions / Conv3d / Linear layers go through
+// the NT GEMMs (ufvideo_amd/train_projector.py), this file holds the rest.  All HBM-bound.
+#include "common.h"
+#include "../../include/ufv.h"
+
+namespace {
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+inline int grid_for(int64_t n, int per_block = 256) {
+    const int64_t g = (n + per_block - 1) / per_block;
+    return (int)(g < 16384 ? (g > 0 ? g : 1) : 16384);
+}
+
+__device__ __forceinline__ float act_grad(float x, int act) {
+    switch (act) {
+        case ACT_SILU: { const float s = 1.0f / (1.0f + __expf(-x)); return s * (1.0f + x * (1.0f - s)); }
+        case ACT_SIGMOID: { const float s = 1.0f / (1.0f + __expf(-x)); return s * (1.0f - s); }
+        case ACT_GELU_ERF: return 0.5f * (1.0f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+        case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+
+// out = act(pre)  /  dpre = dout * act'(pre), 8 elements per thread
+template <bool BWD>
+__global__ __launch_bounds__(256) void act_k(const bf16* __restrict__ pre, const bf16* __restrict__ dout, bf16* __restrict__ out, int64_t n8,
+                                             int act) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 p = reinterpret_cast<const bf16x8*>(pre)[i];
+        bf16x8 o;
+        if (BWD) {
+            const bf16x8 d = reinterpret_cast<const bf16x8*>(dout)[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)d[j] * act_grad((float)p[j], act));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)act_apply((float)p[j], act);
+        }
+        reinterpret_cast<bf16x8*>(out)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_bf16_k(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ out, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 x = reinterpret_cast<const bf16x8*>(a)[i], y = reinterpret_cast<const bf16x8*>(b)[i];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)x[j] + (float)y[j]);
+        reinterpret_cast<bf16x8*>(out)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row LayerNorm (+ optional activation) backward, one wave per row, grid-stride over rows.
+//   xh = (x - mean) * rstd;  y = xh * w + b;  out = act(y)
+//   g = dout * act'(y);  dw += sum_rows g * xh;  db += sum_rows g;  dx = rstd * (g*w - mean(g*w) - xh * mean(g*w*xh))
+// The row (<= 8 KB of bf16) is re-read from L1/L2 for each of the four passes instead of being kept in registers, which
+// leaves the registers to the per-wave dw / db partials (written once per wave, reduced by colsum_f32: deterministic).
+// ---------------------------------------------------------------------------------------------------------
+template <int MAXI>
+__global__ __launch_bounds__(256) void layernorm_bwd_k(const bf16* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
+                                                       const bf16* __restrict__ dout, int64_t ldd, bf16* __restrict__ dx, int64_t lddx,
+                                                       float* __restrict__ part, int M, int C, float eps, int act) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int nch = C >> 3;
+    float aw[MAXI][8], ab[MAXI][8];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { aw[i][j] = 0.f; ab[i][j] = 0.f; }
+    for (int row = wid; row < M; row += nw) {
+        const bf16* xr = x + (int64_t)row * ldx;
+        const bf16* dr = dout + (int64_t)row * ldd;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += (float)v[j];
+            }
+        }
+        const float mean = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / C + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + ch * 8), d = *reinterpret_cast<const bf16x8*>(dr + ch * 8);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + ch * 8), w1 = *reinterpret_cast<const f32x4*>(w + ch * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + ch * 8), b1 = *reinterpret_cast<const f32x4*>(b + ch * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float ww = j < 4 ? w0[j & 3] : w1[j & 3], bb = j < 4 ? b0[j & 3] : b1[j & 3];
+                    const float xh = ((float)v[j] - mean) * rstd;
+                    const float g = (float)d[j] * (act ? act_grad(xh * ww + bb, act) : 1.f);
+                    aw[i][j] += g * xh; ab[i][j] += g;
+                    s1 += g * ww; s2 += g * ww * xh;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int ch = lane + 64 * i;
+            if (ch < nch) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + ch * 8), d = *reinterpret_cast<const bf16x8*>(dr + ch * 8);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + ch * 8), w1 = *reinterpret_cast<const f32x4*>(w + ch * 8 + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + ch * 8), b1 = *reinterpret_cast<const f32x4*>(b + ch * 8 + 4);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float ww = j < 4 ? w0[j & 3] : w1[j & 3], bb = j < 4 ? b0[j & 3] : b1[j & 3];
+                    const float xh = ((float)v[j] - mean) * rstd;
+                    const float g = (float)d[j] * (act ? act_grad(xh * ww + bb, act) : 1.f);
+                    o[j] = (bf16)(rstd * (g * ww - s1 - xh * s2));
+                }
+                *reinterpret_cast<bf16x8*>(dx + (int64_t)row * lddx + ch * 8) = o;
+            }
+        }
+    }
+    float* pw = part + (int64_t)wid * 2 * C;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { pw[ch * 8 + j] = aw[i][j]; pw[C + ch * 8 + j] = ab[i][j]; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum2_f32_k(const float* __restrict__ x, int64_t ld, int R, int C, float* __restrict__ out0,
+                                                     float* __restrict__ out1) {
+    const int c = blockIdx.x * 256 + threadIdx.x;          // column of the [R, 2C] partial image
+    if (c >= 2 * C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += x[(int64_t)r * ld + c];
+    if (c < C) out0[c] += s; else out1[c - C] += s;
+}
+
+// g = dout * silu'(LN_a(z) + (LN_b(s) | s))   (the gradient entering both branches of a bottleneck's output); one wave per row
+template <int MAXI>
+__global__ __launch_bounds__(256) void ln_add_silu_g_k(const bf16* __restrict__ z, const float* __restrict__ wa, const float* __restrict__ ba,
+                                                       const bf16* __restrict__ s, const float* __restrict__ wb, const float* __restrict__ bb,
+                                                       const bf16* __restrict__ dout, bf16* __restrict__ g, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = C >> 3;
+    const bf16* zr = z + (int64_t)row * C;
+    const bf16* sr = s + (int64_t)row * C;
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(zr + ch * 8), u = *reinterpret_cast<const bf16x8*>(sr + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sa += (float)v[j]; sb += (float)u[j]; }
+        }
+    }
+    const float ma = wave_sum(sa) / C, mb = wave_sum(sb) / C;
+    float qa = 0.f, qb = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(zr + ch * 8), u = *reinterpret_cast<const bf16x8*>(sr + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float da = (float)v[j] - ma, db = (float)u[j] - mb;
+                qa += da * da; qb += db * db;
+            }
+        }
+    }
+    const float ra = rsqrtf(wave_sum(qa) / C + eps), rb = rsqrtf(wave_sum(qb) / C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(zr + ch * 8), u = *reinterpret_cast<const bf16x8*>(sr + ch * 8);
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dout + (int64_t)row * C + ch * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = ch * 8 + j;
+                float t = ((float)v[j] - ma) * ra * wa[c] + ba[c];
+                t += wb ? ((float)u[j] - mb) * rb * wb[c] + bb[c] : (float)u[j];
+                o[j] = (bf16)((float)d[j] * act_grad(t, ACT_SILU));
+            }
+            *reinterpret_cast<bf16x8*>(g + (int64_t)row * C + ch * 8) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Depthwise 3x3 convolution, padding 1, NHWC token-major: y[f,h,w,c] = sum_{dy,dx} x[f,h+dy-1,w+dx-1,c] * w9[dy*3+dx][c].
+// flip = 1 uses tap (2-dy, 2-dx): the gradient with respect to the input.  One thread per (pixel, 8 channels).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv3x3_k(const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w9, int F, int H,
+                                                   int W, int C, int flip) {
+    const int cv = C >> 3;
+    const int64_t total = (int64_t)F * H * W * cv;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int c8 = id % cv;
+        int64_t p = id / cv;
+        const int px = p % W; p /= W;
+        const int py = p % H;
+        const int f = (int)(p / H);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = py + dy - 1;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = px + dx - 1;
+                if (xx < 0 || xx >= W) continue;
+                const int tap = flip ? (2 - dy) * 3 + (2 - dx) : dy * 3 + dx;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)f * H + yy) * W + xx) * C + c8 * 8);
+                const float* wk = w9 + tap * C + c8 * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j] * wk[j];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+        *reinterpret_cast<bf16x8*>(y + id * 8) = o;
+    }
+}
+
+// dw9[tap][c] partials: block (channel group of 256, pixel slice) sums dy[p][c] * x[p + tap offset][c] over its pixels
+__global__ __launch_bounds__(256) void dwconv3x3_dw_k(const bf16* __restrict__ x, const bf16* __restrict__ dy, float* __restrict__ part, int F, int H,
+                                                      int W, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int nslice = gridDim.y;
+    const int64_t NP = (int64_t)F * H * W, per = (NP + nslice - 1) / nslice;
+    const int64_t p0 = (int64_t)blockIdx.y * per, p1 = min(NP, p0 + per);
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    if (c < C) {
+        for (int64_t p = p0; p < p1; ++p) {
+            const int px = p % W, py = (p / W) % H;
+            const float g = (float)dy[p * C + c];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[t] += g * (float)x[(p + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * C + c];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) part[((int64_t)blockIdx.y * 9 + t) * C + c] = acc[t];
+    }
+}
+
+__global__ __launch_bounds__(256) void dw_reduce_k(const float* __restrict__ part, int nslice, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslice; ++k) s += part[(int64_t)k * n + i];
+    out[i] += s;
+}
+
+// out[f][c] = sum_p a[f,p,c] * b[f,p,c]   (gradient of the SE gate)
+__global__ __launch_bounds__(256) void prod_colsum_k(const bf16* __restrict__ a, const bf16* __restrict__ b, int F, int P, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    const bf16* ap = a + (int64_t)f * P * C + c;
+    const bf16* bp = b + (int64_t)f * P * C + c;
+    int p = 0;
+    for (; p + 1 < P; p += 2) {
+        s0 += (float)ap[(int64_t)p * C] * (float)bp[(int64_t)p * C];
+        s1 += (float)ap[(int64_t)(p + 1) * C] * (float)bp[(int64_t)(p + 1) * C];
+    }
+    if (p < P) s0 += (float)ap[(int64_t)p * C] * (float)bp[(int64_t)p * C];
+    out[(int64_t)f * C + c] = s0 + s1;
+}
+
+// out[f,p,c] = a[f,p,c] * g[f,c] + s[f,c] * k      (da2 = dy3 * gate + d(colmean) / P)
+__global__ __launch_bounds__(256) void scale_add_bcast_k(const bf16* __restrict__ a, const bf16* __restrict__ g, const float* __restrict__ s, float k,
+                                                         bf16* __restrict__ out, int F, int P, int C) {
+    const int cv = C >> 3;
+    const int64_t total = (int64_t)F * P * cv;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int c8 = id % cv;
+        const int f = (int)(id / ((int64_t)P * cv));
+        const bf16x8 v = reinterpret_cast<const bf16x8*>(a)[id];
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(g + (int64_t)f * C + c8 * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)v[j] * (float)gv[j] + (s ? s[(int64_t)f * C + c8 * 8 + j] * k : 0.f));
+        reinterpret_cast<bf16x8*>(out)[id] = o;
+    }
+}
+
+// inverse of conv3d_gather for padding 0 and stride = kernel (non-overlapping windows): dx[t,y,x,:] = dA[(to,ho,wo),(dt,dh,dw),:];
+// positions outside every window (odd trailing rows) get zeros
+__global__ __launch_bounds__(256) void conv3d_scatter_k(const bf16* __restrict__ dA, bf16* __restrict__ dx, int T, int H, int W, int C, int kt, int kh,
+                                                        int kw, int To, int Ho, int Wo) {
+    const int cv = C >> 3;
+    const int64_t total = (int64_t)T * H * W * cv;
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int c8 = id % cv;
+        int64_t p = id / cv;
+        const int x = p % W; p /= W;
+        const int y = p % H;
+        const int t = (int)(p / H);
+        const int to = t / kt, ho = y / kh, wo = x / kw;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (to < To && ho < Ho && wo < Wo) {
+            const int64_t r = ((int64_t)to * Ho + ho) * Wo + wo;
+            const int tap = ((t % kt) * kh + (y % kh)) * kw + (x % kw);
+            v = *reinterpret_cast<const bf16x8*>(dA + (r * (kt * kh * kw) + tap) * C + c8 * 8);
+        }
+        reinterpret_cast<bf16x8*>(dx)[id] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int ufv_act(const void* pre, void* out, int64_t n, int act, void* stream) {
+    UFV_REQUIRE(pre && out && n > 0 && n % 8 == 0, "ufv_act: n must be a positive multiple of 8");
+    hipLaunchKernelGGL((act_k<false>), dim3(grid_for(n / 8)), dim3(256), 0, ST(stream), (const bf16*)pre, nullptr, (bf16*)out, n / 8, act);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_act_bwd(const void* pre, const void* dout, void* dpre, int64_t n, int act, void* stream) {
+    UFV_REQUIRE(pre && dout && dpre && n > 0 && n % 8 == 0, "ufv_act_bwd: n must be a positive multiple of 8");
+    hipLaunchKernelGGL((act_k<true>), dim3(grid_for(n / 8)), dim3(256), 0, ST(stream), (const bf16*)pre, (const bf16*)dout, (bf16*)dpre, n / 8, act);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+    UFV_REQUIRE(a && b && out && n > 0 && n % 8 == 0, "ufv_add_bf16: n must be a positive multiple of 8");
+    hipLaunchKernelGGL(add_bf16_k, dim3(grid_for(n / 8)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, (bf16*)out, n / 8);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int64_t ufv_layernorm_bwd_ws_bytes(int C) { return (int64_t)1024 * 2 * C * sizeof(float); }
+
+extern "C" int ufv_layernorm_bwd(const void* x, int64_t ldx, const float* w, const float* b, const void* dout, int64_t ldd, void* dx,
+                                 int64_t lddx, float* dw, float* db, int M, int C, float eps, int act, void* ws, void* stream) {
+    UFV_REQUIRE(x && w && b && dout && dx && dw && db && ws && M > 0 && C > 0 && C % 8 == 0 && C <= 4096 && ldx % 8 == 0 && ldd % 8 == 0 &&
+                lddx % 8 == 0, "ufv_layernorm_bwd: C=%d must be a multiple of 8 and <= 4096", C);
+    const int blocks = M < 1024 ? cdiv(M, 4) : 256;
+    float* part = reinterpret_cast<float*>(ws);
+    const int nch = C / 8;
+#define LB(MI) hipLaunchKernelGGL((layernorm_bwd_k<MI>), dim3(blocks), dim3(256), 0, ST(stream), (const bf16*)x, ldx, w, b, (const bf16*)dout, ldd, \
+                                  (bf16*)dx, lddx, part, M, C, eps, act)
+    if (nch <= 64) LB(1); else if (nch <= 128) LB(2); else if (nch <= 256) LB(4); else LB(8);
+#undef LB
+    UFV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum2_f32_k, dim3(cdiv(2 * C, 256)), dim3(256), 0, ST(stream), part, (int64_t)2 * C, blocks * 4, C, dw, db);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_ln_add_silu_g(const void* z, const float* wa, const float* ba, const void* s, const float* wb, const float* bb,
+                                 const void* dout, void* g, int M, int C, float eps, void* stream) {
+    UFV_REQUIRE(z && wa && ba && s && dout && g && M > 0 && C % 8 == 0 && C <= 4096 && ((wb != nullptr) == (bb != nullptr)),
+                "ufv_ln_add_silu_g: C=%d must be a multiple of 8 and <= 4096", C);
+    const int nch = C / 8;
+#define LG(MI) hipLaunchKernelGGL((ln_add_silu_g_k<MI>), dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), (const bf16*)z, wa, ba, (const bf16*)s, wb, bb, \
+                                  (const bf16*)dout, (bf16*)g, M, C, eps)
+    if (nch <= 64) LG(1); else if (nch <= 128) LG(2); else if (nch <= 256) LG(4); else LG(8);
+#undef LG
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_dwconv3x3(const void* x, void* y, const float* w9, int F, int H, int W, int C, int flip, void* stream) {
+    UFV_REQUIRE(x && y && w9 && F > 0 && H > 0 && W > 0 && C % 8 == 0, "ufv_dwconv3x3: C must be a multiple of 8");
+    hipLaunchKernelGGL(dwconv3x3_k, dim3(grid_for((int64_t)F * H * W * (C / 8))), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, F, H, W,
+                       C, flip);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int64_t ufv_dwconv3x3_dw_ws_bytes(int C) { return (int64_t)64 * 9 * C * sizeof(float); }
+
+extern "C" int ufv_dwconv3x3_dw(const void* x, const void* dy, float* dw9, int F, int H, int W, int C, void* ws, void* stream) {
+    UFV_REQUIRE(x && dy && dw9 && ws && F > 0 && C > 0, "ufv_dwconv3x3_dw: bad arguments");
+    const int64_t NP = (int64_t)F * H * W;
+    const int nslice = NP >= 64 * 16 ? 64 : 1;
+    float* part = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(dwconv3x3_dw_k, dim3(cdiv(C, 256), nslice), dim3(256), 0, ST(stream), (const bf16*)x, (const bf16*)dy, part, F, H, W, C);
+    UFV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dw_reduce_k, dim3(cdiv(9 * C, 256)), dim3(256), 0, ST(stream), part, nslice, 9 * C, dw9);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_prod_colsum(const void* a, const void* b, int F, int P, int C, float* out, void* stream) {
+    UFV_REQUIRE(a && b && out && F > 0 && P > 0 && C > 0, "ufv_prod_colsum: bad arguments");
+    hipLaunchKernelGGL(prod_colsum_k, dim3(cdiv(C, 256), F), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)b, F, P, C, out);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_scale_add_bcast(const void* a, const void* g, const float* s, float k, void* out, int F, int P, int C, void* stream) {
+    UFV_REQUIRE(a && g && out && F > 0 && P > 0 && C % 8 == 0, "ufv_scale_add_bcast: C must be a multiple of 8");
+    hipLaunchKernelGGL(scale_add_bcast_k, dim3(grid_for((int64_t)F * P * C / 8)), dim3(256), 0, ST(stream), (const bf16*)a, (const bf16*)g, s, k,
+                       (bf16*)out, F, P, C);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_conv3d_scatter(const void* dA, void* dx, int T, int H, int W, int C, int kt, int kh, int kw, void* stream) {
+    UFV_REQUIRE(dA && dx && C % 8 == 0 && kt > 0 && kh > 0 && kw > 0, "ufv_conv3d_scatter: C must be a multiple of 8");
+    const int To = (T - kt) / kt + 1, Ho = (H - kh) / kh + 1, Wo = (W - kw) / kw + 1;
+    UFV_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "ufv_conv3d_scatter: empty output");
+    hipLaunchKernelGGL(conv3d_scatter_k, dim3(grid_for((int64_t)T * H * W * (C / 8))), dim3(256), 0, ST(stream), (const bf16*)dA, (bf16*)dx, T, H,
+                       W, C, kt, kh, kw, To, Ho, Wo);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}

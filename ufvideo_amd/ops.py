@@ -595,3 +595,84 @@ def sample_top_p(logits, temperature, top_k, top_p, u, out=None, kept=None):
     _lib.call("ufv_sample_top_p", lg.data_ptr(), lg.stride(0), M, V, float(temperature), int(top_k), float(top_p), u.data_ptr(),
               out.data_ptr(), _ptr(kept), _stream())
     return out
+
+
+# ---- projector backward (csrc/train_proj.hip) -----------------------------------------------------------------------------
+
+def act_fwd(pre, act):
+    _chk(pre, torch.bfloat16, "pre"); assert pre.is_contiguous()
+    out = torch.empty_like(pre)
+    _lib.call("ufv_act", pre.data_ptr(), out.data_ptr(), pre.numel(), ACT[act], _stream())
+    return out
+
+
+def act_bwd(pre, dout, act):
+    _chk(pre, torch.bfloat16, "pre"); _chk(dout, torch.bfloat16, "dout"); assert pre.is_contiguous() and dout.is_contiguous()
+    out = torch.empty_like(pre)
+    _lib.call("ufv_act_bwd", pre.data_ptr(), dout.data_ptr(), out.data_ptr(), pre.numel(), ACT[act], _stream())
+    return out
+
+
+def add_bf16(a, b):
+    _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b"); assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel()
+    out = torch.empty_like(a)
+    _lib.call("ufv_add_bf16", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+    return out
+
+
+def layernorm_bwd(x, w, b, dout, dw, db, eps, act=None):
+    """x, dout bf16 [M, C] -> dx bf16; dw, db fp32 [C] are added to"""
+    _chk(x, torch.bfloat16, "x"); _chk(dout, torch.bfloat16, "dout"); _chk(dw, torch.float32, "dw"); _chk(db, torch.float32, "db")
+    M, Cc = x.shape
+    dx = torch.empty((M, Cc), device=x.device, dtype=torch.bfloat16)
+    ws = _ws(x.device, _lib.load().ufv_layernorm_bwd_ws_bytes(Cc), "ln_bwd")
+    _lib.call("ufv_layernorm_bwd", x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(), dout.data_ptr(), dout.stride(0), dx.data_ptr(),
+              dx.stride(0), dw.data_ptr(), db.data_ptr(), M, Cc, float(eps), ACT[act], ws.data_ptr(), _stream())
+    return dx
+
+
+def ln_add_silu_g(z, wa, ba, s, wb, bb, dout, eps):
+    for t_, n in ((z, "z"), (s, "s"), (dout, "dout")):
+        _chk(t_, torch.bfloat16, n); assert t_.is_contiguous()
+    M, Cc = z.shape
+    g = torch.empty_like(z)
+    _lib.call("ufv_ln_add_silu_g", z.data_ptr(), wa.data_ptr(), ba.data_ptr(), s.data_ptr(), _ptr(wb), _ptr(bb), dout.data_ptr(), g.data_ptr(),
+              M, Cc, float(eps), _stream())
+    return g
+
+
+def dwconv3x3(x, w9, F, H, W, flip=False):
+    _chk(x, torch.bfloat16, "x"); _chk(w9, torch.float32, "w9"); assert x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.call("ufv_dwconv3x3", x.data_ptr(), y.data_ptr(), w9.data_ptr(), F, H, W, x.shape[-1], int(flip), _stream())
+    return y
+
+
+def dwconv3x3_dw(x, dy, dw9, F, H, W):
+    _chk(x, torch.bfloat16, "x"); _chk(dy, torch.bfloat16, "dy"); _chk(dw9, torch.float32, "dw9")
+    Cc = x.shape[-1]
+    ws = _ws(x.device, _lib.load().ufv_dwconv3x3_dw_ws_bytes(Cc), "dw9")
+    _lib.call("ufv_dwconv3x3_dw", x.data_ptr(), dy.data_ptr(), dw9.data_ptr(), F, H, W, Cc, ws.data_ptr(), _stream())
+    return dw9
+
+
+def prod_colsum(a, b, F, P):
+    _chk(a, torch.bfloat16, "a"); _chk(b, torch.bfloat16, "b")
+    Cc = a.shape[-1]
+    out = torch.empty((F, Cc), device=a.device, dtype=torch.float32)
+    _lib.call("ufv_prod_colsum", a.data_ptr(), b.data_ptr(), F, P, Cc, out.data_ptr(), _stream())
+    return out
+
+
+def scale_add_bcast(a, g, s, k, F, P):
+    _chk(a, torch.bfloat16, "a"); _chk(g, torch.bfloat16, "g")
+    out = torch.empty_like(a)
+    _lib.call("ufv_scale_add_bcast", a.data_ptr(), g.data_ptr(), _ptr(s), float(k), out.data_ptr(), F, P, a.shape[-1], _stream())
+    return out
+
+
+def conv3d_scatter(dA, T, H, W, C, k):
+    _chk(dA, torch.bfloat16, "dA"); assert dA.is_contiguous()
+    dx = torch.empty((T * H * W, C), device=dA.device, dtype=torch.bfloat16)
+    _lib.call("ufv_conv3d_scatter", dA.data_ptr(), dx.data_ptr(), T, H, W, C, k[0], k[1], k[2], _stream())
+    return dx

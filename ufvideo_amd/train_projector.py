@@ -1,0 +1,177 @@
+"""Backward pass of the STC connector (`stc_connector_v35`, ufvideo/model/projector.py:133-238) on the HIP kernels.
+
+The reference trains `mm_projector` with torch autograd (`tune_mm_mlp_adapter` and the full fine-tune both have it in the
+trainable set, train.py:873-912).  `ProjectorGrad` re-runs the connector forward with every pre-activation kept (the inference
+path fuses conv+LN+SiLU and bias+activation into single kernels and keeps nothing) and differentiates it: 1x1 convs / Conv3d /
+Linear through the NT GEMMs (dX = dY W on a transposed weight copy, dW = dY^T X on transposed activations), the rest through
+csrc/train_proj.hip.  RegStage follows timm's bottleneck as restated in ufvideo_amd/model/projector.py (parity-unpinned, see
+DESIGN.md); gradients come back under the reference's parameter names.
+
+Supported: depth >= 0 RegStages, Conv3d sampler with padding 0 and stride = kernel (v35), readout MLP.  bf16 weights only.
+"""
+import torch
+
+from . import ops
+from .model.projector import STCConnector
+
+
+def _lin_bwd(x, w, dy, want_dx=True):
+    """y = x @ w^T: x bf16 [M, K], w bf16 [N, K], dy bf16 [M, N] -> (dx bf16 [M, K] | None, dw fp32 [N, K])"""
+    M, K = x.shape
+    N = w.shape[0]
+    dx = None
+    if want_dx:
+        wT = ops.transpose(w, rpad=ops.round_up(N, 8))                        # [K, N(pad)]
+        dyp = dy
+        if wT.shape[1] != N:                                                  # K dim of the dX GEMM must match: pad dy columns
+            dyp = torch.zeros((M, wT.shape[1]), device=dy.device, dtype=dy.dtype)
+            dyp[:, :N] = dy
+        dx = ops.gemm(dyp, wT)
+    Mp = ops.round_up(M, 128)
+    dyT = ops.transpose(dy, rpad=Mp)                                          # [N, Mp]
+    xT = ops.transpose(x, rpad=Mp)                                            # [K, Mp]
+    dw = ops.gemm(dyT, xT, out_dtype=torch.float32)
+    return dx, dw
+
+
+class ProjectorGrad:
+    def __init__(self, proj):
+        if not isinstance(proj, STCConnector) or proj.AVGPOOL or proj.PADDING != 0:
+            raise NotImplementedError("projector backward is built for the Conv3d connectors with padding 0 (stc_connector_v35)")
+        if getattr(proj, "gemm_dtype", "bf16") != "bf16":
+            raise NotImplementedError("training runs on the bf16 weights")
+        self.proj = proj
+        self.st = None
+
+    # ---- forward with stash ------------------------------------------------------------------------------------------------
+    def _block_fwd(self, x, blk, F, H, W):
+        eps, P = self.proj.ln_eps, H * W
+        C = blk["w1"].shape[0]
+        s = dict(x=x, F=F, H=H, W=W)
+        s["y1"] = ops.gemm(x, blk["w1"])
+        s["a1"] = ops.layernorm(s["y1"], blk["n1"][0], blk["n1"][1], eps, act="silu")
+        s["y2"] = ops.dwconv3x3(s["a1"], blk["w9"], F, H, W)
+        s["a2"] = ops.layernorm(s["y2"], blk["n2"][0], blk["n2"][1], eps, act="silu")
+        s["m"] = ops.colmean(s["a2"], F, P)
+        s["p1"] = ops.gemm(s["m"], blk["se1"][0], bias=blk["se1"][1])
+        s["s1"] = ops.act_fwd(s["p1"], "silu")
+        s["p2"] = ops.gemm(s["s1"], blk["se2"][0], bias=blk["se2"][1])
+        s["gate"] = ops.act_fwd(s["p2"], "sigmoid")
+        s["y3"] = ops.scale_add_bcast(s["a2"], s["gate"], None, 0.0, F, P)
+        s["z"] = ops.gemm(s["y3"], blk["w3"])
+        if blk["ds"] is not None:
+            s["sc"] = ops.gemm(x, blk["ds"][0])
+            out = ops.ln_add_silu(s["z"], blk["n3"][0], blk["n3"][1], s["sc"], blk["ds"][1], blk["ds"][2], eps)
+        else:
+            s["sc"] = None
+            out = ops.ln_add_silu(s["z"], blk["n3"][0], blk["n3"][1], x, None, None, eps)
+        return out, s
+
+    def forward(self, x, t, hw):
+        """x [t*hw*hw, C_in] (one video, token-major, any float dtype) -> fp32 [tokens, hidden]; keeps what backward needs"""
+        pj = self.proj
+        pk = pj.packed()
+        st = dict(t=t, hw=hw, s1=[], s2=[])
+        h = ops.convert(x.contiguous(), torch.bfloat16)
+        for blk in (pk["s1"] if pj.depth else []):
+            h, s = self._block_fwd(h, blk, t, hw, hw)
+            st["s1"].append(s)
+        C = h.shape[1]
+        st["h_pre_sampler_shape"] = (t, hw, hw, C)
+        A, (To, Ho, Wo) = ops.conv3d_gather(h, t, hw, hw, C, pj.downsample, 0)
+        st["A"] = A
+        st["samp_pre"] = ops.gemm(A, pk["samp_w"], bias=pk["samp_b"])
+        h = ops.act_fwd(st["samp_pre"], "silu")
+        for blk in (pk["s2"] if pj.depth else []):
+            h, s = self._block_fwd(h, blk, To, Ho, Wo)
+            st["s2"].append(s)
+        n = len(pk["readout"])
+        st["ro_in"], st["ro_pre"] = [], []
+        for i, (w, b) in enumerate(pk["readout"]):
+            st["ro_in"].append(h)
+            if i == n - 1:
+                h = ops.gemm(h, w, bias=b, out_dtype=torch.float32)
+            else:
+                pre = ops.gemm(h, w, bias=b)
+                st["ro_pre"].append(pre)
+                h = ops.act_fwd(pre, "gelu")
+        self.st = st
+        return h
+
+    # ---- backward ----------------------------------------------------------------------------------------------------
+    def _block_bwd(self, dout, blk, s, g, prefix):
+        eps = self.proj.ln_eps
+        F, H, W = s["F"], s["H"], s["W"]
+        P = H * W
+        x = s["x"]
+        C = blk["w1"].shape[0]
+        dev = dout.device
+        z32 = lambda n: torch.zeros((n,), device=dev, dtype=torch.float32)
+        has_ds = blk["ds"] is not None
+        gg = ops.ln_add_silu_g(s["z"], blk["n3"][0], blk["n3"][1], s["sc"] if has_ds else x, blk["ds"][1] if has_ds else None,
+                               blk["ds"][2] if has_ds else None, dout, eps)
+        dw, db = z32(C), z32(C)
+        dz = ops.layernorm_bwd(s["z"], blk["n3"][0], blk["n3"][1], gg, dw, db, eps)
+        g[prefix + "conv3.bn.weight"], g[prefix + "conv3.bn.bias"] = dw, db
+        if has_ds:
+            dw, db = z32(C), z32(C)
+            dsc = ops.layernorm_bwd(s["sc"], blk["ds"][1], blk["ds"][2], gg, dw, db, eps)
+            g[prefix + "downsample.bn.weight"], g[prefix + "downsample.bn.bias"] = dw, db
+            dx_short, dwd = _lin_bwd(x, blk["ds"][0], dsc)
+            g[prefix + "downsample.conv.weight"] = dwd.view(C, -1, 1, 1)
+        else:
+            dx_short = gg
+        dy3, dw3 = _lin_bwd(s["y3"], blk["w3"], dz)
+        g[prefix + "conv3.conv.weight"] = dw3.view(C, C, 1, 1)
+        # squeeze-excite
+        dgate = ops.convert(ops.prod_colsum(dy3, s["a2"], F, P), torch.bfloat16)
+        dp2 = ops.act_bwd(s["p2"], dgate, "sigmoid")
+        ds1, dwse2 = _lin_bwd(s["s1"], blk["se2"][0], dp2)
+        g[prefix + "se.fc2.weight"] = dwse2.view(C, -1, 1, 1)
+        g[prefix + "se.fc2.bias"] = ops.colsum(dp2, z32(C))
+        dp1 = ops.act_bwd(s["p1"], ds1, "silu")
+        rd = blk["se1"][0].shape[0]
+        dm, dwse1 = _lin_bwd(s["m"], blk["se1"][0], dp1)
+        g[prefix + "se.fc1.weight"] = dwse1.view(rd, C, 1, 1)
+        g[prefix + "se.fc1.bias"] = ops.colsum(dp1, z32(rd))
+        da2 = ops.scale_add_bcast(dy3, s["gate"], ops.convert(dm, torch.float32), 1.0 / P, F, P)
+        dw, db = z32(C), z32(C)
+        dy2 = ops.layernorm_bwd(s["y2"], blk["n2"][0], blk["n2"][1], da2, dw, db, eps, act="silu")
+        g[prefix + "conv2.bn.weight"], g[prefix + "conv2.bn.bias"] = dw, db
+        da1 = ops.dwconv3x3(dy2, blk["w9"], F, H, W, flip=True)
+        dw9 = ops.dwconv3x3_dw(s["a1"], dy2, torch.zeros((9, C), device=dev, dtype=torch.float32), F, H, W)
+        g[prefix + "conv2.conv.weight"] = dw9.t().reshape(C, 1, 3, 3)
+        dw, db = z32(C), z32(C)
+        dy1 = ops.layernorm_bwd(s["y1"], blk["n1"][0], blk["n1"][1], da1, dw, db, eps, act="silu")
+        g[prefix + "conv1.bn.weight"], g[prefix + "conv1.bn.bias"] = dw, db
+        dx_main, dw1 = _lin_bwd(x, blk["w1"], dy1)
+        g[prefix + "conv1.conv.weight"] = dw1.view(C, -1, 1, 1)
+        return ops.add_bf16(dx_main, dx_short.contiguous())
+
+    def backward(self, dout):
+        """dout fp32 [tokens, hidden] = dL / d(projector output) -> ({reference parameter name: fp32 gradient}, dL/dx bf16)"""
+        pj, st = self.proj, self.st
+        pk = pj.packed()
+        g = {}
+        d = ops.convert(dout.contiguous(), torch.bfloat16)
+        n = len(pk["readout"])
+        for i in range(n - 1, -1, -1):
+            w, _ = pk["readout"][i]
+            if i < n - 1:
+                d = ops.act_bwd(st["ro_pre"][i], d, "gelu")
+            g[f"readout.{2 * i}.bias"] = ops.colsum(d, torch.zeros((w.shape[0],), device=d.device, dtype=torch.float32))
+            d, dw = _lin_bwd(st["ro_in"][i], w, d)
+            g[f"readout.{2 * i}.weight"] = dw
+        for i in range(len(st["s2"]) - 1, -1, -1):
+            d = self._block_bwd(d, pk["s2"][i], st["s2"][i], g, f"s2.b{i + 1}.")
+        d = ops.act_bwd(st["samp_pre"], d, "silu")
+        C = pk["samp_w"].shape[0]
+        g["sampler.0.bias"] = ops.colsum(d, torch.zeros((C,), device=d.device, dtype=torch.float32))
+        dA, dws = _lin_bwd(st["A"], pk["samp_w"], d)
+        kt, kh, kw = pj.downsample
+        g["sampler.0.weight"] = dws.view(C, kt, kh, kw, -1).permute(0, 4, 1, 2, 3).contiguous()
+        t, hh, ww, Cc = st["h_pre_sampler_shape"]
+        d = ops.conv3d_scatter(dA, t, hh, ww, Cc, pj.downsample)
+        for i in range(len(st["s1"]) - 1, -1, -1):
+            d = self._block_bwd(d, pk["s1"][i], st["s1"][i], g, f"s1.b{i + 1}.")
+        return g, d
