@@ -367,10 +367,65 @@ def test_projector_grad_vs_oracle_autograd(cin, hid, t, hw, depth):
         y = O.stc_connector(p, xr.view(1, t, hw * hw, cin), downsample=(2, 2, 2), padding=0, depth=depth)
         y[0].backward(dout)
     pg = ProjectorGrad(pj)
-    out = pg.forward(x.to(DEV), t, hw)
+    out, st = pg.forward(x.to(DEV), t, hw)
     assert rel_err(out.cpu(), y[0].detach()) < 3e-2
-    grads, dx = pg.backward(dout.to(DEV))
+    grads, dx = pg.backward(dout.to(DEV), st)
     assert set(grads) == set(sd), set(sd) ^ set(grads)
     worst = max((rel_err(grads[k].cpu().reshape(p[k].shape), p[k].grad), k) for k in sd)
     assert worst[0] < 6e-2, worst
     assert rel_err(dx.float().cpu(), xr.grad) < 6e-2
+
+
+def test_train_step_with_projector_grads_vs_oracle_autograd():
+    """train_projector=True: tower (frozen) -> projector -> splice -> decoder -> CE; the projector's gradients that reach the
+    optimizer equal torch autograd through the oracle's connector + splice + decoder, and the step lowers the loss"""
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
+    vit = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=56, patch_size=14)
+    llm = dict(vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+               rope_theta=10000.0, rms_norm_eps=1e-6)
+    cfg = VideoReferQwen2Config(**llm, mm_vision_tower="siglip", mm_vision_select_layer=-2, mm_vision_select_feature="patch",
+                                mm_projector_type="stc_connector_v35", mm_hidden_size=64, mm_region_encoder_type="pooling",
+                                image_aspect_ratio="square", train_mask_decoder=False, sam_out_dim=256, num_frames=4, sam2_trunk=None,
+                                seg_token_id=299, vision_config=vit)
+    sd = {}
+    sd.update({"model.vision_tower.vision_tower.vision_model." + k: v for k, v in O.make_siglip_weights(vit, seed=1).items()})
+    psd = {k: bfr(v * (3.0 if v.ndim >= 2 else 1.0)) for k, v in O.make_stc_weights(64, 64, seed=2).items()}
+    sd.update({"model.mm_projector." + k: v for k, v in psd.items()})
+    lsd = {k: bfr(v * 3 if v.ndim == 2 else v) for k, v in O.make_qwen2_weights(llm, seed=3).items()}
+    sd.update(lsd)
+    m = VideoReferQwen2ForCausalLM(cfg)
+    m.get_vision_tower().load_model()
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV)
+
+    class Tok:
+        def convert_tokens_to_ids(self, t_):
+            return [290]
+    for mod in m.modules():
+        mod.tokenizer = Tok()
+    g_ = torch.Generator().manual_seed(4)
+    video = torch.randn(4, 3, 56, 56, generator=g_)
+    ids = torch.tensor([[5, 6, -201, 7, 8, 9, 12, 13]])
+    labels = ids.clone(); labels[labels < 0] = -100; labels[:, :2] = -100
+    tr = DecoderTrainer(m, lr=1e-3, train_projector=True)
+    batch = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), attention_mask=torch.ones_like(ids).to(DEV), images=[(video.to(DEV), "video")])
+    r1 = tr.train_step(**batch)
+    # oracle: autograd through connector + splice + decoder
+    feats = O.siglip_tower(sd, vit, video, prefix="model.vision_tower.vision_tower.vision_model.")
+    with torch.enable_grad():
+        p = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
+        mm = O.stc_connector(p, feats[None])
+        am, emb, lab2, _ = O.splice(lsd["model.embed_tokens.weight"].float(), ids, torch.ones_like(ids), labels, mm, [], [], 290, False)
+        out = O.qwen2_forward(lsd, llm, emb, am)
+        loss = O.causal_lm_loss(out["logits"], lab2)
+        loss.backward()
+    assert abs(float(r1["loss"]) - float(loss)) < 3e-2 * float(loss)
+    pb = tr.proj_bucket
+    worst = max((rel_err(pb.view(pb.g, k).cpu(), p[k].grad), k) for k in psd)
+    assert worst[0] < 8e-2, worst
+    r2 = tr.train_step(**batch)
+    r3 = tr.train_step(**batch)
+    assert float(r3["loss"]) < float(r1["loss"])
+    # the connector's own parameters moved (and its packed copies were rebuilt)
+    moved = sum(int((v.detach().float().cpu() != psd[k]).any()) for k, v in m.get_model().mm_projector.named_parameters())
+    assert moved > len(psd) // 2

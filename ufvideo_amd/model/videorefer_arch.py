@@ -284,6 +284,7 @@ class VideoReferMetaForCausalLM(ABC):
         if t_src:
             eids[torch.tensor(t_dst, dtype=torch.int64)] = torch.tensor(t_src, dtype=torch.int64)
         self._last_embed_ids = eids.view(B, S)
+        self._last_mm_map = (list(m_src), list(m_dst), n_mm, tok)       # visual-token rows: mm_features row m_src -> spliced row m_dst
         return None, new_mask, past_key_values, embeds.view(B, S, D), new_labels, plan.mark
 
     def initialize_MM_tokenizer(self, tokenizer):

@@ -100,7 +100,7 @@ class DecoderTrainer:
     initialised, else single process)."""
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 train_embed=True):
+                 train_embed=True, train_projector=False):
         self.model = model
         self.cfg = cfg = model.config
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
@@ -148,6 +148,19 @@ class DecoderTrainer:
             for k in ("ln1", "ln2", "bqkv"):
                 self.small.view(self.small.w, f"{k}.{i}").copy_(L[k])
                 L[k] = self.small.view(self.small.w, f"{k}.{i}")
+        # ---- optional: the multimodal projector (reference: mm_projector is in the trainable set, train.py:873-912).  Its
+        # parameters keep the reference layout (the connector re-packs them after every step); replicated update like `small`.
+        self.pgrad = None
+        self.proj_bucket = None
+        if train_projector:
+            from .train_projector import ProjectorGrad
+            proj = model.get_model().mm_projector
+            self.pgrad = ProjectorGrad(proj)
+            self.proj_params = {k: v for k, v in proj.named_parameters()}
+            self.proj_bucket = _Bucket([(k, tuple(v.shape)) for k, v in self.proj_params.items()], dev, 1, 0, torch.float32, True)
+            for k, v in self.proj_params.items():
+                self.proj_bucket.view(self.proj_bucket.w, k).copy_(v)
+            self.proj_nodecay = [k for k, v in self.proj_params.items() if v.ndim < 2]
         for b in self.buckets():
             b.init_states()
         # ---- transposed weight copies for dX = dY W (the NT GEMM wants W^T rows)
@@ -163,7 +176,7 @@ class DecoderTrainer:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
 
     def buckets(self):
-        return self.layers + [self.head, self.small]
+        return self.layers + [self.head, self.small] + ([self.proj_bucket] if self.proj_bucket is not None else [])
 
     def _refresh_transposes(self):
         for b, t in zip(self.layers, self.wT):
@@ -200,6 +213,8 @@ class DecoderTrainer:
         OVERWRITES them (its dW GEMMs run without the fp32 residual input), which saves one write and one read of the 30 GB
         gradient buffers per step; only the small fp32 gradients and the embedding rows (scatter-add) are zeroed."""
         self.small.g.zero_()
+        if self.proj_bucket is not None:
+            self.proj_bucket.g.zero_()
         if self.train_embed:
             self.head.view(self.head.g, "embed").zero_()
         self._fresh = True
@@ -310,9 +325,24 @@ class DecoderTrainer:
         causal-LM loss averaged over the batch's supervised tokens (HF Qwen2ForCausalLM), backward, exchange, AdamW.
         Returns {"loss", "ce_loss", "grad_norm"}."""
         m = self.model
+        stashes = None
         with torch.no_grad():
+            mm_features = None
+            if self.pgrad is not None:                 # projector forward with every pre-activation kept, one stash per video
+                nf = m.num_frames()
+                vids = torch.stack([d.expand(nf, -1, -1, -1) if modal == "image" else d for d, modal in images], 0)
+                Bv, T = vids.shape[:2]
+                feats = m.get_model().get_vision_tower().encode(vids.reshape(Bv * T, *vids.shape[2:]))      # frozen tower
+                feats = feats.view(Bv, T, feats.shape[1], feats.shape[2])
+                hw = int(feats.shape[2] ** 0.5)
+                outs, stashes = [], []
+                for i in range(Bv):
+                    o, st_ = self.pgrad.forward(feats[i].reshape(T * hw * hw, feats.shape[3]), T, hw)
+                    outs.append(o); stashes.append(st_)
+                mm_features = torch.stack(outs, 0)
             (_, am, _, embeds, new_labels, _) = m.prepare_inputs_labels_for_multimodal(input_ids, attention_mask, None, labels, images, masks,
-                                                                                      frame, ann_indices, frame_nums, video_file)
+                                                                                      frame, ann_indices, frame_nums, video_file,
+                                                                                      mm_features=mm_features)
         if embeds is None:
             raise ValueError("train_step needs multimodal inputs (images=...) as the reference's training batches have")
         eids = m._last_embed_ids
@@ -327,9 +357,22 @@ class DecoderTrainer:
         w = 1.0 / max(n_valid, 1)
         self.zero_grad()
         loss = torch.zeros((), device=self.dev)
+        dxs = torch.zeros((B * S, embeds.shape[2]), device=self.dev, dtype=torch.float32) if stashes is not None else None
         for b in range(B):
-            l_b, _ = self.forward_backward(embeds[b, :lens[b]], shifted[b], embed_ids=eids[b, :lens[b]], loss_weight=w, last=(b == B - 1))
+            l_b, dx_b = self.forward_backward(embeds[b, :lens[b]], shifted[b], embed_ids=eids[b, :lens[b]], loss_weight=w, last=(b == B - 1))
             loss = loss + l_b
+            if dxs is not None:
+                dxs[b * S:b * S + lens[b]].copy_(dx_b)
+        if stashes is not None:                        # visual-token rows of d(inputs_embeds) -> projector backward, per video
+            m_src, m_dst, n_mm, tok = m._last_mm_map
+            d_mm = torch.zeros((n_mm * tok, embeds.shape[2]), device=self.dev, dtype=torch.float32)
+            i64 = lambda l: torch.tensor(l, dtype=torch.int64, device=self.dev)
+            if m_src:
+                ops.gather_rows(dxs, i64(m_dst), d_mm, i64(m_src))
+            for k, st_ in enumerate(stashes):
+                grads, _ = self.pgrad.backward(d_mm[k * tok:(k + 1) * tok], st_)
+                for name, gval in grads.items():
+                    self.proj_bucket.view(self.proj_bucket.g, name).add_(gval.reshape(self.proj_params[name].shape))
         self.step()
         ce = getattr(self.cfg, "ce_loss_weight", 1.0) * loss
         return {"loss": ce, "ce_loss": ce, "grad_norm": getattr(self, "last_grad_norm", None)}
@@ -357,14 +400,15 @@ class DecoderTrainer:
                 if not getattr(b, "reduced", False):              # not already started by _reduce_async
                     reduce_scatter_mean(b.gshard, b.g, self.group)
                 b.reduced = False
-            dist.all_reduce(self.small.g, op=dist.ReduceOp.SUM, group=self.group)
-            self.small.g.mul_(1.0 / self.world)
+            for rb in [self.small] + ([self.proj_bucket] if self.proj_bucket is not None else []):      # replicated buckets
+                dist.all_reduce(rb.g, op=dist.ReduceOp.SUM, group=self.group)
+                rb.g.mul_(1.0 / self.world)
         torch.cuda.current_stream().wait_stream(cs)
 
     def _grad_shards(self):
         out = []
         for b in self.buckets():
-            out.append((b, b.g if (self.world == 1 or b is self.small) else b.gshard))
+            out.append((b, b.g if (self.world == 1 or b.world == 1) else b.gshard))
         return out
 
     def step(self):
@@ -376,22 +420,31 @@ class DecoderTrainer:
         if self.max_grad_norm and self.max_grad_norm > 0:
             tot = torch.zeros((), device=self.dev, dtype=torch.float32)
             small_sq = None
+            small_sq = torch.zeros((), device=self.dev, dtype=torch.float32)
             for b, g in shards:
                 s = ops.sumsq(g).sum()
-                if b is self.small:
-                    small_sq = s
+                if b.world == 1 and self.world > 1:
+                    small_sq = small_sq + s
                 else:
                     tot = tot + s
             if self.world > 1:
                 dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)         # shards are disjoint
-            tot = tot + small_sq                                                     # replicated: counted once
+            tot = tot + small_sq                                                     # replicated buckets: counted once
             norm = tot.sqrt()
             gscale = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0).reshape(1).contiguous()
             self.last_grad_norm = norm
         b1, b2 = self.betas
         for b, g in shards:
             wd = self.wd if b.decay else 0.0
-            if b is self.small:
+            if b is self.proj_bucket:                 # decay on matrices only: two passes over the flat buffer by entry
+                for name, shape, off, n in b.entries:
+                    ops.adamw(b.master[off:off + n], g[off:off + n], b.m[off:off + n], b.v[off:off + n], None, self.lr, b1, b2, self.eps,
+                              0.0 if name in self.proj_nodecay else self.wd, self.t, gscale)
+                b.w.copy_(b.master)
+                for k, v in self.proj_params.items():
+                    v.data.copy_(b.view(b.w, k))
+                self.pgrad.proj.invalidate()
+            elif b is self.small:
                 ops.adamw(b.master, g, b.m, b.v, None, self.lr, b1, b2, self.eps, wd, self.t, gscale)
                 b.w.copy_(b.master)
             else:

@@ -41,7 +41,6 @@ class ProjectorGrad:
         if getattr(proj, "gemm_dtype", "bf16") != "bf16":
             raise NotImplementedError("training runs on the bf16 weights")
         self.proj = proj
-        self.st = None
 
     # ---- forward with stash ------------------------------------------------------------------------------------------------
     def _block_fwd(self, x, blk, F, H, W):
@@ -68,7 +67,7 @@ class ProjectorGrad:
         return out, s
 
     def forward(self, x, t, hw):
-        """x [t*hw*hw, C_in] (one video, token-major, any float dtype) -> fp32 [tokens, hidden]; keeps what backward needs"""
+        """x [t*hw*hw, C_in] (one video, token-major, any float dtype) -> (fp32 [tokens, hidden], stash for backward)"""
         pj = self.proj
         pk = pj.packed()
         st = dict(t=t, hw=hw, s1=[], s2=[])
@@ -95,8 +94,7 @@ class ProjectorGrad:
                 pre = ops.gemm(h, w, bias=b)
                 st["ro_pre"].append(pre)
                 h = ops.act_fwd(pre, "gelu")
-        self.st = st
-        return h
+        return h, st
 
     # ---- backward ----------------------------------------------------------------------------------------------------
     def _block_bwd(self, dout, blk, s, g, prefix):
@@ -148,9 +146,10 @@ class ProjectorGrad:
         g[prefix + "conv1.conv.weight"] = dw1.view(C, -1, 1, 1)
         return ops.add_bf16(dx_main, dx_short.contiguous())
 
-    def backward(self, dout):
-        """dout fp32 [tokens, hidden] = dL / d(projector output) -> ({reference parameter name: fp32 gradient}, dL/dx bf16)"""
-        pj, st = self.proj, self.st
+    def backward(self, dout, st):
+        """dout fp32 [tokens, hidden] = dL / d(projector output), st = the stash forward() returned
+        -> ({reference parameter name: fp32 gradient}, dL/dx bf16)"""
+        pj = self.proj
         pk = pj.packed()
         g = {}
         d = ops.convert(dout.contiguous(), torch.bfloat16)
