@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void add_bf16_k(const bf16* __restrict__ a, co
 // Row LayerNorm (+ optional activation) backward, one wave per row, grid-stride over rows.
 //   xh = (x - mean) * rstd;  y = xh * w + b;  out = act(y)
 //   g = dout * act'(y);  dw += sum_rows g * xh;  db += sum_rows g;  dx = rstd * (g*w - mean(g*w) - xh * mean(g*w*xh))
-// The row (<= 8 KB of bf16) is re-read from L1/L2 for each of the four passes instead of being kept in registers, which
-// leaves the registers to the per-wave dw / db partials (written once per wave, reduced by colsum_f32: deterministic).
+// The row and its incoming gradient are loaded once and stay in registers as bf16 (64 VGPRs at C = 4096) beside the per-wave
+// dw / db partials (128 VGPRs), which are written once per wave and reduced in two ordered stages (deterministic, no atomics).
 // ---------------------------------------------------------------------------------------------------------
 template <int MAXI>
 __global__ __launch_bounds__(256) void layernorm_bwd_k(const bf16* __restrict__ x, int64_t ldx, const float* __restrict__ w, const float* __restrict__ b,
@@ -75,43 +75,42 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const bf16* __restrict__ 
     for (int row = wid; row < M; row += nw) {
         const bf16* xr = x + (int64_t)row * ldx;
         const bf16* dr = dout + (int64_t)row * ldd;
+        bf16x8 xv[MAXI], dv[MAXI];                                   // the row and its incoming gradient stay in registers (bf16)
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+                xv[i] = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+                dv[i] = *reinterpret_cast<const bf16x8*>(dr + ch * 8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += (float)v[j];
+                for (int j = 0; j < 8; ++j) s += (float)xv[i][j];
             }
         }
         const float mean = wave_sum(s) / C;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int ch = lane + 64 * i;
-            if (ch < nch) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + ch * 8);
+        for (int i = 0; i < MAXI; ++i)
+            if (lane + 64 * i < nch) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mean; q += d * d; }
+                for (int j = 0; j < 8; ++j) { const float d = (float)xv[i][j] - mean; q += d * d; }
             }
-        }
         const float rstd = rsqrtf(wave_sum(q) / C + eps);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + ch * 8), d = *reinterpret_cast<const bf16x8*>(dr + ch * 8);
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + ch * 8), w1 = *reinterpret_cast<const f32x4*>(w + ch * 8 + 4);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + ch * 8), b1 = *reinterpret_cast<const f32x4*>(b + ch * 8 + 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float ww = j < 4 ? w0[j & 3] : w1[j & 3], bb = j < 4 ? b0[j & 3] : b1[j & 3];
-                    const float xh = ((float)v[j] - mean) * rstd;
-                    const float g = (float)d[j] * (act ? act_grad(xh * ww + bb, act) : 1.f);
+                    const float xh = ((float)xv[i][j] - mean) * rstd;
+                    const float g = (float)dv[i][j] * (act ? act_grad(xh * ww + bb, act) : 1.f);
                     aw[i][j] += g * xh; ab[i][j] += g;
                     s1 += g * ww; s2 += g * ww * xh;
+                    dv[i][j] = (bf16)g;                               // g replaces dout (bf16-rounded; dx below uses the same value)
                 }
             }
         }
@@ -120,16 +119,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const bf16* __restrict__ 
         for (int i = 0; i < MAXI; ++i) {
             const int ch = lane + 64 * i;
             if (ch < nch) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + ch * 8), d = *reinterpret_cast<const bf16x8*>(dr + ch * 8);
                 const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + ch * 8), w1 = *reinterpret_cast<const f32x4*>(w + ch * 8 + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + ch * 8), b1 = *reinterpret_cast<const f32x4*>(b + ch * 8 + 4);
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float ww = j < 4 ? w0[j & 3] : w1[j & 3], bb = j < 4 ? b0[j & 3] : b1[j & 3];
-                    const float xh = ((float)v[j] - mean) * rstd;
-                    const float g = (float)d[j] * (act ? act_grad(xh * ww + bb, act) : 1.f);
-                    o[j] = (bf16)(rstd * (g * ww - s1 - xh * s2));
+                    const float ww = j < 4 ? w0[j & 3] : w1[j & 3];
+                    const float xh = ((float)xv[i][j] - mean) * rstd;
+                    o[j] = (bf16)(rstd * ((float)dv[i][j] * ww - s1 - xh * s2));
                 }
                 *reinterpret_cast<bf16x8*>(dx + (int64_t)row * lddx + ch * 8) = o;
             }
@@ -146,13 +142,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_k(const bf16* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void colsum2_f32_k(const float* __restrict__ x, int64_t ld, int R, int C, float* __restrict__ out0,
-                                                     float* __restrict__ out1) {
-    const int c = blockIdx.x * 256 + threadIdx.x;          // column of the [R, 2C] partial image
+// stage 1: tmp[slice][c] = sum of the slice's rows of the [R, 2C] partial image;  stage 2 (gridDim.y == 1, out0/out1 given):
+// adds the slices into dw (columns < C) and db (columns >= C)
+__global__ __launch_bounds__(256) void colsum2_f32_k(const float* __restrict__ x, int64_t ld, int R, int C, float* __restrict__ tmp,
+                                                     float* __restrict__ out0, float* __restrict__ out1) {
+    const int c = blockIdx.x * 256 + threadIdx.x;          // column of the [R, 2C] image
     if (c >= 2 * C) return;
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += x[(int64_t)r * ld + c];
-    if (c < C) out0[c] += s; else out1[c - C] += s;
+    const int per = (R + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(R, r0 + per);
+    float s0 = 0.f, s1 = 0.f;
+    int r = r0;
+    for (; r + 1 < r1; r += 2) { s0 += x[(int64_t)r * ld + c]; s1 += x[(int64_t)(r + 1) * ld + c]; }
+    if (r < r1) s0 += x[(int64_t)r * ld + c];
+    const float s = s0 + s1;
+    if (tmp) tmp[(int64_t)blockIdx.y * 2 * C + c] = s;
+    else if (c < C) out0[c] += s;
+    else out1[c - C] += s;
 }
 
 // g = dout * silu'(LN_a(z) + (LN_b(s) | s))   (the gradient entering both branches of a bottleneck's output); one wave per row
@@ -361,7 +365,7 @@ extern "C" int ufv_add_bf16(const void* a, const void* b, void* out, int64_t n, 
     return UFV_OK;
 }
 
-extern "C" int64_t ufv_layernorm_bwd_ws_bytes(int C) { return (int64_t)1024 * 2 * C * sizeof(float); }
+extern "C" int64_t ufv_layernorm_bwd_ws_bytes(int C) { return (int64_t)(1024 + 32) * 2 * C * sizeof(float); }
 
 extern "C" int ufv_layernorm_bwd(const void* x, int64_t ldx, const float* w, const float* b, const void* dout, int64_t ldd, void* dx,
                                  int64_t lddx, float* dw, float* db, int M, int C, float eps, int act, void* ws, void* stream) {
@@ -375,7 +379,15 @@ extern "C" int ufv_layernorm_bwd(const void* x, int64_t ldx, const float* w, con
     if (nch <= 64) LB(1); else if (nch <= 128) LB(2); else if (nch <= 256) LB(4); else LB(8);
 #undef LB
     UFV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum2_f32_k, dim3(cdiv(2 * C, 256)), dim3(256), 0, ST(stream), part, (int64_t)2 * C, blocks * 4, C, dw, db);
+    float* tmp = part + (int64_t)1024 * 2 * C;
+    const int R = blocks * 4, slices = R >= 64 ? 32 : 1;
+    if (slices > 1) {
+        hipLaunchKernelGGL(colsum2_f32_k, dim3(cdiv(2 * C, 256), slices), dim3(256), 0, ST(stream), part, (int64_t)2 * C, R, C, tmp, nullptr, nullptr);
+        UFV_CHECK_LAUNCH();
+        hipLaunchKernelGGL(colsum2_f32_k, dim3(cdiv(2 * C, 256), 1), dim3(256), 0, ST(stream), tmp, (int64_t)2 * C, slices, C, nullptr, dw, db);
+    } else {
+        hipLaunchKernelGGL(colsum2_f32_k, dim3(cdiv(2 * C, 256), 1), dim3(256), 0, ST(stream), part, (int64_t)2 * C, R, C, nullptr, dw, db);
+    }
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
