@@ -421,7 +421,7 @@ def test_train_step_with_projector_grads_vs_oracle_autograd():
         loss.backward()
     assert abs(float(r1["loss"]) - float(loss)) < 3e-2 * float(loss)
     pb = tr.proj_bucket
-    worst = max((rel_err(pb.view(pb.g, k).cpu(), p[k].grad), k) for k in psd)
+    worst = max((rel_err(pb.view(pb.g, "mm_projector." + k).cpu(), p[k].grad), k) for k in psd)
     assert worst[0] < 8e-2, worst
     r2 = tr.train_step(**batch)
     r3 = tr.train_step(**batch)
@@ -429,3 +429,33 @@ def test_train_step_with_projector_grads_vs_oracle_autograd():
     # the connector's own parameters moved (and its packed copies were rebuilt)
     moved = sum(int((v.detach().float().cpu() != psd[k]).any()) for k, v in m.get_model().mm_projector.named_parameters())
     assert moved > len(psd) // 2
+
+
+def test_train_step_with_region_encoder_grads_vs_oracle_autograd():
+    """train_region_encoder=True on the golden `vid_region` sample (two region tokens): the MLP's gradients equal torch autograd
+    through oracle mask_extractor + splice + decoder"""
+    m, a, w = tiny_model()
+    video, frame, mask = t(a["video"]).to(DEV), t(a["frame"]).to(DEV), t(a["mask"]).to(DEV)
+    ids = t(a["sp_vid_region_ids"])
+    labels = ids.clone(); labels[labels < 0] = -100; labels[:, :2] = -100
+    tr = DecoderTrainer(m, lr=1e-3, train_region_encoder=True)
+    r1 = tr.train_step(input_ids=ids.to(DEV), labels=labels.to(DEV), attention_mask=torch.ones_like(ids).to(DEV), images=[(video, "video")],
+                       masks=[mask], frame=[frame], ann_indices=[[[0], [1]]], frame_nums=[2])
+    vt = "model.vision_tower.vision_tower.vision_model."
+    vt = vt if any(k.startswith(vt) for k in w) else "model.vision_tower.vision_tower."
+    feats = O.siglip_tower(w, dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=56, patch_size=14),
+                           t(a["frame"]), prefix=vt)
+    names = [k for k in w if k.startswith("model.region_encoder.")]
+    with torch.enable_grad():
+        p = {k: bfr(w[k]).requires_grad_(True) for k in names}
+        full = dict(w); full.update(p)
+        mf, nums = O.mask_extractor(full, feats, [t(a["mask"])], [[[0], [1]]], prefix="model.region_encoder.")
+        wl = {k: bfr(v) for k, v in w.items()}
+        am, emb, lab2, _ = O.splice(wl["model.embed_tokens.weight"].float(), ids, torch.ones_like(ids), labels, t(a["mm_features"]), mf, nums, 290, True)
+        loss = O.causal_lm_loss(O.qwen2_forward(wl, TINY_LLM, emb, am)["logits"], lab2)
+        loss.backward()
+    assert abs(float(r1["loss"]) - float(loss)) < 3e-2 * float(loss)
+    pb = tr.proj_bucket
+    for k in names:
+        kk = k[len("model."):]
+        assert rel_err(pb.view(pb.g, kk).cpu(), p[k].grad) < 8e-2, k

@@ -45,7 +45,7 @@ class MaskExtractor(PackedModule):
     def _pack(self):
         return [(bf(self.feat_linear.get(f"{2 * i}.weight")), f32(self.feat_linear.get(f"{2 * i}.bias"))) for i in range(self.depth)]
 
-    def forward(self, feats, masks, X_features, ann_indices, frame_nums):
+    def forward(self, feats, masks, X_features, ann_indices, frame_nums, stash=None):
         """feats [n_frames, P, C] tower features; masks: list of [q, H, W]; -> (tokens [sum, hidden] fp32, region_token_nums)"""
         dev = feats.device
         N = int(pow(feats.shape[1], 0.5))
@@ -74,11 +74,38 @@ class MaskExtractor(PackedModule):
                 start += len(index)
             query_feats.append(torch.cat(merged, dim=1).reshape(-1, raw.shape[-1]))
         mf = ops.convert(torch.cat(query_feats, dim=0).contiguous(), torch.bfloat16)
+        if stash is not None:                       # training (ufvideo_amd.train): keep the MLP input and its pre-activations
+            stash["in"], stash["pre"] = [], []
         pk = self.packed()
         for i, (w, b) in enumerate(pk):
             last = i == len(pk) - 1
-            mf = ops.gemm(mf, w, bias=b, act=None if last else "gelu", out_dtype=torch.float32 if last else torch.bfloat16)
+            if stash is None:
+                mf = ops.gemm(mf, w, bias=b, act=None if last else "gelu", out_dtype=torch.float32 if last else torch.bfloat16)
+            else:
+                stash["in"].append(mf)
+                if last:
+                    mf = ops.gemm(mf, w, bias=b, out_dtype=torch.float32)
+                else:
+                    pre = ops.gemm(mf, w, bias=b)
+                    stash["pre"].append(pre)
+                    mf = ops.act_fwd(pre, "gelu")
         return mf, region_token_nums
+
+    def backward(self, dout, stash):
+        """dout fp32 [tokens, hidden] -> {feat_linear.N.weight / bias: fp32 gradient} (the pooled tower features are constants:
+        the tower is frozen in the reference, encoder.py:122,134)"""
+        from ..train_projector import _lin_bwd
+        pk = self.packed()
+        g = {}
+        d = ops.convert(dout.contiguous(), torch.bfloat16)
+        for i in range(len(pk) - 1, -1, -1):
+            w, _ = pk[i]
+            if i < len(pk) - 1:
+                d = ops.act_bwd(stash["pre"][i], d, "gelu")
+            g[f"feat_linear.{2 * i}.bias"] = ops.colsum(d, torch.zeros((w.shape[0],), device=d.device, dtype=torch.float32))
+            d, dw = _lin_bwd(stash["in"][i], w, d, want_dx=i > 0)
+            g[f"feat_linear.{2 * i}.weight"] = dw
+        return g
 
 
 def build_region_encoder(config, image_aspect_ratio, **kw):

@@ -244,7 +244,7 @@ class VideoReferMetaForCausalLM(ABC):
         raise Exception(f"Unsupported projector type {kind}!!!")
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, attention_mask, past_key_values, labels, images, masks, frame,
-                                             ann_indices, frame_nums, video_file="", mm_features=None):
+                                             ann_indices, frame_nums, video_file="", mm_features=None, region_stash=None):
         """-> (None, attention_mask, past_key_values, inputs_embeds [B,S,D] fp32, labels, mark_mm_token_indices)
         (ref :218-370).  `mm_features` (extension): visual tokens computed elsewhere, e.g. by
         parallel.encode_frame_sharded, skip the local encode."""
@@ -257,7 +257,7 @@ class VideoReferMetaForCausalLM(ABC):
         if frame is not None:
             frame_cns = torch.cat(frame, dim=0)
             first = vision_tower.encode(frame_cns)
-            mask_feats, region_token_nums = model.region_encoder(first, masks, mm_features, ann_indices, frame_nums)
+            mask_feats, region_token_nums = model.region_encoder(first, masks, mm_features, ann_indices, frame_nums, stash=region_stash)
         else:
             mask_feats, region_token_nums = None, []
         ids_host = input_ids.tolist()
@@ -285,6 +285,7 @@ class VideoReferMetaForCausalLM(ABC):
             eids[torch.tensor(t_dst, dtype=torch.int64)] = torch.tensor(t_src, dtype=torch.int64)
         self._last_embed_ids = eids.view(B, S)
         self._last_mm_map = (list(m_src), list(m_dst), n_mm, tok)       # visual-token rows: mm_features row m_src -> spliced row m_dst
+        self._last_region_map = (list(r_src), list(r_dst), 0 if mask_feats is None else mask_feats.shape[0])
         return None, new_mask, past_key_values, embeds.view(B, S, D), new_labels, plan.mark
 
     def initialize_MM_tokenizer(self, tokenizer):

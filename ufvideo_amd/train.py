@@ -100,7 +100,7 @@ class DecoderTrainer:
     initialised, else single process)."""
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 train_embed=True, train_projector=False):
+                 train_embed=True, train_projector=False, train_region_encoder=False):
         self.model = model
         self.cfg = cfg = model.config
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
@@ -151,12 +151,17 @@ class DecoderTrainer:
         # ---- optional: the multimodal projector (reference: mm_projector is in the trainable set, train.py:873-912).  Its
         # parameters keep the reference layout (the connector re-packs them after every step); replicated update like `small`.
         self.pgrad = None
-        self.proj_bucket = None
+        self.proj_bucket = None                # "auxiliary" bucket: projector and / or region encoder, replicated update
+        self.aux_modules = {}
         if train_projector:
             from .train_projector import ProjectorGrad
-            proj = model.get_model().mm_projector
-            self.pgrad = ProjectorGrad(proj)
-            self.proj_params = {k: v for k, v in proj.named_parameters()}
+            self.pgrad = ProjectorGrad(model.get_model().mm_projector)
+            self.aux_modules["mm_projector."] = model.get_model().mm_projector
+        self.train_region = bool(train_region_encoder)
+        if self.train_region:
+            self.aux_modules["region_encoder."] = model.get_model().region_encoder
+        if self.aux_modules:
+            self.proj_params = {pre + k: v for pre, mod in self.aux_modules.items() for k, v in mod.named_parameters()}
             self.proj_bucket = _Bucket([(k, tuple(v.shape)) for k, v in self.proj_params.items()], dev, 1, 0, torch.float32, True)
             for k, v in self.proj_params.items():
                 self.proj_bucket.view(self.proj_bucket.w, k).copy_(v)
@@ -321,7 +326,8 @@ class DecoderTrainer:
     def train_step(self, input_ids=None, labels=None, attention_mask=None, images=None, masks=None, frame=None, ann_indices=None,
                    frame_nums=None, video_file=None, **_unused):
         """One optimizer step on a collated batch with the keys the reference's collator produces (train.py:706-732; SURVEY
-        §3.5): splice (tower + projector + region encoder run forward-only: they are outside this slice's trainable set),
+        §3.5): splice (the tower is frozen; projector / region encoder are trained when the trainer was built with
+        train_projector / train_region_encoder, else they run forward-only),
         causal-LM loss averaged over the batch's supervised tokens (HF Qwen2ForCausalLM), backward, exchange, AdamW.
         Returns {"loss", "ce_loss", "grad_norm"}."""
         m = self.model
@@ -340,9 +346,10 @@ class DecoderTrainer:
                     o, st_ = self.pgrad.forward(feats[i].reshape(T * hw * hw, feats.shape[3]), T, hw)
                     outs.append(o); stashes.append(st_)
                 mm_features = torch.stack(outs, 0)
+            region_stash = {} if (self.train_region and frame is not None) else None
             (_, am, _, embeds, new_labels, _) = m.prepare_inputs_labels_for_multimodal(input_ids, attention_mask, None, labels, images, masks,
                                                                                       frame, ann_indices, frame_nums, video_file,
-                                                                                      mm_features=mm_features)
+                                                                                      mm_features=mm_features, region_stash=region_stash)
         if embeds is None:
             raise ValueError("train_step needs multimodal inputs (images=...) as the reference's training batches have")
         eids = m._last_embed_ids
@@ -357,7 +364,8 @@ class DecoderTrainer:
         w = 1.0 / max(n_valid, 1)
         self.zero_grad()
         loss = torch.zeros((), device=self.dev)
-        dxs = torch.zeros((B * S, embeds.shape[2]), device=self.dev, dtype=torch.float32) if stashes is not None else None
+        need_dx = stashes is not None or region_stash is not None
+        dxs = torch.zeros((B * S, embeds.shape[2]), device=self.dev, dtype=torch.float32) if need_dx else None
         for b in range(B):
             l_b, dx_b = self.forward_backward(embeds[b, :lens[b]], shifted[b], embed_ids=eids[b, :lens[b]], loss_weight=w, last=(b == B - 1))
             loss = loss + l_b
@@ -372,6 +380,16 @@ class DecoderTrainer:
             for k, st_ in enumerate(stashes):
                 grads, _ = self.pgrad.backward(d_mm[k * tok:(k + 1) * tok], st_)
                 for name, gval in grads.items():
+                    name = "mm_projector." + name
+                    self.proj_bucket.view(self.proj_bucket.g, name).add_(gval.reshape(self.proj_params[name].shape))
+        if region_stash:                               # region-token rows -> the region encoder's MLP
+            r_src, r_dst, n_reg = m._last_region_map
+            if r_src:
+                i64 = lambda l: torch.tensor(l, dtype=torch.int64, device=self.dev)
+                d_reg = torch.zeros((n_reg, embeds.shape[2]), device=self.dev, dtype=torch.float32)
+                ops.gather_rows(dxs, i64(r_dst), d_reg, i64(r_src))
+                for name, gval in m.get_model().region_encoder.backward(d_reg, region_stash).items():
+                    name = "region_encoder." + name
                     self.proj_bucket.view(self.proj_bucket.g, name).add_(gval.reshape(self.proj_params[name].shape))
         self.step()
         ce = getattr(self.cfg, "ce_loss_weight", 1.0) * loss
@@ -443,7 +461,8 @@ class DecoderTrainer:
                 b.w.copy_(b.master)
                 for k, v in self.proj_params.items():
                     v.data.copy_(b.view(b.w, k))
-                self.pgrad.proj.invalidate()
+                for mod in self.aux_modules.values():
+                    mod.invalidate()
             elif b is self.small:
                 ops.adamw(b.master, g, b.m, b.v, None, self.lr, b1, b2, self.eps, wd, self.t, gscale)
                 b.w.copy_(b.master)
