@@ -459,3 +459,61 @@ def test_train_step_with_region_encoder_grads_vs_oracle_autograd():
     for k in names:
         kk = k[len("model."):]
         assert rel_err(pb.view(pb.g, kk).cpu(), p[k].grad) < 8e-2, k
+
+
+# ---- projector-backward kernels alone vs torch ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("act,fn", [("silu", F.silu), ("sigmoid", torch.sigmoid), ("gelu", F.gelu), ("relu", F.relu)])
+def test_act_fwd_bwd_vs_autograd(act, fn):
+    g = torch.Generator().manual_seed(41)
+    pre, dout = bfr(torch.randn(33, 72, generator=g) * 2), bfr(torch.randn(33, 72, generator=g))
+    pr = pre.clone().requires_grad_(True)
+    y = fn(pr); y.backward(dout)
+    assert rel_err(ops.act_fwd(pre.to(torch.bfloat16).to(DEV), act).float().cpu(), y.detach()) < 1e-2
+    assert rel_err(ops.act_bwd(pre.to(torch.bfloat16).to(DEV), dout.to(torch.bfloat16).to(DEV), act).float().cpu(), pr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("M,C,act", [(37, 64, None), (300, 1152, "silu"), (1100, 3584, "silu")])
+def test_layernorm_bwd_vs_autograd(M, C, act):
+    g = torch.Generator().manual_seed(M + C)
+    x, dout = bfr(torch.randn(M, C, generator=g) * 2 + 0.3), bfr(torch.randn(M, C, generator=g))
+    w, b = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (C,), wr, br, 1e-5)
+    (F.silu(y) if act else y).backward(dout)
+    dw, db = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.layernorm_bwd(x.to(torch.bfloat16).to(DEV), w.to(DEV), b.to(DEV), dout.to(torch.bfloat16).to(DEV), dw, db, 1e-5, act=act)
+    assert rel_err(dx.float().cpu(), xr.grad) < 2e-2
+    assert rel_err(dw.cpu() - 1, wr.grad) < 1e-2 and rel_err(db.cpu(), br.grad) < 1e-2          # dw / db are added to
+
+
+def test_dwconv_se_gather_kernels_vs_torch():
+    g = torch.Generator().manual_seed(43)
+    Fr, H, W, C = 3, 5, 6, 64
+    x = bfr(torch.randn(Fr, H, W, C, generator=g)); w9 = torch.randn(9, C, generator=g)
+    dy = bfr(torch.randn(Fr, H, W, C, generator=g))
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w9.t().reshape(C, 1, 3, 3).clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, padding=1, groups=C)
+    y.backward(dy.permute(0, 3, 1, 2))
+    xd, dyd = x.reshape(-1, C).to(torch.bfloat16).to(DEV), dy.reshape(-1, C).to(torch.bfloat16).to(DEV)
+    assert rel_err(ops.dwconv3x3(xd, w9.to(DEV), Fr, H, W).float().cpu().view(Fr, H, W, C), y.detach().permute(0, 2, 3, 1)) < 1e-2
+    assert rel_err(ops.dwconv3x3(dyd, w9.to(DEV), Fr, H, W, flip=True).float().cpu().view(Fr, H, W, C), xr.grad.permute(0, 2, 3, 1)) < 1e-2
+    dw9 = ops.dwconv3x3_dw(xd, dyd, torch.zeros(9, C, device=DEV), Fr, H, W)
+    assert rel_err(dw9.cpu(), wr.grad.reshape(C, 9).t()) < 1e-2
+    # SE pieces
+    P = H * W
+    a, b_ = bfr(torch.randn(Fr, P, C, generator=g)), bfr(torch.randn(Fr, P, C, generator=g))
+    assert rel_err(ops.prod_colsum(a.to(torch.bfloat16).to(DEV), b_.to(torch.bfloat16).to(DEV), Fr, P).cpu(), (a * b_).sum(1)) < 1e-4
+    gate, s = bfr(torch.rand(Fr, C, generator=g)), torch.randn(Fr, C, generator=g)
+    out = ops.scale_add_bcast(a.reshape(-1, C).to(torch.bfloat16).to(DEV), gate.to(torch.bfloat16).to(DEV), s.to(DEV), 0.25, Fr, P)
+    assert rel_err(out.float().cpu().view(Fr, P, C), a * gate[:, None] + 0.25 * s[:, None]) < 1e-2
+    # conv3d scatter is the inverse of the non-overlapping gather (odd trailing rows get zeros)
+    T, Hh, Ww = 5, 4, 6
+    h = bfr(torch.randn(T * Hh * Ww, C, generator=g)).to(torch.bfloat16).to(DEV)
+    A, (To, Ho, Wo) = ops.conv3d_gather(h, T, Hh, Ww, C, (2, 2, 2), 0)
+    back = ops.conv3d_scatter(A, T, Hh, Ww, C, (2, 2, 2)).view(T, Hh, Ww, C)
+    ref = h.view(T, Hh, Ww, C).clone(); ref[2 * To:] = 0
+    assert torch.equal(back, ref)
+    s2 = ops.add_bf16(h, h)
+    assert torch.equal(s2.float(), (h.float() * 2).to(torch.bfloat16).float())
