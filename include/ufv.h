@@ -201,6 +201,22 @@ int64_t ufv_qwen2_decode_ws_bytes(const ufv_qwen2_model* m);
  * [vocab], optional hidden_out f32 [d] (final-norm hidden state), next_token_dev = argmax. */
 int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* token_dev, int pos, void* ws, int64_t ws_bytes, float* logits,
                           float* hidden_out, int64_t* next_token_dev, void* stream);
+/* the same with the position in device memory (*pos_dev, incremented by the step): every launch argument is identical from
+ * token to token, so the step can be recorded once into a HIP graph and replayed (ufv_graph_*) */
+int ufv_qwen2_decode_step_dev(const ufv_qwen2_model* m, const int64_t* token_dev, int* pos_dev, void* ws, int64_t ws_bytes, float* logits,
+                              float* hidden_out, int64_t* next_token_dev, void* stream);
+/* pieces of it: RoPE + KV append of ONE token at position *pos_dev; decode attention over *pos_dev + 1 <= max_keys keys; *p += v */
+int ufv_rope_kv1_dev(void* qkv, int Hq, int Hkv, int hd, const float* inv_freq, const int* pos_dev, void* kv_cache, int ldkv, void* stream);
+int ufv_attention_decode_dev(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_ss, const void* v, int64_t v_bs,
+                             int64_t v_ss, void* o, int64_t o_bs, int B, int Hq, int Hkv, const int* pos_dev, int max_keys, int hd,
+                             float scale, void* ws, int nsplit, void* stream);
+int ufv_add_int(int* p, int v, void* stream);
+/* HIP-graph capture of a launch-bound call sequence: begin; ufv_* calls on `stream` (a created stream, not the legacy default
+ * one) are recorded instead of executed; end returns an executable graph; launch replays it on a stream */
+int ufv_graph_begin(void* stream);
+int ufv_graph_end(void* stream, void** exec_out);
+int ufv_graph_launch(void* exec, void* stream);
+int ufv_graph_destroy(void* exec);
 
 /* ---- W8A8 fp8 GEMM path (SURVEY §8f row 1 / BASELINE config #5a; not in the reference, which runs bf16/fp16) ----
  * OCP e4m3 operands with one fp32 scale per row: x[m,k] ~ q[m,k] * scale[m], scale = max|x[m,:]| / 448,

@@ -369,3 +369,24 @@ def test_generate_do_sample_reproducible_and_top_k1_is_greedy():
         torch.manual_seed(seed)
         outs.add(tuple(m.generate(ids, do_sample=True, temperature=3.0, top_p=1.0, top_k=0, **kw)["output"].cpu().flatten().tolist()))
     assert len(outs) > 1                                                                   # hot sampling actually varies
+
+
+def test_decode_graph_replay_equals_per_launch_decode():
+    """generate() with the decode step replayed from a HIP graph (device-side position) == the per-launch decode loop: same
+    tokens, same per-step hidden states, greedy and sampled"""
+    m, a, _ = tiny_model()
+    video = t(a["video"]).to(DEV)
+    ids = torch.tensor([[5, 6, -201, 7, 8, 9]], device=DEV)
+    kw = dict(attention_mask=torch.ones_like(ids), images=[(video, "video")], images_sam=torch.zeros(1, 4, 3, 8, 8, device=DEV), offset=[0, 1],
+              label_list=torch.zeros(56, 56), max_new_tokens=12, eos_token_id=-1, pad_token_id=0)
+    outs = {}
+    for g in (False, True):
+        o = m.generate(ids, decode_graph=g, **kw)["output"].cpu()
+        outs[g] = (o, [h.cpu() for h in m.last_generate["hidden_last"]])
+    assert torch.equal(outs[False][0], outs[True][0]) and outs[True][0].shape[1] == 12
+    assert len(outs[False][1]) == len(outs[True][1])
+    for h0, h1 in zip(outs[False][1], outs[True][1]):
+        assert torch.equal(h0, h1)
+    torch.manual_seed(7); s0 = m.generate(ids, do_sample=True, temperature=2.0, top_p=0.9, decode_graph=False, **kw)["output"].cpu()
+    torch.manual_seed(7); s1 = m.generate(ids, do_sample=True, temperature=2.0, top_p=0.9, decode_graph=True, **kw)["output"].cpu()
+    assert torch.equal(s0, s1)

@@ -53,6 +53,14 @@ SIGNATURES = {
     "ufv_argmax_rows": [_p, _l, _i, _i, _p, _p],
     "ufv_attention_decode": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
+    "ufv_qwen2_decode_step_dev": [_p, _p, _p, _p, _l, _p, _p, _p, _p],
+    "ufv_rope_kv1_dev": [_p, _i, _i, _i, _p, _p, _p, _i, _p],
+    "ufv_attention_decode_dev": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _f, _p, _i, _p],
+    "ufv_add_int": [_p, _i, _p],
+    "ufv_graph_begin": [_p],
+    "ufv_graph_end": [_p, _p],
+    "ufv_graph_launch": [_p, _p],
+    "ufv_graph_destroy": [_p],
     "ufv_act": [_p, _p, _l, _i, _p],
     "ufv_act_bwd": [_p, _p, _p, _l, _i, _p],
     "ufv_add_bf16": [_p, _p, _p, _l, _p],

@@ -794,7 +794,7 @@ __global__ __launch_bounds__(2 * NW * 64, 1) void attn_fwd_pair(AttnArgs a) {
 // scores go to LDS, each block writes an un-normalised partial (max, sum, o[hd]); attn_decode_combine merges them.
 // ---------------------------------------------------------------------------------------------------------
 template <int HD>
-__global__ __launch_bounds__(256) void attn_decode_split(AttnArgs a, float* ws, int nsplit) {
+__global__ __launch_bounds__(256) void attn_decode_split(AttnArgs a, float* ws, int nsplit, const int* __restrict__ pos_dev) {
     constexpr int CPR = HD / 8, KPI = 64 / CPR;            // lanes per key row, keys per wave instruction
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     float* sc = reinterpret_cast<float*>(smem_d);           // [keys in this split]
@@ -803,7 +803,9 @@ __global__ __launch_bounds__(256) void attn_decode_split(AttnArgs a, float* ws, 
     const int split = blockIdx.x, hq = blockIdx.y, b = blockIdx.z, hkv = hq / (a.Hq / a.Hkv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane / CPR, ch = lane % CPR;
-    const int nk = a.Sk;                                    // Sq == 1 with q_pos0 = Sk-1: every cached key is visible
+    // Sq == 1 with q_pos0 = Sk-1: every cached key is visible.  pos_dev (graph-captured decode): the key count lives in
+    // device memory (position of the new token + 1), so the launch arguments are the same for every token
+    const int nk = pos_dev ? *pos_dev + 1 : a.Sk;
     const int per = (nk + nsplit - 1) / nsplit;
     const int k0 = split * per, k1 = min(nk, k0 + per), n = max(k1 - k0, 0);
     float* out = ws + ((size_t)(b * a.Hq + hq) * nsplit + split) * (HD + 2);
@@ -1110,9 +1112,9 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
 }
 
 template <int HD>
-static int launch_decode(const AttnArgs& a, float* ws, int nsplit, hipStream_t st) {
-    const int per = cdiv(a.Sk, nsplit);
-    hipLaunchKernelGGL((attn_decode_split<HD>), dim3(nsplit, a.Hq, a.B), dim3(256), per * sizeof(float), st, a, ws, nsplit);
+static int launch_decode(const AttnArgs& a, float* ws, int nsplit, const int* pos_dev, int max_keys, hipStream_t st) {
+    const int per = cdiv(pos_dev ? max_keys : a.Sk, nsplit);          // score buffer: sized for the longest split this launch can see
+    hipLaunchKernelGGL((attn_decode_split<HD>), dim3(nsplit, a.Hq, a.B), dim3(256), per * sizeof(float), st, a, ws, nsplit, pos_dev);
     hipLaunchKernelGGL((attn_decode_combine<HD>), dim3(a.Hq, a.B), dim3(HD < 64 ? 64 : HD), 0, st, ws, a.o, a.o_bs, a.Hq, nsplit);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
@@ -1122,9 +1124,9 @@ extern "C" int ufv_attention_decode_ws_bytes(int B, int Hq, int hd, int nsplit) 
     return (int)(sizeof(float) * (size_t)B * Hq * nsplit * (hd + 2));
 }
 
-extern "C" int ufv_attention_decode(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_ss, const void* v,
-                                    int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int B, int Hq, int Hkv, int Sk, int hd,
-                                    float scale, void* ws, int nsplit, void* stream) {
+static int attention_decode_impl(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_ss, const void* v,
+                                 int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int B, int Hq, int Hkv, int Sk, int hd,
+                                 float scale, void* ws, int nsplit, const int* pos_dev, void* stream) {
     UFV_REQUIRE(q && k && v && o && ws && B > 0 && Hq > 0 && Hkv > 0 && Sk > 0 && nsplit > 0, "ufv_attention_decode: bad arguments");
     UFV_REQUIRE(Hq % Hkv == 0, "ufv_attention_decode: Hq must be a multiple of Hkv");
     UFV_REQUIRE(cdiv(Sk, nsplit) * sizeof(float) <= 48 * 1024, "ufv_attention_decode: too many keys per split (Sk=%d nsplit=%d)", Sk, nsplit);
@@ -1137,11 +1139,26 @@ extern "C" int ufv_attention_decode(const void* q, int64_t q_bs, const void* k, 
                          (v_ss % 8 == 0) && (k_bs % 8 == 0) && (v_bs % 8 == 0) && (q_bs % 8 == 0);
     UFV_REQUIRE(aligned, "ufv_attention_decode: q/k/v rows must be 16-byte aligned");
     switch (hd) {
-        case 16: return launch_decode<16>(a, (float*)ws, nsplit, st);
-        case 32: return launch_decode<32>(a, (float*)ws, nsplit, st);
-        case 64: return launch_decode<64>(a, (float*)ws, nsplit, st);
-        case 128: return launch_decode<128>(a, (float*)ws, nsplit, st);
+        case 16: return launch_decode<16>(a, (float*)ws, nsplit, pos_dev, Sk, st);
+        case 32: return launch_decode<32>(a, (float*)ws, nsplit, pos_dev, Sk, st);
+        case 64: return launch_decode<64>(a, (float*)ws, nsplit, pos_dev, Sk, st);
+        case 128: return launch_decode<128>(a, (float*)ws, nsplit, pos_dev, Sk, st);
     }
     ufv_set_error("ufv_attention_decode: head_dim %d not supported (16/32/64/128)", hd);
     return UFV_EUNSUPPORTED;
+}
+
+extern "C" int ufv_attention_decode(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_ss, const void* v,
+                                    int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int B, int Hq, int Hkv, int Sk, int hd,
+                                    float scale, void* ws, int nsplit, void* stream) {
+    return attention_decode_impl(q, q_bs, k, k_bs, k_ss, v, v_bs, v_ss, o, o_bs, B, Hq, Hkv, Sk, hd, scale, ws, nsplit, nullptr, stream);
+}
+
+// the same with the key count read from device memory (*pos_dev + 1 <= max_keys): identical launch arguments for every
+// token, so a decode step can be captured into a HIP graph once and replayed
+extern "C" int ufv_attention_decode_dev(const void* q, int64_t q_bs, const void* k, int64_t k_bs, int64_t k_ss, const void* v,
+                                        int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int B, int Hq, int Hkv, const int* pos_dev,
+                                        int max_keys, int hd, float scale, void* ws, int nsplit, void* stream) {
+    UFV_REQUIRE(pos_dev && max_keys > 0, "ufv_attention_decode_dev: bad arguments");
+    return attention_decode_impl(q, q_bs, k, k_bs, k_ss, v, v_bs, v_ss, o, o_bs, B, Hq, Hkv, max_keys, hd, scale, ws, nsplit, pos_dev, stream);
 }

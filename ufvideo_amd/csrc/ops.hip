@@ -285,6 +285,33 @@ __global__ __launch_bounds__(256) void rope_kv_tab_k(bf16* qkv, int ldqkv, int S
     }
 }
 
+// single new token (decode) with its position read from device memory: same arithmetic as rope_kv_scalar_k, launch arguments
+// independent of the position (HIP-graph capture of the decode step)
+__global__ void rope_kv1_dev_k(bf16* qkv, int Hq, int Hkv, int hd, const float* inv_freq, const int* __restrict__ pos_dev, bf16* kv, int ldkv) {
+    const int half = hd >> 1;
+    const int pos = *pos_dev;
+    const int total = (Hq + 2 * Hkv) * half;
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < total; id += gridDim.x * blockDim.x) {
+        const int i = id % half, hh = id / half;
+        if (hh < Hq + Hkv) {
+            bf16* p = qkv + hh * hd;
+            const float ang = (float)pos * inv_freq[i];
+            const float c = cosf(ang), sn = sinf(ang);
+            const float x1 = (float)p[i], x2 = (float)p[half + i];
+            bf16* d = (hh < Hq) ? p : kv + (int64_t)pos * ldkv + (hh - Hq) * hd;
+            d[i] = (bf16)(x1 * c - x2 * sn);
+            d[half + i] = (bf16)(x2 * c + x1 * sn);
+        } else {
+            const int hv = hh - Hq - Hkv;
+            const bf16* p = qkv + (Hq + Hkv) * hd + hv * hd;
+            bf16* d = kv + (int64_t)pos * ldkv + Hkv * hd + hv * hd;
+            d[i] = p[i]; d[half + i] = p[half + i];
+        }
+    }
+}
+
+__global__ void add_int_k(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += v; }
+
 __global__ void rope_kv_scalar_k(bf16* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* inv_freq, int pos0, bf16* kv,
                                  int ldkv) {
     const int half = hd >> 1;
@@ -801,6 +828,23 @@ extern "C" int ufv_rope_kv(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd,
         hipLaunchKernelGGL(rope_kv_scalar_k, dim3(grid_for(total)), dim3(256), 0, ST(stream), (bf16*)qkv, ldqkv, S, Hq, Hkv, hd, inv_freq,
                            pos0, (bf16*)kv_cache, ldkv);
     }
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_rope_kv1_dev(void* qkv, int Hq, int Hkv, int hd, const float* inv_freq, const int* pos_dev, void* kv_cache, int ldkv,
+                                void* stream) {
+    UFV_REQUIRE(qkv && inv_freq && pos_dev && kv_cache && hd % 2 == 0, "ufv_rope_kv1_dev: bad arguments");
+    const int total = (Hq + 2 * Hkv) * (hd / 2);
+    hipLaunchKernelGGL(rope_kv1_dev_k, dim3(cdiv(total, 256)), dim3(256), 0, ST(stream), (bf16*)qkv, Hq, Hkv, hd, inv_freq, pos_dev,
+                       (bf16*)kv_cache, ldkv);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_add_int(int* p, int v, void* stream) {
+    UFV_REQUIRE(p, "ufv_add_int: null pointer");
+    hipLaunchKernelGGL(add_int_k, dim3(1), dim3(64), 0, ST(stream), p, v);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }

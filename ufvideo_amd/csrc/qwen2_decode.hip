@@ -28,11 +28,14 @@ extern "C" int64_t ufv_qwen2_decode_ws_bytes(const ufv_qwen2_model* m) {
     return (int64_t)b;
 }
 
-extern "C" int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* token_dev, int pos, void* ws, int64_t ws_bytes,
-                                     float* logits, float* hidden_out, int64_t* next_token_dev, void* stream) {
+// pos_dev == nullptr: position `pos` from the host (launch arguments change every token).  pos_dev != nullptr: the position is
+// read from device memory by the two kernels that need it and incremented at the end of the step, so every launch argument is
+// the same for every token and the whole step can be captured into a HIP graph once (ufv_graph_*) and replayed.
+static int decode_step_impl(const ufv_qwen2_model* m, const int64_t* token_dev, int pos, int* pos_dev, void* ws, int64_t ws_bytes,
+                            float* logits, float* hidden_out, int64_t* next_token_dev, void* stream) {
     UFV_REQUIRE(m && token_dev && ws && logits && next_token_dev, "ufv_qwen2_decode_step: null argument");
     UFV_REQUIRE(ws_bytes >= ufv_qwen2_decode_ws_bytes(m), "ufv_qwen2_decode_step: workspace too small");
-    UFV_REQUIRE(pos >= 0 && pos < m->max_len, "ufv_qwen2_decode_step: position %d outside the KV cache (max_len %d)", pos, m->max_len);
+    UFV_REQUIRE(pos_dev || (pos >= 0 && pos < m->max_len), "ufv_qwen2_decode_step: position %d outside the KV cache (max_len %d)", pos, m->max_len);
     const int D = m->d, H = m->n_q, KV = m->n_kv, hd = m->hd, I = m->d_ff;
     const int qkv_n = (H + 2 * KV) * hd;
     char* p = reinterpret_cast<char*>(ws);
@@ -53,9 +56,15 @@ extern "C" int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* to
         const bool q8 = L.wqkv8 && L.wo8 && L.wgu8 && L.wd8;      // W8A8 decode: e4m3 weights, rows quantised inside the GEMV
         UFV_TRY(ufv_gemv1(nullptr, x, L.ln1, m->eps, q8 ? L.wqkv8 : L.wqkv, D, q8 ? L.sqkv : nullptr, qkv, 0, qkv_n, D, L.bqkv, UFV_ACT_NONE,
                           nullptr, 0, stream));
-        UFV_TRY(ufv_rope_kv(qkv, qkv_n, 1, H, KV, hd, m->inv_freq, pos, kv, m->ldkv, stream));
-        UFV_TRY(ufv_attention_decode(qkv, 0, kv, 0, m->ldkv, kv + 2 * (size_t)KV * hd, 0, m->ldkv, o, 0, 1, H, KV, pos + 1, hd, scale,
-                                     aws, m->attn_splits, stream));
+        if (pos_dev) {
+            UFV_TRY(ufv_rope_kv1_dev(qkv, H, KV, hd, m->inv_freq, pos_dev, kv, m->ldkv, stream));
+            UFV_TRY(ufv_attention_decode_dev(qkv, 0, kv, 0, m->ldkv, kv + 2 * (size_t)KV * hd, 0, m->ldkv, o, 0, 1, H, KV, pos_dev, m->max_len,
+                                             hd, scale, aws, m->attn_splits, stream));
+        } else {
+            UFV_TRY(ufv_rope_kv(qkv, qkv_n, 1, H, KV, hd, m->inv_freq, pos, kv, m->ldkv, stream));
+            UFV_TRY(ufv_attention_decode(qkv, 0, kv, 0, m->ldkv, kv + 2 * (size_t)KV * hd, 0, m->ldkv, o, 0, 1, H, KV, pos + 1, hd, scale,
+                                         aws, m->attn_splits, stream));
+        }
         UFV_TRY(ufv_gemv1(o, nullptr, nullptr, 0.f, q8 ? L.wo8 : L.wo, H * hd, q8 ? L.so : nullptr, x, 1, D, H * hd, nullptr, UFV_ACT_NONE, x, 0,
                           stream));
         UFV_TRY(ufv_gemv1(nullptr, x, L.ln2, m->eps, q8 ? L.wgu8 : L.wgu, D, q8 ? L.sgu : nullptr, act, 0, 2 * I, D, nullptr, UFV_ACT_NONE,
@@ -68,5 +77,61 @@ extern "C" int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* to
     UFV_TRY(ufv_convert(normed, UFV_DT_F32, h, UFV_DT_BF16, D, stream));
     UFV_TRY(ufv_gemv1(h, nullptr, nullptr, 0.f, m->lm_head, D, nullptr, logits, 1, m->vocab, D, nullptr, UFV_ACT_NONE, nullptr, 0, stream));
     UFV_TRY(ufv_argmax(logits, m->vocab, next_token_dev, stream));
+    if (pos_dev) UFV_TRY(ufv_add_int(pos_dev, 1, stream));
+    return UFV_OK;
+}
+
+extern "C" int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* token_dev, int pos, void* ws, int64_t ws_bytes,
+                                     float* logits, float* hidden_out, int64_t* next_token_dev, void* stream) {
+    return decode_step_impl(m, token_dev, pos, nullptr, ws, ws_bytes, logits, hidden_out, next_token_dev, stream);
+}
+
+extern "C" int ufv_qwen2_decode_step_dev(const ufv_qwen2_model* m, const int64_t* token_dev, int* pos_dev, void* ws, int64_t ws_bytes,
+                                         float* logits, float* hidden_out, int64_t* next_token_dev, void* stream) {
+    UFV_REQUIRE(pos_dev, "ufv_qwen2_decode_step_dev: null position");
+    return decode_step_impl(m, token_dev, 0, pos_dev, ws, ws_bytes, logits, hidden_out, next_token_dev, stream);
+}
+
+// ---- HIP graph capture of a launch-bound sequence (the ~200 dependent launches of one decode step) --------------------
+// begin -> any ufv_* calls on `stream` (recorded, not executed) -> end returns an executable graph; launch replays it.
+// `stream` must not be the legacy default stream.  Nothing may synchronise or allocate between begin and end.
+extern "C" int ufv_graph_begin(void* stream) {
+    UFV_REQUIRE(stream, "ufv_graph_begin: the legacy default stream cannot be captured; use a created stream");
+    if (hipStreamBeginCapture(reinterpret_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        ufv_set_error("ufv_graph_begin: %s", hipGetErrorString(hipGetLastError()));
+        return UFV_EHIP;
+    }
+    return UFV_OK;
+}
+
+extern "C" int ufv_graph_end(void* stream, void** exec_out) {
+    UFV_REQUIRE(stream && exec_out, "ufv_graph_end: bad arguments");
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(reinterpret_cast<hipStream_t>(stream), &g) != hipSuccess || !g) {
+        ufv_set_error("ufv_graph_end: capture failed: %s", hipGetErrorString(hipGetLastError()));
+        return UFV_EHIP;
+    }
+    hipGraphExec_t ex = nullptr;
+    const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess || !ex) {
+        ufv_set_error("ufv_graph_end: instantiate failed: %s", hipGetErrorString(e));
+        return UFV_EHIP;
+    }
+    *exec_out = ex;
+    return UFV_OK;
+}
+
+extern "C" int ufv_graph_launch(void* exec, void* stream) {
+    UFV_REQUIRE(exec, "ufv_graph_launch: null graph");
+    if (hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(exec), reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
+        ufv_set_error("ufv_graph_launch: %s", hipGetErrorString(hipGetLastError()));
+        return UFV_EHIP;
+    }
+    return UFV_OK;
+}
+
+extern "C" int ufv_graph_destroy(void* exec) {
+    if (exec) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(exec));
     return UFV_OK;
 }

@@ -485,14 +485,31 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         else:
             ops.argmax(logits.view(-1), out=tok)
         step = self._decode_step_ctx(cache)
+        use_graph = bool(unused.get("decode_graph", os.environ.get("UFV_DECODE_GRAPH", "1") != "0")) and max_new_tokens > 2
+        if use_graph:
+            self._decode_loop_graph(step, cache, tok, tokens, hidden_steps, max_new_tokens, eos, stopping_criteria,
+                                    (temperature, top_k or 0, top_p, uni) if sample else None)
+        else:
+            self._decode_loop(step, cache, tok, nxt, tokens, hidden_steps, max_new_tokens, eos, stopping_criteria,
+                              (temperature, top_k or 0, top_p, uni) if sample else None)
+        return {"sequences": torch.tensor([tokens], dtype=torch.long, device=dev), "hidden_last": hidden_steps, "cache": cache}
+
+    @staticmethod
+    def _stop(tokens, t, eos, stopping_criteria, dev):
+        if t in eos:
+            return True
+        if stopping_criteria:
+            ids = torch.tensor([tokens], dtype=torch.long, device=dev)
+            return any(bool(c(ids, None)) for c in stopping_criteria)
+        return False
+
+    def _decode_loop(self, step, cache, tok, nxt, tokens, hidden_steps, max_new_tokens, eos, stopping_criteria, samp):
+        """one C call (~200 launches) per token on the current stream"""
+        cfg, dev = self.config, tok.device
         for i in range(max_new_tokens):
             t = int(tok.item())                                   # the only host<->device sync per token
             tokens.append(t)
-            done = t in eos
-            if not done and stopping_criteria:
-                ids = torch.tensor([tokens], dtype=torch.long, device=dev)
-                done = any(bool(c(ids, None)) for c in stopping_criteria)
-            if done or i == max_new_tokens - 1:
+            if self._stop(tokens, t, eos, stopping_criteria, dev) or i == max_new_tokens - 1:
                 break
             hid = torch.empty((1, cfg.hidden_size), device=dev, dtype=torch.float32)
             _lib.call("ufv_qwen2_decode_step", ctypes.byref(step["model"]), tok.data_ptr(), cache.len, step["ws"].data_ptr(),
@@ -500,10 +517,45 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
                       torch.cuda.current_stream().cuda_stream)
             cache.len += 1
             hidden_steps.append(hid)
-            if sample:                                            # the step's own argmax is ignored: draw from its logits instead
-                ops.sample_top_p(step["logits"].view(1, -1), temperature, top_k or 0, top_p, uni[i + 1:i + 2], out=nxt)
+            if samp:                                              # the step's own argmax is ignored: draw from its logits instead
+                ops.sample_top_p(step["logits"].view(1, -1), samp[0], samp[1], samp[2], samp[3][i + 1:i + 2], out=nxt)
             tok, nxt = nxt, tok
-        return {"sequences": torch.tensor([tokens], dtype=torch.long, device=dev), "hidden_last": hidden_steps, "cache": cache}
+
+    def _decode_loop_graph(self, step, cache, tok, tokens, hidden_steps, max_new_tokens, eos, stopping_criteria, samp):
+        """The decode step recorded ONCE into a HIP graph (the position lives in device memory and is advanced by the step, so
+        the launch arguments never change) and replayed per token: one graph launch instead of ~200 kernel launches.  Runs on
+        a side stream (the legacy default stream cannot be captured)."""
+        cfg, dev = self.config, tok.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        exec_ = ctypes.c_void_p(None)
+        try:
+            with torch.cuda.stream(side):
+                st = side.cuda_stream
+                pos_dev = torch.tensor([cache.len], dtype=torch.int32, device=dev)
+                hid = torch.empty((1, cfg.hidden_size), device=dev, dtype=torch.float32)
+                for i in range(max_new_tokens):
+                    t = int(tok.item())
+                    tokens.append(t)
+                    if self._stop(tokens, t, eos, stopping_criteria, dev) or i == max_new_tokens - 1:
+                        break
+                    if not exec_:
+                        _lib.call("ufv_graph_begin", st)
+                        try:
+                            _lib.call("ufv_qwen2_decode_step_dev", ctypes.byref(step["model"]), tok.data_ptr(), pos_dev.data_ptr(),
+                                      step["ws"].data_ptr(), step["ws"].numel(), step["logits"].data_ptr(), hid.data_ptr(), tok.data_ptr(), st)
+                        finally:
+                            _lib.call("ufv_graph_end", st, ctypes.byref(exec_))
+                    _lib.call("ufv_graph_launch", exec_, st)
+                    cache.len += 1
+                    hidden_steps.append(hid.clone())
+                    if samp:
+                        ops.sample_top_p(step["logits"].view(1, -1), samp[0], samp[1], samp[2], samp[3][i + 1:i + 2], out=tok)
+        finally:
+            torch.cuda.current_stream().wait_stream(side)
+            if exec_:
+                side.synchronize()
+                _lib.call("ufv_graph_destroy", exec_)
 
     def _decode_step_ctx(self, cache):
         """ctypes view of the packed decoder + this generation's KV cache for ufv_qwen2_decode_step (include/ufv.h)."""
