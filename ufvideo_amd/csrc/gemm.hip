@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void gemv_nt_fp8(const uint8_t* __restrict__ A
 // ---- single-row GEMV for the decode step: y[N] = epilogue(h[K] . W[N,K]^T), h = the bf16 row `a`, or (RMS) the RMSNorm of
 //      an fp32 row computed in the prologue exactly as rmsnorm_k rounds it (so fusing the norm changes no bit).  h lives in
 //      LDS; a wave produces 4 outputs at once (4 or 8 weight rows in flight per lane: latency hidden, 4x fewer blocks).
-template <bool OUT_F32, bool SWIGLU, bool RMS, bool W8>
+template <bool OUT_F32, bool SWIGLU, bool RMS, bool W8, int NO = 4>
 __global__ __launch_bounds__(256) void gemv1_nt(const bf16* __restrict__ a, const float* __restrict__ x, const float* __restrict__ g,
                                                 float eps, const void* __restrict__ Wv, const float* __restrict__ w_scale, Epi e, int N,
                                                 int K, int ldw) {
@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void gemv1_nt(const bf16* __restrict__ a, cons
         }
         __syncthreads();
     }
-    constexpr int NO = 4;                                     // outputs per wave
+    // NO = outputs per wave: 4 for the wide layers (4x fewer blocks, 4-8 weight rows in flight per lane), 1 for N <= 8192 (QKV, o,
+    // down: with 4 the grid is 224-288 blocks = one 4-wave block per CU and the weight stream runs at 2 TB/s)
     constexpr int ES = W8 ? 1 : 2;
     const char* W = reinterpret_cast<const char*>(Wv);
     const int n_out = SWIGLU ? N / 2 : N;
@@ -731,10 +732,12 @@ extern "C" int ufv_gemv1(const void* a, const float* x, const float* ln_w, float
     e.dump_f32 = 0; e.ksplit = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int n_out = swiglu ? N / 2 : N;
-    dim3 grid(cdiv(n_out, 16)), blk(256);
+    const bool narrow = n_out <= 8192 && !w_scale;      // fp8 rows are half as long and every block re-quantises the input row: 4 outputs per wave stays faster there
+    dim3 grid(cdiv(n_out, narrow ? 4 : 16)), blk(256);
     const size_t sm = (size_t)K * (w_scale ? 3 : 2);
     const bf16* ab = reinterpret_cast<const bf16*>(a);
-#define G1(F_, S_, R_, Q_) hipLaunchKernelGGL((gemv1_nt<F_, S_, R_, Q_>), grid, blk, sm, st, ab, x, ln_w, eps, W, w_scale, e, N, K, ldw)
+#define G1(F_, S_, R_, Q_) do { if (narrow) hipLaunchKernelGGL((gemv1_nt<F_, S_, R_, Q_, 1>), grid, blk, sm, st, ab, x, ln_w, eps, W, w_scale, e, N, K, ldw); \
+                                else hipLaunchKernelGGL((gemv1_nt<F_, S_, R_, Q_, 4>), grid, blk, sm, st, ab, x, ln_w, eps, W, w_scale, e, N, K, ldw); } while (0)
 #define G1Q(F_, S_, R_) do { if (w_scale) G1(F_, S_, R_, true); else G1(F_, S_, R_, false); } while (0)
     if (x) {
         if (out_f32) { if (swiglu) G1Q(true, true, true); else G1Q(true, false, true); }
