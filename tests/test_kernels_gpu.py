@@ -253,6 +253,15 @@ def test_gather_rows_and_argmax_and_convert():
     x[1234] = 50.0; x[99999] = 50.0
     assert ops.argmax(x).item() == 1234 == torch.argmax(x).item()
     assert ops.argmax(g(7, seed=44)).item() == torch.argmax(g(7, seed=44)).item()
+    for n in (4097, 16384, 151747):                          # vector body + scalar tail, ties across threads, unaligned views
+        y = g(n + 1, seed=45 + n)
+        for view in (y[:n], y[1:]):
+            assert ops.argmax(view.contiguous()).item() == torch.argmax(view).item()
+            assert ops.argmax(view).item() == torch.argmax(view).item()
+        z = torch.zeros(n, device=DEV); z[n - 1] = 1.0; z[n // 2] = 1.0
+        assert ops.argmax(z).item() == n // 2
+        z[5] = float("nan")
+        assert ops.argmax(z).item() == 5
     for a, b_ in [(torch.float32, torch.bfloat16), (torch.float16, torch.bfloat16), (torch.bfloat16, torch.float32)]:
         t = g(1000, seed=45).to(a)
         assert torch.equal(ops.convert(t, b_), t.to(b_))
