@@ -529,6 +529,7 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         exec_ = ctypes.c_void_p(None)
+        graph_ok = True
         try:
             with torch.cuda.stream(side):
                 st = side.cuda_stream
@@ -539,14 +540,21 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
                     tokens.append(t)
                     if self._stop(tokens, t, eos, stopping_criteria, dev) or i == max_new_tokens - 1:
                         break
-                    if not exec_:
-                        _lib.call("ufv_graph_begin", st)
+                    if not exec_ and graph_ok:
                         try:
-                            _lib.call("ufv_qwen2_decode_step_dev", ctypes.byref(step["model"]), tok.data_ptr(), pos_dev.data_ptr(),
-                                      step["ws"].data_ptr(), step["ws"].numel(), step["logits"].data_ptr(), hid.data_ptr(), tok.data_ptr(), st)
-                        finally:
-                            _lib.call("ufv_graph_end", st, ctypes.byref(exec_))
-                    _lib.call("ufv_graph_launch", exec_, st)
+                            _lib.call("ufv_graph_begin", st)
+                            try:
+                                _lib.call("ufv_qwen2_decode_step_dev", ctypes.byref(step["model"]), tok.data_ptr(), pos_dev.data_ptr(),
+                                          step["ws"].data_ptr(), step["ws"].numel(), step["logits"].data_ptr(), hid.data_ptr(), tok.data_ptr(), st)
+                            finally:
+                                _lib.call("ufv_graph_end", st, ctypes.byref(exec_))
+                        except _lib.UfvError:      # capture unavailable: nothing was executed, carry on with per-launch steps
+                            graph_ok, exec_ = False, ctypes.c_void_p(None)
+                    if exec_:
+                        _lib.call("ufv_graph_launch", exec_, st)
+                    else:
+                        _lib.call("ufv_qwen2_decode_step", ctypes.byref(step["model"]), tok.data_ptr(), cache.len, step["ws"].data_ptr(),
+                                  step["ws"].numel(), step["logits"].data_ptr(), hid.data_ptr(), tok.data_ptr(), st)
                     cache.len += 1
                     hidden_steps.append(hid.clone())
                     if samp:
