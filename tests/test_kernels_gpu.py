@@ -157,7 +157,8 @@ def attn_ref(q, k, v, causal, q_pos0=0):
     (16, 4, 2, 61, 61, True, 2), (72, 2, 2, 50, 50, False, 2), (128, 4, 2, 1, 333, True, 2), (128, 4, 2, 1, 333, True, 0),
     (80, 2, 1, 70, 70, False, 1), (96, 2, 2, 33, 200, False, 1),
     (72, 2, 2, 200, 200, True, 1), (72, 2, 1, 70, 300, True, 1), (72, 3, 3, 192, 192, False, 1), (72, 2, 2, 64, 64, False, 1),
-    (72, 4, 4, 576, 576, False, 3), (72, 16, 16, 130, 130, False, 1), (72, 4, 4, 576, 576, False, 7), (72, 6, 6, 384, 500, False, 8)])
+    (72, 4, 4, 576, 576, False, 3), (72, 16, 16, 130, 130, False, 1), (72, 4, 4, 576, 576, False, 7), (72, 6, 6, 384, 500, False, 8),
+    (72, 16, 16, 576, 576, False, 1), (72, 3, 3, 300, 100, False, 1), (72, 5, 5, 288, 576, False, 9)])
 def test_attention(hd, Hq, Hkv, Sq, Sk, causal, kernel):
     B = 2
     # fused qkv buffer like the real path: [B*S, (Hq + 2 Hkv) * hd]

@@ -321,15 +321,30 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
     const int qblk0 = qt * 32 * NW, q0 = qblk0 + wave * 32;
     const int qi = q0 + l31;
 
+    // Q: the wave's 32 rows are fetched as whole rows (16 bytes per lane in row-major chunk order: a wave instruction covers 7
+    // rows x 144 B; a per-lane fetch of "my row" touches 32 lines per instruction), parked in the wave's staging area behind the
+    // K/V ring (row pitch HD*2 + 16 bytes) and read back as MFMA B fragments: lane (col q = l31, k = 8h + j) <- Q[q][16ks + 8h + j]
+    constexpr int OP = HD * 2 + 16, CPRW = HD / 8;
+    char* stg = smem + NST * STG + wave * (32 * OP);
     bf16x8 qf[KS];
     {
-        const bf16* qp = a.q + b * a.q_bs + (int64_t)min(qi, a.Sq - 1) * a.q_ss + hq * HD;
+        const bf16* qbase = a.q + b * a.q_bs + hq * HD;
+#pragma unroll
+        for (int i = 0; i < (32 * CPRW + 63) / 64; ++i) {
+            const int c = lane + 64 * i, row = c / CPRW, ch = c % CPRW;
+            if (c < 32 * CPRW)
+                *reinterpret_cast<bf16x8*>(stg + row * OP + ch * 16) =
+                    *reinterpret_cast<const bf16x8*>(qbase + (int64_t)min(q0 + row, a.Sq - 1) * a.q_ss + ch * 8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d0 = ks * 16 + h * 8;
-            if (d0 < HD) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + d0);
+            if (d0 < HD) qf[ks] = *reinterpret_cast<const bf16x8*>(stg + l31 * OP + d0 * 2);
             else qf[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // Q in registers before any DMA is in flight
 #pragma unroll
@@ -516,19 +531,29 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qi < a.Sq) {
-        bf16* op = a.o + b * a.o_bs + (int64_t)qi * a.o_ss + hq * HD;
+    // O^T accumulators -> this wave's 32 rows x HD in LDS (row pitch HD*2 + 16 bytes; every wave is past its last ring read) ->
+    // whole rows out with 16 bytes per lane: a wave instruction covers 7 rows x 144 B instead of 64 scattered 8-byte pieces
+    // (per-lane stores at a row stride touch 32-64 lines each)
+    char* ob = stg;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int d0 = dt * 32 + g4 * 8 + h * 4;
-                if (d0 < HD) {
-                    bf16x4 ov = {(bf16)(oacc[dt][g4 * 4 + 0] * inv), (bf16)(oacc[dt][g4 * 4 + 1] * inv),
-                                 (bf16)(oacc[dt][g4 * 4 + 2] * inv), (bf16)(oacc[dt][g4 * 4 + 3] * inv)};
-                    *reinterpret_cast<bf16x4*>(op + d0) = ov;
-                }
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = dt * 32 + g4 * 8 + h * 4;
+            if (d0 < HD) {
+                bf16x4 ov = {(bf16)(oacc[dt][g4 * 4 + 0] * inv), (bf16)(oacc[dt][g4 * 4 + 1] * inv),
+                             (bf16)(oacc[dt][g4 * 4 + 2] * inv), (bf16)(oacc[dt][g4 * 4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(ob + l31 * OP + d0 * 2) = ov;
             }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bf16* obase = a.o + b * a.o_bs + hq * HD;
+#pragma unroll
+    for (int i = 0; i < (32 * CPRW + 63) / 64; ++i) {
+        const int c = lane + 64 * i, row = c / CPRW, ch = c % CPRW;
+        if (c < 32 * CPRW && q0 + row < a.Sq)
+            *reinterpret_cast<bf16x8*>(obase + (int64_t)(q0 + row) * a.o_ss + ch * 8) = *reinterpret_cast<const bf16x8*>(ob + row * OP + ch * 16);
     }
 }
 
@@ -1022,7 +1047,7 @@ int launch_mfma(const AttnArgs& a, int causal, hipStream_t st) {
 
 template <int HD, int NW, bool PP>
 int launch_mfma_dma(const AttnArgs& a, int causal, hipStream_t st) {
-    constexpr int smem = (PP ? 4 : 3) * (2 * 64 * HD * 2 + 256);
+    constexpr int smem = (PP ? 4 : 3) * (2 * 64 * HD * 2 + 256) + NW * 32 * (HD * 2 + 16);      // K/V ring + per-wave Q / O staging
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_dma<HD, NW, true, PP>),
