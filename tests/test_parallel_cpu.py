@@ -97,7 +97,7 @@ def _zero2_worker(rank, world, port, q):
             grad = torch.randn(n, generator=torch.Generator().manual_seed(100 * t_ + rank)) * (5.0 if t_ == 2 else 0.01)
             TR.zero2_step_reference(params, grad, (m, v), 1e-2, (0.9, 0.999), 1e-8, 0.1, t_, 1.0)
             hist.append(params.clone())
-        q.put((rank, torch.stack(hist)))
+        q.put((rank, torch.stack(hist).numpy().tolist()))      # by value: a tensor travels as a shared-memory fd that dies with the worker
     finally:
         dist.destroy_process_group()
 
@@ -115,6 +115,7 @@ def test_zero2_exchange_world2_gloo_matches_single_process_adamw():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    res = {r: torch.tensor(v) for r, v in res.items()}
     assert torch.equal(res[0], res[1])
     n = 4096
     p = torch.nn.Parameter(torch.randn(n, generator=torch.Generator().manual_seed(7)))
