@@ -126,3 +126,25 @@ def test_zero2_exchange_world2_gloo_matches_single_process_adamw():
         torch.nn.utils.clip_grad_norm_([p], 1.0)
         opt.step()
         assert torch.allclose(res[0][i], p.detach(), atol=1e-6, rtol=1e-5), f"step {t_}"
+
+
+def test_bucket_layout_and_shard_bounds():
+    """host logic of the ZeRO-2 buckets (no GPU): every parameter view starts on a 128-byte boundary, the flat length divides by
+    64 x world (so every rank's shard is whole and aligned), views alias the flat buffers, shards tile the buffer"""
+    from ufvideo_amd import train as TR
+    for world in (1, 2, 8):
+        b = TR._Bucket([("a", (3, 5)), ("b", (7,)), ("c", (2, 2, 3))], "cpu", world, 0, torch.bfloat16, True)
+        assert b.n % (64 * world) == 0 and b.shard * world == b.n
+        offs = [off for _, _, off, _ in b.entries]
+        assert all(o % 64 == 0 for o in offs) and offs == sorted(offs)
+        b.view(b.w, "b").fill_(2.0)
+        _, _, off, n = b.entries[1]
+        assert float(b.w[off:off + n].float().sum()) == 14.0 and float(b.w.float().sum()) == 14.0
+        assert b.view(b.g, "c").shape == (2, 2, 3) and b.g.dtype == torch.float32
+        got = []
+        for r in range(world):
+            lo, hi = TR.shard_bounds(b.n, world, r)
+            got += list(range(lo, hi))
+        assert got == list(range(b.n))
+    with pytest.raises(KeyError):
+        b.view(b.w, "missing")
