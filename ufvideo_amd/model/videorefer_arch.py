@@ -9,6 +9,8 @@ row-gather launches (text rows from embed_tokens, visual rows, region rows).
 """
 from abc import ABC, abstractmethod
 
+import os
+
 import torch
 
 from .. import ops
@@ -252,6 +254,9 @@ class VideoReferMetaForCausalLM(ABC):
         if vision_tower is None or images is None or input_ids.shape[1] == 1:
             return input_ids, attention_mask, past_key_values, None, labels, None
         model = self.get_model()
+        # the ids come to the host BEFORE the encoder is queued (the copy synchronises: at this point the stream is idle); the
+        # splice plan below is then built while the GPU is still busy with the tower, instead of stalling it after the encoder
+        ids_host = input_ids.tolist()
         if mm_features is None:
             mm_features = self.encode_images_or_videos(images)                   # [n_mm, tok, D] fp32
         if frame is not None:
@@ -260,7 +265,6 @@ class VideoReferMetaForCausalLM(ABC):
             mask_feats, region_token_nums = model.region_encoder(first, masks, mm_features, ann_indices, frame_nums, stash=region_stash)
         else:
             mask_feats, region_token_nums = None, []
-        ids_host = input_ids.tolist()
         n_mm, tok = mm_features.shape[0], mm_features.shape[1]
         mm_lens = [tok] * n_mm
         region_id = self.tokenizer.convert_tokens_to_ids(["<region>"])[0]
@@ -271,7 +275,8 @@ class VideoReferMetaForCausalLM(ABC):
         D = mm_features.shape[-1]
         B, S = len(plan.lengths), max(plan.lengths)
         embeds = torch.zeros((B * S, D), device=dev, dtype=torch.float32)
-        i64 = lambda l: torch.tensor(l, dtype=torch.int64, device=dev)
+        # pinned + non_blocking: the host does not wait for the stream (a pageable H2D copy blocks until the encoder is done)
+        i64 = lambda l: torch.tensor(l, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
         if t_src:
             ops.gather_rows(model.embed_table(), i64(t_src), embeds, i64(t_dst))
         if m_src:
