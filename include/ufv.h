@@ -334,6 +334,16 @@ int ufv_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C, int
                     int nsplit, void* ws, void* stream);
 int ufv_attention_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* dO, int64_t lddo, void* dq,
                       int64_t lddq, void* dk, void* dv, int64_t lddkv, int S, int Hq, int Hkv, int hd, float scale, void* ws, void* stream);
+/* Fused (flash-style) form of the same backward for hd == 128: nothing of size S x S is written.  ufv_attention_causal_lse is the
+ * training forward (same kernel as ufv_attention with causal = 1, batch 1, q_pos0 = 0; *_ss = token strides in elements) that also
+ * stores lse fp32 [Hq, S] = log2-domain log-sum-exp of the scaled scores; ufv_attention_bwd_fused takes it with the forward output
+ * o bf16 [S, ldo].  k / v need only S rows here.  ws = ufv_attention_bwd_fused_ws_bytes(S, Hq). */
+int ufv_attention_causal_lse(const void* q, int64_t q_ss, const void* k, int64_t k_ss, const void* v, int64_t v_ss, void* o, int64_t o_ss,
+                             int Hq, int Hkv, int S, int hd, float scale, float* lse, void* stream);
+int64_t ufv_attention_bwd_fused_ws_bytes(int S, int Hq);
+int ufv_attention_bwd_fused(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* o, int64_t ldo,
+                            const void* dO, int64_t lddo, const float* lse, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv,
+                            int S, int Hq, int Hkv, int hd, float scale, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

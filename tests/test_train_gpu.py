@@ -1,5 +1,6 @@
 """GPU: the decoder training step (csrc/train.hip + ufvideo_amd/train.py) against torch autograd of the CPU oracle and the
 golden vectors captured from the reference's own backward / AdamW step (oracle/gen_fixtures_train_grad.py)."""
+import math
 import os
 
 import numpy as np
@@ -161,6 +162,42 @@ def test_attention_bwd_vs_autograd(S, H, KV, hd):
     assert rel_err(d[:, :H * hd], qr.grad) < 2e-2
     assert rel_err(d[:, H * hd:(H + KV) * hd], kr.grad) < 2e-2
     assert rel_err(d[:, (H + KV) * hd:], vr.grad) < 2e-2
+
+
+@pytest.mark.parametrize("S,H,KV", [(37, 4, 2), (128, 2, 2), (300, 4, 2), (515, 7, 1), (1000, 14, 2)])
+def test_attention_bwd_fused_vs_autograd(S, H, KV):
+    """flash-style backward (hd 128): forward kernel's lse + output, then dQ / dK / dV without any S x S buffer"""
+    hd = 128
+    g = torch.Generator().manual_seed(S)
+    q, k, v = (bfr(torch.randn(S, n * hd, generator=g)) for n in (H, KV, KV))
+    dO = bfr(torch.randn(S, H * hd, generator=g))
+    qr, kr, vr = (x.clone().requires_grad_(True) for x in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, H, KV, hd)
+    ref.backward(dO)
+    kv = torch.cat([k, v], 1).to(torch.bfloat16).to(DEV)
+    qd, dod = q.to(torch.bfloat16).to(DEV), dO.to(torch.bfloat16).to(DEV)
+    o = torch.empty(S, H * hd, device=DEV, dtype=torch.bfloat16)
+    lse = torch.full((H, S), float("nan"), device=DEV, dtype=torch.float32)
+    ops.attention_causal_lse(qd, kv, kv[:, KV * hd:], o, lse, S, H, KV, hd)
+    assert rel_err(o.float().cpu(), ref.detach()) < 1e-2
+    # lse (log2 domain) against the eager scores
+    sc = torch.einsum("shd,thd->hst", q.view(S, H, hd), k.view(S, KV, hd).repeat_interleave(H // KV, 1)) * hd ** -0.5
+    sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    assert (lse.cpu() - torch.logsumexp(sc, -1) / math.log(2.0)).abs().max() < 2e-2
+    o2 = ops.attention(qd, kv, kv[:, KV * hd:], 1, H, KV, S, S, hd, (0, qd.stride(0)), (0, kv.stride(0)), (0, kv.stride(0)), causal=True)
+    assert torch.equal(o, o2)                                                        # same kernel, same bits as the inference path
+    dqkv = torch.full((S, (H + 2 * KV) * hd), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.attention_bwd_fused(qd, kv, kv[:, KV * hd:], o, dod, lse, dqkv, dqkv[:, H * hd:], dqkv[:, (H + KV) * hd:], S, H, KV, hd)
+    d = dqkv.float().cpu()
+    assert rel_err(d[:, :H * hd], qr.grad) < 2e-2
+    assert rel_err(d[:, H * hd:(H + KV) * hd], kr.grad) < 2e-2
+    assert rel_err(d[:, (H + KV) * hd:], vr.grad) < 2e-2
+    # and against the materialised kernel path
+    Sp = ops.round_up(S, 128)
+    kvp = torch.zeros(Sp, 2 * KV * hd, device=DEV, dtype=torch.bfloat16); kvp[:S] = kv
+    d2 = torch.zeros_like(dqkv)
+    ops.attention_bwd(qd, kvp, kvp[:, KV * hd:], dod, d2, d2[:, H * hd:], d2[:, (H + KV) * hd:], S, H, KV, hd)
+    assert rel_err(d, d2.float().cpu()) < 1.5e-2
 
 
 # ---- the whole step on the tiny model vs the reference's own backward / optimizer step ------------------------------------------

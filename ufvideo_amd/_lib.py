@@ -84,10 +84,12 @@ SIGNATURES = {
     "ufv_adamw": [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _p],
     "ufv_gemm_splitk": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p],
     "ufv_attention_bwd": [_p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p],
+    "ufv_attention_causal_lse": [_p, _l, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _f, _p, _p],
+    "ufv_attention_bwd_fused": [_p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p],
 }
 # entry points that return a size instead of a status
 SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l),
-              "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l),
+              "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l), "ufv_attention_bwd_fused_ws_bytes": ([_i, _i], _l),
               "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l)}
 
 

@@ -72,6 +72,7 @@ struct AttnArgs {
     int B, Hq, Hkv, Sq, Sk, hd;
     float scale;
     int q_pos0;
+    float* lse;        // optional [B, Hq, Sq]: log2-domain log-sum-exp of the scaled scores (m + log2 l), for the fused backward
 };
 
 template <int HD>
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 ? 3 : 2)) void attn_fwd_mfma(Att
     // ---- normalise and store O[q][d], d = 32dt + (r&3) + 8(r>>2) + 4h  (4 consecutive d per register quad)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (a.lse && h == 0 && qi < a.Sq) a.lse[((int64_t)b * a.Hq + hq) * a.Sq + qi] = m_run + log2f(l_tot);
     if (qi < a.Sq) {
         bf16* op = a.o + b * a.o_bs + (int64_t)qi * a.o_ss + hq * HD;
 #pragma unroll
@@ -1088,7 +1090,7 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
     AttnArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
     a.q_bs = q_bs; a.q_ss = q_ss; a.k_bs = k_bs; a.k_ss = k_ss; a.v_bs = v_bs; a.v_ss = v_ss; a.o_bs = o_bs; a.o_ss = o_ss;
-    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Sk = Sk; a.hd = hd; a.scale = scale; a.q_pos0 = q_pos0;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Sk = Sk; a.hd = hd; a.scale = scale; a.q_pos0 = q_pos0; a.lse = nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
                          ((uintptr_t)o % 8 == 0) && (q_ss % 8 == 0) && (k_ss % 8 == 0) && (v_ss % 8 == 0) && (o_ss % 4 == 0) &&
@@ -1136,6 +1138,20 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
     return UFV_OK;
 }
 
+// causal self-attention forward that also returns the log2-domain log-sum-exp per (head, query): the training forward of the
+// fused backward (ufv_attention_bwd_fused).  Same kernel as ufv_attention's hd = 128 path.
+extern "C" int ufv_attention_causal_lse(const void* q, int64_t q_ss, const void* k, int64_t k_ss, const void* v, int64_t v_ss, void* o,
+                                        int64_t o_ss, int Hq, int Hkv, int S, int hd, float scale, float* lse, void* stream) {
+    UFV_REQUIRE(q && k && v && o && lse && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && S > 0, "ufv_attention_causal_lse: bad arguments");
+    UFV_REQUIRE(hd == 128 && ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)o % 8 == 0) &&
+                q_ss % 8 == 0 && k_ss % 8 == 0 && v_ss % 8 == 0 && o_ss % 4 == 0, "ufv_attention_causal_lse: needs head_dim 128 and 16-byte aligned rows");
+    AttnArgs a;
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
+    a.q_bs = 0; a.q_ss = q_ss; a.k_bs = 0; a.k_ss = k_ss; a.v_bs = 0; a.v_ss = v_ss; a.o_bs = 0; a.o_ss = o_ss;
+    a.B = 1; a.Hq = Hq; a.Hkv = Hkv; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = scale; a.q_pos0 = 0; a.lse = lse;
+    return launch_mfma<128, 4>(a, 1, reinterpret_cast<hipStream_t>(stream));
+}
+
 template <int HD>
 static int launch_decode(const AttnArgs& a, float* ws, int nsplit, const int* pos_dev, int max_keys, hipStream_t st) {
     const int per = cdiv(pos_dev ? max_keys : a.Sk, nsplit);          // score buffer: sized for the longest split this launch can see
@@ -1158,7 +1174,7 @@ static int attention_decode_impl(const void* q, int64_t q_bs, const void* k, int
     AttnArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
     a.q_bs = q_bs; a.q_ss = 0; a.k_bs = k_bs; a.k_ss = k_ss; a.v_bs = v_bs; a.v_ss = v_ss; a.o_bs = o_bs; a.o_ss = 0;
-    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = 1; a.Sk = Sk; a.hd = hd; a.scale = scale; a.q_pos0 = Sk - 1;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = 1; a.Sk = Sk; a.hd = hd; a.scale = scale; a.q_pos0 = Sk - 1; a.lse = nullptr;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool aligned = ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && (k_ss % 8 == 0) &&
                          (v_ss % 8 == 0) && (k_bs % 8 == 0) && (v_bs % 8 == 0) && (q_bs % 8 == 0);

@@ -1,0 +1,339 @@
+// Fused (flash-style) backward of causal GQA self-attention for head_dim 128 (Qwen2 decoder; HF eager attention,
+// modeling_qwen2.py:150-172, differentiated).  Nothing of size S x S is materialised: with the forward's log-sum-exp L (log2
+// domain) and delta = rowsum(dO * O) per (head, query),
+//     P = exp2(s * scale * log2e - L),   dS = scale * P * (dP - delta),   dP = dO V^T
+// Two kernels, both built from the forward kernel's fragments (attn.hip: S^T = K Q^T with v_mfma_f32_32x32x16_bf16 so a lane
+// owns one column; the exponentiated tile is re-used as the B operand of the second product; transposed operands come from
+// row-major LDS tiles through ds_read_b64_tr_b16):
+//   attn_bwd_dq   one wave = 32 queries (Q^T, dO^T fragments in registers), loops over 64-key tiles:
+//                 S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
+//   attn_bwd_dkv  one wave = 32 keys of one kv head (K^T, V^T fragments in registers), one block per (128 keys, q head), loops
+//                 over 64-query tiles from the diagonal on:  S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS;
+//                 per-head fp32 partials, summed over the heads of the kv group by attn_bwd_reduce.
+// Tiles are staged global -> registers -> LDS once per step in the two layouts the reads need (row pitch 272 B for the
+// conflict-free ds_read_b128 row fragments, 320 B for the transposed reads), single-buffered: correctness and zero S^2 traffic
+// first; the prefetch ring of the forward kernel is the obvious next step.
+#include "common.h"
+#include "../../include/ufv.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    const bf16x2 p0 = __builtin_convertvector((f32x2){a0, a1}, bf16x2), p1 = __builtin_convertvector((f32x2){a2, a3}, bf16x2);
+    const bf16x2 p2 = __builtin_convertvector((f32x2){a4, a5}, bf16x2), p3 = __builtin_convertvector((f32x2){a6, a7}, bf16x2);
+    const bf16x4 q0 = __builtin_shufflevector(p0, p1, 0, 1, 2, 3), q1 = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
+    return __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+constexpr int HD = 128, KS = 8, DT = 4, NCH = 16;            // k-steps of 16, d-tiles of 32, 16-byte chunks per row
+constexpr int PR = 272, PT = 320;                            // row pitch for row fragments / for transposed reads
+constexpr int NT = 256;
+
+struct BwdArgs {
+    const bf16 *q, *k, *v, *dO;
+    int64_t ldq, ldkv, lddo;
+    const float *lse, *delta;      // [Hq, S]
+    int S, Hq, Hkv;
+    float scale;
+};
+
+// copy a 64-row x 128-col bf16 tile (rows row0.., clamped to nrows - 1) into LDS at pitch `pitch`
+__device__ __forceinline__ void stage_tile(const bf16* src, int64_t ld, int row0, int nrows, char* dst, int pitch, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + i * NT, row = id / NCH, c = id % NCH;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (int64_t)min(row0 + row, nrows - 1) * ld + c * 8);
+        *reinterpret_cast<bf16x8*>(dst + row * pitch + c * 16) = v;
+    }
+}
+__device__ __forceinline__ void stage_tile2(const bf16* src, int64_t ld, int row0, int nrows, char* dst_a, int pitch_a, char* dst_b,
+                                            int pitch_b, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + i * NT, row = id / NCH, c = id % NCH;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (int64_t)min(row0 + row, nrows - 1) * ld + c * 8);
+        *reinterpret_cast<bf16x8*>(dst_a + row * pitch_a + c * 16) = v;
+        *reinterpret_cast<bf16x8*>(dst_b + row * pitch_b + c * 16) = v;
+    }
+}
+
+// acc[dt] (+)= T^T[d][i] * B[i][col]: T = the 64-row tile at `tb` (pitch PT), contracted over its rows in the forward kernel's
+// chunk order; pf[c] = the B operand of 16-row chunk c (c = half * 2 + sub, see attn.hip)
+__device__ __forceinline__ void mma_transposed(const char* tb, int v_off, const bf16x8 (&pf)[4], f32x16 (&acc)[DT]) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const char* vp = tb + (16 * c) * PT + v_off + dt * 64;
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp + 8 * PT));
+            const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], acc[dt], 0, 0, 0);
+        }
+}
+
+// delta[h][s] = sum_d dO[s][h*128 + d] * O[s][h*128 + d]; one wave per (s, h)
+__global__ __launch_bounds__(256) void attn_bwd_delta_k(const bf16* __restrict__ dO, int64_t lddo, const bf16* __restrict__ O, int64_t ldo, int S,
+                                                        int Hq, float* __restrict__ delta) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (int64_t)S * Hq) return;
+    const int s = w / Hq, h = w % Hq;
+    const bf16x2 a = *reinterpret_cast<const bf16x2*>(dO + (int64_t)s * lddo + h * HD + lane * 2);
+    const bf16x2 b = *reinterpret_cast<const bf16x2*>(O + (int64_t)s * ldo + h * HD + lane * 2);
+    float t = (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1];
+    t = wave_sum(t);
+    if (lane == 0) delta[(int64_t)h * S + s] = t;
+}
+
+// ---- dQ: grid (q tiles of 128, Hq) -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(BwdArgs a, bf16* __restrict__ dq, int64_t lddq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_row = smem;                       // 64 x PR
+    char* v_row = k_row + 64 * PR;            // 64 x PR
+    char* k_tr = v_row + 64 * PR;             // 64 x PT
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int qt = gridDim.x - 1 - blockIdx.x;                       // heaviest (last) q tiles first
+    const int hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+    const int q0 = qt * 128 + wave * 32, qi = q0 + l31;
+    const int qc = min(qi, a.S - 1);
+    bf16x8 qf[KS], dof[KS];
+    {
+        const bf16* qp = a.q + (int64_t)qc * a.ldq + hq * HD;
+        const bf16* dp = a.dO + (int64_t)qc * a.lddo + hq * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16 + h * 8);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dp + ks * 16 + h * 8);
+        }
+    }
+    const float lse = a.lse[(int64_t)hq * a.S + qc], dl = a.delta[(int64_t)hq * a.S + qc];
+    const float sl2 = a.scale * 1.4426950408889634f;
+    f32x16 acc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int k_off = l31 * PR + h * 16;
+    const int v_off = (4 * h + ((lane & 15) >> 2)) * PT + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const bf16* kbase = a.k + hkv * HD;
+    const bf16* vbase = a.v + hkv * HD;
+    const int kmax = min(a.S, qt * 128 + 128);                       // causal: keys <= last query of the block
+    const int ntiles = (kmax + 63) / 64;
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();                                             // previous tile fully consumed
+        stage_tile2(kbase, a.ldkv, t * 64, a.S, k_row, PR, k_tr, PT, tid);
+        stage_tile(vbase, a.ldkv, t * 64, a.S, v_row, PR, tid);
+        __syncthreads();
+        if (t * 64 > q0 + 31) continue;                              // wave-uniform: every key of the tile is after this wave's queries
+        f32x16 s0, s1, p0, p1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; p0[r] = 0.f; p1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(k_row + k_off + ks * 32);
+            const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(k_row + 32 * PR + k_off + ks * 32);
+            const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(v_row + k_off + ks * 32);
+            const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(v_row + 32 * PR + k_off + ks * 32);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, dof[ks], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, dof[ks], p1, 0, 0, 0);
+        }
+        // dS^T[key][q] = scale * P * (dP - delta); keys of register r: (r&3) + 8(r>>2) + 4h (+32 for the second half)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = t * 64 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool ok0 = kj <= qi && kj < a.S, ok1 = kj + 32 <= qi && kj + 32 < a.S;
+            const float e0 = ok0 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -lse)) : 0.f;
+            const float e1 = ok1 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -lse)) : 0.f;
+            s0[r] = a.scale * e0 * (p0[r] - dl);
+            s1[r] = a.scale * e1 * (p1[r] - dl);
+        }
+        bf16x8 pf[4];
+        pf[0] = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
+        pf[1] = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
+        pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
+        pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
+        mma_transposed(k_tr, v_off, pf, acc);                        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+    }
+    if (qi < a.S) {
+        bf16* op = dq + (int64_t)qi * lddq + hq * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = dt * 32 + g4 * 8 + h * 4;
+                bf16x4 ov = {(bf16)acc[dt][g4 * 4 + 0], (bf16)acc[dt][g4 * 4 + 1], (bf16)acc[dt][g4 * 4 + 2], (bf16)acc[dt][g4 * 4 + 3]};
+                *reinterpret_cast<bf16x4*>(op + d0) = ov;
+            }
+    }
+}
+
+// ---- dK, dV partials per q head: grid (key tiles of 128, Hq) -----------------------------------------------------------
+__global__ __launch_bounds__(NT, 1) void attn_bwd_dkv_k(BwdArgs a, float* __restrict__ dk_part, float* __restrict__ dv_part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* q_row = smem;                        // 64 x PR
+    char* do_row = q_row + 64 * PR;            // 64 x PR
+    char* q_tr = do_row + 64 * PR;             // 64 x PT
+    char* do_tr = q_tr + 64 * PT;              // 64 x PT
+    float* lse_s = reinterpret_cast<float*>(do_tr + 64 * PT);       // [64]
+    float* dl_s = lse_s + 64;                                        // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int kt = blockIdx.x, hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+    const int k0 = kt * 128 + wave * 32, ki = k0 + l31;
+    const int kc = min(ki, a.S - 1);
+    bf16x8 kf[KS], vf[KS];                                           // B fragments: lane (col key = l31, k = d)
+    {
+        const bf16* kp = a.k + (int64_t)kc * a.ldkv + hkv * HD;
+        const bf16* vp = a.v + (int64_t)kc * a.ldkv + hkv * HD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(kp + ks * 16 + h * 8);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(vp + ks * 16 + h * 8);
+        }
+    }
+    const float sl2 = a.scale * 1.4426950408889634f;
+    f32x16 dka[DT], dva[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dka[i][r] = 0.f; dva[i][r] = 0.f; }
+    const int k_off = l31 * PR + h * 16;
+    const int v_off = (4 * h + ((lane & 15) >> 2)) * PT + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const bf16* qbase = a.q + hq * HD;
+    const bf16* dobase = a.dO + hq * HD;
+    const float* lse_h = a.lse + (int64_t)hq * a.S;
+    const float* dl_h = a.delta + (int64_t)hq * a.S;
+    const int nqt = (a.S + 63) / 64;
+    for (int t = (kt * 128) / 64; t < nqt; ++t) {                    // causal: queries from this block's first key on
+        __syncthreads();
+        stage_tile2(qbase, a.ldq, t * 64, a.S, q_row, PR, q_tr, PT, tid);
+        stage_tile2(dobase, a.lddo, t * 64, a.S, do_row, PR, do_tr, PT, tid);
+        if (tid < 64) {
+            const int qq = t * 64 + tid;
+            lse_s[tid] = qq < a.S ? lse_h[qq] : INFINITY;            // exp2(-inf) = 0 for the rows past the sequence end
+            dl_s[tid] = qq < a.S ? dl_h[qq] : 0.f;
+        }
+        __syncthreads();
+        if (t * 64 + 63 < k0) continue;                              // wave-uniform: every query of the tile is before this wave's keys
+        f32x16 s0, s1, p0, p1;                                       // [q][key]: lane = key column l31, rows = queries
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; p0[r] = 0.f; p1[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qa0 = *reinterpret_cast<const bf16x8*>(q_row + k_off + ks * 32);
+            const bf16x8 qa1 = *reinterpret_cast<const bf16x8*>(q_row + 32 * PR + k_off + ks * 32);
+            const bf16x8 da0 = *reinterpret_cast<const bf16x8*>(do_row + k_off + ks * 32);
+            const bf16x8 da1 = *reinterpret_cast<const bf16x8*>(do_row + 32 * PR + k_off + ks * 32);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kf[ks], s1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, vf[ks], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, vf[ks], p1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = (r & 3) + 8 * (r >> 2) + 4 * h;           // query row inside the 32-row half
+            const int qa = t * 64 + ql, qb = qa + 32;
+            const bool ok0 = ki <= qa && ki < a.S, ok1 = ki <= qb && ki < a.S;
+            const float e0 = ok0 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -lse_s[ql])) : 0.f;
+            const float e1 = ok1 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -lse_s[ql + 32])) : 0.f;
+            s0[r] = e0; s1[r] = e1;
+            p0[r] = a.scale * e0 * (p0[r] - dl_s[ql]);
+            p1[r] = a.scale * e1 * (p1[r] - dl_s[ql + 32]);
+        }
+        bf16x8 pf[4], df[4];
+        pf[0] = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
+        pf[1] = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
+        pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
+        pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
+        df[0] = pack8(p0[0], p0[1], p0[2], p0[3], p0[4], p0[5], p0[6], p0[7]);
+        df[1] = pack8(p0[8], p0[9], p0[10], p0[11], p0[12], p0[13], p0[14], p0[15]);
+        df[2] = pack8(p1[0], p1[1], p1[2], p1[3], p1[4], p1[5], p1[6], p1[7]);
+        df[3] = pack8(p1[8], p1[9], p1[10], p1[11], p1[12], p1[13], p1[14], p1[15]);
+        mma_transposed(do_tr, v_off, pf, dva);                       // dV^T[d][key] += dO^T[d][q] P[q][key]
+        mma_transposed(q_tr, v_off, df, dka);                        // dK^T[d][key] += Q^T[d][q] dS[q][key]
+    }
+    if (ki < a.S) {
+        float* ok = dk_part + ((int64_t)hq * a.S + ki) * HD;
+        float* ov = dv_part + ((int64_t)hq * a.S + ki) * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = dt * 32 + g4 * 8 + h * 4;
+                *reinterpret_cast<f32x4*>(ok + d0) = f32x4{dka[dt][g4 * 4 + 0], dka[dt][g4 * 4 + 1], dka[dt][g4 * 4 + 2], dka[dt][g4 * 4 + 3]};
+                *reinterpret_cast<f32x4*>(ov + d0) = f32x4{dva[dt][g4 * 4 + 0], dva[dt][g4 * 4 + 1], dva[dt][g4 * 4 + 2], dva[dt][g4 * 4 + 3]};
+            }
+    }
+}
+
+// dk[s][g*128 + d] = sum over the q heads of group g of the per-head partials (fixed order: deterministic); same for dv
+__global__ __launch_bounds__(256) void attn_bwd_reduce_k(const float* __restrict__ dk_part, const float* __restrict__ dv_part, bf16* __restrict__ dk,
+                                                         bf16* __restrict__ dv, int64_t lddkv, int S, int Hq, int Hkv) {
+    const int rep = Hq / Hkv;
+    const int64_t total = (int64_t)S * Hkv * (HD / 4);
+    for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+        const int c = id % (HD / 4);
+        const int g = (id / (HD / 4)) % Hkv;
+        const int s = id / ((int64_t)(HD / 4) * Hkv);
+        f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = ak;
+        for (int j = 0; j < rep; ++j) {
+            const int64_t off = ((int64_t)(g * rep + j) * S + s) * HD + c * 4;
+            ak += *reinterpret_cast<const f32x4*>(dk_part + off);
+            av += *reinterpret_cast<const f32x4*>(dv_part + off);
+        }
+        *reinterpret_cast<bf16x4*>(dk + (int64_t)s * lddkv + g * HD + c * 4) = bf16x4{(bf16)ak[0], (bf16)ak[1], (bf16)ak[2], (bf16)ak[3]};
+        *reinterpret_cast<bf16x4*>(dv + (int64_t)s * lddkv + g * HD + c * 4) = bf16x4{(bf16)av[0], (bf16)av[1], (bf16)av[2], (bf16)av[3]};
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t ufv_attention_bwd_fused_ws_bytes(int S, int Hq) {
+    return (int64_t)Hq * S * sizeof(float) + 2 * (int64_t)Hq * S * 128 * sizeof(float) + 1024;       // delta + dK / dV partials per q head
+}
+
+extern "C" int ufv_attention_bwd_fused(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* o, int64_t ldo,
+                                       const void* dO, int64_t lddo, const float* lse, void* dq, int64_t lddq, void* dk, void* dv,
+                                       int64_t lddkv, int S, int Hq, int Hkv, int hd, float scale, void* ws, void* stream) {
+    UFV_REQUIRE(q && k && v && o && dO && lse && dq && dk && dv && ws && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0,
+                "ufv_attention_bwd_fused: bad arguments");
+    UFV_REQUIRE(hd == 128, "ufv_attention_bwd_fused: head_dim %d (128 only; use ufv_attention_bwd)", hd);
+    UFV_REQUIRE(ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0 && lddkv % 4 == 0 &&
+                ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)dO % 16 == 0) &&
+                ((uintptr_t)o % 16 == 0) && ((uintptr_t)dq % 8 == 0) && ((uintptr_t)dk % 8 == 0) && ((uintptr_t)dv % 8 == 0),
+                "ufv_attention_bwd_fused: rows must be 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    float* delta = reinterpret_cast<float*>(w);
+    float* dk_part = delta + (((int64_t)Hq * S + 63) & ~(int64_t)63);
+    float* dv_part = dk_part + (int64_t)Hq * S * 128;
+    BwdArgs a;
+    a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.dO = (const bf16*)dO;
+    a.ldq = ldq; a.ldkv = ldkv; a.lddo = lddo; a.lse = lse; a.delta = delta; a.S = S; a.Hq = Hq; a.Hkv = Hkv; a.scale = scale;
+    static bool attr_set = false;
+    constexpr int SM_DQ = 2 * 64 * PR + 64 * PT, SM_DKV = 2 * 64 * PR + 2 * 64 * PT + 512;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_k), hipFuncAttributeMaxDynamicSharedMemorySize, SM_DQ);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_k), hipFuncAttributeMaxDynamicSharedMemorySize, SM_DKV);
+        attr_set = true;
+    }
+    const int64_t nw = (int64_t)S * Hq;
+    hipLaunchKernelGGL(attn_bwd_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, (const bf16*)dO, lddo, (const bf16*)o, ldo, S, Hq, delta);
+    UFV_CHECK_LAUNCH();
+    const int nblk = (S + 127) / 128;
+    hipLaunchKernelGGL(attn_bwd_dq_k, dim3(nblk, Hq), dim3(NT), SM_DQ, st, a, (bf16*)dq, lddq);
+    UFV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_dkv_k, dim3(nblk, Hq), dim3(NT), SM_DKV, st, a, dk_part, dv_part);
+    UFV_CHECK_LAUNCH();
+    const int64_t total = (int64_t)S * Hkv * 32;
+    hipLaunchKernelGGL(attn_bwd_reduce_k, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, st, dk_part,
+                       dv_part, (bf16*)dk, (bf16*)dv, lddkv, S, Hq, Hkv);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}

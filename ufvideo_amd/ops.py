@@ -564,6 +564,31 @@ def attention_bwd(q, k, v, dO, dq, dk, dv, S, Hq, Hkv, hd, scale=None):
               _stream())
 
 
+def attention_causal_lse(q, k, v, out, lse, S, Hq, Hkv, hd, scale=None):
+    """Training forward of causal self-attention (hd 128): out [S, Hq*hd] bf16 and lse fp32 [Hq, S] (log2 domain) for
+    attention_bwd_fused.  q / k / v: row views (head h at column h*hd)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
+        _chk(t, torch.bfloat16, n)
+    _chk(lse, torch.float32, "lse"); assert lse.is_contiguous() and lse.numel() >= Hq * S
+    scale = hd ** -0.5 if scale is None else scale
+    _lib.call("ufv_attention_causal_lse", q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), out.data_ptr(),
+              out.stride(0), Hq, Hkv, S, hd, float(scale), lse.data_ptr(), _stream())
+    return out
+
+
+def attention_bwd_fused(q, k, v, o, dO, lse, dq, dk, dv, S, Hq, Hkv, hd, scale=None):
+    """Flash-style causal GQA attention backward (hd 128): same conventions as attention_bwd plus the forward output o and lse."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (dO, "dO"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _chk(t, torch.bfloat16, n)
+    _chk(lse, torch.float32, "lse")
+    assert k.stride(0) == v.stride(0) and dk.stride(0) == dv.stride(0) and k.shape[0] >= S and v.shape[0] >= S
+    scale = hd ** -0.5 if scale is None else scale
+    ws = _ws(q.device, _lib.load().ufv_attention_bwd_fused_ws_bytes(S, Hq), "attn_bwd_fused")
+    _lib.call("ufv_attention_bwd_fused", q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), k.stride(0), o.data_ptr(), o.stride(0),
+              dO.data_ptr(), dO.stride(0), lse.data_ptr(), dq.data_ptr(), dq.stride(0), dk.data_ptr(), dv.data_ptr(), dk.stride(0), S, Hq,
+              Hkv, hd, float(scale), ws.data_ptr(), _stream())
+
+
 def convert_into(src, dst):
     """dst[...] = src converted to dst.dtype (both contiguous, same number of elements)"""
     _chk(src, name="src"); _chk(dst, name="dst")

@@ -17,6 +17,7 @@ gradient buffer beside it, so the data-parallel exchange is one reduce-scatter p
 backward has finished and overlapped with the next layer's, and one all-gather of the updated bf16 shard.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -176,6 +177,8 @@ class DecoderTrainer:
         self.lm_headT = torch.empty((D, self.Vp), device=dev, dtype=torch.bfloat16)
         self._refresh_transposes()
         self._stash_S = 0
+        # flash-style attention backward (csrc/attn_bwd.hip) for head_dim 128; UFV_TRAIN_ATTN=materialised keeps the per-group GEMM pipeline
+        self.fused_attn_bwd = hd == 128 and os.environ.get("UFV_TRAIN_ATTN", "fused") != "materialised"
         self._fresh = True
         self._last_micro = False
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
@@ -203,7 +206,7 @@ class DecoderTrainer:
                         qkv=torch.empty((S, self.QW), device=dev, dtype=bf), kv=torch.zeros((Sp, 2 * KV * hd), device=dev, dtype=bf),
                         o=torch.empty((S, H * hd), device=dev, dtype=bf), x_mid=torch.empty((S, D), device=dev, dtype=f32),
                         h2=torch.empty((S, D), device=dev, dtype=bf), gu=torch.empty((S, 2 * I), device=dev, dtype=bf),
-                        act=torch.empty((S, I), device=dev, dtype=bf)) for _ in self.layers]
+                        act=torch.empty((S, I), device=dev, dtype=bf), lse=torch.empty((H, S), device=dev, dtype=f32)) for _ in self.layers]
         # scratch shared by all layers
         W = max(2 * I, self.QW, D, H * hd)
         self.sc = dict(dxb=torch.empty((S, D), device=dev, dtype=bf), dxbT=torch.empty((D, Sp), device=dev, dtype=bf),
@@ -249,8 +252,11 @@ class DecoderTrainer:
             ops.rmsnorm(x, L["ln1"], eps, out=h1)
             ops.gemm(h1, L["wqkv"], bias=L["bqkv"], out=qkv)
             ops.rope_kv(qkv, S, H, KV, hd, self.inv_freq, 0, kv, table=rope_tab)
-            ops.attention(qkv, kv, kv[:, KV * hd:], 1, H, KV, S, S, hd, (0, qkv.stride(0)), (0, kv.stride(0)), (0, kv.stride(0)),
-                          causal=True, q_pos0=0, out=o)
+            if self.fused_attn_bwd:                                                  # same kernel + the log-sum-exp the backward needs
+                ops.attention_causal_lse(qkv, kv, kv[:, KV * hd:], o, st["lse"], S, H, KV, hd)
+            else:
+                ops.attention(qkv, kv, kv[:, KV * hd:], 1, H, KV, S, S, hd, (0, qkv.stride(0)), (0, kv.stride(0)), (0, kv.stride(0)),
+                              causal=True, q_pos0=0, out=o)
             ops.gemm(o, L["wo"], resid=x, out=x)
             st["x_mid"][:S].copy_(x)
             ops.rmsnorm(x, L["ln2"], eps, out=h2)
@@ -309,7 +315,11 @@ class DecoderTrainer:
             ops.transpose(o, rpad=Sp, out=inT)
             dW(b, "wo", dxbT, inT, D, H * hd)
             dqkv = sc["dqkv"][:S]
-            ops.attention_bwd(qkv, kv, kv[:, KV * hd:], sc["do"][:S], dqkv, dqkv[:, H * hd:], dqkv[:, (H + KV) * hd:], S, H, KV, hd)
+            if self.fused_attn_bwd:
+                ops.attention_bwd_fused(qkv, kv, kv[:, KV * hd:], o, sc["do"][:S], st["lse"], dqkv, dqkv[:, H * hd:],
+                                        dqkv[:, (H + KV) * hd:], S, H, KV, hd)
+            else:
+                ops.attention_bwd(qkv, kv, kv[:, KV * hd:], sc["do"][:S], dqkv, dqkv[:, H * hd:], dqkv[:, (H + KV) * hd:], S, H, KV, hd)
             ops.rope_rows(dqkv, 0, H + KV, hd, self.inv_freq, 0, backward=True)
             ops.gemm(dqkv, wT["wqkv"], out=dh)                                       # d h1, fp32
             ops.transpose(dqkv, rpad=Sp, out=dyT)
