@@ -10,9 +10,8 @@
 //   attn_bwd_dkv  one wave = 32 keys of one kv head (K^T, V^T fragments in registers), one block per (128 keys, q head), loops
 //                 over 64-query tiles from the diagonal on:  S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS;
 //                 per-head fp32 partials, summed over the heads of the kv group by attn_bwd_reduce.
-// Tiles are staged global -> registers -> LDS once per step in the two layouts the reads need (row pitch 272 B for the
-// conflict-free ds_read_b128 row fragments, 320 B for the transposed reads), single-buffered: correctness and zero S^2 traffic
-// first; the prefetch ring of the forward kernel is the obvious next step.
+// Tiles go global -> registers (issued one tile ahead) -> LDS (two stages, one barrier per tile) in the two layouts the reads
+// need: row pitch 272 B for the conflict-free ds_read_b128 row fragments, 320 B for the transposed reads.
 #include "common.h"
 #include "../../include/ufv.h"
 
@@ -30,6 +29,7 @@ __device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, 
 constexpr int HD = 128, KS = 8, DT = 4, NCH = 16;            // k-steps of 16, d-tiles of 32, 16-byte chunks per row
 constexpr int PR = 272, PT = 320;                            // row pitch for row fragments / for transposed reads
 constexpr int NT = 256;
+constexpr int STAGE_DQ = 2 * 64 * PR + 64 * PT, STAGE_DKV = 2 * 64 * PR + 2 * 64 * PT + 512;
 
 struct BwdArgs {
     const bf16 *q, *k, *v, *dO;
@@ -39,39 +39,23 @@ struct BwdArgs {
     float scale;
 };
 
-// copy a 64-row x 128-col bf16 tile (rows row0.., clamped to nrows - 1) into LDS at pitch `pitch`
-__device__ __forceinline__ void stage_tile(const bf16* src, int64_t ld, int row0, int nrows, char* dst, int pitch, int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + i * NT, row = id / NCH, c = id % NCH;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (int64_t)min(row0 + row, nrows - 1) * ld + c * 8);
-        *reinterpret_cast<bf16x8*>(dst + row * pitch + c * 16) = v;
-    }
-}
-__device__ __forceinline__ void stage_tile2(const bf16* src, int64_t ld, int row0, int nrows, char* dst_a, int pitch_a, char* dst_b,
-                                            int pitch_b, int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + i * NT, row = id / NCH, c = id % NCH;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (int64_t)min(row0 + row, nrows - 1) * ld + c * 8);
-        *reinterpret_cast<bf16x8*>(dst_a + row * pitch_a + c * 16) = v;
-        *reinterpret_cast<bf16x8*>(dst_b + row * pitch_b + c * 16) = v;
-    }
-}
-
-// acc[dt] (+)= T^T[d][i] * B[i][col]: T = the 64-row tile at `tb` (pitch PT), contracted over its rows in the forward kernel's
-// chunk order; pf[c] = the B operand of 16-row chunk c (c = half * 2 + sub, see attn.hip)
-__device__ __forceinline__ void mma_transposed(const char* tb, int v_off, const bf16x8 (&pf)[4], f32x16 (&acc)[DT]) {
+// acc[dt] (+)= T^T[d][i] * B[i][col] over one 32-row half of a staged tile: T = 32 rows at `tb` (pitch PT), contracted over its
+// rows in the forward kernel's chunk order; pf[c] = the B operand of 16-row chunk c (see attn.hip)
+__device__ __forceinline__ void mma_transposed_half(const char* tb, int v_off, const bf16x8 (&pf)[2], f32x16 (&acc)[DT]) {
+    bf16x8 vf[DT][2];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 2; ++c) {
             const char* vp = tb + (16 * c) * PT + v_off + dt * 64;
             const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp));
             const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp + 8 * PT));
-            const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], acc[dt], 0, 0, 0);
+            vf[dt][c] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][c], pf[c], acc[dt], 0, 0, 0);
 }
 
 // delta[h][s] = sum_d dO[s][h*128 + d] * O[s][h*128 + d]; one wave per (s, h)
@@ -91,13 +75,12 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_k(const bf16* __restrict__
 // ---- dQ: grid (q tiles of 128, Hq) -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(BwdArgs a, bf16* __restrict__ dq, int64_t lddq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_row = smem;                       // 64 x PR
-    char* v_row = k_row + 64 * PR;            // 64 x PR
-    char* k_tr = v_row + 64 * PR;             // 64 x PT
+    // two stages of [K rows (pitch PR) | V rows (PR) | K rows again at the transposed-read pitch PT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
-    const int qt = gridDim.x - 1 - blockIdx.x;                       // heaviest (last) q tiles first
-    const int hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+    const int bi = blockIdx.x + gridDim.x * blockIdx.y;              // heaviest (last) q tiles of every head first
+    const int qt = gridDim.x - 1 - bi / a.Hq;
+    const int hq = bi % a.Hq, hkv = hq / (a.Hq / a.Hkv);
     const int q0 = qt * 128 + wave * 32, qi = q0 + l31;
     const int qc = min(qi, a.S - 1);
     bf16x8 qf[KS], dof[KS];
@@ -123,25 +106,55 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(BwdArgs a, bf16* __restri
     const bf16* vbase = a.v + hkv * HD;
     const int kmax = min(a.S, qt * 128 + 128);                       // causal: keys <= last query of the block
     const int ntiles = (kmax + 63) / 64;
+    bf16x8 kreg[4], vreg[4];                                         // next tile in flight while this one is consumed
+    auto issue_loads = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * NT, row = min(t * 64 + id / NCH, a.S - 1), c = id % NCH;
+            kreg[i] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)row * a.ldkv + c * 8);
+            vreg[i] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)row * a.ldkv + c * 8);
+        }
+    };
+    auto write_lds = [&](int st) {
+        char* b = smem + st * STAGE_DQ;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * NT, row = id / NCH, c = id % NCH;
+            *reinterpret_cast<bf16x8*>(b + row * PR + c * 16) = kreg[i];
+            *reinterpret_cast<bf16x8*>(b + 64 * PR + row * PR + c * 16) = vreg[i];
+            *reinterpret_cast<bf16x8*>(b + 128 * PR + row * PT + c * 16) = kreg[i];
+        }
+    };
+    issue_loads(0);
+    write_lds(0);
+    __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();                                             // previous tile fully consumed
-        stage_tile2(kbase, a.ldkv, t * 64, a.S, k_row, PR, k_tr, PT, tid);
-        stage_tile(vbase, a.ldkv, t * 64, a.S, v_row, PR, tid);
-        __syncthreads();
-        if (t * 64 > q0 + 31) continue;                              // wave-uniform: every key of the tile is after this wave's queries
+        if (t + 1 < ntiles) issue_loads(t + 1);
+        const char* k_row = smem + (t & 1) * STAGE_DQ;
+        const char* v_row = k_row + 64 * PR;
+        const char* k_tr = v_row + 64 * PR;
+        {   // (tiles past this wave's diagonal are computed too: everything in them is masked to zero; a wave-level skip costs more in register shuffling than the one or two tiles it saves)
         f32x16 s0, s1, p0, p1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; p0[r] = 0.f; p1[r] = 0.f; }
+        {
+            bf16x8 f0[KS], f1[KS];                                   // all row fragments of one operand in flight before its MFMAs
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(k_row + k_off + ks * 32);
-            const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(k_row + 32 * PR + k_off + ks * 32);
-            const bf16x8 vf0 = *reinterpret_cast<const bf16x8*>(v_row + k_off + ks * 32);
-            const bf16x8 vf1 = *reinterpret_cast<const bf16x8*>(v_row + 32 * PR + k_off + ks * 32);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
-            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, dof[ks], p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, dof[ks], p1, 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) f0[ks] = *reinterpret_cast<const bf16x8*>(k_row + k_off + ks * 32);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) f1[ks] = *reinterpret_cast<const bf16x8*>(k_row + 32 * PR + k_off + ks * 32);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[ks], qf[ks], s0, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) f0[ks] = *reinterpret_cast<const bf16x8*>(v_row + k_off + ks * 32);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[ks], qf[ks], s1, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) f1[ks] = *reinterpret_cast<const bf16x8*>(v_row + 32 * PR + k_off + ks * 32);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[ks], dof[ks], p0, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[ks], dof[ks], p1, 0, 0, 0);
         }
         // dS^T[key][q] = scale * P * (dP - delta); keys of register r: (r&3) + 8(r>>2) + 4h (+32 for the second half)
 #pragma unroll
@@ -158,7 +171,14 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(BwdArgs a, bf16* __restri
         pf[1] = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
         pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
         pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
-        mma_transposed(k_tr, v_off, pf, acc);                        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+        {                                                            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+            const bf16x8 pa[2] = {pf[0], pf[1]}, pb[2] = {pf[2], pf[3]};
+            mma_transposed_half(k_tr, v_off, pa, acc);
+            mma_transposed_half(k_tr + 32 * PT, v_off, pb, acc);
+        }
+        }
+        if (t + 1 < ntiles) write_lds((t + 1) & 1);
+        __syncthreads();
     }
     if (qi < a.S) {
         bf16* op = dq + (int64_t)qi * lddq + hq * HD;
@@ -176,15 +196,11 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(BwdArgs a, bf16* __restri
 // ---- dK, dV partials per q head: grid (key tiles of 128, Hq) -----------------------------------------------------------
 __global__ __launch_bounds__(NT, 1) void attn_bwd_dkv_k(BwdArgs a, float* __restrict__ dk_part, float* __restrict__ dv_part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* q_row = smem;                        // 64 x PR
-    char* do_row = q_row + 64 * PR;            // 64 x PR
-    char* q_tr = do_row + 64 * PR;             // 64 x PT
-    char* do_tr = q_tr + 64 * PT;              // 64 x PT
-    float* lse_s = reinterpret_cast<float*>(do_tr + 64 * PT);       // [64]
-    float* dl_s = lse_s + 64;                                        // [64]
+    // two stages of [Q rows (pitch PR) | dO rows (PR) | Q rows (PT) | dO rows (PT) | lse[64] | delta[64]]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
-    const int kt = blockIdx.x, hq = blockIdx.y, hkv = hq / (a.Hq / a.Hkv);
+    const int bi = blockIdx.x + gridDim.x * blockIdx.y;              // heaviest (first) key tiles of every head first
+    const int kt = bi / a.Hq, hq = bi % a.Hq, hkv = hq / (a.Hq / a.Hkv);
     const int k0 = kt * 128 + wave * 32, ki = k0 + l31;
     const int kc = min(ki, a.S - 1);
     bf16x8 kf[KS], vf[KS];                                           // B fragments: lane (col key = l31, k = d)
@@ -210,53 +226,90 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkv_k(BwdArgs a, float* __rest
     const float* lse_h = a.lse + (int64_t)hq * a.S;
     const float* dl_h = a.delta + (int64_t)hq * a.S;
     const int nqt = (a.S + 63) / 64;
-    for (int t = (kt * 128) / 64; t < nqt; ++t) {                    // causal: queries from this block's first key on
-        __syncthreads();
-        stage_tile2(qbase, a.ldq, t * 64, a.S, q_row, PR, q_tr, PT, tid);
-        stage_tile2(dobase, a.lddo, t * 64, a.S, do_row, PR, do_tr, PT, tid);
+    bf16x8 qreg[4], dreg[4];
+    float lreg = 0.f, dlreg = 0.f;
+    auto issue_loads = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * NT, row = min(t * 64 + id / NCH, a.S - 1), c = id % NCH;
+            qreg[i] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)row * a.ldq + c * 8);
+            dreg[i] = *reinterpret_cast<const bf16x8*>(dobase + (int64_t)row * a.lddo + c * 8);
+        }
         if (tid < 64) {
             const int qq = t * 64 + tid;
-            lse_s[tid] = qq < a.S ? lse_h[qq] : INFINITY;            // exp2(-inf) = 0 for the rows past the sequence end
-            dl_s[tid] = qq < a.S ? dl_h[qq] : 0.f;
+            lreg = qq < a.S ? lse_h[qq] : INFINITY;                  // exp2(-inf) = 0 for the rows past the sequence end
+            dlreg = qq < a.S ? dl_h[qq] : 0.f;
         }
+    };
+    auto write_lds = [&](int st) {
+        char* b = smem + st * STAGE_DKV;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + i * NT, row = id / NCH, c = id % NCH;
+            *reinterpret_cast<bf16x8*>(b + row * PR + c * 16) = qreg[i];
+            *reinterpret_cast<bf16x8*>(b + 64 * PR + row * PR + c * 16) = dreg[i];
+            *reinterpret_cast<bf16x8*>(b + 128 * PR + row * PT + c * 16) = qreg[i];
+            *reinterpret_cast<bf16x8*>(b + 128 * PR + 64 * PT + row * PT + c * 16) = dreg[i];
+        }
+        if (tid < 64) {
+            float* f = reinterpret_cast<float*>(b + 128 * PR + 128 * PT);
+            f[tid] = lreg;
+            f[64 + tid] = dlreg;
+        }
+    };
+    const int t0 = (kt * 128) / 64;                                  // causal: queries from this block's first key on
+    issue_loads(t0);
+    write_lds(0);
+    __syncthreads();
+    for (int t = t0; t < nqt; ++t) {
+        if (t + 1 < nqt) issue_loads(t + 1);
+        const char* q_row = smem + ((t - t0) & 1) * STAGE_DKV;
+        const char* do_row = q_row + 64 * PR;
+        const char* q_tr = do_row + 64 * PR;
+        const char* do_tr = q_tr + 64 * PT;
+        const float* lse_s = reinterpret_cast<const float*>(do_tr + 64 * PT);
+        const float* dl_s = lse_s + 64;
+        {   // (a tile wholly before this wave's keys is computed too and masked to zero, see attn_bwd_dq_k)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {                             // the two 32-query halves in turn (keeps the live tile at 32 VGPRs)
+            f32x16 sv, pv;                                           // [q][key]: lane = key column l31, rows = queries
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sv[r] = 0.f; pv[r] = 0.f; }
+            bf16x8 qa[KS], da[KS];                                   // all row fragments in flight before the first MFMA
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qa[ks] = *reinterpret_cast<const bf16x8*>(q_row + hh * 32 * PR + k_off + ks * 32);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) da[ks] = *reinterpret_cast<const bf16x8*>(do_row + hh * 32 * PR + k_off + ks * 32);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], sv, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) pv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[ks], vf[ks], pv, 0, 0, 0);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                         // registers 4g4..4g4+3 = 4 consecutive queries
+                const int ql = hh * 32 + 8 * g4 + 4 * h;             // query row inside the tile
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + ql);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = g4 * 4 + j;
+                    float x = __builtin_fmaf(sv[r], sl2, -l4[j]);
+                    x = (ki <= t * 64 + ql + j) ? x : -INFINITY;     // select, not a branch; rows past the end have lse = +inf
+                    const float e = __builtin_amdgcn_exp2f(x);
+                    sv[r] = e;
+                    pv[r] = a.scale * e * (pv[r] - d4[j]);
+                }
+            }
+            bf16x8 pf[2], df[2];
+            pf[0] = pack8(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
+            pf[1] = pack8(sv[8], sv[9], sv[10], sv[11], sv[12], sv[13], sv[14], sv[15]);
+            df[0] = pack8(pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7]);
+            df[1] = pack8(pv[8], pv[9], pv[10], pv[11], pv[12], pv[13], pv[14], pv[15]);
+            mma_transposed_half(do_tr + hh * 32 * PT, v_off, pf, dva);       // dV^T[d][key] += dO^T[d][q] P[q][key]
+            mma_transposed_half(q_tr + hh * 32 * PT, v_off, df, dka);        // dK^T[d][key] += Q^T[d][q] dS[q][key]
+        }
+        }
+        if (t + 1 < nqt) write_lds(((t - t0) + 1) & 1);
         __syncthreads();
-        if (t * 64 + 63 < k0) continue;                              // wave-uniform: every query of the tile is before this wave's keys
-        f32x16 s0, s1, p0, p1;                                       // [q][key]: lane = key column l31, rows = queries
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; p0[r] = 0.f; p1[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 qa0 = *reinterpret_cast<const bf16x8*>(q_row + k_off + ks * 32);
-            const bf16x8 qa1 = *reinterpret_cast<const bf16x8*>(q_row + 32 * PR + k_off + ks * 32);
-            const bf16x8 da0 = *reinterpret_cast<const bf16x8*>(do_row + k_off + ks * 32);
-            const bf16x8 da1 = *reinterpret_cast<const bf16x8*>(do_row + 32 * PR + k_off + ks * 32);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kf[ks], s1, 0, 0, 0);
-            p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0, vf[ks], p0, 0, 0, 0);
-            p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1, vf[ks], p1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ql = (r & 3) + 8 * (r >> 2) + 4 * h;           // query row inside the 32-row half
-            const int qa = t * 64 + ql, qb = qa + 32;
-            const bool ok0 = ki <= qa && ki < a.S, ok1 = ki <= qb && ki < a.S;
-            const float e0 = ok0 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -lse_s[ql])) : 0.f;
-            const float e1 = ok1 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -lse_s[ql + 32])) : 0.f;
-            s0[r] = e0; s1[r] = e1;
-            p0[r] = a.scale * e0 * (p0[r] - dl_s[ql]);
-            p1[r] = a.scale * e1 * (p1[r] - dl_s[ql + 32]);
-        }
-        bf16x8 pf[4], df[4];
-        pf[0] = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
-        pf[1] = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
-        pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
-        pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
-        df[0] = pack8(p0[0], p0[1], p0[2], p0[3], p0[4], p0[5], p0[6], p0[7]);
-        df[1] = pack8(p0[8], p0[9], p0[10], p0[11], p0[12], p0[13], p0[14], p0[15]);
-        df[2] = pack8(p1[0], p1[1], p1[2], p1[3], p1[4], p1[5], p1[6], p1[7]);
-        df[3] = pack8(p1[8], p1[9], p1[10], p1[11], p1[12], p1[13], p1[14], p1[15]);
-        mma_transposed(do_tr, v_off, pf, dva);                       // dV^T[d][key] += dO^T[d][q] P[q][key]
-        mma_transposed(q_tr, v_off, df, dka);                        // dK^T[d][key] += Q^T[d][q] dS[q][key]
     }
     if (ki < a.S) {
         float* ok = dk_part + ((int64_t)hq * a.S + ki) * HD;
@@ -317,7 +370,7 @@ extern "C" int ufv_attention_bwd_fused(const void* q, int64_t ldq, const void* k
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.dO = (const bf16*)dO;
     a.ldq = ldq; a.ldkv = ldkv; a.lddo = lddo; a.lse = lse; a.delta = delta; a.S = S; a.Hq = Hq; a.Hkv = Hkv; a.scale = scale;
     static bool attr_set = false;
-    constexpr int SM_DQ = 2 * 64 * PR + 64 * PT, SM_DKV = 2 * 64 * PR + 2 * 64 * PT + 512;
+    constexpr int SM_DQ = 2 * STAGE_DQ, SM_DKV = 2 * STAGE_DKV;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_k), hipFuncAttributeMaxDynamicSharedMemorySize, SM_DQ);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_k), hipFuncAttributeMaxDynamicSharedMemorySize, SM_DKV);
