@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(BwdArgs a, bf16* __restri
         }
     }
     const float lse = a.lse[(int64_t)hq * a.S + qc], dl = a.delta[(int64_t)hq * a.S + qc];
-    const float sl2 = a.scale * 1.4426950408889634f;
+    const float sl2 = a.scale * 1.4426950408889634f, scale_ = a.scale;
     f32x16 acc[DT];
 #pragma unroll
     for (int i = 0; i < DT; ++i)
@@ -127,6 +127,10 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(BwdArgs a, bf16* __restri
     };
     issue_loads(0);
     write_lds(0);
+    // pin the resident fragments here: a load still counted as pending at the loop header makes the compiler's vmcnt waits inside
+    // the loop cover the freshly issued prefetch as well
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) issue_loads(t + 1);
@@ -134,47 +138,32 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dq_k(BwdArgs a, bf16* __restri
         const char* v_row = k_row + 64 * PR;
         const char* k_tr = v_row + 64 * PR;
         {   // (tiles past this wave's diagonal are computed too: everything in them is masked to zero; a wave-level skip costs more in register shuffling than the one or two tiles it saves)
-        f32x16 s0, s1, p0, p1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; p0[r] = 0.f; p1[r] = 0.f; }
-        {
-            bf16x8 f0[KS], f1[KS];                                   // all row fragments of one operand in flight before its MFMAs
+        for (int hh = 0; hh < 2; ++hh) {                             // the two 32-key halves in turn (keeps the live tile at 32 VGPRs)
+            f32x16 sv, pv;                                           // [key][q]: lane = query column l31, rows = keys
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) f0[ks] = *reinterpret_cast<const bf16x8*>(k_row + k_off + ks * 32);
+            for (int r = 0; r < 16; ++r) { sv[r] = 0.f; pv[r] = 0.f; }
+            bf16x8 kfr[KS], vfr[KS];                                 // all row fragments in flight before the first MFMA
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) f1[ks] = *reinterpret_cast<const bf16x8*>(k_row + 32 * PR + k_off + ks * 32);
+            for (int ks = 0; ks < KS; ++ks) kfr[ks] = *reinterpret_cast<const bf16x8*>(k_row + hh * 32 * PR + k_off + ks * 32);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[ks], qf[ks], s0, 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) vfr[ks] = *reinterpret_cast<const bf16x8*>(v_row + hh * 32 * PR + k_off + ks * 32);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) f0[ks] = *reinterpret_cast<const bf16x8*>(v_row + k_off + ks * 32);
+            for (int ks = 0; ks < KS; ++ks) sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[ks], sv, 0, 0, 0);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[ks], qf[ks], s1, 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) pv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks], dof[ks], pv, 0, 0, 0);
+            // dS^T[key][q] = scale * P * (dP - delta); key of register r: 32hh + (r&3) + 8(r>>2) + 4h
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) f1[ks] = *reinterpret_cast<const bf16x8*>(v_row + 32 * PR + k_off + ks * 32);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[ks], dof[ks], p0, 0, 0, 0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) p1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[ks], dof[ks], p1, 0, 0, 0);
-        }
-        // dS^T[key][q] = scale * P * (dP - delta); keys of register r: (r&3) + 8(r>>2) + 4h (+32 for the second half)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kj = t * 64 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool ok0 = kj <= qi && kj < a.S, ok1 = kj + 32 <= qi && kj + 32 < a.S;
-            const float e0 = ok0 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -lse)) : 0.f;
-            const float e1 = ok1 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -lse)) : 0.f;
-            s0[r] = a.scale * e0 * (p0[r] - dl);
-            s1[r] = a.scale * e1 * (p1[r] - dl);
-        }
-        bf16x8 pf[4];
-        pf[0] = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
-        pf[1] = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
-        pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
-        pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
-        {                                                            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
-            const bf16x8 pa[2] = {pf[0], pf[1]}, pb[2] = {pf[2], pf[3]};
-            mma_transposed_half(k_tr, v_off, pa, acc);
-            mma_transposed_half(k_tr + 32 * PT, v_off, pb, acc);
+            for (int r = 0; r < 16; ++r) {
+                const int kj = t * 64 + hh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float x = __builtin_fmaf(sv[r], sl2, -lse);
+                x = (kj <= qi) ? x : -INFINITY;                      // select, not a branch (qi < S for every stored row, so kj < S too)
+                sv[r] = scale_ * __builtin_amdgcn_exp2f(x) * (pv[r] - dl);
+            }
+            bf16x8 pf[2];
+            pf[0] = pack8(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
+            pf[1] = pack8(sv[8], sv[9], sv[10], sv[11], sv[12], sv[13], sv[14], sv[15]);
+            mma_transposed_half(k_tr + hh * 32 * PT, v_off, pf, acc);        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
         }
         }
         if (t + 1 < ntiles) write_lds((t + 1) & 1);
@@ -260,6 +249,8 @@ __global__ __launch_bounds__(NT, 1) void attn_bwd_dkv_k(BwdArgs a, float* __rest
     const int t0 = (kt * 128) / 64;                                  // causal: queries from this block's first key on
     issue_loads(t0);
     write_lds(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));      // see attn_bwd_dq_k
     __syncthreads();
     for (int t = t0; t < nqt; ++t) {
         if (t + 1 < nqt) issue_loads(t + 1);
