@@ -34,7 +34,7 @@ def test_transpose_zero_padded(R, C):
     assert torch.equal(out[:, :R].cpu(), x.cpu().t()) and (out[:, R:] == 0).all()
 
 
-@pytest.mark.parametrize("M,D", [(9, 64), (300, 1024), (2399, 3584)])
+@pytest.mark.parametrize("M,D", [(9, 64), (300, 1024), (1030, 1028), (5, 4096), (2399, 3584)])
 def test_rmsnorm_bwd_vs_autograd(M, D):
     g = torch.Generator().manual_seed(M + D)
     x = torch.randn(M, D, generator=g) * 2
