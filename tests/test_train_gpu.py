@@ -413,9 +413,8 @@ def test_projector_grad_vs_oracle_autograd(cin, hid, t, hw, depth):
     assert rel_err(dx.float().cpu(), xr.grad) < 6e-2
 
 
-def test_train_step_with_projector_grads_vs_oracle_autograd():
-    """train_projector=True: tower (frozen) -> projector -> splice -> decoder -> CE; the projector's gradients that reach the
-    optimizer equal torch autograd through the oracle's connector + splice + decoder, and the step lowers the loss"""
+def _mm_tiny_model():
+    """tiny tower + STC-v35 connector + decoder with a one-video sample (weights from the oracle's generators)"""
     from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
     vit = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=56, patch_size=14)
     llm = dict(vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
@@ -444,6 +443,13 @@ def test_train_step_with_projector_grads_vs_oracle_autograd():
     video = torch.randn(4, 3, 56, 56, generator=g_)
     ids = torch.tensor([[5, 6, -201, 7, 8, 9, 12, 13]])
     labels = ids.clone(); labels[labels < 0] = -100; labels[:, :2] = -100
+    return m, sd, psd, lsd, vit, llm, video, ids, labels
+
+
+def test_train_step_with_projector_grads_vs_oracle_autograd():
+    """train_projector=True: tower (frozen) -> projector -> splice -> decoder -> CE; the projector's gradients that reach the
+    optimizer equal torch autograd through the oracle's connector + splice + decoder, and the step lowers the loss"""
+    m, sd, psd, lsd, vit, llm, video, ids, labels = _mm_tiny_model()
     tr = DecoderTrainer(m, lr=1e-3, train_projector=True)
     batch = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), attention_mask=torch.ones_like(ids).to(DEV), images=[(video.to(DEV), "video")])
     r1 = tr.train_step(**batch)
@@ -466,6 +472,29 @@ def test_train_step_with_projector_grads_vs_oracle_autograd():
     # the connector's own parameters moved (and its packed copies were rebuilt)
     moved = sum(int((v.detach().float().cpu() != psd[k]).any()) for k, v in m.get_model().mm_projector.named_parameters())
     assert moved > len(psd) // 2
+
+
+def test_adapter_only_step_freezes_the_decoder():
+    """train_decoder=False = the reference's tune_mm_mlp_adapter stage (train.py:882-885: everything frozen, then the projector
+    re-enabled).  Same kernels carry dL/dx through the frozen layers, so loss, projector gradients and the updated projector are
+    bit-identical to the full trainer's (clipping off: the clip norm covers the trainable set, which differs); the decoder has
+    no gradient / optimizer buffers and its weights do not move."""
+    outs = []
+    for td in (True, False):
+        m, sd, psd, lsd, vit, llm, video, ids, labels = _mm_tiny_model()
+        tr = DecoderTrainer(m, lr=1e-3, train_projector=True, train_decoder=td, max_grad_norm=0.0)
+        before = [b.w.clone() for b in tr.layers] + [tr.head.w.clone(), tr.small.w.clone()]
+        batch = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), attention_mask=torch.ones_like(ids).to(DEV), images=[(video.to(DEV), "video")])
+        r = tr.train_step(**batch)
+        after = [b.w for b in tr.layers] + [tr.head.w, tr.small.w]
+        outs.append((float(r["loss"]), tr.proj_bucket.g.clone(), tr.proj_bucket.w.clone(), [torch.equal(x, y) for x, y in zip(before, after)], tr))
+    (l1, g1, w1, same1, _), (l2, g2, w2, same2, tr2) = outs
+    assert l1 == l2 and torch.equal(g1, g2) and torch.equal(w1, w2)
+    assert not any(same1[:-1]) and all(same2)                      # full trainer moved every matrix bucket; adapter-only moved none
+    assert all(b.g is None and b.master is None for b in tr2.layers) and tr2.head.g is None
+    assert tr2.buckets() == [tr2.proj_bucket]
+    with pytest.raises(ValueError):
+        DecoderTrainer(tr2.model, train_decoder=False)
 
 
 def test_train_step_with_region_encoder_grads_vs_oracle_autograd():
@@ -510,7 +539,7 @@ def test_act_fwd_bwd_vs_autograd(act, fn):
     assert rel_err(ops.act_bwd(pre.to(torch.bfloat16).to(DEV), dout.to(torch.bfloat16).to(DEV), act).float().cpu(), pr.grad) < 1e-2
 
 
-@pytest.mark.parametrize("M,C,act", [(37, 64, None), (300, 1152, "silu"), (1100, 3584, "silu")])
+@pytest.mark.parametrize("M,C,act", [(37, 64, None), (300, 1152, "silu"), (1100, 3584, "silu"), (5000, 1152, "silu")])
 def test_layernorm_bwd_vs_autograd(M, C, act):
     g = torch.Generator().manual_seed(M + C)
     x, dout = bfr(torch.randn(M, C, generator=g) * 2 + 0.3), bfr(torch.randn(M, C, generator=g))
@@ -524,9 +553,10 @@ def test_layernorm_bwd_vs_autograd(M, C, act):
     assert rel_err(dw.cpu() - 1, wr.grad) < 1e-2 and rel_err(db.cpu(), br.grad) < 1e-2          # dw / db are added to
 
 
-def test_dwconv_se_gather_kernels_vs_torch():
+@pytest.mark.parametrize("Fr,H,W,C", [(3, 5, 6, 64), (6, 12, 10, 328)])
+def test_dwconv_se_gather_kernels_vs_torch(Fr, H, W, C):
+    """the second shape spans two 32-chunk block columns (the last one partial) and several pixel slices"""
     g = torch.Generator().manual_seed(43)
-    Fr, H, W, C = 3, 5, 6, 64
     x = bfr(torch.randn(Fr, H, W, C, generator=g)); w9 = torch.randn(9, C, generator=g)
     dy = bfr(torch.randn(Fr, H, W, C, generator=g))
     xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)

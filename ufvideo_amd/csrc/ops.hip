@@ -803,6 +803,8 @@ extern "C" int ufv_layernorm(const void* x, int x_dtype, int ldx, void* y, int y
     do {                                                                          \
         if (act == ACT_NONE && D <= 1280) LN_LAUNCH2(XD, YF, 5, ACT_NONE);        \
         else if (act == ACT_NONE) LN_LAUNCH2(XD, YF, MAXV, ACT_NONE);             \
+        else if (act == ACT_SILU && D <= 1280) LN_LAUNCH2(XD, YF, 5, ACT_SILU);   \
+        else if (act == ACT_SILU) LN_LAUNCH2(XD, YF, MAXV, ACT_SILU);             \
         else LN_LAUNCH2(XD, YF, MAXV, -1);                                        \
     } while (0)
     if (x_dtype == UFV_DT_F32) { if (y_f32) LN_LAUNCH(UFV_DT_F32, true); else LN_LAUNCH(UFV_DT_F32, false); }

@@ -63,7 +63,8 @@ class _Bucket:
     """Parameters that are exchanged and updated together: flat bf16 working copy `wb` (or fp32 `wf` for the small
     fp32 parameters), flat fp32 gradient `g`, and this rank's shard of master / m / v."""
 
-    def __init__(self, names_shapes, device, world, rank, dtype, decay):
+    def __init__(self, names_shapes, device, world, rank, dtype, decay, trainable=True, keep_grad=False):
+        self.trainable = trainable
         self.entries = []
         off = 0
         for name, shape in names_shapes:
@@ -74,7 +75,7 @@ class _Bucket:
         self.world, self.rank, self.decay = world, rank, decay
         self.dtype = dtype
         self.w = torch.zeros((self.n,), device=device, dtype=dtype)
-        self.g = torch.zeros((self.n,), device=device, dtype=torch.float32)
+        self.g = torch.zeros((self.n,), device=device, dtype=torch.float32) if (trainable or keep_grad) else None
         self.shard = self.n // world
         self.master = None
         self.work = None                                          # pending reduce-scatter
@@ -86,6 +87,8 @@ class _Bucket:
         raise KeyError(name)
 
     def init_states(self):
+        if not self.trainable:
+            return
         lo = self.rank * self.shard
         self.master = self.w[lo:lo + self.shard].to(torch.float32).clone()
         self.m = torch.zeros_like(self.master)
@@ -101,7 +104,10 @@ class DecoderTrainer:
     initialised, else single process)."""
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 train_embed=True, train_projector=False, train_region_encoder=False):
+                 train_embed=True, train_projector=False, train_region_encoder=False, train_decoder=True):
+        """train_decoder=False freezes the language model (the reference's tune_mm_mlp_adapter / tune_region_encoder stages,
+        train.py:882-890: model.requires_grad_(False), then only the adapter's parameters are re-enabled): backward still carries
+        dL/dx through every layer, but no weight gradient, no fp32 states and no update exist for the decoder."""
         self.model = model
         self.cfg = cfg = model.config
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
@@ -109,7 +115,10 @@ class DecoderTrainer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.t = 0
-        self.train_embed = train_embed
+        self.train_decoder = bool(train_decoder)
+        self.train_embed = train_embed = bool(train_embed) and self.train_decoder
+        if not self.train_decoder and not (train_projector or train_region_encoder):
+            raise ValueError("nothing to train: train_decoder=False needs train_projector and / or train_region_encoder")
         dev = model.device
         self.dev = dev
         D, I = cfg.hidden_size, cfg.intermediate_size
@@ -124,7 +133,7 @@ class DecoderTrainer:
             if "wqkv8" in L:
                 raise NotImplementedError("training runs on the bf16 weights (set_gemm_dtype('bf16'))")
             b = _Bucket([("wqkv", (self.QW, D)), ("wo", (D, H * hd)), ("wgu", (2 * I, D)), ("wd", (D, I))], dev, self.world, self.rank,
-                        torch.bfloat16, True)
+                        torch.bfloat16, True, trainable=self.train_decoder)
             for k in ("wqkv", "wo", "wgu", "wd"):
                 b.view(b.w, k).copy_(L[k])
                 L[k] = b.view(b.w, k)                             # the model now reads the trainer's buffer
@@ -133,7 +142,7 @@ class DecoderTrainer:
         self.V, self.Vp = V, _ru(V, 128)
         hpk = model.packed()
         head = [("lm_head", (self.Vp, D))] + ([("embed", (V, D))] if train_embed else [])
-        self.head = _Bucket(head, dev, self.world, self.rank, torch.bfloat16, True)
+        self.head = _Bucket(head, dev, self.world, self.rank, torch.bfloat16, True, trainable=self.train_decoder)
         self.head.view(self.head.w, "lm_head")[:V].copy_(hpk["lm_head"])
         hpk["lm_head_pad"] = self.head.view(self.head.w, "lm_head")
         hpk["lm_head"] = hpk["lm_head_pad"][:V]
@@ -143,7 +152,8 @@ class DecoderTrainer:
         small = [("norm", (D,))]
         for i in range(len(self.layers)):
             small += [(f"ln1.{i}", (D,)), (f"ln2.{i}", (D,)), (f"bqkv.{i}", (self.QW,))]
-        self.small = _Bucket(small, dev, 1, 0, torch.float32, False)          # replicated: all-reduced, updated by every rank
+        # replicated: all-reduced, updated by every rank (frozen decoder: the gradient buffer is only the kernels' scratch output)
+        self.small = _Bucket(small, dev, 1, 0, torch.float32, False, trainable=self.train_decoder, keep_grad=True)
         self.small.view(self.small.w, "norm").copy_(pk["norm"]); pk["norm"] = self.small.view(self.small.w, "norm")
         for i, L in enumerate(pk["layers"]):
             for k in ("ln1", "ln2", "bqkv"):
@@ -184,7 +194,9 @@ class DecoderTrainer:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
 
     def buckets(self):
-        return self.layers + [self.head, self.small] + ([self.proj_bucket] if self.proj_bucket is not None else [])
+        """the buckets that are exchanged and updated"""
+        dec = self.layers + [self.head, self.small] if self.train_decoder else []
+        return dec + ([self.proj_bucket] if self.proj_bucket is not None else [])
 
     def _refresh_transposes(self):
         for b, t in zip(self.layers, self.wT):
@@ -280,6 +292,8 @@ class DecoderTrainer:
         dxb, dxbT, inT, dyT, dh = sc["dxb"][:S], sc["dxbT"], sc["inT"], sc["dyT"], sc["dh"][:S]
         g_small = self.small.g
 
+        td = self.train_decoder
+
         def dW(b_or_buf, name, dy_T, x_T, rows, cols):
             """grad[name] [rows, cols] += dy^T [rows, Sp] . (x^T [cols, Sp])^T"""
             gw = b_or_buf.view(b_or_buf.g, name)
@@ -288,10 +302,12 @@ class DecoderTrainer:
         # lm_head + final norm
         dx = torch.empty((S, D), device=self.dev, dtype=torch.float32)
         ops.gemm(dl, self.lm_headT, out=dh)                                          # d hb, fp32 [S, D]
-        dlT = ops.transpose(dl, rpad=Sp)                                             # [Vp, Sp]
-        hbT = ops.transpose(hb, rpad=Sp, out=inT)
-        dW(self.head, "lm_head", dlT, hbT, self.Vp, D)
-        del dlT, dl
+        if td:
+            dlT = ops.transpose(dl, rpad=Sp)                                         # [Vp, Sp]
+            hbT = ops.transpose(hb, rpad=Sp, out=inT)
+            dW(self.head, "lm_head", dlT, hbT, self.Vp, D)
+            del dlT
+        del dl
         ops.rmsnorm_bwd(x_last, pk["norm"], dh, dx, self.small.view(g_small, "norm"), eps, accumulate=False)
         for li in range(len(self.layers) - 1, -1, -1):
             L, st, b, wT = pk["layers"][li], self.st[li], self.layers[li], self.wT[li]
@@ -299,21 +315,24 @@ class DecoderTrainer:
             # ---- MLP: x_out = x_mid + down(act)
             ops.convert_into(dx, dxb)
             ops.gemm(dxb, wT["wd"], out=sc["dact"][:S])                              # dact [S, I]
-            ops.transpose(dxb, rpad=Sp, out=dxbT)
-            ops.transpose(act, rpad=Sp, out=inT)
-            dW(b, "wd", dxbT, inT, D, I)
+            if td:
+                ops.transpose(dxb, rpad=Sp, out=dxbT)
+                ops.transpose(act, rpad=Sp, out=inT)
+                dW(b, "wd", dxbT, inT, D, I)
             ops.swiglu_bwd(gu, sc["dact"][:S], out=sc["dgu"][:S])
             ops.gemm(sc["dgu"][:S], wT["wgu"], out=dh)                               # d h2, fp32
-            ops.transpose(sc["dgu"][:S], rpad=Sp, out=dyT)
-            ops.transpose(h2, rpad=Sp, out=inT)
-            dW(b, "wgu", dyT, inT, 2 * I, D)
+            if td:
+                ops.transpose(sc["dgu"][:S], rpad=Sp, out=dyT)
+                ops.transpose(h2, rpad=Sp, out=inT)
+                dW(b, "wgu", dyT, inT, 2 * I, D)
             ops.rmsnorm_bwd(st["x_mid"][:S], L["ln2"], dh, dx, self.small.view(g_small, f"ln2.{li}"), eps)
             # ---- attention: x_mid = x_in + o_proj(attn)
             ops.convert_into(dx, dxb)
             ops.gemm(dxb, wT["wo"], out=sc["do"][:S])                                # d o [S, H*hd]
-            ops.transpose(dxb, rpad=Sp, out=dxbT)
-            ops.transpose(o, rpad=Sp, out=inT)
-            dW(b, "wo", dxbT, inT, D, H * hd)
+            if td:
+                ops.transpose(dxb, rpad=Sp, out=dxbT)
+                ops.transpose(o, rpad=Sp, out=inT)
+                dW(b, "wo", dxbT, inT, D, H * hd)
             dqkv = sc["dqkv"][:S]
             if self.fused_attn_bwd:
                 ops.attention_bwd_fused(qkv, kv, kv[:, KV * hd:], o, sc["do"][:S], st["lse"], dqkv, dqkv[:, H * hd:],
@@ -322,12 +341,14 @@ class DecoderTrainer:
                 ops.attention_bwd(qkv, kv, kv[:, KV * hd:], sc["do"][:S], dqkv, dqkv[:, H * hd:], dqkv[:, (H + KV) * hd:], S, H, KV, hd)
             ops.rope_rows(dqkv, 0, H + KV, hd, self.inv_freq, 0, backward=True)
             ops.gemm(dqkv, wT["wqkv"], out=dh)                                       # d h1, fp32
-            ops.transpose(dqkv, rpad=Sp, out=dyT)
-            ops.transpose(h1, rpad=Sp, out=inT)
-            dW(b, "wqkv", dyT, inT, self.QW, D)
-            ops.colsum(dqkv, self.small.view(g_small, f"bqkv.{li}"))
+            if td:
+                ops.transpose(dqkv, rpad=Sp, out=dyT)
+                ops.transpose(h1, rpad=Sp, out=inT)
+                dW(b, "wqkv", dyT, inT, self.QW, D)
+                ops.colsum(dqkv, self.small.view(g_small, f"bqkv.{li}"))
             ops.rmsnorm_bwd(st["x_in"][:S], L["ln1"], dh, dx, self.small.view(g_small, f"ln1.{li}"), eps)
-            self._reduce_async(b)
+            if td:
+                self._reduce_async(b)
         self._fresh = False
         if self.train_embed and embed_ids is not None:
             ops.scatter_add_rows(dx, embed_ids.to(self.dev).contiguous(), self.head.view(self.head.g, "embed"))
@@ -424,11 +445,11 @@ class DecoderTrainer:
         cs = self.comm_stream
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):
-            for b in list(reversed(self.layers)) + [self.head]:   # the order backward produced them
+            for b in (list(reversed(self.layers)) + [self.head]) if self.train_decoder else []:   # the order backward produced them
                 if not getattr(b, "reduced", False):              # not already started by _reduce_async
                     reduce_scatter_mean(b.gshard, b.g, self.group)
                 b.reduced = False
-            for rb in [self.small] + ([self.proj_bucket] if self.proj_bucket is not None else []):      # replicated buckets
+            for rb in ([self.small] if self.train_decoder else []) + ([self.proj_bucket] if self.proj_bucket is not None else []):      # replicated buckets
                 dist.all_reduce(rb.g, op=dist.ReduceOp.SUM, group=self.group)
                 rb.g.mul_(1.0 / self.world)
         torch.cuda.current_stream().wait_stream(cs)
@@ -479,10 +500,11 @@ class DecoderTrainer:
             else:
                 lo = b.rank * b.shard
                 ops.adamw(b.master, g, b.m, b.v, b.w[lo:lo + b.shard], self.lr, b1, b2, self.eps, wd, self.t, gscale)
-        if self.world > 1:
-            for b in self.layers + [self.head]:
-                all_gather_shards(b.w, self.group)
-        self._refresh_transposes()
+        if self.train_decoder:
+            if self.world > 1:
+                for b in self.layers + [self.head]:
+                    all_gather_shards(b.w, self.group)
+            self._refresh_transposes()
 
     # ---- export in the reference's parameter names --------------------------------------------------------------------
     def export_state_dict(self):
