@@ -270,9 +270,12 @@ def test_export_state_dict_roundtrip_before_any_step():
     assert "model.embed_tokens.weight" not in sd
 
 
-def test_fulldim_layer_grads_vs_oracle_autograd():
+@pytest.mark.parametrize("attn", ["fused", "materialised"])
+def test_fulldim_layer_grads_vs_oracle_autograd(attn, monkeypatch):
     """One decoder layer at the 7B dims (D 3584, 28/4 heads x 128, d_ff 18944), S = 256, vocab 1024: every GEMM of the backward
-    runs on the MFMA tile kernels (N % 128 == 0, K % 64 == 0).  Checker: torch autograd over the oracle on the host."""
+    runs on the MFMA tile kernels (N % 128 == 0, K % 64 == 0), with either attention backward (flash-style kernels / per-group GEMM
+    pipeline).  Checker: torch autograd over the oracle on the host."""
+    monkeypatch.setenv("UFV_TRAIN_ATTN", attn)
     from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
     llm = dict(vocab_size=1024, hidden_size=3584, intermediate_size=18944, num_hidden_layers=1, num_attention_heads=28,
                num_key_value_heads=4, rope_theta=1e6, rms_norm_eps=1e-6)
@@ -283,6 +286,7 @@ def test_fulldim_layer_grads_vs_oracle_autograd():
     m.load_state_dict(w, strict=False)
     m = m.to(DEV)
     tr = DecoderTrainer(m, train_embed=False)
+    assert tr.fused_attn_bwd == (attn == "fused")
     g = torch.Generator().manual_seed(12)
     S = 256
     emb = torch.randn(S, 3584, generator=g)

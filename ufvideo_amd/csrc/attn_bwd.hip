@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_k(const bf16* __restrict__
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= (int64_t)S * Hq) return;
-    const int s = w / Hq, h = w % Hq;
+    const int h = w / S, s = w % S;                                  // consecutive waves -> consecutive floats of delta[h][*]
     const bf16x2 a = *reinterpret_cast<const bf16x2*>(dO + (int64_t)s * lddo + h * HD + lane * 2);
     const bf16x2 b = *reinterpret_cast<const bf16x2*>(O + (int64_t)s * ldo + h * HD + lane * 2);
     float t = (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1];
