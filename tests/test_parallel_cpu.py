@@ -148,3 +148,16 @@ def test_bucket_layout_and_shard_bounds():
         assert got == list(range(b.n))
     with pytest.raises(KeyError):
         b.view(b.w, "missing")
+
+
+def test_warmup_cosine_ratio_shape():
+    """DeepSpeed WarmupCosineLR as scripts/zero2.json configures it (restated, parity unpinned): linear ramp from 0, 1.0-ish at the
+    end of the warm-up, cosine decay to cos_min_ratio at the last step, monotone in both phases"""
+    from ufvideo_amd.train import warmup_cosine_ratio as r
+    total, warm = 100, 10
+    v = [r(i, total, warm) for i in range(total)]
+    assert v[0] == 0.0 and abs(v[5] - 0.5) < 1e-12 and all(b > a for a, b in zip(v[:warm], v[1:warm]))
+    assert all(b < a for a, b in zip(v[warm:], v[warm + 1:])) and v[warm] < 1.0 and v[warm] > 0.99
+    assert abs(r(total - 1, total, warm) - 0.03) < 1e-12 and r(-1, total, warm) == 0.0
+    assert abs(r(3, total, warm, warmup_type="log") - __import__("math").log(4) / __import__("math").log(10)) < 1e-12
+    assert r(0, 100, 0) == 0.0 and r(1, 100, 0) == 0.5            # warm-up is at least 2 steps

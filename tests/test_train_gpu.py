@@ -501,6 +501,18 @@ def test_adapter_only_step_freezes_the_decoder():
         DecoderTrainer(tr2.model, train_decoder=False)
 
 
+def test_mm_projector_lr_group_and_lr_ratio():
+    """--mm_projector_lr gives mm_projector.* its own rate (videorefer_trainer.py:278-306); set_lr_ratio scales every group"""
+    ws = []
+    for kw, ratio in ((dict(lr=2e-3), 1.0), (dict(lr=1e-3, mm_projector_lr=2e-3), 1.0), (dict(lr=8e-3, mm_projector_lr=4e-3), 0.5)):
+        m, sd, psd, lsd, vit, llm, video, ids, labels = _mm_tiny_model()
+        tr = DecoderTrainer(m, train_projector=True, train_decoder=False, max_grad_norm=0.0, **kw)
+        tr.set_lr_ratio(ratio)
+        tr.train_step(input_ids=ids.to(DEV), labels=labels.to(DEV), attention_mask=torch.ones_like(ids).to(DEV), images=[(video.to(DEV), "video")])
+        ws.append(tr.proj_bucket.w.clone())
+    assert torch.equal(ws[0], ws[1]) and torch.equal(ws[0], ws[2])
+
+
 def test_train_step_with_region_encoder_grads_vs_oracle_autograd():
     """train_region_encoder=True on the golden `vid_region` sample (two region tokens): the MLP's gradients equal torch autograd
     through oracle mask_extractor + splice + decoder"""

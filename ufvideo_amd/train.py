@@ -104,13 +104,17 @@ class DecoderTrainer:
     initialised, else single process)."""
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 train_embed=True, train_projector=False, train_region_encoder=False, train_decoder=True):
+                 train_embed=True, train_projector=False, train_region_encoder=False, train_decoder=True, mm_projector_lr=None):
         """train_decoder=False freezes the language model (the reference's tune_mm_mlp_adapter / tune_region_encoder stages,
         train.py:882-890: model.requires_grad_(False), then only the adapter's parameters are re-enabled): backward still carries
         dL/dx through every layer, but no weight gradient, no fp32 states and no update exist for the decoder."""
         self.model = model
         self.cfg = cfg = model.config
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        # the reference's optimizer groups give mm_projector.* its own learning rate when --mm_projector_lr is set
+        # (videorefer_trainer.py:278-306); None = the common rate.  set_lr_ratio() scales both, as its scheduler does per group.
+        self.base_lr, self.mm_projector_lr = lr, mm_projector_lr
+        self.base_mm_projector_lr = mm_projector_lr
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
@@ -487,7 +491,8 @@ class DecoderTrainer:
             wd = self.wd if b.decay else 0.0
             if b is self.proj_bucket:                 # decay on matrices only: two passes over the flat buffer by entry
                 for name, shape, off, n in b.entries:
-                    ops.adamw(b.master[off:off + n], g[off:off + n], b.m[off:off + n], b.v[off:off + n], None, self.lr, b1, b2, self.eps,
+                    lr_e = self.mm_projector_lr if (self.mm_projector_lr is not None and name.startswith("mm_projector.")) else self.lr
+                    ops.adamw(b.master[off:off + n], g[off:off + n], b.m[off:off + n], b.v[off:off + n], None, lr_e, b1, b2, self.eps,
                               0.0 if name in self.proj_nodecay else self.wd, self.t, gscale)
                 b.w.copy_(b.master)
                 for k, v in self.proj_params.items():
@@ -505,6 +510,12 @@ class DecoderTrainer:
                 for b in self.layers + [self.head]:
                     all_gather_shards(b.w, self.group)
             self._refresh_transposes()
+
+    def set_lr_ratio(self, ratio):
+        """learning rates of the next step() = initial rates x ratio (what an LR scheduler does to every optimizer group)"""
+        self.lr = self.base_lr * ratio
+        if self.base_mm_projector_lr is not None:
+            self.mm_projector_lr = self.base_mm_projector_lr * ratio
 
     # ---- export in the reference's parameter names --------------------------------------------------------------------
     def export_state_dict(self):
@@ -531,6 +542,23 @@ class DecoderTrainer:
         if self.train_embed:
             sd["model.embed_tokens.weight"] = self.head.view(self.head.w, "embed").clone()
         return sd
+
+
+def warmup_cosine_ratio(it, total_num_steps, warmup_num_steps, warmup_min_ratio=0.0, cos_min_ratio=0.03, warmup_type="linear"):
+    """LR multiplier at scheduler iteration `it` (0-based count of optimizer steps already taken) of the schedule the reference
+    trains with: DeepSpeed `WarmupCosineLR` as configured in scripts/zero2.json:13-22 (warmup_min_ratio 0, cos_min_ratio 0.03,
+    linear warm-up; total / warm-up steps filled in by the HF Trainer).  DeepSpeed (0.17.5 pinned, requirements.txt:33) is not in
+    this image and the reference holds no test for it: restated from its published lr_schedules.py -- parity unpinned.
+      it <  warmup:  warmup_min_ratio + (1 - warmup_min_ratio) * (it / warmup   |   log(it + 1) / log(warmup))
+      it >= warmup:  max(0, cos_min_ratio + (1 - cos_min_ratio) * (1 + cos(pi * (it - warmup + 1) / (total - warmup))) / 2)"""
+    warmup = max(2, int(warmup_num_steps))
+    if it < 0:
+        return 0.0
+    if it < warmup:
+        r = it / warmup if warmup_type == "linear" else math.log(it + 1) / math.log(warmup)
+        return warmup_min_ratio + (1.0 - warmup_min_ratio) * r
+    done, span = it - warmup + 1, max(1, total_num_steps - warmup)
+    return max(0.0, cos_min_ratio + (1.0 - cos_min_ratio) * (1.0 + math.cos(math.pi * done / span)) / 2.0)
 
 
 def shard_bounds(n, world, rank):
