@@ -200,6 +200,27 @@ def test_attention_bwd_fused_vs_autograd(S, H, KV):
     assert rel_err(d, d2.float().cpu()) < 1.5e-2
 
 
+def test_attention_bwd_fused_rejects_what_it_does_not_serve():
+    """head_dim other than 128 and misaligned rows are errors of the C entry (UfvError with a message), never a silent fallback"""
+    from ufvideo_amd import _lib
+    S, H, KV, hd = 40, 2, 1, 64
+    q = torch.zeros(S, H * hd, device=DEV, dtype=torch.bfloat16)
+    kv = torch.zeros(S, 2 * KV * hd, device=DEV, dtype=torch.bfloat16)
+    lse = torch.zeros(H, S, device=DEV)
+    d = torch.zeros(S, (H + 2 * KV) * hd, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(_lib.UfvError, match="head_dim"):
+        ops.attention_bwd_fused(q, kv, kv[:, KV * hd:], q, q, lse, d, d[:, H * hd:], d[:, (H + KV) * hd:], S, H, KV, hd)
+    with pytest.raises(_lib.UfvError):
+        ops.attention_causal_lse(q, kv, kv[:, KV * hd:], q.clone(), lse, S, H, KV, hd)
+    hd = 128
+    q = torch.zeros(S, H * hd + 4, device=DEV, dtype=torch.bfloat16)[:, 4:]           # rows start 8 bytes off a 16-byte boundary
+    kv = torch.zeros(S, 2 * KV * hd, device=DEV, dtype=torch.bfloat16)
+    d = torch.zeros(S, (H + 2 * KV) * hd, device=DEV, dtype=torch.bfloat16)
+    o = torch.zeros(S, H * hd, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(_lib.UfvError, match="aligned"):
+        ops.attention_bwd_fused(q, kv, kv[:, KV * hd:], o, o, lse, d, d[:, H * hd:], d[:, (H + KV) * hd:], S, H, KV, hd)
+
+
 # ---- the whole step on the tiny model vs the reference's own backward / optimizer step ------------------------------------------
 
 def _shift(labels):
