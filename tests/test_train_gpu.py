@@ -164,7 +164,7 @@ def test_attention_bwd_vs_autograd(S, H, KV, hd):
     assert rel_err(d[:, (H + KV) * hd:], vr.grad) < 2e-2
 
 
-@pytest.mark.parametrize("S,H,KV", [(37, 4, 2), (128, 2, 2), (300, 4, 2), (515, 7, 1), (1000, 14, 2)])
+@pytest.mark.parametrize("S,H,KV", [(37, 4, 2), (128, 2, 2), (192, 2, 1), (300, 4, 2), (515, 7, 1), (1000, 14, 2)])
 def test_attention_bwd_fused_vs_autograd(S, H, KV):
     """flash-style backward (hd 128): forward kernel's lse + output, then dQ / dK / dV without any S x S buffer"""
     hd = 128
