@@ -176,11 +176,28 @@ class DecoderTrainer:
         if self.train_region:
             self.aux_modules["region_encoder."] = model.get_model().region_encoder
         if self.aux_modules:
-            self.proj_params = {pre + k: v for pre, mod in self.aux_modules.items() for k, v in mod.named_parameters()}
-            self.proj_bucket = _Bucket([(k, tuple(v.shape)) for k, v in self.proj_params.items()], dev, 1, 0, torch.float32, True)
-            for k, v in self.proj_params.items():
-                self.proj_bucket.view(self.proj_bucket.w, k).copy_(v)
-            self.proj_nodecay = [k for k, v in self.proj_params.items() if v.ndim < 2]
+            named = [(pre + k, v) for pre, mod in self.aux_modules.items() for k, v in mod.named_parameters()]
+            # per module: matrices first, then vectors, so that every (learning rate, decay) group is ONE contiguous range of the flat
+            # buffers and the update is a handful of launches instead of one per parameter (the connector has 113)
+            named.sort(key=lambda kv: (not kv[0].startswith("mm_projector."), kv[1].ndim < 2))
+            self.proj_params = dict(named)
+            self.proj_bucket = pb = _Bucket([(k, tuple(v.shape)) for k, v in named], dev, 1, 0, torch.float32, True)
+            self.proj_nodecay = [k for k, v in named if v.ndim < 2]
+            self.proj_ranges = []                                  # [lo, hi, is_projector, decay]; alignment gaps hold zeros and stay zero
+            for name, shape, off, n in pb.entries:
+                key = (name.startswith("mm_projector."), name not in self.proj_nodecay)
+                if self.proj_ranges and self.proj_ranges[-1][2:] == list(key):
+                    self.proj_ranges[-1][1] = off + n
+                else:
+                    self.proj_ranges.append([off, off + n, *key])
+            # the modules' (bf16) parameters become views of one flat buffer: refreshed from the masters with one conversion per step
+            same = len({v.dtype for _, v in named}) == 1
+            self.proj_flat = torch.zeros((pb.n,), device=dev, dtype=named[0][1].dtype) if same else None
+            for (k, v), (_, shape, off, n) in zip(named, pb.entries):
+                pb.view(pb.w, k).copy_(v)
+                if same:
+                    self.proj_flat[off:off + n].view(shape).copy_(v)
+                    v.data = self.proj_flat[off:off + n].view(shape)
         for b in self.buckets():
             b.init_states()
         # ---- transposed weight copies for dX = dY W (the NT GEMM wants W^T rows)
@@ -414,9 +431,9 @@ class DecoderTrainer:
                 ops.gather_rows(dxs, i64(m_dst), d_mm, i64(m_src))
             for k, st_ in enumerate(stashes):
                 grads, _ = self.pgrad.backward(d_mm[k * tok:(k + 1) * tok], st_)
-                for name, gval in grads.items():
-                    name = "mm_projector." + name
-                    self.proj_bucket.view(self.proj_bucket.g, name).add_(gval.reshape(self.proj_params[name].shape))
+                names = ["mm_projector." + name for name in grads]
+                torch._foreach_add_([self.proj_bucket.view(self.proj_bucket.g, nm) for nm in names],
+                                    [gval.reshape(self.proj_params[nm].shape) for nm, gval in zip(names, grads.values())])
         if region_stash:                               # region-token rows -> the region encoder's MLP
             r_src, r_dst, n_reg = m._last_region_map
             if r_src:
@@ -490,13 +507,16 @@ class DecoderTrainer:
         for b, g in shards:
             wd = self.wd if b.decay else 0.0
             if b is self.proj_bucket:                 # decay on matrices only: two passes over the flat buffer by entry
-                for name, shape, off, n in b.entries:
-                    lr_e = self.mm_projector_lr if (self.mm_projector_lr is not None and name.startswith("mm_projector.")) else self.lr
-                    ops.adamw(b.master[off:off + n], g[off:off + n], b.m[off:off + n], b.v[off:off + n], None, lr_e, b1, b2, self.eps,
-                              0.0 if name in self.proj_nodecay else self.wd, self.t, gscale)
+                for lo, hi, is_proj, decay in self.proj_ranges:
+                    lr_e = self.mm_projector_lr if (self.mm_projector_lr is not None and is_proj) else self.lr
+                    ops.adamw(b.master[lo:hi], g[lo:hi], b.m[lo:hi], b.v[lo:hi], None, lr_e, b1, b2, self.eps, self.wd if decay else 0.0,
+                              self.t, gscale)
                 b.w.copy_(b.master)
-                for k, v in self.proj_params.items():
-                    v.data.copy_(b.view(b.w, k))
+                if self.proj_flat is not None:
+                    self.proj_flat.copy_(b.master)
+                else:
+                    for k, v in self.proj_params.items():
+                        v.data.copy_(b.view(b.w, k))
                 for mod in self.aux_modules.values():
                     mod.invalidate()
             elif b is self.small:
