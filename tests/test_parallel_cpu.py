@@ -161,3 +161,19 @@ def test_warmup_cosine_ratio_shape():
     assert abs(r(total - 1, total, warm) - 0.03) < 1e-12 and r(-1, total, warm) == 0.0
     assert abs(r(3, total, warm, warmup_type="log") - __import__("math").log(4) / __import__("math").log(10)) < 1e-12
     assert r(0, 100, 0) == 0.0 and r(1, 100, 0) == 0.5            # warm-up is at least 2 steps
+
+
+def test_frozen_bucket_holds_no_gradient_or_optimizer_state():
+    """train_decoder=False builds the decoder buckets with trainable=False: parameters only (what the forward reads), no fp32
+    gradient, master, m or v; keep_grad keeps the gradient buffer alone (scratch output of the norm-backward kernels)"""
+    from ufvideo_amd import train as TR
+    spec = [("a", (3, 5)), ("b", (7,))]
+    b = TR._Bucket(spec, "cpu", 1, 0, torch.bfloat16, True, trainable=False)
+    b.init_states()
+    assert b.g is None and b.master is None and not hasattr(b, "m") and b.w.numel() == b.n
+    k = TR._Bucket(spec, "cpu", 1, 0, torch.float32, False, trainable=False, keep_grad=True)
+    k.init_states()
+    assert k.g is not None and k.g.dtype == torch.float32 and k.master is None
+    t = TR._Bucket(spec, "cpu", 1, 0, torch.bfloat16, True)
+    t.init_states()
+    assert t.g is not None and t.master.dtype == torch.float32 and t.m.shape == t.master.shape == t.v.shape
