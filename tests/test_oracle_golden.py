@@ -299,6 +299,33 @@ def test_decoder_train_grads_vs_reference_backward():
         assert torch.allclose(new[k], torch.from_numpy(z["p1::" + k]), atol=2e-6, rtol=1e-5), k
 
 
+def hd128_golden():
+    """train_grad_hd128.npz (reference's own backward on a 2-layer decoder with 2 / 1 heads of 128): arrays, llm dict and the
+    weights, regenerated from the stored seed exactly as the generating script built them (bf16-rounded, matrices x 3)"""
+    import os
+    a, _ = load_golden("train_grad_hd128")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_grad_hd128.npz"))
+    V, D, I, L, H, KV = (int(x) for x in a["llm"])
+    llm = dict(vocab_size=V, hidden_size=D, intermediate_size=I, num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=KV,
+               rope_theta=10000.0, rms_norm_eps=1e-6)
+    sc = float(a["weight_scale"])
+    w = {k: (v * (sc if v.ndim == 2 else 1.0)).to(torch.bfloat16).to(torch.float32) for k, v in O.make_qwen2_weights(llm, seed=int(a["seed"])).items()}
+    ref_g = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g::")}
+    return a, llm, w, ref_g
+
+
+def test_decoder_train_grads_hd128_vs_reference_backward():
+    """the same pin at head_dim 128 (the shape the fused attention-backward kernels serve): oracle autograd == the reference
+    class's own loss.backward()"""
+    a, llm, w, ref_g = hd128_golden()
+    loss, grads, de = O.decoder_train_grads(w, llm, t(a["inputs_embeds"]), t(a["labels"]))
+    assert abs(float(loss) - float(a["loss"])) < 1e-5
+    assert rel_err(de, t(a["d_inputs_embeds"])) < 1e-4
+    assert len(ref_g) == 13
+    for k, g in ref_g.items():
+        assert rel_err(grads[k], g) < 1e-4, k
+
+
 def test_sampling_distribution_vs_transformers_warpers():
     """the oracle's temperature / top-k / top-p restatement == transformers' own LogitsWarpers (the chain HF generate() builds
     from the kwargs the reference forwards)"""

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 from ufvideo_amd import ops  # noqa: E402
 from ufvideo_amd.train import DecoderTrainer  # noqa: E402
 from test_model_gpu import tiny_model, TINY_LLM, DEV  # noqa: E402
-from test_oracle_golden import spliced_embed_ids  # noqa: E402
+from test_oracle_golden import spliced_embed_ids, hd128_golden  # noqa: E402
 
 
 def bfr(x):
@@ -280,6 +280,38 @@ def test_tiny_model_step_vs_reference_golden():
     tr.zero_grad()
     loss2, _ = tr.forward_backward(emb, _shift(labels), embed_ids=eids)
     assert float(loss2) < float(loss)
+
+
+@pytest.mark.parametrize("attn", ["fused", "materialised"])
+def test_hd128_step_vs_reference_golden(attn, monkeypatch):
+    """train_grad_hd128: the reference class's own loss.backward() on a decoder with heads of 128 -- the shape served by the fused
+    attention backward (csrc/attn_bwd.hip; S = 200 spans two query / key blocks) and, for comparison, the per-group GEMM pipeline"""
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
+    monkeypatch.setenv("UFV_TRAIN_ATTN", attn)
+    a, llm, w, ref_g = hd128_golden()
+    m = VideoReferQwen2ForCausalLM(VideoReferQwen2Config(**llm, sam2_trunk=None))
+    m.load_state_dict(w, strict=False)
+    m = m.to(DEV)
+    tr = DecoderTrainer(m, train_embed=False)
+    assert tr.fused_attn_bwd == (attn == "fused")
+    tr.zero_grad()
+    loss, dx = tr.forward_backward(t(a["inputs_embeds"])[0].to(DEV), _shift(t(a["labels"])[0]))
+    assert abs(float(loss) - float(a["loss"])) < 2e-2 * float(a["loss"])
+    assert rel_err(dx.cpu(), t(a["d_inputs_embeds"])[0]) < 4e-2
+    H, KV, hd = llm["num_attention_heads"], llm["num_key_value_heads"], 128
+    got = {"model.norm.weight": tr.small.view(tr.small.g, "norm")}
+    for i, b in enumerate(tr.layers):
+        p = f"model.layers.{i}."
+        bq = tr.small.view(tr.small.g, f"bqkv.{i}")
+        got[p + "self_attn.q_proj.bias"], got[p + "self_attn.k_proj.bias"], got[p + "self_attn.v_proj.bias"] = \
+            bq[:H * hd], bq[H * hd:(H + KV) * hd], bq[(H + KV) * hd:]
+        got[p + "input_layernorm.weight"] = tr.small.view(tr.small.g, f"ln1.{i}")
+        got[p + "post_attention_layernorm.weight"] = tr.small.view(tr.small.g, f"ln2.{i}")
+        gq = b.view(b.g, "wqkv")
+        got[p + "self_attn.k_proj.weight"], got[p + "self_attn.v_proj.weight"] = gq[H * hd:(H + KV) * hd], gq[(H + KV) * hd:]
+    assert set(ref_g) <= set(got)
+    worst = max((rel_err(got[k].float().cpu(), g), k) for k, g in ref_g.items())
+    assert worst[0] < 5e-2, worst
 
 
 def test_export_state_dict_roundtrip_before_any_step():
