@@ -13,7 +13,7 @@ GEMM_AUTO, GEMM_FAST, GEMM_GENERIC, GEMM_GEMV, GEMM_FAST256, GEMM_STREAMK = 0, 1
 
 _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
-# name -> argtypes; this table is also what tests/test_abi.py checks against include/ufv.h
+# name -> argtypes; this table is also what tests/test_host_cpu.py (test_c_abi_exports_every_declared_symbol) checks against include/ufv.h
 SIGNATURES = {
     "ufv_gemm": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p],
     "ufv_layernorm": [_p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _f, _i, _p],

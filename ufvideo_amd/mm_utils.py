@@ -68,29 +68,23 @@ def load_image_from_base64(image):
 
 
 def create_photo_grid(arr, rows=None, cols=None):
-    """[t, h, w, c] frames (array / list of arrays / list of PIL) -> one [rows*h, cols*w, c] grid image (ref mm_utils.py:57-104)."""
+    """Tile t frames [t, h, w, c] (ndarray, list of ndarrays or list of PIL images) row-major into one
+    [rows*h, cols*w, c] contact sheet; missing grid dimensions default to a near-square layout and unused
+    cells stay zero (same call contract as ref mm_utils.py:57-104)."""
     if isinstance(arr, list):
-        if isinstance(arr[0], Image.Image):
-            arr = np.stack([np.array(img) for img in arr])
-        elif isinstance(arr[0], np.ndarray):
-            arr = np.stack(arr)
-        else:
+        if not isinstance(arr[0], (Image.Image, np.ndarray)):
             raise ValueError("Invalid input type. Expected list of Images or numpy arrays.")
+        arr = np.stack([np.asarray(a) for a in arr])
     t, h, w, c = arr.shape
-    if rows is None and cols is None:
-        rows = math.ceil(math.sqrt(t))
-        cols = math.ceil(t / rows)
-    elif rows is None:
-        rows = math.ceil(t / cols)
-    elif cols is None:
+    if rows is None:
+        rows = math.ceil(math.sqrt(t)) if cols is None else math.ceil(t / cols)
+    if cols is None:
         cols = math.ceil(t / rows)
     if rows * cols < t:
         raise ValueError(f"Not enough grid cells ({rows}x{cols}) to hold all images ({t}).")
-    grid = np.zeros((h * rows, w * cols, c), dtype=arr.dtype)
-    for i in range(t):
-        r, cc = i // cols, i % cols
-        grid[r * h:(r + 1) * h, cc * w:(cc + 1) * w, :] = arr[i]
-    return grid
+    cells = np.zeros((rows * cols, h, w, c), dtype=arr.dtype)
+    cells[:t] = arr
+    return cells.reshape(rows, cols, h, w, c).transpose(0, 2, 1, 3, 4).reshape(rows * h, cols * w, c)
 
 
 def chunk_list(input_list, chunk_size):
