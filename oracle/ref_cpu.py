@@ -28,6 +28,18 @@ timm is absent offline, so for that one function: PARITY UNPINNED.
 
 All tensors are fp32 on CPU.  Weights arrive as flat ``dict[str, Tensor]`` with the
 reference's state-dict key names (HF / timm naming) under a caller-chosen prefix.
+
+Two precisions of the SAME graph:
+* default: fp32 everywhere -- this is what is pinned against the reference's goldens;
+* ``with bf16_mirror():`` -- the identical functions, with values rounded to bf16 (round-to-nearest-even,
+  kept in fp32 storage) at exactly the points where the HIP path stores bf16: every parameter (the model keeps
+  bf16 parameters, as the reference's checkpoints do), GEMM outputs that are not residual-stream updates, norm
+  outputs, q / k after RoPE, the softmax numerators P before the PV product (the row sum uses the un-rounded
+  values, as the kernel does), attention outputs, activation outputs.  The residual streams, norm statistics,
+  softmax, and every accumulation stay fp32, as in the kernels (and as HF itself does at modeling_qwen2.py:238-254,
+  modeling_siglip.py:241).  The mirror exists so the north-star tolerance ("within 1e-3 bf16 tolerance") can be
+  asserted: HIP vs mirror isolates implementation error from the bf16 quantisation that any bf16 run carries
+  (SURVEY 7.2 item (ii)); tests/test_oracle_golden.py pins the mirror against the fp32 graph on the goldens.
 """
 from __future__ import annotations
 
@@ -44,8 +56,78 @@ MODAL_INDEX_MAP = {"<image>": -200, "<video>": -201, "<audio>": -202}   # consta
 SD = Dict[str, torch.Tensor]
 
 
+_MIRROR = False          # set by `bf16_mirror`; never by product code (the product never imports this module)
+_LOG2E = 1.4426950408889634
+
+
+class bf16_mirror:
+    """Context manager: run the restatement with bf16 rounding at the HIP path's storage points (module docstring)."""
+
+    def __enter__(self):
+        global _MIRROR
+        self._saved, _MIRROR = _MIRROR, True
+        return self
+
+    def __exit__(self, *exc):
+        global _MIRROR
+        _MIRROR = self._saved
+        return False
+
+
+def _rb(x: torch.Tensor) -> torch.Tensor:
+    """Round to bf16 (RNE) in mirror mode; identity otherwise."""
+    return x.to(torch.bfloat16).float() if _MIRROR else x
+
+
 def _g(sd: SD, prefix: str, name: str) -> torch.Tensor:
-    return sd[prefix + name].float()
+    return _rb(sd[prefix + name].float())
+
+
+def _flash_pv_mirror(s2: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """The MFMA flash kernels' arithmetic (csrc/attn.hip `attn_fwd_mfma*`), tile for tile, so that the bf16 rounding of P happens
+    against the same running maximum as on the GPU: keys in tiles of 64; a wave owns 32 consecutive query rows; the running max
+    of a row only moves when SOME row of its wave sees a tile max more than 2^6 above its running max (deferred rescale,
+    RESCALE_THR = 6 in the log2 domain), and then every row of the wave takes max(m, tile max); O and l are rescaled in fp32.
+    s2 = scores * scale * log2(e) with masked entries at -inf, [..., Sq, Sk]; v [..., Sk, hd]."""
+    Sq, Sk = s2.shape[-2:]
+    lead = s2.shape[:-2]
+    ninf = float("-inf")
+    m = torch.full(lead + (Sq,), ninf)
+    l = torch.zeros(lead + (Sq,))
+    acc = torch.zeros(lead + (Sq, v.shape[-1]))
+    G = (Sq + 31) // 32
+    for t0 in range(0, Sk, 64):
+        st = s2[..., t0:t0 + 64]
+        tmax = st.amax(dim=-1)
+        trig_row = tmax > m + 6.0
+        pad = G * 32 - Sq
+        tr = torch.cat([trig_row, trig_row[..., -1:].expand(lead + (pad,))], dim=-1) if pad else trig_row
+        trig = tr.reshape(lead + (G, 32)).any(dim=-1, keepdim=True).expand(lead + (G, 32)).reshape(lead + (G * 32,))[..., :Sq]
+        mnew = torch.where(trig, torch.maximum(m, tmax), m)
+        alpha = torch.where(mnew == ninf, torch.ones_like(m), torch.exp2(m - mnew))
+        alpha = torch.where(trig, alpha, torch.ones_like(alpha))
+        l = l * alpha
+        acc = acc * alpha[..., None]
+        m = mnew
+        msub = torch.where(m == ninf, torch.zeros_like(m), m)
+        p = torch.exp2(st - msub[..., None])
+        l = l + p.sum(dim=-1)
+        acc = acc + torch.matmul(_rb(p), v[..., t0:t0 + 64, :])
+    return acc / l[..., None]
+
+
+def _softmax_pv(scores: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """softmax(scores) @ v; scores [..., Sq, Sk] (scaled, masked entries very negative), v [..., Sk, hd].  Mirror mode follows
+    csrc/attn.hip: the MFMA flash kernels (dispatch rule of `ufv_attention`: head_dim in {64,72,80,96,128} and >= 16 queries)
+    round p to bf16 as the operand of the second MFMA, tile by tile (`_flash_pv_mirror`); the scalar kernels (decode, other head
+    dims) keep p = exp(s - max) in fp32.  In both the row sum uses the un-rounded p and the division comes last."""
+    if not _MIRROR:
+        return torch.matmul(torch.softmax(scores.float(), dim=-1), v)
+    s2 = scores.float() * _LOG2E
+    if v.shape[-1] in (64, 72, 80, 96, 128) and scores.shape[-2] >= 16:
+        return _flash_pv_mirror(s2, v)
+    p = torch.exp2(s2 - s2.amax(dim=-1, keepdim=True))
+    return torch.matmul(p, v) / p.sum(dim=-1, keepdim=True)
 
 
 # --------------------------------------------------------------------------------------
@@ -70,21 +152,20 @@ def vit_encoder_layer(sd: SD, p: str, x: torch.Tensor, heads: int, eps: float, a
     """One pre-LN encoder layer (modeling_siglip.py:325-357; CLIP's layer is the same graph)."""
     B, N, D = x.shape
     hd = D // heads
-    h = F.layer_norm(x, (D,), _g(sd, p, "layer_norm1.weight"), _g(sd, p, "layer_norm1.bias"), eps)
-    q = F.linear(h, _g(sd, p, "self_attn.q_proj.weight"), _g(sd, p, "self_attn.q_proj.bias"))
-    k = F.linear(h, _g(sd, p, "self_attn.k_proj.weight"), _g(sd, p, "self_attn.k_proj.bias"))
-    v = F.linear(h, _g(sd, p, "self_attn.v_proj.weight"), _g(sd, p, "self_attn.v_proj.bias"))
+    h = _rb(F.layer_norm(x, (D,), _g(sd, p, "layer_norm1.weight"), _g(sd, p, "layer_norm1.bias"), eps))
+    q = _rb(F.linear(h, _g(sd, p, "self_attn.q_proj.weight"), _g(sd, p, "self_attn.q_proj.bias")))
+    k = _rb(F.linear(h, _g(sd, p, "self_attn.k_proj.weight"), _g(sd, p, "self_attn.k_proj.bias")))
+    v = _rb(F.linear(h, _g(sd, p, "self_attn.v_proj.weight"), _g(sd, p, "self_attn.v_proj.bias")))
     q = q.view(B, N, heads, hd).transpose(1, 2)
     k = k.view(B, N, heads, hd).transpose(1, 2)
     v = v.view(B, N, heads, hd).transpose(1, 2)
     att = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)          # :237
-    att = torch.softmax(att.float(), dim=-1)                            # :241 (fp32 softmax)
-    o = torch.matmul(att, v).transpose(1, 2).reshape(B, N, D)
+    o = _rb(_softmax_pv(att, v)).transpose(1, 2).reshape(B, N, D)       # :241 (fp32 softmax)
     o = F.linear(o, _g(sd, p, "self_attn.out_proj.weight"), _g(sd, p, "self_attn.out_proj.bias"))
     x = x + o
-    h = F.layer_norm(x, (D,), _g(sd, p, "layer_norm2.weight"), _g(sd, p, "layer_norm2.bias"), eps)
+    h = _rb(F.layer_norm(x, (D,), _g(sd, p, "layer_norm2.weight"), _g(sd, p, "layer_norm2.bias"), eps))
     h = F.linear(h, _g(sd, p, "mlp.fc1.weight"), _g(sd, p, "mlp.fc1.bias"))
-    h = _ACT[act](h)
+    h = _rb(_ACT[act](h))
     h = F.linear(h, _g(sd, p, "mlp.fc2.weight"), _g(sd, p, "mlp.fc2.bias"))
     return x + h
 
@@ -93,7 +174,7 @@ def siglip_embeddings(sd: SD, p: str, pixel_values: torch.Tensor, patch: int) ->
     """Conv2d(k=s=patch, valid) -> flatten -> + learned position table (modeling_siglip.py:175-186)."""
     w = _g(sd, p, "embeddings.patch_embedding.weight")
     b = _g(sd, p, "embeddings.patch_embedding.bias")
-    e = F.conv2d(pixel_values.float(), w, b, stride=patch)
+    e = F.conv2d(_rb(pixel_values.float()), w, b, stride=patch)        # mirror: the im2col matrix is bf16
     e = e.flatten(2).transpose(1, 2)
     return e + _g(sd, p, "embeddings.position_embedding.weight")[None]
 
@@ -129,7 +210,7 @@ def clip_tower(sd: SD, cfg: dict, pixel_values: torch.Tensor, prefix: str = "",
     D = cfg["hidden_size"]
     eps = cfg.get("layer_norm_eps", 1e-5)
     w = _g(sd, p, "embeddings.patch_embedding.weight")
-    e = F.conv2d(pixel_values.float(), w, None, stride=cfg["patch_size"]).flatten(2).transpose(1, 2)
+    e = F.conv2d(_rb(pixel_values.float()), w, None, stride=cfg["patch_size"]).flatten(2).transpose(1, 2)
     cls = _g(sd, p, "embeddings.class_embedding").expand(e.shape[0], 1, -1)
     x = torch.cat([cls, e], dim=1) + _g(sd, p, "embeddings.position_embedding.weight")[None]
     x = F.layer_norm(x, (D,), _g(sd, p, "pre_layrnorm.weight"), _g(sd, p, "pre_layrnorm.bias"), eps)
@@ -161,21 +242,21 @@ def regstage_block(sd: SD, p: str, x: torch.Tensor, eps: float) -> torch.Tensor:
         + shortcut (1x1 conv + LN2d when in_chs != out_chs, identity otherwise) -> SiLU
     """
     sc = x
-    y = F.conv2d(x, _g(sd, p, "conv1.conv.weight"))
-    y = F.silu(layernorm2d(y, _g(sd, p, "conv1.bn.weight"), _g(sd, p, "conv1.bn.bias"), eps))
+    y = _rb(F.conv2d(x, _g(sd, p, "conv1.conv.weight")))
+    y = _rb(F.silu(layernorm2d(y, _g(sd, p, "conv1.bn.weight"), _g(sd, p, "conv1.bn.bias"), eps)))
     C = y.shape[1]
-    y = F.conv2d(y, _g(sd, p, "conv2.conv.weight"), padding=1, groups=C)
-    y = F.silu(layernorm2d(y, _g(sd, p, "conv2.bn.weight"), _g(sd, p, "conv2.bn.bias"), eps))
-    s = y.mean((2, 3), keepdim=True)
-    s = F.silu(F.conv2d(s, _g(sd, p, "se.fc1.weight"), _g(sd, p, "se.fc1.bias")))
-    s = torch.sigmoid(F.conv2d(s, _g(sd, p, "se.fc2.weight"), _g(sd, p, "se.fc2.bias")))
-    y = y * s
-    y = F.conv2d(y, _g(sd, p, "conv3.conv.weight"))
+    y = F.conv2d(y, _g(sd, p, "conv2.conv.weight"), padding=1, groups=C)          # conv + LN + SiLU are one kernel: no rounding between
+    y = _rb(F.silu(layernorm2d(y, _g(sd, p, "conv2.bn.weight"), _g(sd, p, "conv2.bn.bias"), eps)))
+    s = _rb(y.mean((2, 3), keepdim=True))
+    s = _rb(F.silu(F.conv2d(s, _g(sd, p, "se.fc1.weight"), _g(sd, p, "se.fc1.bias"))))
+    s = _rb(torch.sigmoid(F.conv2d(s, _g(sd, p, "se.fc2.weight"), _g(sd, p, "se.fc2.bias"))))
+    y = _rb(y * s)
+    y = _rb(F.conv2d(y, _g(sd, p, "conv3.conv.weight")))
     y = layernorm2d(y, _g(sd, p, "conv3.bn.weight"), _g(sd, p, "conv3.bn.bias"), eps)
     if (p + "downsample.conv.weight") in sd:
-        sc = F.conv2d(sc, _g(sd, p, "downsample.conv.weight"))
+        sc = _rb(F.conv2d(sc, _g(sd, p, "downsample.conv.weight")))
         sc = layernorm2d(sc, _g(sd, p, "downsample.bn.weight"), _g(sd, p, "downsample.bn.bias"), eps)
-    return F.silu(y + sc)
+    return _rb(F.silu(y + sc))                                                    # LN(y) + LN(sc) + SiLU: one kernel
 
 
 def regstage(sd: SD, p: str, x: torch.Tensor, depth: int, eps: float = 1e-5) -> torch.Tensor:
@@ -192,7 +273,7 @@ def stc_connector(sd: SD, x: torch.Tensor, prefix: str = "", downsample=(2, 2, 2
     p = prefix
     b, t, n, d = x.shape
     hw = int(n ** 0.5)
-    x = x.view(b, t, hw, hw, d).permute(0, 1, 4, 2, 3).reshape(b * t, d, hw, hw)     # (b t) d h w
+    x = _rb(x.float()).view(b, t, hw, hw, d).permute(0, 1, 4, 2, 3).reshape(b * t, d, hw, hw)     # (b t) d h w
     if depth:
         x = regstage(sd, p + "s1.", x, depth, ln_eps)
     C = x.shape[1]
@@ -202,7 +283,7 @@ def stc_connector(sd: SD, x: torch.Tensor, prefix: str = "", downsample=(2, 2, 2
     else:
         x = F.conv3d(x, _g(sd, p, "sampler.0.weight"), _g(sd, p, "sampler.0.bias"),
                      stride=downsample, padding=padding)
-    x = F.silu(x)
+    x = _rb(F.silu(x))
     nt, nh, nw = x.shape[2:]
     x = x.permute(0, 2, 1, 3, 4).reshape(b * nt, C, nh, nw)
     if depth:
@@ -210,7 +291,7 @@ def stc_connector(sd: SD, x: torch.Tensor, prefix: str = "", downsample=(2, 2, 2
     x = x.view(b, nt, C, nh * nw).permute(0, 1, 3, 2).reshape(b, nt * nh * nw, C)   # b (t h w) d
     for i in range(mlp_depth):                                                       # build_mlp :125-130
         if i:
-            x = F.gelu(x)
+            x = _rb(F.gelu(x))
         x = F.linear(x, _g(sd, p, f"readout.{2 * i}.weight"), _g(sd, p, f"readout.{2 * i}.bias"))
     return x
 
@@ -269,9 +350,9 @@ def mask_extractor(sd: SD, feats: torch.Tensor, masks: Sequence[torch.Tensor], a
             merged.append(mf)
             start += len(index)
         query_feats.append(torch.cat(merged, dim=1).reshape(-1, raw.shape[-1]))
-    mf = torch.cat(query_feats, dim=0)
+    mf = _rb(torch.cat(query_feats, dim=0))
     mf = F.linear(mf, _g(sd, p, "feat_linear.0.weight"), _g(sd, p, "feat_linear.0.bias"))
-    mf = F.gelu(mf)
+    mf = _rb(F.gelu(mf))
     mf = F.linear(mf, _g(sd, p, "feat_linear.2.weight"), _g(sd, p, "feat_linear.2.bias"))
     return mf, region_token_nums
 
@@ -407,13 +488,13 @@ def qwen2_layer(sd: SD, p: str, x: torch.Tensor, cfg: dict, cos, sin, kv: Option
     H, KV = cfg["num_attention_heads"], cfg["num_key_value_heads"]
     hd = cfg.get("head_dim", D // H)
     eps = cfg.get("rms_norm_eps", 1e-6)
-    h = rmsnorm(x, _g(sd, p, "input_layernorm.weight"), eps)
-    q = F.linear(h, _g(sd, p, "self_attn.q_proj.weight"), _g(sd, p, "self_attn.q_proj.bias")).view(B, S, H, hd).transpose(1, 2)
-    k = F.linear(h, _g(sd, p, "self_attn.k_proj.weight"), _g(sd, p, "self_attn.k_proj.bias")).view(B, S, KV, hd).transpose(1, 2)
-    v = F.linear(h, _g(sd, p, "self_attn.v_proj.weight"), _g(sd, p, "self_attn.v_proj.bias")).view(B, S, KV, hd).transpose(1, 2)
+    h = _rb(rmsnorm(x, _g(sd, p, "input_layernorm.weight"), eps))
+    q = _rb(F.linear(h, _g(sd, p, "self_attn.q_proj.weight"), _g(sd, p, "self_attn.q_proj.bias"))).view(B, S, H, hd).transpose(1, 2)
+    k = _rb(F.linear(h, _g(sd, p, "self_attn.k_proj.weight"), _g(sd, p, "self_attn.k_proj.bias"))).view(B, S, KV, hd).transpose(1, 2)
+    v = _rb(F.linear(h, _g(sd, p, "self_attn.v_proj.weight"), _g(sd, p, "self_attn.v_proj.bias"))).view(B, S, KV, hd).transpose(1, 2)
     c, s = cos[None, None], sin[None, None]
-    q = q * c + rotate_half(q) * s
-    k = k * c + rotate_half(k) * s
+    q = _rb(q * c + rotate_half(q) * s)
+    k = _rb(k * c + rotate_half(k) * s)
     if kv is not None:
         k = torch.cat([kv[0], k], dim=2)
         v = torch.cat([kv[1], v], dim=2)
@@ -423,13 +504,12 @@ def qwen2_layer(sd: SD, p: str, x: torch.Tensor, cfg: dict, cos, sin, kv: Option
     vv = v[:, :, None].expand(B, KV, rep, v.shape[2], hd).reshape(B, H, v.shape[2], hd)
     att = torch.matmul(q, kk.transpose(2, 3)) * (hd ** -0.5)
     att = att + bias_mask
-    att = torch.softmax(att.float(), dim=-1)
-    o = torch.matmul(att, vv).transpose(1, 2).reshape(B, S, H * hd)
+    o = _rb(_softmax_pv(att, vv)).transpose(1, 2).reshape(B, S, H * hd)
     x = x + F.linear(o, _g(sd, p, "self_attn.o_proj.weight"))
-    h = rmsnorm(x, _g(sd, p, "post_attention_layernorm.weight"), eps)
+    h = _rb(rmsnorm(x, _g(sd, p, "post_attention_layernorm.weight"), eps))
     g = F.linear(h, _g(sd, p, "mlp.gate_proj.weight"))
     u = F.linear(h, _g(sd, p, "mlp.up_proj.weight"))
-    x = x + F.linear(F.silu(g) * u, _g(sd, p, "mlp.down_proj.weight"))
+    x = x + F.linear(_rb(F.silu(g) * u), _g(sd, p, "mlp.down_proj.weight"))       # SwiGLU is the gate/up GEMM's epilogue
     return x, new_kv
 
 
@@ -466,8 +546,8 @@ def qwen2_forward(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, attention_mask
         hs.append(x)
     x = rmsnorm(x, _g(sd, prefix, "norm.weight"), cfg.get("rms_norm_eps", 1e-6))
     hs[-1] = x
-    head = sd[lm_head_key].float()
-    logits = F.linear(x if all_logits else x[:, -1:], head)
+    head = _rb(sd[lm_head_key].float())
+    logits = F.linear(_rb(x if all_logits else x[:, -1:]), head)
     return {"logits": logits, "hidden_states": hs, "past": new_past}
 
 
@@ -478,7 +558,7 @@ def greedy_generate(sd: SD, cfg: dict, inputs_embeds: torch.Tensor, attention_ma
     prefill with inputs_embeds, then one token at a time through the KV cache; returns only
     the NEW tokens (HF returns no prompt ids when generation starts from inputs_embeds),
     plus per-step last-layer hidden states (what `output.hidden_states[o_idx][-1]` holds)."""
-    table = sd[embed_key].float()
+    table = _rb(sd[embed_key].float())
     out = qwen2_forward(sd, cfg, inputs_embeds, attention_mask, None, all_logits=False, **kw)
     tokens, hiddens = [], [out["hidden_states"][-1]]
     am = attention_mask
@@ -527,7 +607,7 @@ def tokenizer_multimodal_token(prompt: str, tokenize, multimodal_token: str = "<
 
 def text_hidden_fcs(sd: SD, x: torch.Tensor, prefix: str = "model.text_hidden_fcs.0.") -> torch.Tensor:
     """videorefer_arch.py:137-149: Linear -> ReLU -> Linear -> Dropout(0)."""
-    h = F.relu(F.linear(x.float(), _g(sd, prefix, "0.weight"), _g(sd, prefix, "0.bias")))
+    h = _rb(F.relu(F.linear(_rb(x.float()), _g(sd, prefix, "0.weight"), _g(sd, prefix, "0.bias"))))
     return F.linear(h, _g(sd, prefix, "2.weight"), _g(sd, prefix, "2.bias"))
 
 

@@ -341,3 +341,72 @@ def test_sampling_distribution_vs_transformers_warpers():
         ref = x.softmax(-1)[0]
         got = O.sampling_distribution(lg[0], T, k, p)
         assert torch.equal(got > 0, ref > 0) and torch.allclose(got, ref, atol=1e-7)
+
+
+def test_bf16_mirror_is_the_same_graph_with_bf16_storage_points():
+    """`O.bf16_mirror()` (the checker for the north star's 1e-3 bf16 tolerance) pinned on CPU against the fp32 restatement and
+    the reference's goldens: same graph, values rounded where the HIP path stores bf16 -- so it stays within bf16 noise of the
+    reference, what it stores is exactly bf16-representable, and leaving the context restores the fp32 graph bit for bit."""
+    def is_bf16(x):
+        return torch.equal(x, x.to(torch.bfloat16).float())
+
+    a, w = load_golden("siglip_tiny")
+    pre = bytes(a["prefix"]).decode()
+    x = t(a["x"])
+    y32 = O.siglip_tower(w, TINY_VIT, x, prefix=pre)
+    with O.bf16_mirror():
+        y16 = O.siglip_tower(w, TINY_VIT, x, prefix=pre)
+        assert O._MIRROR
+    assert not O._MIRROR and torch.equal(O.siglip_tower(w, TINY_VIT, x, prefix=pre), y32)
+    e = rel_err(y16, t(a["y"]))
+    assert 1e-4 < e < 1e-2, e                                   # bf16 storage is visible, and stays bf16-sized
+    # decoder: logits / hidden within bf16 noise of the reference, KV cache entries and greedy tokens as the reference's
+    a, w = load_golden("model_tiny")
+    emb = t(a["sp_vid_region_nolab_emb"]); am = t(a["sp_vid_region_nolab_am"])
+    with O.bf16_mirror():
+        o = O.qwen2_forward(w, TINY_LLM, emb, am)
+        toks, _ = O.greedy_generate(w, TINY_LLM, emb, am, 8, eos_token_ids=(298,))
+        fcs = O.text_hidden_fcs(w, t(a["fw_hidden_last"]))
+    assert 1e-4 < rel_err(o["logits"], t(a["fw_logits"])) < 2e-2
+    assert rel_err(o["hidden_states"][-1], t(a["fw_hidden_last"])) < 2e-2
+    assert is_bf16(o["past"][0][0]) and is_bf16(o["past"][1][1])            # what the KV cache holds
+    assert not is_bf16(o["hidden_states"][1])                              # the residual stream stays fp32
+    assert toks.tolist() == a["gen_tokens"].tolist()
+    assert rel_err(fcs, t(a["fcs_out"])) < 1e-2
+    # connector (RegStage blocks included) and region encoder
+    sd = O.make_stc_weights(64, 128, seed=5)
+    xs = torch.randn(1, 4, 36, 64, generator=torch.Generator().manual_seed(6))
+    with O.bf16_mirror():
+        ym = O.stc_connector(sd, xs)
+    assert 1e-4 < rel_err(ym, O.stc_connector(sd, xs)) < 2e-2
+    a, w = load_golden("region")
+    masks = [t(a["mask0"]), t(a["mask1"])]
+    ann = [[[0], [1, 2]], [[1, 2, 3, 4, 5, 6]]]
+    with O.bf16_mirror():
+        y, nums = O.mask_extractor(w, t(a["feats"]), masks, ann)
+    assert nums == a["nums"].tolist() and rel_err(y, t(a["y"])) < 1e-2
+
+
+def test_bf16_chain_noise_floor():
+    """Why a chain of bf16 stages cannot be compared at 1e-3 in the max norm: the SAME correct bf16 algorithm (the mirror) run
+    on inputs that differ by 1e-7 relative -- less than any two fp32 accumulation orders differ -- ends up apart by the order of
+    one bf16 ulp after three small decoder layers (after ONE at the 7B dimensions, where more elements sit near a rounding
+    boundary: 3.4e-3 max / 2.5e-3 rms), because every storage point turns a discrepancy d into one-ulp flips with
+    probability d / ulp (rms sqrt(d * ulp): 1e-7 -> 2e-5 -> 3e-4 -> 1e-3 ...).  The fp32 graph is stable under the same
+    perturbation.  tests/test_parity_bf16_gpu.py reports HIP-vs-mirror next to this floor; tests/test_kernel_rounding_gpu.py makes
+    the per-kernel statement that does not suffer from it."""
+    cfg = dict(vocab_size=64, hidden_size=512, intermediate_size=1536, num_hidden_layers=3, num_attention_heads=4,
+               num_key_value_heads=2, rope_theta=1e6, rms_norm_eps=1e-6)
+    sd = O.make_qwen2_weights(cfg, seed=12, std=0.06)     # branch outputs comparable to the residual stream, as at 7B dims
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(1, 160, 512, generator=g) * 0.5
+    xp = x * (1 + 1e-7 * torch.randn(x.shape, generator=g))
+    with O.bf16_mirror():
+        a = O.qwen2_forward(sd, cfg, x)["hidden_states"][-1]
+        b = O.qwen2_forward(sd, cfg, xp)["hidden_states"][-1]
+    f = O.qwen2_forward(sd, cfg, x)["hidden_states"][-1]
+    fp = O.qwen2_forward(sd, cfg, xp)["hidden_states"][-1]
+    assert rel_err(fp, f) < 1e-5                       # fp32: the perturbation stays a perturbation
+    floor = rel_err(b, a)
+    assert 1e-3 < floor < 3e-2, floor                  # bf16 storage: amplified to the ulp scale
+    assert floor > 0.1 * rel_err(a, f)                 # ... i.e. a sizeable part of the whole bf16-vs-fp32 distance
