@@ -1,4 +1,8 @@
-"""GPU: every HIP kernel of the C ABI against a plain PyTorch fp32 reference of the same op."""
+"""GPU: every HIP kernel of the C ABI against a plain PyTorch fp32 reference of the same op.
+Tolerances: fp32 outputs 1e-5..2e-5 of the largest element; bf16 outputs ONE_ULP = 2^-8 (+ fp32 noise) of the largest element --
+the resolution of the storage format in the max norm (a correctly rounded result cannot be closer; the per-element statement,
+"never more than one ulp at the element's own magnitude, <= 2e-3 of the elements differ", is tests/test_kernel_rounding_gpu.py);
+flash attention additionally rounds P to bf16 before the second MFMA: ATTN_TOL = 6e-3 against the fp32 softmax."""
 import math
 
 import pytest
@@ -9,6 +13,8 @@ pytestmark = pytest.mark.gpu
 from ufvideo_amd import ops  # noqa: E402
 
 DEV = "cuda"
+ONE_ULP = 2.0 ** -8 + 1e-4
+ATTN_TOL = 6e-3
 
 
 def rel(a, b):
@@ -37,7 +43,7 @@ def test_gemm_plain(M, N, K, kernel):
     a, w = bf(g(M, K, seed=1)), bf(g(N, K, seed=2, scale=0.05))
     ref = a.float() @ w.float().t()
     out = ops.gemm(a, w, kernel=kernel)
-    assert rel(out, ref) < 8e-3
+    assert rel(out, ref) <= ONE_ULP
     out32 = ops.gemm(a, w, out_dtype=torch.float32, kernel=kernel)
     assert rel(out32, ref) < 2e-5
 
@@ -113,7 +119,7 @@ def test_layernorm(D, dt):
     w, b = 1 + 0.1 * g(D, seed=17), 0.1 * g(D, seed=18)
     ref = torch.nn.functional.layer_norm(x.float(), (D,), w, b, 1e-6)
     assert rel(ops.layernorm(x, w, b, 1e-6, out_dtype=torch.float32), ref) < 1e-5
-    assert rel(ops.layernorm(x, w, b, 1e-6), ref) < 8e-3
+    assert rel(ops.layernorm(x, w, b, 1e-6), ref) <= ONE_ULP
     refs = torch.nn.functional.silu(ref)
     assert rel(ops.layernorm(x, w, b, 1e-6, act="silu", out_dtype=torch.float32), refs) < 1e-5
 
@@ -123,8 +129,8 @@ def test_ln_add_silu():
     a, b = bf(g(M, D, seed=19)), bf(g(M, D, seed=20))
     wa, ba, wb, bb = 1 + 0.1 * g(D, seed=21), 0.1 * g(D, seed=22), 1 + 0.1 * g(D, seed=23), 0.1 * g(D, seed=24)
     ln = lambda x, w, b_: torch.nn.functional.layer_norm(x.float(), (D,), w, b_, 1e-5)
-    assert rel(ops.ln_add_silu(a, wa, ba, b, wb, bb, 1e-5), torch.nn.functional.silu(ln(a, wa, ba) + ln(b, wb, bb))) < 8e-3
-    assert rel(ops.ln_add_silu(a, wa, ba, b, None, None, 1e-5), torch.nn.functional.silu(ln(a, wa, ba) + b.float())) < 8e-3
+    assert rel(ops.ln_add_silu(a, wa, ba, b, wb, bb, 1e-5), torch.nn.functional.silu(ln(a, wa, ba) + ln(b, wb, bb))) <= ONE_ULP
+    assert rel(ops.ln_add_silu(a, wa, ba, b, None, None, 1e-5), torch.nn.functional.silu(ln(a, wa, ba) + b.float())) <= ONE_ULP
 
 
 @pytest.mark.parametrize("D", [64, 3584])
@@ -170,7 +176,7 @@ def test_attention(hd, Hq, Hkv, Sq, Sk, causal, kernel):
     o = ops.attention(q, k, v, B, Hq, Hkv, Sq, Sk, hd, (Sq * Hq * hd, Hq * hd), (Sk * Hkv * hd, Hkv * hd),
                       (Sk * Hkv * hd, Hkv * hd), causal=causal, q_pos0=q_pos0, kernel=kernel)
     ref = attn_ref(q, k, v, causal, q_pos0)
-    assert rel(o, ref) < 1.2e-2, rel(o, ref)
+    assert rel(o, ref) <= ATTN_TOL, rel(o, ref)
 
 
 def test_attention_spike_forces_rescale():
@@ -180,7 +186,7 @@ def test_attention_spike_forces_rescale():
     k[:, 200] = q[:, 5] * 4.0
     q, k, v = bf(q), bf(k), bf(v)
     o = ops.attention(q, k, v, B, H, H, S, S, hd, (S * H * hd, H * hd), (S * H * hd, H * hd), (S * H * hd, H * hd), kernel=1)
-    assert rel(o, attn_ref(q, k, v, False)) < 1.2e-2
+    assert rel(o, attn_ref(q, k, v, False)) <= ATTN_TOL
 
 
 def test_rope_kv():
@@ -195,8 +201,8 @@ def test_rope_kv():
     cos, sin = ang.cos()[:, None], ang.sin()[:, None]
     rot = lambda x: torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1)
     qr = ref_in[:, :Hq * hd].view(S, Hq, hd); kr = ref_in[:, Hq * hd:(Hq + Hkv) * hd].view(S, Hkv, hd)
-    assert rel(qkv[:, :Hq * hd].float().view(S, Hq, hd), qr * cos + rot(qr) * sin) < 8e-3
-    assert rel(cache[pos0:pos0 + S, :Hkv * hd].float().view(S, Hkv, hd), kr * cos + rot(kr) * sin) < 8e-3
+    assert rel(qkv[:, :Hq * hd].float().view(S, Hq, hd), qr * cos + rot(qr) * sin) <= ONE_ULP
+    assert rel(cache[pos0:pos0 + S, :Hkv * hd].float().view(S, Hkv, hd), kr * cos + rot(kr) * sin) <= ONE_ULP
     assert torch.equal(cache[pos0:pos0 + S, Hkv * hd:], bf(ref_in[:, (Hq + Hkv) * hd:]))
     assert cache[:pos0].abs().sum() == 0
 
@@ -221,13 +227,13 @@ def test_dwconv_ln_silu_and_se_pieces(F, H, W, C):
     xc = x.float().permute(0, 3, 1, 2)
     r = torch.nn.functional.conv2d(xc, w, padding=1, groups=C).permute(0, 2, 3, 1)
     r = torch.nn.functional.silu(torch.nn.functional.layer_norm(r, (C,), lnw, lnb, 1e-5))
-    assert rel(y, r) < 8e-3
+    assert rel(y, r) <= ONE_ULP
     m = ops.colmean(y.view(F * H * W, C), F, H * W)
-    assert rel(m, y.float().view(F, H * W, C).mean(1)) < 8e-3
+    assert rel(m, y.float().view(F, H * W, C).mean(1)) <= ONE_ULP
     gate = bf(torch.sigmoid(g(F, C, seed=39)))
     y2 = y.clone().view(F * H * W, C)
     ops.scale_channels(y2, gate, F, H * W)
-    assert rel(y2.view(F, H * W, C), y.float().view(F, H * W, C) * gate.float()[:, None]) < 8e-3
+    assert rel(y2.view(F, H * W, C), y.float().view(F, H * W, C) * gate.float()[:, None]) <= ONE_ULP
 
 
 @pytest.mark.parametrize("k,pad", [((2, 2, 2), 0), ((1, 2, 2), 1), ((2, 2, 2), 1)])
@@ -279,7 +285,7 @@ def test_mask_pool_and_preprocess():
     fr = torch.randint(0, 256, (2, 8, 10, 3), dtype=torch.uint8, device=DEV)
     o = ops.preprocess_u8(fr, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
     ref = ((fr.float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
-    assert rel(o, ref) < 8e-3
+    assert rel(o, ref) <= ONE_ULP
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 384, 192), (1000, 768, 1152), (2399, 1024, 448),
@@ -295,7 +301,7 @@ def test_gemm256_bitwise_equals_128_kernel(M, N, K):
         assert torch.equal(out, ref)
     refb = ops.gemm(a, w, kernel=ops.GEMM_FAST)
     assert torch.equal(ops.gemm(a, w, kernel=ops.GEMM_FAST256), refb)
-    assert rel(refb, a.float() @ w.float().t()) < 8e-3
+    assert rel(refb, a.float() @ w.float().t()) <= ONE_ULP
 
 
 def test_gemm256_swiglu_and_layout():
@@ -323,7 +329,7 @@ def test_rope_kv_scalar_path():
     cos, sin = ang.cos()[:, None], ang.sin()[:, None]
     rot = lambda x: torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1)
     qr = ref_in[:, :Hq * hd].view(S, Hq, hd)
-    assert rel(qkv[:, :Hq * hd].float().view(S, Hq, hd), qr * cos + rot(qr) * sin) < 8e-3
+    assert rel(qkv[:, :Hq * hd].float().view(S, Hq, hd), qr * cos + rot(qr) * sin) <= ONE_ULP
     assert torch.equal(cache[pos0:pos0 + S, Hkv * hd:], bf(ref_in[:, (Hq + Hkv) * hd:]))
 
 
@@ -333,7 +339,7 @@ def test_attention_decode(hd, Hq, Hkv, Sk, nsplit):
     kv = bf(g(Sk + 3, 2 * Hkv * hd, seed=71))                 # cache rows [k | v]
     o = ops.attention_decode(q.view(1, Hq * hd), kv, kv[:, Hkv * hd:], Hq, Hkv, Sk, hd, kv.stride(0), kv.stride(0), nsplit=nsplit)
     k = kv[:Sk, :Hkv * hd].view(1, Sk, Hkv, hd); v = kv[:Sk, Hkv * hd:].view(1, Sk, Hkv, hd)
-    assert rel(o, attn_ref(q, k, v, True, Sk - 1)) < 1.2e-2
+    assert rel(o, attn_ref(q, k, v, True, Sk - 1)) <= ATTN_TOL
 
 
 @pytest.mark.parametrize("M,N,K", [(2000, 1024, 4096), (2399, 3584, 18944), (2399, 4608, 3584), (18432, 1152, 1152), (515, 768, 8192),
@@ -349,7 +355,7 @@ def test_gemm_streamk_vs_tile_kernel(M, N, K):
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
     refb = ops.gemm(a, w, kernel=ops.GEMM_FAST256)
     ob = ops.gemm(a, w, kernel=ops.GEMM_STREAMK)
-    assert rel(ob, refb) < 8e-3 and torch.equal(ob, ops.gemm(a, w, kernel=ops.GEMM_STREAMK))
+    assert rel(ob, refb) <= ONE_ULP and torch.equal(ob, ops.gemm(a, w, kernel=ops.GEMM_STREAMK))
     # in-place fp32 residual stream (the decoder's o_proj / down_proj form)
     x1, x2 = resid.clone(), resid.clone()
     ops.gemm(a, w, resid=x1, out=x1, kernel=ops.GEMM_FAST256)
@@ -392,7 +398,7 @@ def test_gemv1_fused_rmsnorm_bit_identical(N, K):
     if N % 32 == 0:
         yb = ops.gemv1(w, x=x[0].contiguous(), ln_w=gw, eps=1e-6, swiglu=True)
         refb = ops.gemm(h, w, swiglu=True, kernel=ops.GEMM_GEMV)[0]
-        assert rel(yb, refb) < 8e-3
+        assert rel(yb, refb) <= ONE_ULP
 
 
 def test_device_frame_batching_matches_pillow_bit_for_bit():

@@ -1,9 +1,10 @@
 """GPU: the product path (ufvideo_amd.* -> C ABI -> HIP kernels) against
   (a) golden vectors produced by the REFERENCE on a tiny model (tests/golden/model_tiny.npz ...), and
   (b) the CPU oracle at the full UFVideo-7B layer dimensions with seeded weights.
-Tolerance: BASELINE.json asks 1e-3 'bf16 tolerance'; one bf16 rounding alone is 2^-9 = 2e-3 relative,
-so the operational bar is max|d|/max|ref| per stage: <= 2e-2 for bf16-operand stages
-chained over several layers, <= 1e-2 for single ops; index/mask/token tensors are bit-exact."""
+Tolerance: the per-stage figures (HIP vs the bf16-mirrored oracle and vs fp32, with their derivation) live in
+tests/test_parity_bf16_gpu.py and the per-kernel correct-rounding statement in tests/test_kernel_rounding_gpu.py; the bounds
+here are max|d|/max|ref| against the fp32 reference, no looser than ~2x what MI355X measures;
+index/mask/token tensors are bit-exact."""
 import numpy as np
 import pytest
 import torch
@@ -78,10 +79,10 @@ def test_siglip_tiny_tower_vs_reference_golden():
     x = t(a["x"]).to(DEV)
     y = tower(x)
     assert y.dtype == x.dtype and y.shape == (3, 16, 64)
-    assert rel_err(y.cpu(), t(a["y"])) < 2e-2
+    assert rel_err(y.cpu(), t(a["y"])) < 1e-2
     # half input like the reference's mm_infer (.half().cuda())
     y16 = tower(x.half())
-    assert y16.dtype == torch.float16 and rel_err(y16.float().cpu(), t(a["y"])) < 2e-2
+    assert y16.dtype == torch.float16 and rel_err(y16.float().cpu(), t(a["y"])) < 1e-2
     assert tower.num_patches == 16 and tower.hidden_size == 64 and tower.image_size == 56 and tower.num_patches_per_side == 4
 
 
@@ -197,9 +198,9 @@ def test_end_to_end_tiny_vs_reference_golden():
     fo = m(input_ids=ids, attention_mask=am, images=c["images"], masks=c["masks"], frame=c["frame"], ann_indices=c["ann"],
            frame_nums=c["fn"], images_sam=sam, inference=True, output_hidden_states=True, use_cache=True, return_dict=True)
     assert fo.logits.shape == a["fw_logits"].shape
-    assert rel_err(fo.logits.cpu(), t(a["fw_logits"])) < 3e-2
-    assert rel_err(fo.hidden_states[-1].cpu(), t(a["fw_hidden_last"])) < 3e-2
-    assert rel_err(fo.hidden_states[1].cpu(), t(a["fw_hidden_1"])) < 3e-2
+    assert rel_err(fo.logits.cpu(), t(a["fw_logits"])) < 1.5e-2
+    assert rel_err(fo.hidden_states[-1].cpu(), t(a["fw_hidden_last"])) < 2e-2
+    assert rel_err(fo.hidden_states[1].cpu(), t(a["fw_hidden_1"])) < 2e-2
     assert len(fo.hidden_states) == 3 and fo.past_key_values.get_seq_length() == fo.logits.shape[1]
     k0 = fo.past_key_values.buf[0][: fo.logits.shape[1], :32].float().view(-1, 2, 16).permute(1, 0, 2)[None]
     assert rel_err(k0.cpu(), t(a["fw_k0"])) < 3e-2
@@ -251,7 +252,7 @@ def test_fulldim_siglip_layers_vs_oracle():
     y = tower(x.to(DEV))                       # hidden_states[-2] = 2 layers
     ref = O.siglip_tower(sd, cfg, x)
     assert y.shape == ref.shape == (2, 576, 1152)
-    assert rel_err(y.cpu(), ref) < 2e-2
+    assert rel_err(y.cpu(), ref) < 1e-2
 
 
 def test_fulldim_qwen2_layer_vs_oracle():
@@ -265,13 +266,13 @@ def test_fulldim_qwen2_layer_vs_oracle():
     x = torch.randn(1, S, 3584, generator=torch.Generator().manual_seed(14)) * 0.5
     logits, cache, hs, normed = m._decode_batch(x.to(DEV), None, None, True, 0)
     ref = O.qwen2_forward(sd, cfg, x)
-    assert rel_err(normed.cpu(), ref["hidden_states"][-1][0]) < 2e-2
-    assert rel_err(logits.cpu(), ref["logits"]) < 2e-2
+    assert rel_err(normed.cpu(), ref["hidden_states"][-1][0]) < 1.8e-2
+    assert rel_err(logits.cpu(), ref["logits"]) < 1.8e-2
     # decode one more token through the cache
     x1 = torch.randn(1, 1, 3584, generator=torch.Generator().manual_seed(15)) * 0.5
     l1, *_ = m._decode_batch(x1.to(DEV), None, cache, False, 1)
     ref1 = O.qwen2_forward(sd, cfg, x1, past=ref["past"])
-    assert rel_err(l1.cpu(), ref1["logits"]) < 2e-2
+    assert rel_err(l1.cpu(), ref1["logits"]) < 1e-2
 
 
 def test_generate_seg_branches_vs_reference_golden():
