@@ -116,6 +116,44 @@ def _flash_pv_mirror(s2: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     return acc / l[..., None]
 
 
+def _flash_vit72_mirror(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """The second-generation ViT kernel's arithmetic (csrc/attn_vit.inc `attn_fwd_vit72`: head_dim 72, non-causal, query count a
+    multiple of 288), tile for tile: q' = bf16(q * (scale * log2 e)) (one rounding, the product of the two constants taken in
+    fp32); scores s = q' k^T - m accumulated in fp32 with the running maximum m kept as a bf16 value; tiles of 64 keys, a wave owns 32
+    query rows; tile 0 sets m = bf16(row max); afterwards m only moves when SOME row of the wave sees a tile maximum above 2^6
+    (then every row takes m <- bf16(m + max(tile max, 0)) and O, l are rescaled by exp2(m_old - m_new) in fp32); P = bf16(exp2(s));
+    the row sum l is the fp32 sum of the SAME bf16 P (the kernel gets it from the PV MFMAs through a ones column); O / l at the end.
+    q, k, v [..., S, 72] fp32 holding bf16 values."""
+    c = (torch.tensor(scale, dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32))
+    s_all = torch.matmul(_rb(q.float() * c), k.float().transpose(-1, -2))
+    Sq, Sk = s_all.shape[-2:]
+    lead = s_all.shape[:-2]
+    m = torch.zeros(lead + (Sq,))
+    l = torch.zeros(lead + (Sq,))
+    acc = torch.zeros(lead + (Sq, v.shape[-1]))
+    G = (Sq + 31) // 32
+    for t0 in range(0, Sk, 64):
+        st = s_all[..., t0:t0 + 64] - m[..., None]
+        tmax = st.amax(dim=-1)
+        if t0 == 0:
+            m_new = _rb(m + tmax)
+            trig = torch.ones_like(tmax, dtype=torch.bool)
+        else:
+            trig = (tmax > 6.0).reshape(lead + (G, 32)).any(dim=-1, keepdim=True).expand(lead + (G, 32)).reshape(lead + (Sq,))
+            m_new = torch.where(trig, _rb(m + tmax.clamp_min(0.0)), m)
+        delta = m_new - m
+        if t0:
+            alpha = torch.where(trig, torch.exp2(-delta), torch.ones_like(delta))
+            l = l * alpha
+            acc = acc * alpha[..., None]
+        st = st - delta[..., None]
+        m = m_new
+        p = _rb(torch.exp2(st))
+        l = l + p.sum(dim=-1)
+        acc = acc + torch.matmul(p, v[..., t0:t0 + 64, :].float())
+    return acc / l[..., None]
+
+
 def _softmax_pv(scores: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """softmax(scores) @ v; scores [..., Sq, Sk] (scaled, masked entries very negative), v [..., Sk, hd].  Mirror mode follows
     csrc/attn.hip: the MFMA flash kernels (dispatch rule of `ufv_attention`: head_dim in {64,72,80,96,128} and >= 16 queries)
@@ -128,6 +166,14 @@ def _softmax_pv(scores: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         return _flash_pv_mirror(s2, v)
     p = torch.exp2(s2 - s2.amax(dim=-1, keepdim=True))
     return torch.matmul(p, v) / p.sum(dim=-1, keepdim=True)
+
+
+def attention_noncausal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
+    """softmax(q k^T * scale) v for the vision towers; q, k, v [..., S, hd].  fp32 graph: exactly that (modeling_siglip.py:237-247).
+    Mirror mode picks the arithmetic of the kernel `ufv_attention` dispatches to for this shape."""
+    if _MIRROR and q.shape[-1] == 72 and q.shape[-2] % 288 == 0:
+        return _flash_vit72_mirror(q, k, v, scale)
+    return _softmax_pv(torch.matmul(q, k.transpose(-1, -2)) * scale, v)
 
 
 # --------------------------------------------------------------------------------------
@@ -159,8 +205,7 @@ def vit_encoder_layer(sd: SD, p: str, x: torch.Tensor, heads: int, eps: float, a
     q = q.view(B, N, heads, hd).transpose(1, 2)
     k = k.view(B, N, heads, hd).transpose(1, 2)
     v = v.view(B, N, heads, hd).transpose(1, 2)
-    att = torch.matmul(q, k.transpose(-1, -2)) * (hd ** -0.5)          # :237
-    o = _rb(_softmax_pv(att, v)).transpose(1, 2).reshape(B, N, D)       # :241 (fp32 softmax)
+    o = _rb(attention_noncausal(q, k, v, hd ** -0.5)).transpose(1, 2).reshape(B, N, D)   # :237-247 (fp32 softmax)
     o = F.linear(o, _g(sd, p, "self_attn.out_proj.weight"), _g(sd, p, "self_attn.out_proj.bias"))
     x = x + o
     h = _rb(F.layer_norm(x, (D,), _g(sd, p, "layer_norm2.weight"), _g(sd, p, "layer_norm2.bias"), eps))

@@ -14,6 +14,10 @@
 #include "common.h"
 #include "../../include/ufv.h"
 
+#ifndef UFV_STAMP
+#define UFV_STAMP(i)            // tools/attn_lab.hip defines it to record s_memtime at point i (block-level timeline)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
+    UFV_STAMP(0);
     // 1-D grid; consecutive launch ids go to different XCDs, so give the q-tiles of one (batch, head) ids that are
     // 8 apart: they then share one XCD's L2 for their common K/V.
     const int nqt = (a.Sq + 32 * NW - 1) / (32 * NW);
@@ -349,6 +354,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // Q in registers before any DMA is in flight
+    UFV_STAMP(1);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));   // ... and hipcc's own scoreboard must see them consumed here:
     // it does not understand the asm wait above, and with LDS-DMA issued in between it would otherwise put a vmcnt(0) in
@@ -402,6 +408,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    UFV_STAMP(2);
     const bool grp1 = PP && ((wave >> 2) & 1);                // waves 4..7: one barrier behind (SIMD s holds waves s, s+4, s+8)
     if (grp1) __builtin_amdgcn_s_barrier();
     int st = 0;
@@ -530,6 +537,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
         st = (st == NST - 1) ? 0 : st + 1;
     }
     if (PP && !grp1) __builtin_amdgcn_s_barrier();           // balance the stagger barrier
+    UFV_STAMP(3);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
@@ -557,7 +565,10 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
         if (c < 32 * CPRW && q0 + row < a.Sq)
             *reinterpret_cast<bf16x8*>(obase + (int64_t)(q0 + row) * a.o_ss + ch * 8) = *reinterpret_cast<const bf16x8*>(ob + row * OP + ch * 16);
     }
+    UFV_STAMP(4);
 }
+
+#include "attn_vit.inc"
 
 // ---------------------------------------------------------------------------------------------------------
 // Head-pair variant of the LDS-DMA kernel (diagnostic, kernel ids 7 / 8).  With 168 VGPRs a CU holds 3 waves per SIMD, i.e. ONE
@@ -1101,7 +1112,7 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
     }
-    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || kernel == 10 || (kernel == 0 && mfma_ok && Sq >= 16)) {
+    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || kernel == 10 || kernel == 11 || (kernel == 0 && mfma_ok && Sq >= 16)) {
         const bool six = (Sq % 192 == 0) && (Sq % 128 != 0);     // e.g. 576 ViT tokens: 3 blocks of 6 waves, no idle wave
         switch (hd) {
             case 64: return launch_mfma<64, 4>(a, causal, st);
@@ -1109,6 +1120,8 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
                      // head-pair variants (diagnostic: measured 10-25 % slower than the 9-wave blocks)
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 7) return launch_pair<72, 6, false>(a, st);
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 8) return launch_pair<72, 6, true>(a, st);
+                     if (!causal && Sq % 288 == 0 && (int64_t)Sk * (k_ss > v_ss ? k_ss : v_ss) * 2 < (1ll << 31) && (kernel == 0 || kernel == 1 || kernel == 11))
+                         return launch_vit72<9>(a, st);   // second-generation ViT kernel (attn_vit.inc)
                      if (Sq % 288 == 0 && kernel == 6) return launch_mfma_dma<72, 9, false>(a, causal, st);   // lockstep variant (diagnostic)
                      if (six && kernel == 10) return launch_mfma_dma<72, 6, true>(a, causal, st);               // 6-wave blocks, ping-pong, 2 blocks / CU (diagnostic)
                      if (Sq % 288 == 0 && kernel != 4) return launch_mfma_dma<72, 9, true>(a, causal, st);     // 2 blocks of 9 waves (kernel 9: the former default)
