@@ -216,3 +216,56 @@ def test_ann_to_mask_rle_and_photo_grid():
     proc = MU.UfvImageProcessor(size=56)
     imgs, hh, ww, fl = MU.process_image(Image.fromarray(fr[0]), proc, num_frames=4, image_grid=True)
     assert imgs.shape == (2, 3, 56, 56) and (hh, ww) == (12, 8) and len(fl) == 4
+
+
+def test_checkpoint_loading_reports_missing_and_unexpected_keys(tmp_path):
+    """load_state_dict returns what nn.Module returns (minus the reference's unused SAM2-memory / tower-head tensors), and
+    from_pretrained refuses a checkpoint that would leave weights at their random initialisation; tie_word_embeddings is honoured"""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
+    kw = dict(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=1,
+              train_mask_decoder=True)
+    m = VideoReferQwen2ForCausalLM(VideoReferQwen2Config(**kw))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    full = dict(sd)
+    full["model.mask_encoder.sam2_model.memory_encoder.fuser.layers.0.weight"] = torch.zeros(2)      # ignored by design
+    full["something.else"] = torch.zeros(1)
+    del full["model.layers.0.mlp.up_proj.weight"]
+    res = m.load_state_dict(full, strict=False)
+    assert res.missing_keys == ["model.layers.0.mlp.up_proj.weight"] and res.unexpected_keys == ["something.else"]
+    with pytest.raises(KeyError):
+        m.load_state_dict(full, strict=True)
+    # from_pretrained: a missing tensor is an error, not a silent random init
+    d = tmp_path / "ckpt"; d.mkdir()
+    (d / "config.json").write_text(json.dumps(dict(kw, tie_word_embeddings=False)))
+    part = {k: v.contiguous() for k, v in sd.items() if k != "model.norm.weight"}
+    save_file(part, str(d / "model.safetensors"))
+    with pytest.raises(KeyError, match="model.norm.weight"):
+        VideoReferQwen2ForCausalLM.from_pretrained(str(d))
+    # tied embeddings: the head is taken from embed_tokens
+    tied = {k: v.contiguous() for k, v in sd.items() if k != "lm_head.weight"}
+    save_file(tied, str(d / "model.safetensors"))
+    (d / "config.json").write_text(json.dumps(dict(kw, tie_word_embeddings=True)))
+    m2 = VideoReferQwen2ForCausalLM.from_pretrained(str(d))
+    assert torch.equal(m2.lm_head.weight, m2.get_model().embed_tokens.weight) and torch.equal(m2.lm_head.weight, sd["model.embed_tokens.weight"])
+    (d / "config.json").write_text(json.dumps(dict(kw, tie_word_embeddings=False)))
+    with pytest.raises(KeyError, match="lm_head.weight"):
+        VideoReferQwen2ForCausalLM.from_pretrained(str(d))
+
+
+def test_packed_module_refuses_repacking_while_a_trainer_owns_it():
+    from ufvideo_amd.model._params import PackedModule, set_gemm_dtype
+
+    class M(PackedModule):
+        def _pack(self):
+            return {}
+    m = M()
+    m.packed(); m.invalidate(); m.to("cpu")
+    m._owner = object()
+    for f in (m.invalidate, lambda: m.to("cpu"), lambda: m.load_state_dict({}), lambda: set_gemm_dtype(m, "bf16")):
+        with pytest.raises(RuntimeError, match="DecoderTrainer owns"):
+            f()
+    m._owner = None
+    m.invalidate()

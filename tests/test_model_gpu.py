@@ -223,6 +223,37 @@ def test_end_to_end_tiny_vs_reference_golden():
         m.generate(ids, attention_mask=am, images=c["images"], images_sam=sam, offset=[0, 1, 2])
 
 
+def test_forward_batch_of_two_with_padding_packed_stream():
+    """forward(inference=True) on the collator-style batch of the `batch_pad` golden (two samples of different spliced length, right
+    padding): the decoder runs them as ONE packed token stream (per-sample RoPE positions / KV caches / attention, no padding FLOPs)
+    and returns HF-shaped padded outputs.  Against the oracle on the reference's own spliced inputs, and against the same samples run
+    one at a time."""
+    m, a, w = tiny_model()
+    video = t(a["video"]).to(DEV)
+    ids, am = t(a["sp_batch_pad_ids"]).to(DEV), t(a["sp_batch_pad_am_in"]).to(DEV)
+    images = [(video, "video"), (video.flip(0), "video")]
+    sam = torch.zeros(2, 4, 3, 8, 8, device=DEV)
+    fo = m(input_ids=ids, attention_mask=am, images=images, images_sam=sam, inference=True, output_hidden_states=True, use_cache=True)
+    emb_ref, am_ref = t(a["sp_batch_pad_nolab_emb"]), t(a["sp_batch_pad_nolab_am"])
+    lens = am_ref.sum(1).tolist()
+    assert lens[0] != lens[1] and fo.logits.shape == (2, emb_ref.shape[1], 300) and len(fo.hidden_states) == 3
+    ref = O.qwen2_forward(w, TINY_LLM, emb_ref, am_ref)
+    for b in range(2):
+        n = lens[b]
+        assert rel_err(fo.logits[b, :n].cpu(), ref["logits"][b, :n]) < 1.5e-2
+        assert rel_err(fo.hidden_states[-1][b, :n].cpu(), ref["hidden_states"][-1][b, :n]) < 2e-2
+        assert float(fo.logits[b, n:].abs().sum()) == 0.0                                   # padding rows: zeros, never computed
+        assert fo.past_key_values[b].get_seq_length() == n
+        one = m(input_ids=ids[b:b + 1], attention_mask=am[b:b + 1], images=images[b:b + 1], images_sam=sam[:1], inference=True, output_hidden_states=True)
+        n1 = one.logits.shape[1]
+        assert n1 >= n and rel_err(fo.logits[b, :n].cpu(), one.logits[0, :n].cpu()) < 5e-3      # same kernels, other GEMM row counts
+    last = m(input_ids=ids, attention_mask=am, images=images, images_sam=sam, inference=True, logits_to_keep=1)
+    for b in range(2):
+        assert rel_err(last.logits[b, 0].cpu(), fo.logits[b, lens[b] - 1].cpu()) < 5e-3
+    with pytest.raises(NotImplementedError):
+        m(input_ids=ids, attention_mask=am, images=images, images_sam=sam, inference=True, past_key_values=fo.past_key_values)
+
+
 def test_generate_eos_and_decode_consistency():
     """greedy decode through the KV cache == recomputing the full prefix; EOS stops and is included."""
     m, a, w = tiny_model()

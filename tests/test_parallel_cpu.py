@@ -24,10 +24,19 @@ def test_frame_chunks_and_clip_shards():
 
 class _Proj:
     downsample = (2, 2, 2)
+    PADDING = 0            # stc_connector_v35: windows never straddle a frame group
+
+
+class _Tower:
+    class config:
+        patch_size = 1
 
 
 class _Inner:
     mm_projector = _Proj()
+
+    def get_vision_tower(self):
+        return _Tower()
 
 
 class _Model:
@@ -39,10 +48,10 @@ class _Model:
 
 
 def _stub_encode(frames):
-    # two tokens per frame pair, value = (sum of the pair's frame ids, index) -> order-sensitive
+    # frames [t, 3, 4, 4] with patch 1 -> side 4 -> (4 // 2)^2 = 4 tokens per frame pair; value = (sum of the pair's frame ids) + 0.25 * index
     t = frames.shape[0]
     ids = frames[:, 0, 0, 0].view(t // 2, 2).sum(1)
-    tok = torch.stack([ids, ids + 0.5], dim=1).reshape(-1, 1)
+    tok = (ids[:, None] + 0.25 * torch.arange(4)[None]).reshape(-1, 1)
     return tok.expand(-1, 8).contiguous()
 
 
@@ -50,10 +59,19 @@ def _worker(rank, world, port, T, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        video = torch.arange(T, dtype=torch.float32).view(T, 1, 1, 1).expand(T, 3, 2, 2).contiguous()
+        video = torch.arange(T, dtype=torch.float32).view(T, 1, 1, 1).expand(T, 3, 4, 4).contiguous()
+        calls = {"n": 0}
+        orig_ag, orig_ar = dist.all_gather_into_tensor, dist.all_reduce
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return orig_ag(*a, **k)
+        dist.all_gather_into_tensor = counting
+        dist.all_reduce = lambda *a, **k: (_ for _ in ()).throw(AssertionError("encode_frame_sharded must not all_reduce"))
         out = P.encode_frame_sharded(_Model(), video, encode_fn=_stub_encode)
+        dist.all_gather_into_tensor, dist.all_reduce = orig_ag, orig_ar
         ref = _stub_encode(video)
-        ok = torch.equal(out, ref)
+        ok = torch.equal(out, ref) and calls["n"] == 1               # ONE collective, no other traffic
         # bench.py's timing protocol: barrier, local time, MAX over ranks
         dist.barrier()
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
@@ -77,7 +95,81 @@ def test_frame_sharded_encode_world2_gloo(T):
         assert p.exitcode == 0
     for rank, ok, tmax, shape in res:
         assert ok, f"rank {rank}: gathered tokens differ from the single-process encode"
-        assert tmax == 2.0 and shape == (T, 8)
+        assert tmax == 2.0 and shape == (2 * T, 8)
+
+
+def test_frame_sharding_refuses_projectors_that_look_across_frame_groups():
+    """Conv3d padding 1 (stc_connector, spatial_conv) and the mean-over-all-frames MLP projectors would silently give other tokens"""
+    class Pad1:
+        downsample, PADDING, AVGPOOL = (2, 2, 2), 1, False
+
+    class Mlp:
+        pass
+
+    class Pool:
+        downsample, PADDING, AVGPOOL = (2, 2, 2), 1, True          # STPConnector: AvgPool3d has no padding
+
+    with pytest.raises(ValueError):
+        P.check_frame_shardable(Pad1())
+    with pytest.raises(ValueError):
+        P.check_frame_shardable(Mlp())
+    assert P.check_frame_shardable(Pool()) == (2, 2, 2) and P.check_frame_shardable(_Proj()) == (2, 2, 2)
+    from ufvideo_amd.model.projector import STCConnectorV35, STCConnector, SpatialConv, STPConnector, MlpProjector
+
+    class Cfg:
+        mm_hidden_size, hidden_size = 8, 8
+    assert P.check_frame_shardable(STCConnectorV35(Cfg(), depth=0)) == (2, 2, 2)
+    assert P.check_frame_shardable(STPConnector(Cfg(), depth=0)) == (2, 2, 2)
+    for bad in (STCConnector(Cfg(), depth=0), SpatialConv(Cfg()), MlpProjector(8, 8, 2)):
+        with pytest.raises(ValueError):
+            P.check_frame_shardable(bad)
+
+
+# ---- bench.py's rank plumbing: the real `run()` with a stub model ------------------------------------------------------------------
+
+def _bench_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        import bench
+
+        class Stub:
+            class config:
+                num_hidden_layers, num_key_value_heads, head_dim = 1, 1, 8
+        steps_seen = []
+
+        def step(model, video, ids, am, cache, fs):
+            time.sleep(0.02 * (1 + rank))                        # rank 1 is the slow one: the reported time must be ITS time
+            steps_seen.append(1)
+            return torch.zeros(1), 2399
+        args = bench.parse_args(["--gpus", str(world), "--steps", "5", "--warmup", "2", "--no-cpu-baseline"])
+        out = bench.run(args, rank, world, dist, torch.device("cpu"), build=lambda dev, frames: Stub(), inputs=lambda dev, frames: (None, None, None),
+                        step=step, sync=lambda: None, cache_factory=lambda m: None)
+        q.put((rank, out, len(steps_seen)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_run_protocol_world2_gloo():
+    """bench.run(): W untimed + exactly K timed steps per rank, barrier on both sides, MAX over ranks, value = world * K * tokens / t_max,
+    weak scaling, n_gpus = world"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (o, n) for r, o, n in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (o0, n0), (o1, n1) = res[0], res[1]
+    assert n0 == n1 == 7                                             # 2 warm-up + 5 timed, on every rank
+    assert o0["ms_per_step"] == o1["ms_per_step"] and o0["ms_per_step"] >= 40.0      # both report the slow rank's 2 x 20 ms
+    assert o0["n_gpus"] == 2 and o0["steps"] == 5 and o0["warmup"] == 2 and o0["scaling"] == "weak" and o0["vs_baseline"] is None
+    assert abs(o0["value"] - 2 * 5 * 2304 / (o0["ms_per_step"] * 5e-3)) / o0["value"] < 1e-3
+    assert o0["config"]["parallelism"] == "clip-dp2" and "cpu_baseline" not in o0 and "roofline" not in o0     # stub: no kernel was timed
 
 
 # ---- ZeRO-2 exchange of the training step (ufvideo_amd/train.py) ---------------------------------------------------
@@ -126,6 +218,58 @@ def test_zero2_exchange_world2_gloo_matches_single_process_adamw():
         torch.nn.utils.clip_grad_norm_([p], 1.0)
         opt.step()
         assert torch.allclose(res[0][i], p.detach(), atol=1e-6, rtol=1e-5), f"step {t_}"
+
+
+def _trainer_exchange_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ufvideo_amd import train as TR
+        tr = object.__new__(TR.DecoderTrainer)                    # the exchange logic alone, on CPU buckets (no kernels involved)
+        tr.world, tr.rank, tr.group, tr.comm_stream, tr.train_decoder, tr._last_micro = world, rank, None, None, True, True
+        mk = lambda names, sharded: TR._Bucket(names, "cpu", world if sharded else 1, rank if sharded else 0, torch.float32, True)   # noqa: E731
+        tr.layers = [mk([("w", (40, 8))], True) for _ in range(3)]
+        tr.head = mk([("lm_head", (24, 8))], True)
+        tr.small = mk([("norm", (8,))], False)
+        tr.proj_bucket = None
+        for i, b in enumerate(tr.buckets()):
+            b.init_states()
+            b.g.copy_(torch.arange(b.n, dtype=torch.float32) * (rank + 1) + i)      # rank-dependent gradients
+        tr._reduce_async(tr.layers[2])                            # the last layer's bucket went out early, during backward
+        assert tr.layers[2].reduced
+        tr._exchange()
+        got = {}
+        for i, (b, g) in enumerate(tr._grad_shards()):
+            got[i] = g.clone()
+        q.put((rank, {k: v.numpy().tolist() for k, v in got.items()}, [b.n for b in tr.buckets()], [getattr(b, "reduced", False) for b in tr.layers]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_exchange_order_world2_gloo():
+    """DecoderTrainer._reduce_async / _exchange / _grad_shards on CPU buckets: sharded buckets end with this rank's slice of the
+    rank-mean gradient (whether the reduce-scatter went out early or in _exchange), replicated buckets with the full mean, every
+    `reduced` flag is cleared, and both ranks issue the collectives in the same order (a mismatch would hang or mix buffers)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (g, ns, fl) for r, g, ns, fl in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        got, ns, flags = res[rank]
+        assert flags == [False, False, False]
+        for i, n in enumerate(ns):
+            mean = torch.arange(n, dtype=torch.float32) * 1.5 + i          # mean over ranks of arange * (rank + 1) + i
+            g = torch.tensor(got[i])
+            if g.numel() == n:                                               # replicated bucket: the whole mean
+                assert torch.equal(g, mean), (rank, i)
+            else:
+                assert g.numel() * 2 == n and torch.equal(g, mean[rank * (n // 2):(rank + 1) * (n // 2)]), (rank, i)
 
 
 def test_bucket_layout_and_shard_bounds():

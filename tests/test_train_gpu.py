@@ -433,6 +433,61 @@ def test_train_step_on_the_collator_batch_contract():
     assert torch.isfinite(r["loss"]) and float(r["grad_norm"]) > 0
 
 
+def test_trainer_hands_weights_back_saves_resumes_and_refuses_seg_batches():
+    """(i) while a trainer is attached, anything that would re-pack the model from its stale nn.Parameters raises; sync_to_model() puts the
+    trained weights under the reference's names; detach() releases the model and the re-packed model computes what the trainer's
+    buffers computed; (ii) state_dict() / load_state_dict() of the optimizer shards: a resumed trainer takes bit-identical steps;
+    (iii) a batch with [SEG] targets or ground-truth masks is refused (its mask-loss backward does not exist) instead of being
+    trained on the CE term alone."""
+    a, _ = load_golden("train_grad_tiny")
+    m, arrs, _ = tiny_model()
+    ids, labels = t(a["ids"]).to(DEV), t(a["labels_in"]).to(DEV)
+    video = t(arrs["video"]).to(DEV)
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids), images=[(video, "video")], images_sam=None,
+                 offset=[0, 1], masks_list=None, label_list=None)
+    before = m.state_dict()["model.layers.0.mlp.down_proj.weight"].clone()
+    tr = DecoderTrainer(m, lr=1e-3, weight_decay=0.01)
+    tr.train_step(**batch)
+    for f in (lambda: m.to(DEV), lambda: m.set_gemm_dtype("bf16"), lambda: m.get_model().invalidate(), lambda: m.load_state_dict({}, strict=False)):
+        with pytest.raises(RuntimeError, match="DecoderTrainer owns"):
+            f()
+    assert torch.equal(m.state_dict()["model.layers.0.mlp.down_proj.weight"], before)           # the Parameters are stale ...
+    tr.sync_to_model()
+    after = m.state_dict()["model.layers.0.mlp.down_proj.weight"]
+    assert not torch.equal(after, before) and torch.equal(after, tr.export_state_dict()["model.layers.0.mlp.down_proj.weight"])   # ... until synced
+    # (ii) resume: save, step, restore into a fresh trainer on a fresh model, step -> same parameters bit for bit
+    snap_w = {k: v.clone() for k, v in tr.export_state_dict().items()}
+    snap_o = tr.state_dict()
+    tr.train_step(**batch)
+    want = tr.export_state_dict()
+    sam = torch.zeros(1, 4, 3, 8, 8, device=DEV)
+    logits_attached = m(input_ids=ids, attention_mask=torch.ones_like(ids), images=[(video, "video")], images_sam=sam, inference=True).logits.clone()
+    tr.detach()
+    logits_detached = m(input_ids=ids, attention_mask=torch.ones_like(ids), images=[(video, "video")], images_sam=sam, inference=True).logits
+    # detach() loses nothing but the fp32 precision of the norm weights / biases (the trainer keeps them as fp32 masters, the
+    # model's parameters are bf16 like the reference's checkpoints)
+    assert rel_err(logits_detached, logits_attached) < 1e-2
+    m.get_model().invalidate()                                                                  # allowed again
+    m2, _, _ = tiny_model()
+    m2.load_state_dict({**m2.state_dict(), **snap_w}, strict=True)
+    tr2 = DecoderTrainer(m2, lr=1e-3, weight_decay=0.01)
+    tr2.load_state_dict(snap_o)
+    assert tr2.t == 1
+    tr2.train_step(**batch)
+    got = tr2.export_state_dict()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    with pytest.raises(ValueError):
+        tr2.load_state_dict(dict(snap_o, world=2))
+    # (iii)
+    seg = labels.clone(); seg[0, -2] = m2.config.seg_token_id
+    with pytest.raises(NotImplementedError, match="mask-loss"):
+        tr2.train_step(**dict(batch, labels=seg))
+    with pytest.raises(NotImplementedError, match="mask-loss"):
+        tr2.train_step(**dict(batch, masks_list=[torch.ones(1, 8, 8)]))
+    tr2.train_step(**dict(batch, masks_list=[torch.zeros(0, 8, 8)]))                            # an empty ground truth is the no-[SEG] sample
+
+
 # ---- projector backward ------------------------------------------------------------------------------------------------------
 
 class _PCfg:

@@ -42,6 +42,13 @@ class PackedModule(Holder):
     def __init__(self):
         super().__init__()
         self._packed = None
+        self._owner = None       # set by ufvideo_amd.train.DecoderTrainer while the packed buffers ARE its flat training buffers
+
+    def _check_owner(self, what):
+        if getattr(self, "_owner", None) is not None:
+            raise RuntimeError(f"{what}: a DecoderTrainer owns this module's packed weights (they are views of its gradient buckets). "
+                               "Call trainer.sync_to_model() to write the trained weights into the parameters and trainer.detach() to release "
+                               "them -- re-packing now would silently fall back to the parameters from before training.")
 
     def gw(self, w):
         """A GEMM weight [N, K] in this module's compute format: bf16, or `ops.Fp8Weight` when gemm_dtype == "fp8" and the
@@ -53,14 +60,17 @@ class PackedModule(Holder):
         return w
 
     def _apply(self, fn, *a, **k):
+        self._check_owner("moving / casting the module")
         self._packed = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
+        self._check_owner("load_state_dict")
         self._packed = None
         return super().load_state_dict(*a, **k)
 
     def invalidate(self):
+        self._check_owner("invalidate")
         self._packed = None
         for m in self.modules():
             if isinstance(m, PackedModule):
@@ -110,5 +120,6 @@ def set_gemm_dtype(root, mode):
     assert mode in ("bf16", "fp8")
     for m in root.modules():
         if isinstance(m, PackedModule):
+            m._check_owner("set_gemm_dtype")
             m.gemm_dtype = mode
             m._packed = None

@@ -257,6 +257,7 @@ class VideoReferMetaForCausalLM(ABC):
         # the ids come to the host BEFORE the encoder is queued (the copy synchronises: at this point the stream is idle); the
         # splice plan below is then built while the GPU is still busy with the tower, instead of stalling it after the encoder
         ids_host = input_ids.tolist()
+        am_host = attention_mask.tolist() if attention_mask is not None else None
         if mm_features is None:
             mm_features = self.encode_images_or_videos(images)                   # [n_mm, tok, D] fp32
         if frame is not None:
@@ -270,11 +271,19 @@ class VideoReferMetaForCausalLM(ABC):
         region_id = self.tokenizer.convert_tokens_to_ids(["<region>"])[0]
         plan = build_splice_plan(ids_host, mm_lens, region_token_nums, region_id, frame is not None)
         new_labels, new_mask = splice_labels_and_mask(plan, input_ids, attention_mask, labels, mm_lens)
+        # host-side lengths of the mask just built (left fill = True, then the caller's mask, then right padding): the decoder trims by
+        # them without reading the device tensor back.  Only right-padded masks qualify; anything else is left to the decoder's own check.
+        self._last_mask_info = None
+        if new_mask is not None:
+            L_in = len(am_host[0])
+            valid = [plan.lengths[b] - L_in + sum(1 for v in am_host[b] if v) for b in range(len(am_host))]
+            if all(all(bool(v) for v in am_host[b][:valid[b] - (plan.lengths[b] - L_in)]) for b in range(len(am_host))):
+                self._last_mask_info = (new_mask, valid)
         (t_src, t_dst), (m_src, m_dst), (r_src, r_dst) = splice_index_arrays(plan, ids_host, mm_lens, [k * tok for k in range(n_mm)])
         dev = mm_features.device
         D = mm_features.shape[-1]
         B, S = len(plan.lengths), max(plan.lengths)
-        embeds = torch.zeros((B * S, D), device=dev, dtype=torch.float32)
+        embeds = (torch.zeros if B > 1 else torch.empty)((B * S, D), device=dev, dtype=torch.float32)     # padding rows exist only in a batch
         # pinned + non_blocking: the host does not wait for the stream (a pageable H2D copy blocks until the encoder is done)
         i64 = lambda l: torch.tensor(l, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
         if t_src:

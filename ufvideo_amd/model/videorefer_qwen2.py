@@ -100,6 +100,13 @@ class KVCache:
         self.max_len = new_len
 
 
+class BatchKVCache(list):
+    """past_key_values of a batch > 1 forward: one `KVCache` per sample (samples have different lengths; nothing is padded)."""
+
+    def get_seq_length(self, layer_idx=0):
+        return max(c.get_seq_length() for c in self)
+
+
 def pack_swiglu(gate, up):
     """interleave rows in blocks of 16: [g0..15 | u0..15 | g16..31 | u16..31 ...] (see csrc/gemm.hip)"""
     I, K = gate.shape
@@ -155,36 +162,41 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
         pk["layers"] = layers
         return pk
 
-    # ---- decoder over one sequence: x fp32 [S, D] (modified in place), positions pos0..pos0+S-1 -----------
-    def run_layers(self, x, cache: KVCache, pos0, collect_hidden=None):
+    # ---- decoder over a token stream: x fp32 [S, D] (modified in place).  One sequence at positions pos0..pos0+S-1, or, with
+    #      `segments` = [(row offset, length, KVCache, pos0), ...], several sequences PACKED back to back (the collator's right-padded
+    #      batch without its padding): norms and GEMMs run over all rows at once, RoPE / KV store / attention per sequence --------------
+    def run_layers(self, x, cache, pos0, collect_hidden=None, segments=None):
         cfg, pk = self.config, self.packed()
         S, D = x.shape
         H, KV, hd, eps = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.rms_norm_eps
-        cache.ensure(pos0 + S)
+        segs = segments if segments is not None else [(0, S, cache, pos0)]
+        for _, n, c, p0 in segs:
+            c.ensure(p0 + n)
         dev = x.device
         h = torch.empty((S, D), device=dev, dtype=torch.bfloat16)
         qkv = torch.empty((S, (H + 2 * KV) * hd), device=dev, dtype=torch.bfloat16)
         o = torch.empty((S, H * hd), device=dev, dtype=torch.bfloat16)
         act = torch.empty((S, cfg.intermediate_size), device=dev, dtype=torch.bfloat16)
-        Sk = pos0 + S
-        rope_tab = ops.rope_table(pk["inv_freq"], pos0, S, hd) if S > 1 and hd % 16 == 0 else None
+        tabs = [ops.rope_table(pk["inv_freq"], p0, n, hd) if n > 1 and hd % 16 == 0 else None for _, n, _, p0 in segs]
         for li, L in enumerate(pk["layers"]):
             if "wqkv8" in L:
                 L = dict(L, wqkv=L["wqkv8"], wo=L["wo8"], wgu=L["wgu8"], wd=L["wd8"])
-            kvb = cache.buf[li]
             q8 = isinstance(L["wqkv"], ops.Fp8Weight)          # W8A8 prefill: the norms emit e4m3 + row scale directly
             hq = ops.rmsnorm(x, L["ln1"], eps, quant=True) if q8 else ops.rmsnorm(x, L["ln1"], eps, out=h)
             ops.gemm(hq, L["wqkv"], bias=L["bqkv"], out=qkv)
-            ops.rope_kv(qkv, S, H, KV, hd, pk["inv_freq"], pos0, kvb, table=rope_tab)
-            ops.attention(qkv, kvb, kvb[:, KV * hd:], 1, H, KV, S, Sk, hd, (0, qkv.stride(0)), (0, kvb.stride(0)),
-                          (0, kvb.stride(0)), causal=True, q_pos0=pos0, out=o)
+            for (off, n, c, p0), tab in zip(segs, tabs):
+                kvb, qs = c.buf[li], qkv[off:off + n]
+                ops.rope_kv(qs, n, H, KV, hd, pk["inv_freq"], p0, kvb, table=tab)
+                ops.attention(qs, kvb, kvb[:, KV * hd:], 1, H, KV, n, p0 + n, hd, (0, qkv.stride(0)), (0, kvb.stride(0)),
+                              (0, kvb.stride(0)), causal=True, q_pos0=p0, out=o[off:off + n])
             ops.gemm(o, L["wo"], resid=x, out=x)
             hq = ops.rmsnorm(x, L["ln2"], eps, quant=True) if q8 else ops.rmsnorm(x, L["ln2"], eps, out=h)
             ops.gemm(hq, L["wgu"], swiglu=True, out=act)
             ops.gemm(act, L["wd"], resid=x, out=x)
             if collect_hidden is not None and li < len(pk["layers"]) - 1:
                 collect_hidden.append(x.clone())
-        cache.len = Sk
+        for _, n, c, p0 in segs:
+            c.len = p0 + n
         return x
 
     def final_norm(self, x, out_dtype=torch.float32):
@@ -246,58 +258,115 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         self.config.vocab_size = self.vocab_size = n
         self.invalidate(); self.model.invalidate()
 
+    # keys a reference checkpoint holds that this model does not use (so their absence / presence is not an error): the SAM2 memory
+    # modules (never observable on the [SEG] path, model/sam2.py), the tower layers after hidden_states[select_layer] and its pooling head
+    IGNORED_CHECKPOINT_KEYS = ("model.mask_encoder.sam2_model.memory_", "model.mask_encoder.sam2_model.maskmem_", "model.mask_encoder.sam2_model.obj_ptr",
+                               "model.mask_encoder.sam2_model.mask_downsample", "model.mask_encoder.sam2_model.no_obj_ptr",
+                               "model.mask_encoder.sam2_model.sam_prompt_encoder.mask_downscaling", "model.mask_encoder.sam2_model.sam_prompt_encoder.point_embeddings",
+                               "model.mask_encoder.sam2_model.no_mem_pos_enc", "model.mask_encoder.sam2_model.no_obj_embed_spatial",
+                               "model.vision_tower.vision_tower.vision_model.post_layernorm", "model.vision_tower.vision_tower.vision_model.head",
+                               "model.vision_tower.vision_tower.vision_model.encoder.layers.26.")
+
     def load_state_dict(self, sd, strict=True):
-        """Accepts the reference's keys; vision-tower keys may come with or without `vision_model.`;
-        SAM2 memory modules (unused at inference, see model/sam2.py) and unused tower-head keys are ignored."""
+        """Accepts the reference's keys; vision-tower keys may come with or without `vision_model.`.  Returns (missing, unexpected)
+        like nn.Module does, where keys on IGNORED_CHECKPOINT_KEYS count as neither; strict=True raises on any other missing key."""
+        for m in self.modules():
+            if isinstance(m, PackedModule):
+                m._check_owner("load_state_dict")
         own = self.state_dict()
-        new = {}
+        new, unexpected = {}, []
         vt = "model.vision_tower.vision_tower."
         for k, v in sd.items():
             if k.startswith(vt) and not k.startswith(vt + "vision_model."):
                 k = vt + "vision_model." + k[len(vt):]
             if k in own:
                 new[k] = v
-        missing = [k for k in own if k not in new]
+            elif not k.startswith(self.IGNORED_CHECKPOINT_KEYS):
+                unexpected.append(k)
+        missing = [k for k in own if k not in new and not k.startswith(self.IGNORED_CHECKPOINT_KEYS)]
         if strict and missing:
             raise KeyError(f"missing weights: {missing[:6]}{' ...' if len(missing) > 6 else ''}")
-        res = nn.Module.load_state_dict(self, new, strict=False)
+        nn.Module.load_state_dict(self, new, strict=False)
         for m in self.modules():
             if isinstance(m, PackedModule):
                 m._packed = None
-        return res
+        from torch.nn.modules.module import _IncompatibleKeys
+        return _IncompatibleKeys(missing, unexpected)
 
     # ---- decoder over a batch ----------------------------------------------------------------------------
+    def _valid_lengths(self, attention_mask, B, S):
+        """Per-sample token counts of a right-padded attention mask [B, S+past], on the HOST.  The mask the splice itself built comes
+        with its lengths (no device round trip in the timed path); any other mask is read back once."""
+        if attention_mask is None:
+            return [S] * B
+        info = getattr(self, "_last_mask_info", None)
+        if info is not None and info[0] is attention_mask:
+            return list(info[1])
+        am = attention_mask.to(torch.bool).cpu()
+        tot = am.sum(1).tolist()
+        for b in range(B):
+            if not bool(am[b, :tot[b]].all()):
+                raise NotImplementedError("only right-padded attention masks are supported")
+        return tot
+
     def _decode_batch(self, inputs_embeds, attention_mask, past_key_values, output_hidden_states, logits_to_keep):
-        """inputs_embeds [B,S,D] fp32 (device).  Right padding is trimmed per sample via attention_mask."""
+        """inputs_embeds [B,S,D] fp32 (device).  Right padding is trimmed per sample via attention_mask; a batch > 1 (the training
+        collator's, ref train.py:678-732 / videorefer_arch.py:333-368) runs as ONE packed token stream with per-sample RoPE
+        positions, KV caches and attention (no padding FLOPs) and comes back padded to [B, S, ...] as HF returns it.
+        -> (logits, cache, hidden_states | None, final-norm rows of sample 0 .. B-1 concatenated)"""
         cfg = self.config
         B, S, D = inputs_embeds.shape
         width = 2 * cfg.num_key_value_heads * cfg.head_dim
-        if B != 1:
-            raise NotImplementedError("the accelerated decoder runs batch 1 (the reference's inference batch, SURVEY F8)")
-        pos0 = 0 if past_key_values is None else past_key_values.get_seq_length()
-        valid = S
-        if attention_mask is not None:
-            am = attention_mask[0].to(torch.bool)
-            total = int(am.sum().item())
-            if not bool(am[:total].all()):
-                raise NotImplementedError("only right-padded attention masks are supported")
-            valid = total - pos0
-        cache = past_key_values or KVCache(cfg.num_hidden_layers, max(valid + 64, 256), width, inputs_embeds.device)
-        x = inputs_embeds[0, :valid].to(torch.float32).contiguous().clone()
-        hs = [x.clone()] if output_hidden_states else None
-        x = self.model.run_layers(x, cache, pos0, collect_hidden=hs)
-        normed = self.model.final_norm(x)                                    # fp32 [valid, D]
-        if output_hidden_states:
-            hs.append(normed)
         pk = self.packed()
         V = pk["V"]
+        if B == 1:
+            pos0 = 0 if past_key_values is None else past_key_values.get_seq_length()
+            valid = self._valid_lengths(attention_mask, 1, S)[0] - pos0 if attention_mask is not None else S
+            cache = past_key_values or KVCache(cfg.num_hidden_layers, max(valid + 64, 256), width, inputs_embeds.device)
+            x = ops.convert(inputs_embeds[0, :valid], torch.float32) if inputs_embeds.dtype != torch.float32 else inputs_embeds[0, :valid].clone()
+            hs = [x.clone()] if output_hidden_states else None
+            x = self.model.run_layers(x, cache, pos0, collect_hidden=hs)
+            normed = self.model.final_norm(x)                                    # fp32 [valid, D]
+            if output_hidden_states:
+                hs.append(normed)
+            if logits_to_keep == 1:
+                last = ops.convert(normed[-1:].contiguous(), torch.bfloat16)
+                logits = ops.gemm(last, pk["lm_head"], out_dtype=torch.float32).view(1, 1, V)
+            else:
+                hb = ops.convert(normed, torch.bfloat16)
+                logits = ops.gemm(hb, self._lm_head_padded(), out_dtype=torch.float32)[:, :V].unsqueeze(0)
+            return logits, cache, hs, normed
+        if past_key_values is not None:
+            raise NotImplementedError("a batch > 1 continues no KV cache (the reference decodes batch 1, SURVEY F8)")
+        lens = self._valid_lengths(attention_mask, B, S)
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        dev = inputs_embeds.device
+        x = torch.cat([inputs_embeds[b, :lens[b]] for b in range(B)], 0).to(torch.float32)
+        caches = BatchKVCache(KVCache(cfg.num_hidden_layers, max(n + 64, 256), width, dev) for n in lens)
+        segs = [(offs[b], lens[b], caches[b], 0) for b in range(B)]
+        packed_hs = [x.clone()] if output_hidden_states else None
+        x = self.model.run_layers(x, None, 0, collect_hidden=packed_hs, segments=segs)
+        normed = self.model.final_norm(x)
+
+        def unpack(t):                                                           # packed [sum, C] -> padded [B, S, C] (zeros in the padding)
+            out = torch.zeros((B, S, t.shape[-1]), device=dev, dtype=t.dtype)
+            for b in range(B):
+                out[b, :lens[b]] = t[offs[b]:offs[b + 1]]
+            return out
+        hs = None
+        if output_hidden_states:
+            packed_hs.append(normed)
+            hs = [unpack(t) for t in packed_hs]
         if logits_to_keep == 1:
-            last = ops.convert(normed[-1:].contiguous(), torch.bfloat16)
-            logits = ops.gemm(last, pk["lm_head"], out_dtype=torch.float32).view(1, 1, V)
+            rows = torch.tensor([o - 1 for o in offs[1:]], device=dev)
+            last = ops.convert(normed[rows].contiguous(), torch.bfloat16)
+            logits = ops.gemm(last, pk["lm_head"], out_dtype=torch.float32).view(B, 1, V)
         else:
             hb = ops.convert(normed, torch.bfloat16)
-            logits = ops.gemm(hb, self._lm_head_padded(), out_dtype=torch.float32)[:, :V].unsqueeze(0)
-        return logits, cache, hs, normed
+            logits = unpack(ops.gemm(hb, self._lm_head_padded(), out_dtype=torch.float32)[:, :V])
+        return logits, caches, hs, normed
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
                 labels=None, use_cache=None, output_attentions=None, output_hidden_states=None, images=None, masks=None,
@@ -319,7 +388,7 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         logits, cache, hs, _ = self._decode_batch(inputs_embeds, attention_mask, past_key_values, bool(output_hidden_states),
                                                  kwargs.get("logits_to_keep", 0))
         return ModelOutput(loss=None, logits=logits, past_key_values=cache if use_cache is not False else None,
-                           hidden_states=tuple(h.unsqueeze(0) for h in hs) if hs is not None else None, attentions=None)
+                           hidden_states=tuple(h if h.dim() == 3 else h.unsqueeze(0) for h in hs) if hs is not None else None, attentions=None)
 
     __call__ = forward
 
@@ -471,7 +540,7 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         eos = eos_token_id if eos_token_id is not None else self.generation_config.eos_token_id
         eos = set(eos) if isinstance(eos, (list, tuple)) else ({eos} if eos is not None else set())
         dev = inputs_embeds.device
-        S = inputs_embeds.shape[1] if attention_mask is None else int(attention_mask[0].sum().item())
+        S = self._valid_lengths(attention_mask, 1, inputs_embeds.shape[1])[0]
         cfg = self.config
         width = 2 * cfg.num_key_value_heads * cfg.head_dim
         cache = KVCache(cfg.num_hidden_layers, S + max_new_tokens + 8, width, dev)
@@ -607,7 +676,21 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
             raise FileNotFoundError(f"no *.safetensors under {path}")
         if getattr(model.get_vision_tower(), "is_loaded", True) is False:
             model.get_vision_tower().load_model(device=device, dtype=dtype)
-        model.load_state_dict(sd, strict=False)
+        if getattr(config, "tie_word_embeddings", False) and "lm_head.weight" not in sd and "model.embed_tokens.weight" in sd:
+            sd["lm_head.weight"] = sd["model.embed_tokens.weight"]            # HF ties them instead of storing the head
+        tower_in_ckpt = any(k.startswith("model.vision_tower.") for k in sd)
+        res = model.load_state_dict(sd, strict=False)
+        # a weight that stays at its random initialisation makes the model emit garbage without any error: refuse, unless it is the
+        # vision tower and the tower was just loaded from its own directory (the reference's checkpoints may or may not carry it)
+        tower_loaded_separately = getattr(model.get_vision_tower(), "_local_path", lambda: None)() is not None
+        missing = [k for k in res.missing_keys if not (k.startswith("model.vision_tower.") and not tower_in_ckpt and tower_loaded_separately)]
+        if missing:
+            raise KeyError(f"{path}: {len(missing)} weights of the model are not in the checkpoint (they would keep their random "
+                           f"initialisation): {missing[:6]}{' ...' if len(missing) > 6 else ''}")
+        if res.unexpected_keys:
+            import warnings
+            warnings.warn(f"{path}: {len(res.unexpected_keys)} checkpoint tensors have no counterpart in the model and were ignored: "
+                          f"{res.unexpected_keys[:6]}{' ...' if len(res.unexpected_keys) > 6 else ''}")
         return model
 
 

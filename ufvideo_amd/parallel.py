@@ -5,8 +5,10 @@ Two modes:
     bench.py --gpus N measures): `shard_clips`.
   * frame-sharded encoder for ONE clip — tower + projector are independent per aligned frame group of the Conv3d
     temporal stride (2 for stc_connector_v35), so each rank encodes a contiguous, stride-aligned chunk of frames and
-    a single all-gather of the visual tokens (rank order = temporal order) feeds the decoder, which every rank then
+    ONE all-gather of the visual tokens (rank order = temporal order) feeds the decoder, which every rank then
     runs (it does not frame-shard; Amdahl cap 1.5x at 8 GPUs): `frame_chunks`, `encode_frame_sharded`.
+No scaling curve has been measured on hardware yet (no multi-GPU node in rounds 1-2): the exchange is covered by
+world-size-2 gloo tests (tests/test_parallel_cpu.py).
 """
 import torch
 
@@ -34,44 +36,63 @@ def frame_chunks(num_frames, world, t_stride=2):
 
 
 def all_gather_tokens(local_tokens, counts, group=None):
-    """Concatenate per-rank token blocks [n_r, D] in rank order.  Blocks may differ in length (uneven frame split):
-    padded to the longest for the collective, then trimmed.  One all-gather, no other traffic."""
+    """Concatenate per-rank token blocks [n_r, D] in rank order with ONE collective (`all_gather_into_tensor`): equal blocks
+    (the production case: 32 or 64 frames over 1/2/4/8 ranks) land directly in the result; unequal blocks are padded to the
+    longest for the collective and trimmed afterwards."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    assert len(counts) == world and local_tokens.shape[0] == counts[dist.get_rank(group)]
     n_max = max(counts)
     D = local_tokens.shape[-1]
+    if min(counts) == n_max:
+        out = local_tokens.new_empty((world * n_max, D))
+        dist.all_gather_into_tensor(out, local_tokens.contiguous(), group=group)
+        return out
     buf = local_tokens.new_zeros((n_max, D))
     buf[: local_tokens.shape[0]] = local_tokens
-    gathered = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(gathered, buf, group=group)
-    return torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)
+    gathered = local_tokens.new_empty((world * n_max, D))
+    dist.all_gather_into_tensor(gathered, buf, group=group)
+    return torch.cat([gathered[r * n_max: r * n_max + c] for r, c in enumerate(counts)], dim=0)
+
+
+def check_frame_shardable(proj):
+    """Frame sharding is only valid when the projector treats aligned groups of `t_stride` frames independently: RegStage and
+    the readout are per frame / per token; the sampler must not look across the group boundary, i.e. Conv3d with padding 0
+    (stc_connector_v35) or the AvgPool3d samplers with a temporal kernel > 1.  `stc_connector` / `spatial_conv` (Conv3d padding 1:
+    windows straddle the shard boundary and zero frames are added at both ends) and the `mlpNx_gelu` / `linear` projectors
+    (mean over ALL frames, videorefer_arch.py:203-205) would silently give different tokens: refuse."""
+    pad = getattr(proj, "PADDING", None)
+    avg = getattr(proj, "AVGPOOL", False)
+    down = getattr(proj, "downsample", None)
+    if down is None or not (avg or pad == 0):
+        raise ValueError(f"{type(proj).__name__} cannot be frame-sharded: its output for a frame group depends on frames outside the group "
+                         "(only Conv3d padding 0 / AvgPool3d samplers are independent per aligned group)")
+    return down
 
 
 def encode_frame_sharded(model, video, group=None, encode_fn=None):
     """video [T,3,H,W] (identical on every rank) -> visual tokens [tokens, D] of the whole clip on every rank.
-    `encode_fn(frames) -> [tokens_of_chunk, D]` defaults to the model's tower + projector."""
+    `encode_fn(frames) -> [tokens_of_chunk, D]` defaults to the model's tower + projector.  The only communication is the one
+    all-gather: every rank derives every rank's token count from the geometry (frames per rank x tokens per frame group)."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     proj = model.get_model().mm_projector
-    t_stride = getattr(proj, "downsample", (1, 1, 1))[0]
+    down = check_frame_shardable(proj)
+    t_stride = down[0]
     chunks = frame_chunks(video.shape[0], world, t_stride)
+    tower = model.get_model().get_vision_tower()
+    side = video.shape[-1] // tower.config.patch_size
+    per_group = (side // down[1]) * (side // down[2])           # tokens one aligned frame group yields (no padding: floor)
     if encode_fn is None:
         def encode_fn(frames):
-            feats = model.get_model().get_vision_tower().encode(frames)                 # [t, n, d]
+            feats = tower.encode(frames)                                                  # [t, n, d]
             return model.temporal_aggregator(feats[None])[0]                              # [tokens, D]
     s, e = chunks[rank]
-    # tokens per frame group are shape-determined; compute every rank's count without communication
-    with torch.no_grad():
-        local = encode_fn(video[s:e]) if e > s else None
-    per_group = None
-    if local is not None:
-        per_group = local.shape[0] // ((e - s) // t_stride)
-    # all ranks with a non-empty chunk agree on per_group; share it through the collective-free arithmetic below
-    pg = torch.tensor([per_group or 0], device=video.device, dtype=torch.int64)
-    dist.all_reduce(pg, op=dist.ReduceOp.MAX, group=group)
-    per_group = int(pg.item())
     counts = [((ce - cs) // t_stride) * per_group for cs, ce in chunks]
-    if local is None:
-        D = model.config.hidden_size
-        local = torch.zeros((0, D), device=video.device, dtype=torch.float32)
+    with torch.no_grad():
+        if e > s:
+            local = encode_fn(video[s:e])
+            assert local.shape[0] == counts[rank], (local.shape, counts[rank])
+        else:
+            local = torch.zeros((0, model.config.hidden_size), device=video.device, dtype=torch.float32)
     return all_gather_tokens(local, counts, group)

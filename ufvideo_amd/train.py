@@ -213,6 +213,10 @@ class DecoderTrainer:
         self._fresh = True
         self._last_micro = False
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        # the decoder's packed weights now ARE this trainer's buffers: anything that would re-pack them from the (stale) nn.Parameters
+        # -- .to(), load_state_dict, set_gemm_dtype, resize_token_embeddings, invalidate() -- raises until detach()
+        model.get_model()._owner = self
+        model._owner = self
 
     def buckets(self):
         """the buckets that are exchanged and updated"""
@@ -381,8 +385,20 @@ class DecoderTrainer:
         §3.5): splice (the tower is frozen; projector / region encoder are trained when the trainer was built with
         train_projector / train_region_encoder, else they run forward-only),
         causal-LM loss averaged over the batch's supervised tokens (HF Qwen2ForCausalLM), backward, exchange, AdamW.
-        Returns {"loss", "ce_loss", "grad_norm"}."""
+        The remaining collator keys (images_sam, offset, masks_list, label_list) are accepted; a batch whose labels contain [SEG] or
+        whose masks_list holds ground-truth masks raises NotImplementedError (see below).  Returns {"loss", "ce_loss", "grad_norm"}: for
+        the batches that are accepted the mask terms of the reference's loss are zero, so "loss" is the reference's loss."""
         m = self.model
+        # The reference's objective adds bce_loss_weight * BCE + dice_loss_weight * DICE of the SAM2 masks for every [SEG] in the labels
+        # (videorefer_qwen2.py:198-352) and trains text_hidden_fcs / the mask decoder through it.  That backward is not built: a batch
+        # that would need it is refused instead of being trained on the CE term alone under the name "loss".
+        masks_list = _unused.get("masks_list")
+        seg_id = getattr(self.cfg, "seg_token_id", None)
+        has_gt = masks_list is not None and any(torch.is_tensor(g) and g.numel() > 0 and g.shape[0] > 0 for g in masks_list)
+        has_seg = seg_id is not None and labels is not None and bool((labels == seg_id).any())
+        if has_gt or has_seg:
+            raise NotImplementedError("train_step: this batch carries [SEG] targets / ground-truth masks; the mask-loss (BCE + DICE) backward through "
+                                      "text_hidden_fcs and the SAM2 mask decoder is not implemented -- only the causal-LM objective is trained")
         stashes = None
         with torch.no_grad():
             mm_features = None
@@ -453,26 +469,43 @@ class DecoderTrainer:
         reduce-scatter on the side stream so that it overlaps the backward of the earlier layers."""
         if self.world == 1 or not self._last_micro:
             return
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(ev)
+        if self.comm_stream is None:                      # no side stream (CPU tensors in the gloo tests): same collective, in line
             reduce_scatter_mean(b.gshard, b.g, self.group)
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                reduce_scatter_mean(b.gshard, b.g, self.group)
         b.reduced = True
+
+    def _exchange_order(self):
+        """(sharded buckets in the order backward produced them, replicated buckets): every rank issues its collectives in this
+        order -- the property the gloo test pins, since mismatched orders deadlock or mix buffers on any backend"""
+        sharded = (list(reversed(self.layers)) + [self.head]) if self.train_decoder else []
+        replicated = ([self.small] if self.train_decoder else []) + ([self.proj_bucket] if self.proj_bucket is not None else [])
+        return sharded, replicated
 
     def _exchange(self):
         if self.world == 1:
             return
         cs = self.comm_stream
-        cs.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(cs):
-            for b in (list(reversed(self.layers)) + [self.head]) if self.train_decoder else []:   # the order backward produced them
+        sharded, replicated = self._exchange_order()
+
+        def run():
+            for b in sharded:
                 if not getattr(b, "reduced", False):              # not already started by _reduce_async
                     reduce_scatter_mean(b.gshard, b.g, self.group)
                 b.reduced = False
-            for rb in ([self.small] if self.train_decoder else []) + ([self.proj_bucket] if self.proj_bucket is not None else []):      # replicated buckets
+            for rb in replicated:
                 dist.all_reduce(rb.g, op=dist.ReduceOp.SUM, group=self.group)
                 rb.g.mul_(1.0 / self.world)
+        if cs is None:
+            run()
+            return
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            run()
         torch.cuda.current_stream().wait_stream(cs)
 
     def _grad_shards(self):
@@ -529,6 +562,60 @@ class DecoderTrainer:
             if self.world > 1:
                 for b in self.layers + [self.head]:
                     all_gather_shards(b.w, self.group)
+            self._refresh_transposes()
+
+    # ---- hand the trained weights back / save and resume ----------------------------------------------------------------------
+    def sync_to_model(self):
+        """Writes the trained decoder weights (bf16 working copies of the fp32 masters) into the model's nn.Parameters under the
+        reference's names, so that model.state_dict() / save paths export what was trained.  The projector / region-encoder parameters
+        are views of the trainer's buffer already.  Every rank holds the full bf16 weights after step(), so no communication."""
+        if not self.train_decoder:
+            return
+        own = dict(self.model.named_parameters())
+        with torch.no_grad():
+            for k, v in self.export_state_dict().items():
+                own[k].data.copy_(v.to(own[k].dtype))
+
+    def detach(self):
+        """sync_to_model(), then release the model: its packed buffers are rebuilt from the (now current) parameters on next use"""
+        self.sync_to_model()
+        self.model.get_model()._owner = None
+        self.model._owner = None
+        self.model.invalidate(); self.model.get_model().invalidate()
+
+    def state_dict(self):
+        """This rank's optimizer state: step count, learning rates and, per bucket, the fp32 master / m / v SHARDS (ZeRO-2: each rank
+        saves and restores its own slice; load on the same world size)."""
+        sd = {"t": self.t, "lr": self.lr, "base_lr": self.base_lr, "mm_projector_lr": self.mm_projector_lr, "world": self.world, "rank": self.rank,
+              "buckets": []}
+        for b in self.buckets():
+            sd["buckets"].append({"n": b.n, "master": b.master.clone(), "m": b.m.clone(), "v": b.v.clone()})
+        return sd
+
+    def load_state_dict(self, sd):
+        if sd["world"] != self.world or sd["rank"] != self.rank:
+            raise ValueError(f"optimizer shards were saved by rank {sd['rank']} of {sd['world']}, this is rank {self.rank} of {self.world}")
+        bs = self.buckets()
+        if len(bs) != len(sd["buckets"]) or any(b.n != e["n"] for b, e in zip(bs, sd["buckets"])):
+            raise ValueError("optimizer state does not match this trainer's bucket layout")
+        self.t, self.lr, self.base_lr, self.mm_projector_lr = sd["t"], sd["lr"], sd["base_lr"], sd["mm_projector_lr"]
+        for b, e in zip(bs, sd["buckets"]):
+            b.master.copy_(e["master"]); b.m.copy_(e["m"]); b.v.copy_(e["v"])
+            if b.world == 1:
+                b.w.copy_(b.master)
+            else:
+                lo = b.rank * b.shard
+                b.w[lo:lo + b.shard].copy_(b.master)
+                all_gather_shards(b.w, self.group)
+        if self.proj_bucket is not None:
+            if self.proj_flat is not None:
+                self.proj_flat.copy_(self.proj_bucket.master)
+            else:
+                for k, v in self.proj_params.items():
+                    v.data.copy_(self.proj_bucket.view(self.proj_bucket.w, k))
+            for mod in self.aux_modules.values():
+                mod._packed = None
+        if self.train_decoder:
             self._refresh_transposes()
 
     def set_lr_ratio(self, ratio):
