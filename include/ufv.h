@@ -345,6 +345,23 @@ int ufv_attention_bwd_fused(const void* q, int64_t ldq, const void* k, const voi
                             const void* dO, int64_t lddo, const float* lse, void* dq, int64_t lddq, void* dk, void* dv, int64_t lddkv,
                             int S, int Hq, int Hkv, int hd, float scale, void* ws, void* stream);
 
+/* ---- [SEG] mask-loss backward (videorefer_qwen2.py:34-77,279-338; sam2.py _forward_sam_heads :3276-3452 under
+ * autograd).  The mask decoder's attention is between a handful of prompt tokens and h*w image tokens: q [B, Nq, H*hd], k / v
+ * [B, Nk, H*hd] bf16 contiguous, head_dim 16 or 32; lse fp32 [B, H, Nq] = log sum exp of the scaled scores. */
+int ufv_small_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, int hd, float scale,
+                       void* stream);
+/* dq / dk / dv bf16 (overwritten); delta fp32 [B, H, Nq] is scratch (dO . O) */
+int ufv_small_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse, float* delta, void* dq,
+                       void* dk, void* dv, int B, int H, int Nq, int Nk, int hd, float scale, void* stream);
+/* the selected mask: out[b, p] = sum_c up[b * P + p, c] * h[b, c]  (up bf16 [B*P, C], C <= 32; h, out fp32) and its gradients */
+int ufv_mask_dot_fwd(const void* up, const float* h, float* out, int B, int P, int C, void* stream);
+int64_t ufv_mask_dot_bwd_ws_bytes(int B, int C);
+int ufv_mask_dot_bwd(const void* up, const float* h, const float* dm, void* dup, float* dh, void* ws, int B, int P, int C, void* stream);
+/* backward of ufv_resize_bilinear (no plane selection): din [N, Hs, Ws] = gather of dout [N, Hd, Wd] through the same 2x2 stencils */
+int ufv_resize_bilinear_bwd(const float* dout, float* din, int N, int Hs, int Ws, int Hd, int Wd, void* stream);
+/* dx = cb * (sigmoid(x) - t) + sigmoid(x) (1 - sigmoid(x)) (coef[2n] * t + coef[2n + 1]): BCE-with-logits (mean) + DICE of mask n */
+int ufv_mask_loss_bwd(const float* x, const float* t, const float* coef, float cb, float* dx, int N, int64_t HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -410,3 +410,59 @@ def test_bf16_chain_noise_floor():
     floor = rel_err(b, a)
     assert 1e-3 < floor < 3e-2, floor                  # bf16 storage: amplified to the ulp scale
     assert floor > 0.1 * rel_err(a, f)                 # ... i.e. a sizeable part of the whole bf16-vs-fp32 distance
+
+
+def test_mask_loss_grads_vs_reference_backward():
+    """The rest of row a12: loss = ce + bce_w BCE + dice_w DICE of the reference's forward(inference=False) with
+    train_mask_decoder semantics, `loss.backward()` (oracle/gen_fixtures_seg_grad.py).  torch autograd over the oracle's
+    restatement must reproduce: the losses, d(loss)/d(inputs_embeds), the gradients of text_hidden_fcs and of every decoder
+    parameter in full, and norm / sum / a strided sample of the gradient of every sam_mask_decoder parameter; the IoU and
+    object-score heads receive no gradient (the mask is PICKED by arg-max IoU).  This pins the oracle as the checker of the HIP
+    mask-loss backward (tests/test_seg_train_gpu.py)."""
+    a, _ = load_golden("seg_grad_tiny")
+    _, m, w, cfg, sam = _seg_setup()
+    assert a["sam_seeds"].tolist() == t(load_golden("seg_tiny")[0]["sam_seeds"]).tolist()
+    tab, e1 = w["model.embed_tokens.weight"].float(), t(m["sp_vid_only_nolab_emb"])[0]
+    mm = e1[2:-3]
+    images_sam = t(a["images_sam"])[0]
+    for name in ("two_obj", "one_obj"):
+        ws = {k: v.float().clone().requires_grad_(k.startswith(("model.layers.", "model.norm.", "lm_head.", "model.text_hidden_fcs.", "model.embed_tokens.")))
+              for k, v in w.items()}
+        ss = {k: v.float().clone().requires_grad_(k.startswith("sam_mask_decoder.")) for k, v in sam.items()}
+        ids, labels = t(a[name + "_ids"])[0], t(a[name + "_labels"])
+        k = ids.tolist().index(-201)
+        emb = torch.cat([tab[ids[:k]], mm, tab[ids[k + 1:]]], 0)[None].clone().requires_grad_(True)
+        lab = torch.cat([labels[0, :k], torch.full((mm.shape[0],), -100), labels[0, k + 1:]])[None]
+        gt = t(a[name + "_gt"])
+        r = O.training_losses(ws, TINY_LLM, emb, torch.ones(1, emb.shape[1], dtype=torch.long), lab, 299, ss, cfg, images_sam, [gt],
+                              [torch.zeros(gt.shape[1:])], tuple(a["loss_weights"].tolist()))
+        got = torch.stack([r[k_].detach().float() for k_ in ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss")])
+        assert torch.allclose(got, t(a[name + "_losses"]).float(), rtol=2e-5, atol=1e-6), name
+        r["loss"].backward()
+        assert rel_err(emb.grad, t(a[name + "_d_inputs_embeds"])) < 2e-4, name
+        n_full = n_samp = 0
+        for key in a:
+            if key.startswith(name + "_g::"):
+                pn = key[len(name) + 4:]
+                if pn == "model.embed_tokens.weight":                     # our embeds are a leaf (gathered rows): compare through d_inputs_embeds above
+                    continue
+                assert ws[pn].grad is not None, pn
+                assert rel_err(ws[pn].grad, t(a[key])) < 3e-4, (name, pn, rel_err(ws[pn].grad, t(a[key])))
+                n_full += 1
+            elif key.startswith(name + "_gs::"):
+                pn = key[len(name) + 5:]
+                g_ = ss[pn].grad
+                assert g_ is not None, pn
+                ref = t(a[key]).float()
+                f = g_.reshape(-1)
+                samp = f[torch.linspace(0, f.numel() - 1, min(97, f.numel())).long()]
+                scale = float(ref[0]) + 1e-12
+                # (1e-8 floor: e.g. the key biases of an attention have an analytically zero gradient -- softmax is shift-invariant)
+                assert abs(float(g_.norm()) - float(ref[0])) < 3e-4 * scale + 1e-8, (name, pn)
+                assert abs(float(g_.sum()) - float(ref[1])) < 3e-4 * scale * max(1.0, f.numel() ** 0.5) + 1e-8, (name, pn)
+                assert float((samp - ref[2:]).abs().max()) < 3e-4 * float(g_.abs().max()) + 1e-8, (name, pn)
+                n_samp += 1
+            elif key.startswith(name + "_nograd::"):
+                pn = key[len(name) + 9:]
+                assert ss[pn].grad is None or float(ss[pn].grad.abs().max()) == 0.0, pn
+        assert n_full >= 20 and n_samp >= 100, (n_full, n_samp)

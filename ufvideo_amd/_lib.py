@@ -15,6 +15,12 @@ _p, _i, _f, _l = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 # name -> argtypes; this table is also what tests/test_host_cpu.py (test_c_abi_exports_every_declared_symbol) checks against include/ufv.h
 SIGNATURES = {
+    "ufv_small_attn_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "ufv_small_attn_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
+    "ufv_mask_dot_fwd": [_p, _p, _p, _i, _i, _i, _p],
+    "ufv_mask_dot_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "ufv_resize_bilinear_bwd": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "ufv_mask_loss_bwd": [_p, _p, _p, _f, _p, _i, _l, _p],
     "ufv_gemm": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p],
     "ufv_layernorm": [_p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _f, _i, _p],
     "ufv_ln_add_silu": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
@@ -90,7 +96,7 @@ SIGNATURES = {
 # entry points that return a size instead of a status
 SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l),
               "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l), "ufv_attention_bwd_fused_ws_bytes": ([_i, _i], _l),
-              "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l)}
+              "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l), "ufv_mask_dot_bwd_ws_bytes": ([_i, _i], _l)}
 
 
 class Qwen2Layer(C.Structure):
