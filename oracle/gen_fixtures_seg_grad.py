@@ -91,7 +91,7 @@ def main():
         out[name + "_losses"] = np.array([float(r[k]) for k in ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss")])
         out[name + "_d_inputs_embeds"] = cap["embeds"].grad.detach().clone()
         out[name + "_hidden_last"] = cap["hidden"].detach().clone()
-        out[name + "_d_hidden_fcs"] = cap["hidden"].grad.detach().clone()          # the mask-loss part of d(loss)/d(last hidden): through text_hidden_fcs only
+        out[name + "_d_hidden_fcs"] = cap["hidden"].grad.detach().clone()          # d(loss)/d(last hidden): CE (lm_head reads the same tensor) + the mask terms through text_hidden_fcs
         out[name + "_fcs_out"] = cap["fcs_out"].detach().clone()
         out[name + "_d_fcs_out"] = cap["fcs_out"].grad.detach().clone()
         for n in fcs_names + dec_names:

@@ -466,3 +466,53 @@ def test_mask_loss_grads_vs_reference_backward():
                 pn = key[len(name) + 9:]
                 assert ss[pn].grad is None or float(ss[pn].grad.abs().max()) == 0.0, pn
         assert n_full >= 20 and n_samp >= 100, (n_full, n_samp)
+
+
+def test_mask_loss_grad_bf16_storage_noise():
+    """Why tests/test_seg_train_gpu.py compares the mask-branch gradients at 15 %, not at the 1e-2 of a forward pass: the fixture's ground
+    truth is a random binary mask, so every gradient behind the resizes and the mask product is the remainder of a cancelling sum.  Measured
+    here with the oracle's autograd: the fp32 graph against the SAME graph with bf16 weights and with op outputs (and hence, through
+    autograd's cast rule, the gradients at the same points) rounded to bf16 -- the storage the HIP path and the reference's own bf16
+    training use.  The HIP path measures the same per-tensor figures (text_hidden_fcs.0.0.weight: 9 % / 15 % here, 8 % / 15 % on the GPU).
+    A 2x error of one ROW of that gradient is typical: the row is rank-1 in one element of a 256-term cancelling sum."""
+    a, _ = load_golden("seg_grad_tiny")
+    _, m, w, cfg, sam = _seg_setup()
+    tab, e1 = w["model.embed_tokens.weight"].float(), t(m["sp_vid_only_nolab_emb"])[0]
+    mm = e1[2:-3]
+    real_f = O.F
+
+    class RoundedOps:
+        def __getattr__(self, n):
+            f = getattr(real_f, n)
+            if n in ("linear", "layer_norm", "gelu", "relu", "conv_transpose2d", "conv2d", "silu"):
+                return lambda *a_, **k_: f(*a_, **k_).to(torch.bfloat16).float()
+            return f
+
+    def grads(rounded, name="two_obj"):
+        ws = {k: v.float().clone().requires_grad_(k.startswith("model.text_hidden_fcs.")) for k, v in w.items()}
+        ss = {k: v.float().clone().requires_grad_(k.startswith("sam_mask_decoder.")) for k, v in sam.items()}
+        ids, labels = t(a[name + "_ids"])[0], t(a[name + "_labels"])
+        k = ids.tolist().index(-201)
+        emb = torch.cat([tab[ids[:k]], mm, tab[ids[k + 1:]]], 0)[None].clone()
+        lab = torch.cat([labels[0, :k], torch.full((mm.shape[0],), -100), labels[0, k + 1:]])[None]
+        gt = t(a[name + "_gt"])
+        O.F = RoundedOps() if rounded else real_f
+        O._MIRROR = bool(rounded)                          # ... and the weights are the bf16 copies the kernels read
+        try:
+            r = O.training_losses(ws, TINY_LLM, emb, torch.ones(1, emb.shape[1], dtype=torch.long), lab, 299, ss, cfg, t(a["images_sam"])[0], [gt],
+                                  [torch.zeros(gt.shape[1:])], tuple(a["loss_weights"].tolist()))
+        finally:
+            O.F, O._MIRROR = real_f, False
+        r["mask_loss"].backward()
+        return {k: v.grad for k, v in {**ss, **ws}.items() if v.grad is not None and float(v.grad.norm()) > 1e-8}
+    for name, fcs0 in (("two_obj", 0.094), ("one_obj", 0.157)):
+        g0, g1 = grads(False, name), grads(True, name)
+        errs = {k: rel_err(g1[k], g0[k]) for k in g0}
+        med = sorted(errs.values())[len(errs) // 2]
+        assert 0.03 < med < 0.3 and max(errs.values()) > 0.15, (med, max(errs.values()))   # token-side MLPs / query projections: 20 % and more
+        assert errs["sam_mask_decoder.output_upscaling.3.weight"] < 0.03           # the pixel path is benign: ~1 %
+        assert abs(errs["model.text_hidden_fcs.0.0.weight"] - fcs0) < 0.4 * fcs0, errs["model.text_hidden_fcs.0.0.weight"]
+        # noise adds in quadrature, so the NORMS stay put: that is the sharp check the GPU test keeps (4 % + a floor)
+        for k in g0:
+            if float(g0[k].norm()) > 0.1 * max(float(v.norm()) for v in g0.values()):
+                assert abs(float(g1[k].norm()) / float(g0[k].norm()) - 1) < 0.05, k

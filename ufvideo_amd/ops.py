@@ -701,3 +701,62 @@ def conv3d_scatter(dA, T, H, W, C, k):
     dx = torch.empty((T * H * W, C), device=dA.device, dtype=torch.bfloat16)
     _lib.call("ufv_conv3d_scatter", dA.data_ptr(), dx.data_ptr(), T, H, W, C, k[0], k[1], k[2], _stream())
     return dx
+
+
+# ---- [SEG] mask-loss backward (csrc/seg_train.hip) ---------------------------------------------------------------------------------
+def small_attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale=None):
+    """q [B*Nq, H*hd], k / v [B*Nk, H*hd] bf16 contiguous -> (o bf16 [B*Nq, H*hd], lse fp32 [B, H, Nq])"""
+    for t_, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t_, torch.bfloat16, n); assert t_.is_contiguous()
+    o = torch.empty_like(q)
+    lse = torch.empty((B, H, Nq), device=q.device, dtype=torch.float32)
+    _lib.call("ufv_small_attn_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, Nq, Nk, hd,
+              float(hd ** -0.5 if scale is None else scale), _stream())
+    return o, lse
+
+
+def small_attn_bwd(q, k, v, o, dO, lse, B, H, Nq, Nk, hd, scale=None):
+    for t_, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o"), (dO, "dO")):
+        _chk(t_, torch.bfloat16, n); assert t_.is_contiguous()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty_like(lse)
+    _lib.call("ufv_small_attn_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), dO.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+              dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Nq, Nk, hd, float(hd ** -0.5 if scale is None else scale), _stream())
+    return dq, dk, dv
+
+
+def mask_dot_fwd(up, h, B, P):
+    """up bf16 [B*P, C], h fp32 [B, C] -> fp32 [B, P]"""
+    _chk(up, torch.bfloat16, "up"); _chk(h, torch.float32, "h"); assert up.is_contiguous() and h.is_contiguous()
+    out = torch.empty((B, P), device=up.device, dtype=torch.float32)
+    _lib.call("ufv_mask_dot_fwd", up.data_ptr(), h.data_ptr(), out.data_ptr(), B, P, up.shape[1], _stream())
+    return out
+
+
+def mask_dot_bwd(up, h, dm, B, P):
+    """-> (d_up bf16 [B*P, C], d_h fp32 [B, C])"""
+    _chk(dm, torch.float32, "dm"); assert dm.is_contiguous()
+    C = up.shape[1]
+    dup = torch.empty_like(up)
+    dh = torch.empty_like(h)
+    ws = _ws(up.device, _lib.load().ufv_mask_dot_bwd_ws_bytes(B, C), "mask_dot")
+    _lib.call("ufv_mask_dot_bwd", up.data_ptr(), h.data_ptr(), dm.data_ptr(), dup.data_ptr(), dh.data_ptr(), ws.data_ptr(), B, P, C, _stream())
+    return dup, dh
+
+
+def resize_bilinear_bwd(dout, in_hw):
+    """dout fp32 [N, 1, Hd, Wd] (gradient of resize_bilinear's output) -> fp32 [N, 1, Hs, Ws]"""
+    _chk(dout, torch.float32, "dout"); assert dout.is_contiguous()
+    N = dout.shape[0] * dout.shape[1]
+    din = torch.empty((dout.shape[0], dout.shape[1], in_hw[0], in_hw[1]), device=dout.device, dtype=torch.float32)
+    _lib.call("ufv_resize_bilinear_bwd", dout.data_ptr(), din.data_ptr(), N, in_hw[0], in_hw[1], dout.shape[-2], dout.shape[-1], _stream())
+    return din
+
+
+def mask_loss_bwd(x, t, coef, cb):
+    """x, t fp32 [N, h, w]; coef fp32 [N, 2] -> dx = cb (sigmoid(x) - t) + sigmoid'(x) (coef[n,0] t + coef[n,1])"""
+    _chk(x, torch.float32, "x"); _chk(t, torch.float32, "t"); _chk(coef, torch.float32, "coef")
+    assert x.is_contiguous() and t.is_contiguous() and coef.is_contiguous()
+    dx = torch.empty_like(x)
+    _lib.call("ufv_mask_loss_bwd", x.data_ptr(), t.data_ptr(), coef.data_ptr(), float(cb), dx.data_ptr(), x.shape[0], x.shape[1] * x.shape[2], _stream())
+    return dx

@@ -104,7 +104,8 @@ class DecoderTrainer:
     initialised, else single process)."""
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
-                 train_embed=True, train_projector=False, train_region_encoder=False, train_decoder=True, mm_projector_lr=None):
+                 train_embed=True, train_projector=False, train_region_encoder=False, train_decoder=True, mm_projector_lr=None,
+                 train_seg_head=False):
         """train_decoder=False freezes the language model (the reference's tune_mm_mlp_adapter / tune_region_encoder stages,
         train.py:882-890: model.requires_grad_(False), then only the adapter's parameters are re-enabled): backward still carries
         dL/dx through every layer, but no weight gradient, no fp32 states and no update exist for the decoder."""
@@ -121,8 +122,8 @@ class DecoderTrainer:
         self.t = 0
         self.train_decoder = bool(train_decoder)
         self.train_embed = train_embed = bool(train_embed) and self.train_decoder
-        if not self.train_decoder and not (train_projector or train_region_encoder):
-            raise ValueError("nothing to train: train_decoder=False needs train_projector and / or train_region_encoder")
+        if not self.train_decoder and not (train_projector or train_region_encoder or train_seg_head):
+            raise ValueError("nothing to train: train_decoder=False needs train_projector, train_region_encoder and / or train_seg_head")
         dev = model.device
         self.dev = dev
         D, I = cfg.hidden_size, cfg.intermediate_size
@@ -175,6 +176,17 @@ class DecoderTrainer:
         self.train_region = bool(train_region_encoder)
         if self.train_region:
             self.aux_modules["region_encoder."] = model.get_model().region_encoder
+        # the mask branch (reference: text_hidden_fcs always trainable, sam_mask_decoder with train_mask_decoder, videorefer_arch.py:124-149):
+        # trained through BCE + DICE of the [SEG] masks (ufvideo_amd/train_seg.py); same replicated fp32 bucket as the other adapters
+        self.seg = None
+        if train_seg_head:
+            from .train_seg import SegHeadGrad
+            inner = model.get_model()
+            if inner.mask_encoder is None:
+                raise ValueError("train_seg_head needs the SAM2 head: build the model with config.sam2_trunk set")
+            self.seg = SegHeadGrad(model)
+            self.aux_modules["text_hidden_fcs."] = inner.text_hidden_fcs
+            self.aux_modules["mask_encoder.sam2_model.sam_mask_decoder."] = inner.mask_encoder.sam2_model.sam_mask_decoder
         if self.aux_modules:
             named = [(pre + k, v) for pre, mod in self.aux_modules.items() for k, v in mod.named_parameters()]
             # per module: matrices first, then vectors, so that every (learning rate, decay) group is ONE contiguous range of the flat
@@ -265,12 +277,15 @@ class DecoderTrainer:
         self._fresh = True
 
     # ---- forward with stash + backward ---------------------------------------------------------------------------
-    def forward_backward(self, inputs_embeds, labels, embed_ids=None, loss_weight=None, last=False):
+    def forward_backward(self, inputs_embeds, labels, embed_ids=None, loss_weight=None, last=False, hidden_hook=None):
         """inputs_embeds fp32 [S, D] (one spliced sample), labels int64 [S] ALREADY SHIFTED (labels[p] = target of position p,
         -100 = ignored).  embed_ids int64 [S]: vocabulary row of every position that came from embed_tokens, -1 elsewhere
         (visual / region tokens).  loss_weight: d(total loss)/d(sum of token losses), default 1 / (valid labels of this sample).
         last=True: no further micro-batch follows before step(), so every layer's gradient bucket is handed to the exchange
         as soon as that layer's backward is done (overlapped reduce-scatter).
+        hidden_hook(hb) -> (rows int64 [n], grads fp32 [n, D]) | None: called between forward and backward with the final-norm hidden
+        states hb bf16 [S, D]; what it returns is added to d(loss)/d(hb) at those rows (the mask losses reach the decoder through
+        the hidden states in front of the [SEG] targets).
         Accumulates gradients; returns (loss = loss_weight * sum CE, d_inputs_embeds fp32 [S, D])."""
         self._last_micro = bool(last)
         cfg = self.cfg
@@ -327,6 +342,10 @@ class DecoderTrainer:
         # lm_head + final norm
         dx = torch.empty((S, D), device=self.dev, dtype=torch.float32)
         ops.gemm(dl, self.lm_headT, out=dh)                                          # d hb, fp32 [S, D]
+        if hidden_hook is not None:
+            extra = hidden_hook(hb)
+            if extra is not None:
+                dh.index_add_(0, extra[0].to(self.dev), extra[1].to(torch.float32))
         if td:
             dlT = ops.transpose(dl, rpad=Sp)                                         # [Vp, Sp]
             hbT = ops.transpose(hb, rpad=Sp, out=inT)
@@ -390,15 +409,17 @@ class DecoderTrainer:
         the batches that are accepted the mask terms of the reference's loss are zero, so "loss" is the reference's loss."""
         m = self.model
         # The reference's objective adds bce_loss_weight * BCE + dice_loss_weight * DICE of the SAM2 masks for every [SEG] in the labels
-        # (videorefer_qwen2.py:198-352) and trains text_hidden_fcs / the mask decoder through it.  That backward is not built: a batch
-        # that would need it is refused instead of being trained on the CE term alone under the name "loss".
+        # (videorefer_qwen2.py:198-352) and trains text_hidden_fcs / the mask decoder through it: built in ufvideo_amd/train_seg.py and
+        # enabled with train_seg_head=True.  A trainer without it refuses such a batch instead of training it on the CE term alone
+        # under the name "loss".
         masks_list = _unused.get("masks_list")
+        images_sam, label_list, offset = _unused.get("images_sam"), _unused.get("label_list"), _unused.get("offset")
         seg_id = getattr(self.cfg, "seg_token_id", None)
         has_gt = masks_list is not None and any(torch.is_tensor(g) and g.numel() > 0 and g.shape[0] > 0 for g in masks_list)
         has_seg = seg_id is not None and labels is not None and bool((labels == seg_id).any())
-        if has_gt or has_seg:
-            raise NotImplementedError("train_step: this batch carries [SEG] targets / ground-truth masks; the mask-loss (BCE + DICE) backward through "
-                                      "text_hidden_fcs and the SAM2 mask decoder is not implemented -- only the causal-LM objective is trained")
+        if (has_gt or has_seg) and self.seg is None:
+            raise NotImplementedError("train_step: this batch carries [SEG] targets / ground-truth masks; build the trainer with train_seg_head=True "
+                                      "to train the mask-loss (BCE + DICE) branch -- without it only the causal-LM objective is trained")
         stashes = None
         with torch.no_grad():
             mm_features = None
@@ -429,13 +450,42 @@ class DecoderTrainer:
             shifted.append(torch.cat([lab[1:], torch.full((1,), -100, dtype=lab.dtype)]))
             lens.append(n)
         n_valid = sum(int((s_ != -100).sum()) for s_ in shifted)
-        w = 1.0 / max(n_valid, 1)
+        ce_w = float(getattr(self.cfg, "ce_loss_weight", 1.0))
+        w = ce_w / max(n_valid, 1)
         self.zero_grad()
         loss = torch.zeros((), device=self.dev)
+        mask_bce = torch.zeros((), device=self.dev)
+        mask_dice = torch.zeros((), device=self.dev)
         need_dx = stashes is not None or region_stash is not None
         dxs = torch.zeros((B * S, embeds.shape[2]), device=self.dev, dtype=torch.float32) if need_dx else None
+        seg_leaves = None
+        if self.seg is not None and (has_gt or has_seg):
+            # fp32 leaves over the masters of the mask branch; their .grad is folded into the auxiliary bucket after the last sample
+            pb = self.proj_bucket
+            seg_leaves = {k: pb.view(pb.master, k).detach().requires_grad_(True) for k in self.proj_params
+                          if k.startswith(("text_hidden_fcs.", "mask_encoder."))}
+            if torch.is_tensor(offset):
+                offset = offset.tolist()
+            offset = list(range(B + 1)) if offset is None else [int(o) for o in offset]
+            assert len(offset) == B + 1 and offset == list(range(B + 1)), "train_step: one conversation per sample (offset = [0, 1, ..., B])"
+            num_masks_total = sum(int(g.shape[0]) for g in masks_list)
+            w_bce, w_dice = float(getattr(self.cfg, "bce_loss_weight", 1.0)), float(getattr(self.cfg, "dice_loss_weight", 1.0))
         for b in range(B):
-            l_b, dx_b = self.forward_backward(embeds[b, :lens[b]], shifted[b], embed_ids=eids[b, :lens[b]], loss_weight=w, last=(b == B - 1))
+            hook = None
+            if seg_leaves is not None:
+                rows = torch.nonzero(shifted[b] == seg_id).reshape(-1)          # position p is queried when label p + 1 is [SEG]
+                if rows.numel():
+                    def hook(hb, b=b, rows=rows):
+                        nonlocal mask_bce, mask_dice
+                        hid = hb[rows.to(hb.device)].float().requires_grad_(True)
+                        hw = tuple(label_list[b].shape)
+                        bce_b, dice_b = self.seg.forward_backward(seg_leaves, hid, images_sam[b], masks_list[b], hw, w_bce, w_dice, num_masks_total)
+                        mask_bce, mask_dice = mask_bce + bce_b, mask_dice + dice_b
+                        return rows, hid.grad
+                else:
+                    assert masks_list[b].shape[0] == 0, f"gt_mask.shape: {tuple(masks_list[b].shape)}, pred_mask.shape: (0, ...)"
+            l_b, dx_b = self.forward_backward(embeds[b, :lens[b]], shifted[b], embed_ids=eids[b, :lens[b]], loss_weight=w, last=(b == B - 1),
+                                              hidden_hook=hook)
             loss = loss + l_b
             if dxs is not None:
                 dxs[b * S:b * S + lens[b]].copy_(dx_b)
@@ -459,9 +509,15 @@ class DecoderTrainer:
                 for name, gval in m.get_model().region_encoder.backward(d_reg, region_stash).items():
                     name = "region_encoder." + name
                     self.proj_bucket.view(self.proj_bucket.g, name).add_(gval.reshape(self.proj_params[name].shape))
+        if seg_leaves is not None:
+            for k, leaf in seg_leaves.items():
+                if leaf.grad is not None:
+                    self.proj_bucket.view(self.proj_bucket.g, k).add_(leaf.grad)
         self.step()
-        ce = getattr(self.cfg, "ce_loss_weight", 1.0) * loss
-        return {"loss": ce, "ce_loss": ce, "grad_norm": getattr(self, "last_grad_norm", None)}
+        ce = loss                                          # ce_loss_weight is part of the per-token weight (and so of the gradient)
+        mask_loss = mask_bce + mask_dice
+        return {"loss": ce + mask_loss, "ce_loss": ce, "mask_bce_loss": mask_bce, "mask_dice_loss": mask_dice, "mask_loss": mask_loss,
+                "grad_norm": getattr(self, "last_grad_norm", None)}
 
     # ---- data-parallel exchange + update (ZeRO-2) -----------------------------------------------------------------------
     def _reduce_async(self, b):
