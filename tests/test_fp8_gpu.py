@@ -56,7 +56,10 @@ def test_fused_norm_quant_equals_norm_then_quant():
 
 @pytest.mark.parametrize("M,N,K,kernel", [(300, 256, 256, ops.GEMM_FAST), (300, 256, 256, ops.GEMM_FAST256), (1000, 384, 1152, ops.GEMM_AUTO),
                                           (515, 512, 128, ops.GEMM_FAST256), (7, 200, 272, ops.GEMM_GEMV), (64, 128, 3584, ops.GEMM_AUTO),
-                                          (2399, 1280, 3584, ops.GEMM_FAST), (2399, 1280, 3584, ops.GEMM_FAST256)])
+                                          (2399, 1280, 3584, ops.GEMM_FAST), (2399, 1280, 3584, ops.GEMM_FAST256),
+                                          (2399, 1152, 1152, ops.GEMM_FAST256 | (1431 << 8)), (1000, 1280, 512, ops.GEMM_FAST256 | (1322 << 8)),
+                                          (700, 768, 384, ops.GEMM_FAST256 | (1331 << 8)), (700, 512, 256, ops.GEMM_FAST256 | (1432 << 8)),
+                                          (520, 768, 256, ops.GEMM_FAST256 | (1441 << 8)), (520, 768, 256, ops.GEMM_FAST256 | (1332 << 8))])
 def test_gemm_fp8_vs_restatement(M, N, K, kernel):
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g).to(torch.bfloat16)

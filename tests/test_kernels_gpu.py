@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from ufvideo_amd import ops  # noqa: E402
+from ufvideo_amd import ops, _lib  # noqa: E402
 
 DEV = "cuda"
 ONE_ULP = 2.0 ** -8 + 1e-4
@@ -321,6 +321,48 @@ def test_gemm256_bitwise_equals_128_kernel(M, N, K):
     refb = ops.gemm(a, w, kernel=ops.GEMM_FAST)
     assert torch.equal(ops.gemm(a, w, kernel=ops.GEMM_FAST256), refb)
     assert rel(refb, a.float() @ w.float().t()) <= ONE_ULP
+
+
+PP_SHAPES = {1442: (256, 256), 1432: (224, 256), 1332: (192, 256), 1322: (160, 256), 1441: (256, 192), 1431: (224, 192), 1331: (192, 192)}
+
+
+@pytest.mark.parametrize("shape", sorted(PP_SHAPES))
+def test_gemm_pingpong_tile_shapes_bitwise_equal_128_kernel(shape):
+    """Every tile shape of the ping-pong kernel (UFV_GEMM_PP: unequal A halves of 96 / 64 rows, a 64-column second B half, the two-phase
+    schedule) accumulates k in the same order as the 128-wide kernel: bit-equal results, ragged M, several rounds of the persistent
+    loop, an N that ends on the first half-tile (N % tile width == 128), every epilogue form; repeated launches catch staging races."""
+    bm, bn = PP_SHAPES[shape]
+    kern = ops.GEMM_FAST256 | (shape << 8)
+    full, ragged = (768, 640) if bn == 256 else (1152, 512)           # N % 128 == 0 always (the reference kernel's tile); ragged: ends on the 128-column half
+    for M, N, K in ((bm * 3 + 37, full, 192), (2399, ragged, 448), (max(bm, 256), 2 * bn if bn == 192 else bn, 64), (300, full * 3, 1152)):
+        a, w = bf(g(M, K, seed=shape + 1)), bf(g(N, K, seed=shape + 2, scale=0.05))
+        bias, resid = g(N, seed=shape + 3), g(M, N, seed=shape + 4)
+        ref = ops.gemm(a, w, bias=bias, act="gelu_tanh", resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST)
+        for _ in range(3):
+            assert torch.equal(ops.gemm(a, w, bias=bias, act="gelu_tanh", resid=resid, out_dtype=torch.float32, kernel=kern), ref), (shape, M, N, K)
+        assert torch.equal(ops.gemm(a, w, kernel=kern), ops.gemm(a, w, kernel=ops.GEMM_FAST))
+        x1 = resid.clone()
+        ops.gemm(a, w, resid=x1, out=x1, kernel=kern)                      # in-place residual stream, as the layers use it
+        assert torch.equal(x1, ops.gemm(a, w, resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST))
+    if bn == 192:                                                              # a width the shape cannot end on: refused, not mis-tiled
+        with pytest.raises(_lib.UfvError, match="tile needs N"):
+            ops.gemm(bf(g(256, 64, seed=1)), bf(g(192 + 64, 64, seed=2)), kernel=kern)               # 256 % 192 = 64
+    if shape != 1442:
+        with pytest.raises(_lib.UfvError, match="SwiGLU"):
+            ops.gemm(bf(g(256, 64, seed=1)), bf(g(512, 64, seed=2)), swiglu=True, kernel=kern)
+
+
+def test_gemm_auto_choice_matches_every_kernel_it_can_pick():
+    """GEMM_AUTO routes by a cost model (csrc/gemm.hip choose_kernel); whatever it picks at the config-#2 shapes and around them, the
+    result is the 128-wide kernel's, bit for bit."""
+    for M, N, K, f32 in ((2399, 3584, 512, True), (2399, 4608, 256, False), (18432, 1152, 128, True), (4703, 3584, 192, True), (2304, 3584, 128, False),
+                         (1000, 1152, 1152, True), (257, 128, 64, False)):
+        a, w = bf(g(M, K, seed=M % 97)), bf(g(N, K, seed=N % 89, scale=0.05))
+        if f32:
+            resid = g(M, N, seed=5)
+            assert torch.equal(ops.gemm(a, w, resid=resid, out_dtype=torch.float32), ops.gemm(a, w, resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST))
+        else:
+            assert torch.equal(ops.gemm(a, w), ops.gemm(a, w, kernel=ops.GEMM_FAST))
 
 
 def test_gemm256_swiglu_and_layout():

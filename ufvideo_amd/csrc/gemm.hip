@@ -534,23 +534,40 @@ inline int pick_mt(int M, int N) {
     return best;
 }
 
-// Kernel choice.  Both kernels are modelled as (rounds of resident tiles) x (outputs per CU per round) / (relative
-// rate at this K depth); rates fitted to tools/bench_kernels.py on MI355X: the persistent 256x256 ping-pong
-// kernel sustains ~1.2-1.3x the 128-wide kernel and hides its prologue/epilogue across tile seams, the 128-wide
-// one has the finer tile grid (2 blocks/CU, 128/160/192-row tiles) for small outputs.
-inline bool prefer256(int M, int N, int K, bool out_f32) {
-    const double nk = K / 64.0;
-    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    // the persistent kernel's epilogue is a chip-wide store burst that nothing overlaps: ~5 K-tiles' worth for a bf16 tile,
-    // ~9 for an fp32 tile with an fp32 residual (measured with tools/gemm_exp.py)
-    const double c256 = (double)((t256 + 255) / 256) * 65536.0 / (1.30 / (1.0 + (out_f32 ? 9.0 : 5.0) / nk));
-    double c128 = 1e30;
+// Kernel choice: a cost model in shader ticks, fitted to the in-kernel timeline of tools/lab/gemm_lab.hip and checked against
+// tools/gemm_shapes.py on MI355X (it picks the measured-fastest kernel, or one within 0.3 % of it, on every config-#2 shape).
+//   ping-pong kernel at tile (32*(MA0+MA1)) x (128+64*NB1), one block per CU, persistent:
+//       rounds = ceil(tiles / 256);  K-tile = 2 * sum over the two phases of max(18.5 * MFMAs of the phase, 500)
+//       (a phase's MFMA step runs beside the other wave group's load step, which costs ~500 ticks whatever the tile: 8 LDS-DMA
+//       pieces per wave and K-tile); seam (prologue + epilogue, partly overlapped) = 2500 + area * (0.33 fp32+residual | 0.183 bf16)
+//   128-wide kernel, (32*MT) x 128 tiles, two blocks per CU, not persistent:
+//       rounds = ceil(tiles / 512);  K-tile = 2 * area / 21.4;  seam = 9000 + 2 * area * (0.33 | 0.183)
+// returns 0 for the 128-wide kernel, else the ping-pong shape code (ufv.h UFV_GEMM_PP).  K in elements of a bf16 K-tile (fp8: K / 2).
+struct PPShape { int code, ma0, ma1, nb1; };
+constexpr PPShape PP_SHAPES[] = {{1442, 4, 4, 2}, {1432, 4, 3, 2}, {1332, 3, 3, 2}, {1322, 3, 2, 2}, {1441, 4, 4, 1}, {1431, 4, 3, 1}, {1331, 3, 3, 1}};
+
+inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu) {
+    const double nk = K / 64.0, c_out = out_f32 ? 0.33 : 0.183;
+    double best = 1e30;
+    int pick = 0;
     for (int mt = 4; mt <= 6; ++mt) {
         const long t = (long)cdiv(M, 32 * mt) * (N / BN);
-        const double c = (double)((t + 511) / 512) * (32.0 * mt * 128 * 2) / (1.05 / (1.0 + 8.0 / nk));
-        if (c < c128) c128 = c;
+        const double area = 32.0 * mt * 128;
+        const double c = (double)((t + 511) / 512) * (nk * 2.0 * area / 21.4 + 9000.0 + 2.0 * area * c_out);
+        if (c < best) best = c;
     }
-    return c256 < c128;
+    if (M < 256) return 0;
+    for (const PPShape& s : PP_SHAPES) {
+        const int bm = 32 * (s.ma0 + s.ma1), bn = 128 + 64 * s.nb1, nt = 2 + s.nb1;
+        if (swiglu && s.code != 1442) continue;
+        if (N % bn != 0 && N % bn != 128) continue;
+        const long t = (long)cdiv(M, bm) * cdiv(N, bn);
+        const double pa = s.ma0 * nt * 2 * 18.5, pb = s.ma1 * nt * 2 * 18.5;
+        const double tk = 2.0 * ((pa > 500 ? pa : 500) + (pb > 500 ? pb : 500));
+        const double c = (double)((t + 255) / 256) * (nk * tk + 2500.0 + (double)bm * bn * c_out);
+        if (c < best) { best = c; pick = s.code; }
+    }
+    return pick;
 }
 
 template <bool F, bool S, bool Q>
@@ -565,7 +582,8 @@ int launch_fast(const void* A, const void* W, const Epi& e, int M, int N, int K,
 }
 
 template <bool F, bool S, bool Q>
-int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int force, hipStream_t st) {
+int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int force_shape, hipStream_t st) {
+    const int force = force_shape & 0xff, shape = force_shape >> 8;       // UFV_GEMM_PP(shape): the ping-pong kernel at a named tile shape
     constexpr int KE = Q ? 128 : BK;        // elements per K-tile; row pitches must keep rows 16-byte aligned
     constexpr int LDA = Q ? 16 : 8;
     const bool aligned = ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && (lda % LDA == 0) && (ldw % LDA == 0) &&
@@ -602,9 +620,12 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
         ufv_set_error("ufv_gemm: stream-K kernel needs M>=256, N%%128==0, K%%%d==0 (M=%d N=%d K=%d)", KE, M, N, K);
         return UFV_EUNSUPPORTED;
     }
-    if (force == UFV_GEMM_STREAMK) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, true, st);
-    if (force == UFV_GEMM_FAST256 || (force == UFV_GEMM_AUTO && big_ok && prefer256(M, N, Q ? K / 2 : K, F)))
-        return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, st);
+    if (force == UFV_GEMM_STREAMK) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, true, 0, st);
+    if (force == UFV_GEMM_FAST256) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, shape, st);
+    if (force == UFV_GEMM_AUTO && big_ok) {
+        const int pick = choose_kernel(M, N, Q ? K / 2 : K, F, S);
+        if (pick) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, pick, st);
+    }
     if ((force == UFV_GEMM_AUTO && fast_ok && M > 64) || force == UFV_GEMM_FAST)
         return launch_fast<F, S, Q>(A, W, e, M, N, K, lda, ldw, st);
     if constexpr (Q) {

@@ -1,0 +1,473 @@
+// bf16 GEMM, 256x256x64 block tile, 8 waves, ping-pong schedule ("8 phases" per two K-tiles) for gfx950.
+//
+//   C[M,N] = epilogue(A[M,K] * W[N,K]^T), same epilogues and operand conventions as gemm.hip.
+//
+// Structure (one block per CU, 128 KiB LDS = 2 K-tile buffers x {A0,A1,B0,B1} half-tiles of 128 rows x 64 k):
+//  * 8 waves = 2 (rows) x 4 (cols); wave (wr,wc) owns 64 rows of EACH A half and 32 columns of EACH B half, so a
+//    wave's 128x64 output splits into 4 quadrants (A half x B half) and every LDS half-tile is read in few phases:
+//        phase 0: read A0,B0 -> quadrant (0,0)      phase 1: read B1 -> (0,1)
+//        phase 2: read A1    -> quadrant (1,1)      phase 3: read B0 -> (1,0)
+//  * each phase = [ds_read fragments; issue ONE half-tile of LDS-DMA prefetch] s_barrier [16 MFMA] s_barrier.
+//    Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while its
+//    partner is in its load segment.
+//  * prefetch runs through the whole loop with a COUNTED s_waitcnt vmcnt(4) once per K-tile (never 0 inside the
+//    loop): staging order A1[t+1], B0[t+1], A0[t+2], B1[t+2] in phases 0..3 of K-tile t.
+//      WAR: a half-tile buffer is re-staged exactly 2 phases after its last ds_read (safe for the lagging group);
+//      RAW: the wait in phase 3 retires everything up to B0[t+1]; first read is in the next phase, two barriers later.
+//  * persistent: one block per CU walks tiles b, b+G, ...; the next tile's prologue DMA is issued before the
+//    current tile's epilogue stores (its bias is fetched first so no ordinary load queues behind the DMA).
+//  * operands: 128-byte rows, 16-byte chunks XOR-swizzled by (row & 7) through the LDS-DMA SOURCE address.
+#pragma once
+#include "common.h"
+#include "../../include/ufv.h"
+#include "gemm_epi.h"
+#include <type_traits>
+
+#ifndef UFV_GSTAMP
+#define UFV_GSTAMP(i)      /* lab builds (tools/lab/gemm_lab.hip) record s_memtime here */
+#define UFV_GSTAMP_DECL
+#define UFV_GSTAMP_FLUSH
+#endif
+
+namespace {
+
+constexpr int SMEM256 = 131072;
+
+__device__ __forceinline__ i32x8 cat8(bf16x8 lo, bf16x8 hi) {      // two 16-byte LDS chunks -> the 32-byte fp8 operand
+    const i32x4 a = __builtin_bit_cast(i32x4, lo), b = __builtin_bit_cast(i32x4, hi);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Tile shapes.  The A operand is staged as two half-tiles of 32*MA0 and 32*MA1 rows (wave row `wr` owns 16*MAh consecutive rows
+// of each), the B operand as halves of 128 and 64*NB1 columns (wave column `wc` owns 32 and 16*NB1 of them), so the block tile
+// is (32*(MA0+MA1)) x (128 + 64*NB1): <4,4,2> = 256x256 (the original), <3,2,2> = 160x256, <4,3,1> = 224x192, ...  The phase
+// schedule, the LDS slots (16 KiB per half) and the DMA pattern are the same for every shape; a 96-row half is staged as 128 rows
+// (the extra 32 land in the unused part of its slot).
+template <int MA0, int MA1, int NB1> struct PP {
+    static constexpr int MT = MA0 + MA1, NT = 2 + NB1;
+    static constexpr int BM = 32 * MT, BN = 64 * NT;
+    static constexpr int LA0 = MA0 > 2 ? 2 : 1, LA1 = MA1 > 2 ? 2 : 1, LB0 = 2, LB1 = NB1;     // DMA instructions per wave per half-tile
+};
+
+// acc[nt][mt][j] = C[m0 + row(mt)][n0 + col(nt) + fq*4 + j] with
+//   row(mt) = mt < MA0 ? wr*16*MA0 + mt*16 + frow : 32*MA0 + wr*16*MA1 + (mt-MA0)*16 + frow
+//   col(nt) = nt < 2 ? wc*32 + nt*16 : 128 + wc*16*NB1 + (nt-2)*16
+template <bool OUT_F32, bool SWIGLU, int ACT, bool DUMP, int MA0, int MA1, int NB1>
+__device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2 + NB1][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc,
+                                            int frow, int fq, const f32x4 (&bias)[2 + NB1]) {
+    static_assert(!SWIGLU || NB1 == 2, "the SwiGLU epilogue pairs n-tiles (gate, up) inside each half");
+#pragma unroll
+    for (int mt = 0; mt < MA0 + MA1; ++mt) {
+        const int m = m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow;
+        if (m < M) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const int nb = n0 + nh * 128;
+                if (nb < N) {
+                    if constexpr (SWIGLU) {
+                        const int n = ((nb + wc * 32) >> 1) + fq * 4;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float gte = acc[2 * nh][mt][j], up = acc[2 * nh + 1][mt][j];
+                            v[j] = gte / (1.0f + __expf(-gte)) * up;
+                        }
+                        epi_store4b<OUT_F32, ACT_NONE>(e, m, n, v[0], v[1], v[2], v[3], f32x4{0, 0, 0, 0});
+                    } else {
+                        const int n = nb + wc * 16 * (nh ? NB1 : 2) + fq * 4;
+#pragma unroll
+                        for (int j = 0; j < (nh ? NB1 : 2); ++j)
+                            epi_store4b<OUT_F32, ACT, DUMP>(e, m, n + 16 * j, acc[2 * nh + j][mt][0], acc[2 * nh + j][mt][1], acc[2 * nh + j][mt][2],
+                                                            acc[2 * nh + j][mt][3], bias[2 * nh + j]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// FP8: e4m3 operands, K-tile = 128 elements (the same 128-byte LDS rows and DMA pattern), 8 x v_mfma_f32_16x16x128_f8f6f4
+// per phase instead of 16 x 16x16x32_bf16; accumulators are scaled by scale_m[row] * scale_n[col] before the epilogue.
+//
+// Stream-K (sk_ws != nullptr): instead of whole tiles, block `pos` takes the contiguous range [lo, hi) of the
+// tiles x K-tiles iteration space (tile-major), so every CU does the same number of K-tile iterations whatever the tile
+// count.  A block's range is: [tail of a tile] [whole tiles ...] [head of a tile].  A tail / middle part (k0 > 0) dumps its
+// raw accumulators to workspace slot `pos` and raises flag[pos] = epoch; the block holding a tile's head (k0 == 0) is the
+// tile's owner: it adds the slots of the following blocks in order (deterministic) and runs the epilogue.  Owners hold the
+// head as their LAST item and the other parts are their blocks' FIRST items, so an owner practically never waits.
+// All blocks must be co-resident (grid <= number of CUs, one block per CU) -- guaranteed when nothing else runs on the GPU.
+struct StreamK {
+    float* ws;          // [grid][32][512] f32x4 accumulator dumps (256 KiB per block)
+    int* flags;         // [grid]
+    int epoch;          // value that marks "slot written during THIS launch"
+    int gm;             // row-tiles per group of the tile order (concurrent tiles of a group share A / W panels in L2)
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// PH2: two phases per K-tile instead of four -- phase A reads A0 and ALL of B and multiplies the top half of the wave's tile, phase B
+// reads A1 and multiplies the bottom half with the B fragments still in registers.  Half as many barrier steps per K-tile, each twice
+// as long; staging: A1[t+1] in phase A of K-tile t, A0 / B0 / B1 [t+2] in phase B (every half-tile is re-staged two barrier steps after its
+// last reader and lands six steps = 1.5 K-tiles before its first).
+template <bool OUT_F32, bool SWIGLU, bool FP8, bool SKT, int MA0 = 4, int MA1 = 4, int NB1 = 2, bool PH2 = false>
+__global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ Av, const void* __restrict__ Wv, Epi e, int M,
+                                                       int N, int K, int lda, int ldw, StreamK sk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = FP8 ? 1 : 2;
+    using T = PP<MA0, MA1, NB1>;
+    constexpr int MT = T::MT, NT = T::NT, BM = T::BM, BN = T::BN;
+    static_assert(!SKT || (MA0 == 4 && MA1 == 4 && NB1 == 2), "the stream-K fix-up is written for the 256x256 tile image");
+    const char* A = reinterpret_cast<const char*>(Av);
+    const char* W = reinterpret_cast<const char*>(Wv);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    const int nk = K * ES / 128;
+    const int G = gridDim.x;                       // persistent: block b walks tiles b, b+G, ...
+    // tile sequence position -> (tm, tn): within a round of G tiles give each XCD (launch id % 8) a contiguous run,
+    // and order the sequence in groups of 8 row-tiles so that concurrent tiles share A/W panels in L2.
+    auto tile_coords = [&](int id, int& m0_, int& n0_) {
+        const int GM = sk.gm;
+        const int gsz = GM * tiles_n, g = id / gsz, first_m = g * GM;
+        const int gm = min(tiles_m - first_m, GM);
+        m0_ = (first_m + (id % gsz) % gm) * BM;
+        n0_ = ((id % gsz) / gm) * BN;
+    };
+    constexpr bool SK = SKT;
+    // stream-K: logical position of this block (each XCD = launch id % 8 gets a contiguous run of positions) and its range
+    const int pos = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const long long total = (long long)nwg * nk;
+    const int per = (int)(total / G), rem = (int)(total % G);
+    auto range_lo = [&](int p) -> long long { return (long long)p * per + min(p, rem); };
+    long long cur = SK ? range_lo(pos) : 0;
+    const long long hi = SK ? range_lo(pos + 1) : 0;
+    int round = 0;
+    // next work item: tile (m0_, n0_) and its K-tile range [k0_, k1_)
+    auto next_item = [&](int& m0_, int& n0_, int& k0_, int& k1_) -> bool {
+        if (SK) {
+            if (cur >= hi) return false;
+            const int tile = (int)(cur / nk);
+            k0_ = (int)(cur - (long long)tile * nk);
+            k1_ = (int)min((long long)nk, k0_ + (hi - cur));
+            cur += k1_ - k0_;
+            tile_coords(tile, m0_, n0_);
+            return true;
+        }
+        const int base = round * G;
+        const int cnt = min(G, nwg - base);          // tiles in this round
+        const int bid = blockIdx.x;
+        ++round;
+        if (bid >= cnt) return false;
+        const int q = cnt >> 3, r = cnt & 7, x = bid & 7;
+        tile_coords(base + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3), m0_, n0_);
+        k0_ = 0; k1_ = nk;
+        return true;
+    };
+
+    // ---- LDS-DMA sources: half-tile `which` (0=A0 1=A1 2=B0 3=B1), one or two 8-row pieces per wave (T::L*)
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+    const char* src[4][2];
+    auto set_src = [&](int m0_, int n0_) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int la = h ? T::LA1 : T::LA0, lb = h ? T::LB1 : T::LB0;
+                const int ra = h * 32 * MA0 + (wave * la + i) * 8 + lrow, rb = h * 128 + (wave * lb + i) * 8 + lrow;
+                src[h][i] = A + (size_t)min(m0_ + ra, M - 1) * lda * ES + lchunk * 16;
+                src[2 + h][i] = W + (size_t)min(n0_ + rb, N - 1) * ldw * ES + lchunk * 16;
+            }
+    };
+    int kbeg = 0, kend = 0;                        // K-tile range of the item being loaded
+    auto stage = [&](int d, int which, int kt) {
+        const int l = which == 0 ? T::LA0 : which == 1 ? T::LA1 : which == 2 ? T::LB0 : T::LB1;
+        if (kt < kend) {
+            char* dst = smem + d * 65536 + which * 16384 + wave * (1024 * l);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][0] + kt * 128), LDS_PTR(dst), 16, 0, 0);
+            if (l == 2) __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][1] + kt * 128), LDS_PTR(dst + 1024), 16, 0, 0);
+        }
+    };
+    auto prologue_loads = [&]() {      // first K-tile of the item complete + A0/B1 (PH2: A0/B0/B1) of its second K-tile
+        stage(0, 0, kbeg); stage(0, 2, kbeg); stage(0, 3, kbeg); stage(0, 1, kbeg);
+        stage(1, 0, kbeg + 1);
+        if constexpr (PH2) stage(1, 2, kbeg + 1);
+        stage(1, 3, kbeg + 1);
+    };
+    constexpr int L_ALL = T::LA0 + T::LA1 + T::LB0 + T::LB1;      // PH2: DMA instructions in flight behind the half-tiles that are needed next
+    // the counted wait that leaves exactly the last two staged half-tiles (A0, B1 of the K-tile after next) in flight
+#define UFV_WAIT_KEEP_A0_B1()                                                                              \
+    do {                                                                                                     \
+        if constexpr (T::LA0 + T::LB1 == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              \
+        else if constexpr (T::LA0 + T::LB1 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");         \
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                              \
+    } while (0)
+
+    const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
+    const int a_row_off[2] = {(wr * 16 * MA0 + frow) * 128, (wr * 16 * MA1 + frow) * 128};     // + i*2048 inside the half
+    const int b_row_off[2] = {(wc * 32 + frow) * 128, (wc * 16 * NB1 + frow) * 128};
+    // bf16: k-step kk reads chunk 4*kk + fq;  fp8: the lane's 32 bytes are chunks 2*fq and 2*fq + 1
+    const int coff0 = ((FP8 ? 2 * fq : fq) ^ fx) << 4, coff1 = ((FP8 ? 2 * fq + 1 : 4 + fq) ^ fx) << 4;
+
+    int m0, n0, k0, k1;
+    bool have = next_item(m0, n0, k0, k1);
+    if (have) { set_src(m0, n0); kbeg = k0; kend = k1; prologue_loads(); }
+    while (have) {
+    const int len = k1 - k0;
+    f32x4 acc[NT][MT];   // [nt][mt]
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 afr[4][2], bfr[PH2 ? 4 : 2][2];
+    auto read_a = [&](const char* half, auto hsel) {
+        constexpr int h = decltype(hsel)::value;
+#pragma unroll
+        for (int i = 0; i < (h ? MA1 : MA0); ++i) {
+            afr[i][0] = *reinterpret_cast<const bf16x8*>(half + a_row_off[h] + i * 2048 + coff0);
+            afr[i][1] = *reinterpret_cast<const bf16x8*>(half + a_row_off[h] + i * 2048 + coff1);
+        }
+    };
+    auto read_b = [&](const char* half, auto hsel) {
+        constexpr int h = decltype(hsel)::value, d0 = PH2 ? 2 * h : 0;
+#pragma unroll
+        for (int i = 0; i < (h ? NB1 : 2); ++i) {
+            bfr[d0 + i][0] = *reinterpret_cast<const bf16x8*>(half + b_row_off[h] + i * 2048 + coff0);
+            bfr[d0 + i][1] = *reinterpret_cast<const bf16x8*>(half + b_row_off[h] + i * 2048 + coff1);
+        }
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+#define UFV_SYNC_THEN_MMA(NTB, NCNT, MTB, MCNT, S0, S1, S2)                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    UFV_GSTAMP(S0);                                                                                          \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+    UFV_GSTAMP(S1);                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    if constexpr (FP8) {                                                                                     \
+        _Pragma("unroll") for (int n_ = 0; n_ < NCNT; ++n_)                                                  \
+            _Pragma("unroll") for (int m_ = 0; m_ < MCNT; ++m_)                                              \
+                acc[NTB + n_][MTB + m_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                  \
+                    cat8(bfr[n_][0], bfr[n_][1]), cat8(afr[m_][0], afr[m_][1]), acc[NTB + n_][MTB + m_], 0, 0, 0, 0, 0, 0); \
+    } else {                                                                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
+        _Pragma("unroll") for (int n_ = 0; n_ < NCNT; ++n_)                                                  \
+            _Pragma("unroll") for (int m_ = 0; m_ < MCNT; ++m_)                                              \
+                acc[NTB + n_][MTB + m_] =                                                                    \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n_][kk], afr[m_][kk], acc[NTB + n_][MTB + m_], 0, 0, 0); \
+    }                                                                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    UFV_GSTAMP(S2);                                                                                          \
+    __builtin_amdgcn_s_barrier();
+
+    if constexpr (PH2) {
+        if (len > 1) wait_vmcnt<L_ALL>();              // A0 / B0 / B1 of the first K-tile; its A1 and the second tile's three stay in flight
+        else wait_vmcnt<T::LA1>();
+    } else {
+        if (len > 1) UFV_WAIT_KEEP_A0_B1();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // waves 4-7 run one barrier behind
+
+    UFV_GSTAMP_DECL
+    if constexpr (PH2) {
+    for (int tt = 0; tt < len; ++tt) {
+        const int t = k0 + tt, d = tt & 1;
+        const char* buf = smem + d * 65536;
+        // phase A: A0, B0, B1 -> top half; prefetch A1[t+1]; retire A1[t]
+        UFV_GSTAMP(0);
+        read_b(buf + 32768, H0{});
+        read_a(buf, H0{});
+        read_b(buf + 49152, H1{});
+        stage(d ^ 1, 1, t + 1);
+        if (tt + 1 < len) wait_vmcnt<L_ALL>();        // behind A1[t]: A0/B0/B1[t+1] and A1[t+1]
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UFV_SYNC_THEN_MMA(0, NT, 0, MA0, 1, 2, 3)
+        // phase B: A1 -> bottom half; prefetch A0 / B0 / B1 [t+2]; retire A0 / B0 / B1 [t+1]
+        UFV_GSTAMP(4);
+        read_a(buf + 16384, H1{});
+        stage(d, 0, t + 2);
+        stage(d, 2, t + 2);
+        stage(d, 3, t + 2);
+        if (tt + 2 < len) wait_vmcnt<L_ALL>();        // behind them: A1[t+1] and A0/B0/B1[t+2]
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UFV_SYNC_THEN_MMA(0, NT, MA0, MA1, 5, 6, 7)
+        UFV_GSTAMP(8);
+    }
+    } else {
+    for (int tt = 0; tt < len; ++tt) {
+        const int t = k0 + tt, d = tt & 1;
+        const char* buf = smem + d * 65536;
+        // phase 0: A0, B0 -> quadrant (0,0); prefetch A1[t+1]
+        UFV_GSTAMP(0);
+        read_b(buf + 32768, H0{});
+        read_a(buf, H0{});
+        stage(d ^ 1, 1, t + 1);
+        UFV_SYNC_THEN_MMA(0, 2, 0, MA0, 1, 2, 3)
+        // phase 1: B1 -> quadrant (0,1); prefetch B0[t+1]
+        read_b(buf + 49152, H1{});
+        stage(d ^ 1, 2, t + 1);
+        UFV_SYNC_THEN_MMA(2, NB1, 0, MA0, 4, 5, 6)
+        // phase 2: A1 -> quadrant (1,1); prefetch A0[t+2]
+        read_a(buf + 16384, H1{});
+        stage(d, 0, t + 2);
+        UFV_SYNC_THEN_MMA(2, NB1, MA0, MA1, 7, 8, 9)
+        // phase 3: B0 -> quadrant (1,0); prefetch B1[t+2]; retire K-tile t+1
+        read_b(buf + 32768, H0{});
+        stage(d, 3, t + 2);
+        if (tt + 2 < len) UFV_WAIT_KEEP_A0_B1();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        UFV_SYNC_THEN_MMA(0, 2, MA0, MA1, 10, 11, 12)
+        UFV_GSTAMP(13);
+    }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the stagger barrier
+    UFV_GSTAMP_FLUSH;
+#undef UFV_SYNC_THEN_MMA
+
+
+    // ---- item seam: every wave has finished its LDS reads (final barrier above) -> start the NEXT item's
+    //      LDS-DMA prologue now so that it lands under this item's epilogue stores.  The bias / scales of THIS tile are
+    //      fetched first so that no ordinary load has to wait behind the DMA queue.
+    const bool part_tail = SK && k0 > 0;                 // not the tile's owner: dump the accumulators
+    const bool part_head = SK && k0 == 0 && k1 < nk;     // owner of a split tile: add the other parts first
+    auto row_of = [&](int mt) { return (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow; };
+    // column of n-tile nt (clamped so that a half-tile past N reads valid memory; its outputs are not stored)
+    auto col_of = [&](int nt) {
+        return nt < 2 ? min(n0, N - 128) + wc * 32 + nt * 16 + fq * 4 : min(n0 + 128, N - 64 * NB1) + wc * 16 * NB1 + (nt - 2) * 16 + fq * 4;
+    };
+    if constexpr (FP8) {     // de-quantise in place: acc *= scale_m[row] * scale_n[col]; per element, so it distributes over
+        f32x4 sn[NT];        // the stream-K partial sums (every part scales its own accumulators)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) sn[nt] = *reinterpret_cast<const f32x4*>(e.scale_n + col_of(nt));
+        float sm[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) sm[mt] = e.scale_m[min(m0 + row_of(mt), M - 1)];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][mt] *= sn[nt] * sm[mt];
+    }
+    f32x4 bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias[nt] = f32x4{0, 0, 0, 0};
+    if (!part_tail && !SWIGLU && e.bias) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(e.bias + col_of(nt));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const int cm0 = m0, cn0 = n0;
+    have = next_item(m0, n0, k0, k1);
+    if (have) { set_src(m0, n0); kbeg = k0; kend = k1; prologue_loads(); }
+    if constexpr (SK) if (part_head) {
+        // this block's range ended inside the tile: the following blocks hold the rest, in order
+        int covered = len;                          // K-tiles of the tile accounted for so far (this block's k0 was 0)
+        for (int q = pos + 1; covered < nk; ++q) {
+            if (tid == 0)
+                while (__hip_atomic_load(sk.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(2);
+            __syncthreads();
+            const float* img = sk.ws + (size_t)q * 65536;          // 256x256 fp32 tile image written by block q's epilogue
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const float* rowp = img + ((mt >> 2) * 128 + wr * 64 + (mt & 3) * 16 + frow) * 256 + wc * 32 + fq * 4;
+                f32x4 p0, p1, p2, p3;        // system-scope loads: bypass this XCD's (non-coherent) L2
+                asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+                             "global_load_dwordx4 %1, %4, off offset:64 sc0 sc1\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:512 sc0 sc1\n\t"
+                             "global_load_dwordx4 %3, %4, off offset:576 sc0 sc1\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(rowp) : "memory");
+                acc[0][mt] += p0; acc[1][mt] += p1; acc[2][mt] += p2; acc[3][mt] += p3;
+            }
+            covered += (int)min((long long)(nk - covered), range_lo(q + 1) - range_lo(q));
+        }
+    }
+    // ---- epilogue (activation resolved once per tile so the body unrolls with acc in registers).  A stream-K tail / middle
+    //      part goes through the same code with the output redirected to its fp32 workspace slot (a 256x256 tile image).
+    if constexpr (SK) {
+        Epi pe = e;
+        int eM = M, eN = N, em0 = cm0, en0 = cn0;
+        if (part_tail) {
+            pe.out = reinterpret_cast<char*>(sk.ws) + (size_t)pos * 262144;
+            pe.ldc = 256; pe.bias = nullptr; pe.resid = nullptr; pe.act = ACT_NONE; pe.dump_f32 = 1;
+            eM = 256; eN = 256; em0 = 0; en0 = 0;
+        }
+        UFV_ACT_SWITCH(pe.act, (epilogue256<OUT_F32, SWIGLU, ACT_, true, MA0, MA1, NB1>(acc, pe, eM, eN, em0, en0, wr, wc, frow, fq, bias)))
+        if (part_tail) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's write-through stores are acknowledged ...
+            __syncthreads();                                        // ... before one thread publishes the slot
+            if (tid == 0) __hip_atomic_store(sk.flags + pos, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_, false, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias)))
+    }
+    }   // persistent tile loop
+#undef UFV_WAIT_KEEP_A0_B1
+}
+
+}  // namespace
+
+
+static inline int pp_n_cu() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
+
+// row-tiles per tile-order group: all of them when there are few (M = 2399 -> 10 row tiles: a ragged second group of 2 rows
+// made its XCDs fetch 16 W panels per round instead of 4; 1203 -> 1244 TF/s on gate/up), else ~8 in equal groups
+static inline int pp_group(int tiles_m) { return tiles_m <= 16 ? tiles_m : cdiv(tiles_m, cdiv(tiles_m, 8)); }
+
+template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false>
+static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM256);
+        attr_set = true;
+    }
+    using T = PP<MA0, MA1, NB1>;
+    const int rem = N % T::BN;
+    if (rem != 0 && rem != 128) {
+        ufv_set_error("ufv_gemm: the %dx%d tile needs N %% %d in {0, 128} (N=%d)", T::BM, T::BN, T::BN, N);
+        return UFV_EUNSUPPORTED;
+    }
+    const int tiles_m = cdiv(M, T::BM), tiles = tiles_m * cdiv(N, T::BN), n_cu = pp_n_cu();
+    StreamK sk = {nullptr, nullptr, 0, pp_group(tiles_m)};
+    hipLaunchKernelGGL((gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), SMEM256, st, A, W, e, M, N, K,
+                       lda, ldw, sk);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+// the named tile shapes live in their own translation units (gemm256_b.hip: bf16 operands, gemm256_q.hip: e4m3), one build job each
+int ufv_launch_pp_shape_bf16(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32, int shape, hipStream_t st);
+int ufv_launch_pp_shape_fp8(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32, int shape, hipStream_t st);
+
+template <bool F, bool Q>
+static int launch_pp_shape(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int shape, hipStream_t st) {
+    switch (shape) {                      // 1000 + MA0 MA1 NB1 as decimal digits (two phases per K-tile)
+        case 1322: return launch_pp<F, false, Q, 3, 2, 2, true>(A, W, e, M, N, K, lda, ldw, st);      // 160 x 256
+        case 1332: return launch_pp<F, false, Q, 3, 3, 2, true>(A, W, e, M, N, K, lda, ldw, st);      // 192 x 256
+        case 1432: return launch_pp<F, false, Q, 4, 3, 2, true>(A, W, e, M, N, K, lda, ldw, st);      // 224 x 256
+        case 1331: return launch_pp<F, false, Q, 3, 3, 1, true>(A, W, e, M, N, K, lda, ldw, st);      // 192 x 192
+        case 1431: return launch_pp<F, false, Q, 4, 3, 1, true>(A, W, e, M, N, K, lda, ldw, st);      // 224 x 192
+        case 1441: return launch_pp<F, false, Q, 4, 4, 1, true>(A, W, e, M, N, K, lda, ldw, st);      // 256 x 192
+    }
+    ufv_set_error("ufv_gemm: unknown ping-pong tile shape %d", shape);
+    return UFV_EINVAL;
+}
+

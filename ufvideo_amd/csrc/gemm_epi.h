@@ -76,4 +76,4 @@ __device__ __forceinline__ void epi_store4b(const Epi& e, int m, int n, float v0
 }
 
 int ufv_launch_gemm256(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
-                       bool swiglu, bool fp8, bool streamk, hipStream_t st);
+                       bool swiglu, bool fp8, bool streamk, int shape, hipStream_t st);
