@@ -204,6 +204,42 @@ int64_t ufv_qwen2_decode_ws_bytes(const ufv_qwen2_model* m);
  * [vocab], optional hidden_out f32 [d] (final-norm hidden state), next_token_dev = argmax. */
 int ufv_qwen2_decode_step(const ufv_qwen2_model* m, const int64_t* token_dev, int pos, void* ws, int64_t ws_bytes, float* logits,
                           float* hidden_out, int64_t* next_token_dev, void* stream);
+/* ---- whole-stage calls: the layer loops as ONE call each; compositions of the op-level entry points above on one
+ * stream, bit-identical to issuing that sequence from the host.
+ * Prefill of S > 0 positions pos0 .. pos0+S-1 of one sequence (HF Qwen2Model.forward under videorefer_qwen2.py:154-196):
+ * x f32 [S, d] holds inputs_embeds on entry and the last layer's output on exit (in place); every layer's K / V rows are written
+ * to its kv_cache (which must hold pos0 + S rows); hidden_layers (optional) f32 [n_layers-1, S, d] = the stream after each layer but
+ * the last (HF output_hidden_states[1:-1]); normed (optional) f32 [S, d] = final RMSNorm of all rows (= hidden_states[-1]);
+ * logits_last (optional) f32 [vocab] = lm_head of the last position. */
+int64_t ufv_qwen2_prefill_ws_bytes(const ufv_qwen2_model* m, int S);
+int ufv_qwen2_prefill(const ufv_qwen2_model* m, float* x, int S, int pos0, void* ws, int64_t ws_bytes, float* hidden_layers, float* normed,
+                      float* logits_last, void* stream);
+
+/* SigLIP vision tower (HF SiglipVisionTransformer embeddings + the first n_layers encoder layers, as the reference's
+ * `hidden_states[select_layer]` asks; encoder.py:96-146): packed weights as for the op-level calls -- q|k|v rows fused, the MLP
+ * width zero-padded to a multiple of 128, the patch kernel flattened to [d, kpad] with k = c*P*P + py*P + px. */
+typedef struct {
+    const float* ln1_w; const float* ln1_b; const float* ln2_w; const float* ln2_b;
+    const void* wqkv; const float* bqkv;   /* bf16 [3d, d],        f32 [3d] */
+    const void* wo; const float* bo;       /* bf16 [d, d],         f32 [d] */
+    const void* w1; const float* b1;       /* bf16 [d_ff_pad, d],  f32 [d_ff_pad] (zero rows past d_ff) */
+    const void* w2; const float* b2;       /* bf16 [d, d_ff_pad],  f32 [d] */
+} ufv_vit_layer;
+
+typedef struct {
+    int32_t n_layers, d, n_heads, d_ff_pad, patch, channels, kpad, n_patches, act;
+    float eps;
+    const void* patch_w;    /* bf16 [d, kpad] */
+    const float* patch_b;   /* f32 [d] */
+    const float* pos;       /* f32 [n_patches, d] position embedding */
+    const ufv_vit_layer* layers;
+} ufv_vit_model;
+
+int64_t ufv_vit_forward_ws_bytes(const ufv_vit_model* m, int T);
+/* pixels [T, channels, H, W] of dtype id `dtype` -> x f32 [T * n_patches, d]: the residual stream after n_layers layers */
+int ufv_vit_forward(const ufv_vit_model* m, const void* pixels, int dtype, int T, int H, int W, int n_layers, float* x, void* ws,
+                    int64_t ws_bytes, void* stream);
+
 /* the same with the position in device memory (*pos_dev, incremented by the step): every launch argument is identical from
  * token to token, so the step can be recorded once into a HIP graph and replayed (ufv_graph_*) */
 int ufv_qwen2_decode_step_dev(const ufv_qwen2_model* m, const int64_t* token_dev, int* pos_dev, void* ws, int64_t ws_bytes, float* logits,

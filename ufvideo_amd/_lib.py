@@ -59,6 +59,8 @@ SIGNATURES = {
     "ufv_argmax_rows": [_p, _l, _i, _i, _p, _p],
     "ufv_attention_decode": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
+    "ufv_qwen2_prefill": [_p, _p, _i, _i, _p, _l, _p, _p, _p, _p],
+    "ufv_vit_forward": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _l, _p],
     "ufv_qwen2_decode_step_dev": [_p, _p, _p, _p, _l, _p, _p, _p, _p],
     "ufv_rope_kv1_dev": [_p, _i, _i, _i, _p, _p, _p, _i, _p],
     "ufv_attention_decode_dev": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _f, _p, _i, _p],
@@ -95,6 +97,7 @@ SIGNATURES = {
 }
 # entry points that return a size instead of a status
 SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l),
+              "ufv_qwen2_prefill_ws_bytes": ([_p, _i], _l), "ufv_vit_forward_ws_bytes": ([_p, _i], _l),
               "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l), "ufv_attention_bwd_fused_ws_bytes": ([_i, _i], _l),
               "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l), "ufv_mask_dot_bwd_ws_bytes": ([_i, _i], _l)}
 
@@ -107,6 +110,16 @@ class Qwen2Layer(C.Structure):
 class Qwen2Model(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_layers", "d", "n_q", "n_kv", "hd", "d_ff", "vocab", "ldkv", "max_len", "attn_splits")] + \
                [("eps", _f), ("inv_freq", _p), ("norm", _p), ("embed", _p), ("lm_head", _p), ("layers", C.POINTER(Qwen2Layer))]
+
+
+
+class VitLayer(C.Structure):
+    _fields_ = [(n, _p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2")]
+
+
+class VitModel(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_layers", "d", "n_heads", "d_ff_pad", "patch", "channels", "kpad", "n_patches", "act")] + \
+               [("eps", _f), ("patch_w", _p), ("patch_b", _p), ("pos", _p), ("layers", C.POINTER(VitLayer))]
 
 _lib = None
 

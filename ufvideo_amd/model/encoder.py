@@ -110,6 +110,18 @@ class _VitBody(PackedModule):
         pk["layers"] = layers
         return pk
 
+    def _encode_c(self, pixels, n_layers, n):
+        import ctypes
+        from .. import _lib
+        m, keep = _vit_c_model(self)
+        T = pixels.shape[0]
+        nbytes = _lib.load().ufv_vit_forward_ws_bytes(ctypes.byref(m), T)
+        ws = torch.empty((nbytes,), device=pixels.device, dtype=torch.uint8)
+        x = torch.empty((T * n, self.cfg.hidden_size), device=pixels.device, dtype=torch.float32)
+        _lib.call("ufv_vit_forward", ctypes.byref(m), pixels.data_ptr(), ops._DT[pixels.dtype], T, pixels.shape[-2], pixels.shape[-1], n_layers,
+                  x.data_ptr(), ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+        return x
+
     def encode(self, pixels, n_layers):
         """pixels [T,3,H,W] (f32/f16/bf16, device) -> fp32 residual stream [T*S, D] after `n_layers` layers
         (S = patches (+1 with CLS))."""
@@ -120,6 +132,10 @@ class _VitBody(PackedModule):
         if n != pk["pos"].shape[0]:
             raise ValueError(f"vision tower built for {pk['pos'].shape[0]} patches, got {n} (image {tuple(pixels.shape[-2:])})")
         hd = D // H
+        if (not self.clip and not any(isinstance(L["wqkv"], ops.Fp8Weight) for L in pk["layers"][:n_layers])
+                and os.environ.get("UFV_STAGE_CALLS", "1") != "0"):
+            # the whole tower as ONE C call (ufv_vit_forward, csrc/stages.hip): the same launches in the same order, bit-identical
+            return self._encode_c(pixels.contiguous(), n_layers, n), n
         cols = ops.patchify(pixels.contiguous(), P, pk["Kp"])
         x = ops.gemm(cols, pk["patch_w"], bias=pk["patch_b"], resid=pk["pos"], resid_rows=n, out_dtype=torch.float32)
         S = n
@@ -149,6 +165,23 @@ class _VitBody(PackedModule):
             ops.gemm(hq, L["w1"], bias=L["b1"], act=cfg.hidden_act, out=ff)
             ops.gemm(ff, L["w2"], bias=L["b2"], resid=x, out=x)
         return x, S
+
+
+def _vit_c_model(tower):
+    """ctypes view (include/ufv.h ufv_vit_model) of a packed SigLIP tower -> (struct, layer array to keep alive)"""
+    from .. import _lib
+    cfg, pk = tower.cfg, tower.packed()
+    n = len(pk["layers"])
+    layers = (_lib.VitLayer * n)()
+    for i, L in enumerate(pk["layers"]):
+        layers[i] = _lib.VitLayer(L["ln1"][0].data_ptr(), L["ln1"][1].data_ptr(), L["ln2"][0].data_ptr(), L["ln2"][1].data_ptr(),
+                                  L["wqkv"].data_ptr(), L["bqkv"].data_ptr(), L["wo"].data_ptr(), L["bo"].data_ptr(),
+                                  L["w1"].data_ptr(), L["b1"].data_ptr(), L["w2"].data_ptr(), L["b2"].data_ptr())
+    m = _lib.VitModel(n_layers=n, d=cfg.hidden_size, n_heads=cfg.num_attention_heads, d_ff_pad=pk["Ip"], patch=cfg.patch_size,
+                      channels=cfg.num_channels, kpad=pk["Kp"], n_patches=pk["pos"].shape[0], act=ops.ACT[cfg.hidden_act],
+                      eps=cfg.layer_norm_eps, patch_w=pk["patch_w"].data_ptr(), patch_b=pk["patch_b"].data_ptr(), pos=pk["pos"].data_ptr(),
+                      layers=layers)
+    return m, layers
 
 
 class _TowerBase(nn.Module):

@@ -173,6 +173,20 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
         for _, n, c, p0 in segs:
             c.ensure(p0 + n)
         dev = x.device
+        if (segments is None and S > 1 and hd % 16 == 0 and not any("wqkv8" in L for L in pk["layers"]) and x.is_contiguous()
+                and os.environ.get("UFV_STAGE_CALLS", "1") != "0"):
+            # the whole layer loop as ONE C call (ufv_qwen2_prefill, csrc/stages.hip): the same launches in the same order, bit-identical
+            m, keep = self.c_model(cache)
+            nbytes = _lib.load().ufv_qwen2_prefill_ws_bytes(ctypes.byref(m), S)
+            ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+            nl = len(pk["layers"])
+            hid = torch.empty((nl - 1, S, D), device=dev, dtype=torch.float32) if (collect_hidden is not None and nl > 1) else None
+            _lib.call("ufv_qwen2_prefill", ctypes.byref(m), x.data_ptr(), S, pos0, ws.data_ptr(), nbytes, hid.data_ptr() if hid is not None else None,
+                      None, None, torch.cuda.current_stream().cuda_stream)
+            if hid is not None:
+                collect_hidden.extend(hid[i] for i in range(nl - 1))
+            cache.len = pos0 + S
+            return x
         h = torch.empty((S, D), device=dev, dtype=torch.bfloat16)
         qkv = torch.empty((S, (H + 2 * KV) * hd), device=dev, dtype=torch.bfloat16)
         o = torch.empty((S, H * hd), device=dev, dtype=torch.bfloat16)
@@ -198,6 +212,24 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
         for _, n, c, p0 in segs:
             c.len = p0 + n
         return x
+
+    def c_model(self, cache, lm_head=None, vocab=0):
+        """ctypes view (include/ufv.h ufv_qwen2_model) of the packed decoder + one sequence's KV cache -> (struct, objects to keep alive)"""
+        cfg, pk = self.config, self.packed()
+        L = cfg.num_hidden_layers
+        layers = (_lib.Qwen2Layer * L)()
+        for i, w in enumerate(pk["layers"]):
+            q8 = []
+            for k in ("wqkv8", "wo8", "wgu8", "wd8"):                  # fp8 mode: the decode step streams the e4m3 weights too
+                fw = w.get(k)
+                q8 += [fw.q.data_ptr(), fw.scale.data_ptr()] if fw is not None else [None, None]
+            layers[i] = _lib.Qwen2Layer(w["wqkv"].data_ptr(), w["bqkv"].data_ptr(), w["wo"].data_ptr(), w["wgu"].data_ptr(),
+                                        w["wd"].data_ptr(), w["ln1"].data_ptr(), w["ln2"].data_ptr(), cache.buf[i].data_ptr(), *q8)
+        m = _lib.Qwen2Model(n_layers=L, d=cfg.hidden_size, n_q=cfg.num_attention_heads, n_kv=cfg.num_key_value_heads, hd=cfg.head_dim,
+                            d_ff=cfg.intermediate_size, vocab=vocab, ldkv=cache.buf[0].stride(0), max_len=cache.max_len,
+                            attn_splits=16, eps=cfg.rms_norm_eps, inv_freq=pk["inv_freq"].data_ptr(), norm=pk["norm"].data_ptr(),
+                            embed=pk["embed"].data_ptr(), lm_head=lm_head.data_ptr() if lm_head is not None else None, layers=layers)
+        return m, layers
 
     def final_norm(self, x, out_dtype=torch.float32):
         return ops.rmsnorm(x, self.packed()["norm"], self.config.rms_norm_eps, out_dtype=out_dtype)
@@ -636,20 +668,8 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
 
     def _decode_step_ctx(self, cache):
         """ctypes view of the packed decoder + this generation's KV cache for ufv_qwen2_decode_step (include/ufv.h)."""
-        cfg, pk, head = self.config, self.model.packed(), self.packed()
-        L = cfg.num_hidden_layers
-        layers = (_lib.Qwen2Layer * L)()
-        for i, w in enumerate(pk["layers"]):
-            q8 = []
-            for k in ("wqkv8", "wo8", "wgu8", "wd8"):                  # fp8 mode: the decode step streams the e4m3 weights too
-                fw = w.get(k)
-                q8 += [fw.q.data_ptr(), fw.scale.data_ptr()] if fw is not None else [None, None]
-            layers[i] = _lib.Qwen2Layer(w["wqkv"].data_ptr(), w["bqkv"].data_ptr(), w["wo"].data_ptr(), w["wgu"].data_ptr(),
-                                        w["wd"].data_ptr(), w["ln1"].data_ptr(), w["ln2"].data_ptr(), cache.buf[i].data_ptr(), *q8)
-        m = _lib.Qwen2Model(n_layers=L, d=cfg.hidden_size, n_q=cfg.num_attention_heads, n_kv=cfg.num_key_value_heads, hd=cfg.head_dim,
-                            d_ff=cfg.intermediate_size, vocab=head["V"], ldkv=cache.buf[0].stride(0), max_len=cache.max_len,
-                            attn_splits=16, eps=cfg.rms_norm_eps, inv_freq=pk["inv_freq"].data_ptr(), norm=pk["norm"].data_ptr(),
-                            embed=pk["embed"].data_ptr(), lm_head=head["lm_head"].data_ptr(), layers=layers)
+        head = self.packed()
+        m, layers = self.model.c_model(cache, lm_head=head["lm_head"], vocab=head["V"])
         nbytes = _lib.load().ufv_qwen2_decode_ws_bytes(ctypes.byref(m))
         dev = cache.buf[0].device
         return {"model": m, "layers": layers, "ws": torch.empty((nbytes,), device=dev, dtype=torch.uint8),
