@@ -240,6 +240,31 @@ int64_t ufv_vit_forward_ws_bytes(const ufv_vit_model* m, int T);
 int ufv_vit_forward(const ufv_vit_model* m, const void* pixels, int dtype, int T, int H, int W, int n_layers, float* x, void* ws,
                     int64_t ws_bytes, void* stream);
 
+/* STC connector = `temporal_aggregator` for the stc_connector / stc_connector_v35 / stp_connector / spatial_conv / spatial_pool projectors
+ * (projector.py:133-250): RegStage x depth -> Conv3d(kernel = stride = (kt,kh,kw), padding pad) + SiLU | AvgPool3d + SiLU -> RegStage x depth ->
+ * readout MLP (Linear, GELU, ..., Linear).  One RegNet bottleneck (timm Bottleneck, bottle_ratio 1, group width 1 = depthwise, SE):
+ * conv1 1x1 -> LN -> SiLU -> depthwise 3x3 -> LN -> SiLU -> SE -> conv3 1x1 -> LN -> (+ shortcut [conv 1x1 -> LN when c_in != c_out]) -> SiLU. */
+typedef struct {
+    int32_t c_in, c_out, se_rd, _pad;
+    const void* w1; const float* n1_w; const float* n1_b;                    /* bf16 [c_out, c_in] */
+    const float* w9; const float* n2_w; const float* n2_b;                   /* f32 [9, c_out] depthwise taps */
+    const void* se1_w; const float* se1_b; const void* se2_w; const float* se2_b;   /* bf16 [se_rd, c_out], bf16 [c_out, se_rd] */
+    const void* w3; const float* n3_w; const float* n3_b;                    /* bf16 [c_out, c_out] */
+    const void* ds_w; const float* ds_nw; const float* ds_nb;                /* shortcut conv + norm, NULL when c_in == c_out */
+} ufv_stc_block;
+
+typedef struct {
+    int32_t depth, mlp_depth, kt, kh, kw, pad, avgpool, c_in, c_hid, _pad;
+    float eps, _padf;
+    const ufv_stc_block* s1; const ufv_stc_block* s2;                        /* depth blocks each */
+    const void* samp_w; const float* samp_b;                                 /* bf16 [c_hid, kt*kh*kw*C], k = ((dt*kh+dh)*kw+dw)*C + c; NULL with avgpool */
+    const void* const* readout_w; const float* const* readout_b;            /* mlp_depth entries: bf16 [c_hid, c_hid], f32 [c_hid] */
+} ufv_stc_model;
+
+int64_t ufv_stc_forward_ws_bytes(const ufv_stc_model* m, int T, int HW);
+/* x [T*HW*HW, c_in] token-major features of ONE video (dtype id x_dtype) -> out f32 [To*Ho*Wo, c_hid] */
+int ufv_stc_forward(const ufv_stc_model* m, const void* x, int x_dtype, int T, int HW, float* out, void* ws, int64_t ws_bytes, void* stream);
+
 /* the same with the position in device memory (*pos_dev, incremented by the step): every launch argument is identical from
  * token to token, so the step can be recorded once into a HIP graph and replayed (ufv_graph_*) */
 int ufv_qwen2_decode_step_dev(const ufv_qwen2_model* m, const int64_t* token_dev, int* pos_dev, void* ws, int64_t ws_bytes, float* logits,

@@ -120,3 +120,53 @@ def test_full_dimension_stages_bit_identical_and_direct_call_outputs():
         _lib.call("ufv_vit_forward", ctypes.byref(vm), frames.data_ptr(), ops._DT[frames.dtype], 4, 224, 224, 2, out.data_ptr(), vws.data_ptr(), vb, st)
     _lib.call("ufv_vit_forward", ctypes.byref(vm), frames.data_ptr(), ops._DT[frames.dtype], 4, 336, 336, 2, out.data_ptr(), vws.data_ptr(), vb, st)
     assert torch.equal(out.view(4, 576, 1152), f0)                  # select_layer -2 of 3 layers = after 2 layers
+
+
+def test_connector_stage_call_bit_identical_for_every_sampler_and_at_full_dimensions():
+    """`ufv_stc_forward` == the host op loop of projector.py for: RegStage blocks with and without a shortcut conv (v35, depth 4), Conv3d padding 0
+    and padding 1, the AvgPool3d samplers (odd sizes floor), depth 0; then stc_connector_v35 at production dimensions (1152 -> 3584, 4 frames 24x24)."""
+    from oracle import ref_cpu as O
+    from ufvideo_amd.model.projector import STCConnector, STCConnectorV35, STPConnector, SpatialConv, SpatialPool
+
+    class Cfg:
+        mm_hidden_size = 64
+        hidden_size = 128
+
+    class Cfg32:
+        mm_hidden_size = 32
+        hidden_size = 32
+    g = torch.Generator().manual_seed(6)
+    cases = [(STCConnectorV35(Cfg(), seed=3), torch.randn(2, 4, 36, 64, generator=g)), (STCConnector(Cfg(), seed=4), torch.randn(1, 4, 25, 64, generator=g)),
+             (STPConnector(Cfg(), seed=5), torch.randn(1, 5, 49, 64, generator=g)), (SpatialConv(Cfg32(), seed=6), torch.randn(1, 3, 36, 32, generator=g)),
+             (SpatialPool(Cfg32(), seed=7), torch.randn(1, 3, 25, 32, generator=g)), (STCConnectorV35(Cfg32(), depth=0, seed=8), torch.randn(1, 4, 16, 32, generator=g))]
+    for m, x in cases:
+        m = m.to(DEV)
+        with torch.no_grad():
+            y1 = m(x.to(DEV))
+            with host_loops():
+                y0 = m(x.to(DEV))
+            yb = m(x.to(DEV).to(torch.bfloat16))                         # the tower hands bf16 / fp16 features
+        assert y1.shape == y0.shape and torch.equal(y1, y0), type(m).__name__
+        assert torch.isfinite(yb).all()
+    # v35 against the oracle through the stage call (as test_model_gpu does through whichever path is active)
+    sd = O.make_stc_weights(64, 128, seed=5)
+    m = STCConnectorV35(Cfg()); m.load_state_dict(sd); m = m.to(DEV)
+    x = torch.randn(1, 4, 36, 64, generator=torch.Generator().manual_seed(6))
+    from conftest import rel_err
+    assert rel_err(m(x.to(DEV)).cpu(), O.stc_connector(sd, x)) < 2e-2
+
+    class Prod:
+        mm_hidden_size = 1152
+        hidden_size = 3584
+    m = STCConnectorV35(Prod(), device=torch.device("cuda", 0), seed=9)
+    x = torch.randn(1, 4, 576, 1152, generator=g).to(DEV)
+    with torch.no_grad():
+        y1 = m(x)
+        with host_loops():
+            y0 = m(x)
+    assert y1.shape == (1, 2 * 12 * 12, 3584) and torch.equal(y1, y0)
+    import ctypes
+    cm, keep = m.c_model()
+    nb = _lib.load().ufv_stc_forward_ws_bytes(ctypes.byref(cm), 4, 24)
+    with pytest.raises(_lib.UfvError, match="workspace too small"):
+        _lib.call("ufv_stc_forward", ctypes.byref(cm), x.data_ptr(), ops._DT[x.dtype], 4, 24, y1.data_ptr(), x.data_ptr(), nb - 1, torch.cuda.current_stream().cuda_stream)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
     "ufv_qwen2_prefill": [_p, _p, _i, _i, _p, _l, _p, _p, _p, _p],
     "ufv_vit_forward": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _l, _p],
+    "ufv_stc_forward": [_p, _p, _i, _i, _i, _p, _p, _l, _p],
     "ufv_qwen2_decode_step_dev": [_p, _p, _p, _p, _l, _p, _p, _p, _p],
     "ufv_rope_kv1_dev": [_p, _i, _i, _i, _p, _p, _p, _i, _p],
     "ufv_attention_decode_dev": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _f, _p, _i, _p],
@@ -97,7 +98,7 @@ SIGNATURES = {
 }
 # entry points that return a size instead of a status
 SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l),
-              "ufv_qwen2_prefill_ws_bytes": ([_p, _i], _l), "ufv_vit_forward_ws_bytes": ([_p, _i], _l),
+              "ufv_qwen2_prefill_ws_bytes": ([_p, _i], _l), "ufv_vit_forward_ws_bytes": ([_p, _i], _l), "ufv_stc_forward_ws_bytes": ([_p, _i, _i], _l),
               "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l), "ufv_attention_bwd_fused_ws_bytes": ([_i, _i], _l),
               "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l), "ufv_mask_dot_bwd_ws_bytes": ([_i, _i], _l)}
 
@@ -120,6 +121,18 @@ class VitLayer(C.Structure):
 class VitModel(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_layers", "d", "n_heads", "d_ff_pad", "patch", "channels", "kpad", "n_patches", "act")] + \
                [("eps", _f), ("patch_w", _p), ("patch_b", _p), ("pos", _p), ("layers", C.POINTER(VitLayer))]
+
+
+
+class StcBlock(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("c_in", "c_out", "se_rd", "_pad")] + \
+               [(n, _p) for n in ("w1", "n1_w", "n1_b", "w9", "n2_w", "n2_b", "se1_w", "se1_b", "se2_w", "se2_b", "w3", "n3_w", "n3_b", "ds_w", "ds_nw", "ds_nb")]
+
+
+class StcModel(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("depth", "mlp_depth", "kt", "kh", "kw", "pad", "avgpool", "c_in", "c_hid", "_pad")] + \
+               [("eps", _f), ("_padf", _f), ("s1", C.POINTER(StcBlock)), ("s2", C.POINTER(StcBlock)), ("samp_w", _p), ("samp_b", _p),
+                ("readout_w", C.POINTER(_p)), ("readout_b", C.POINTER(_p))]
 
 _lib = None
 

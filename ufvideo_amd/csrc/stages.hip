@@ -117,3 +117,82 @@ extern "C" int ufv_vit_forward(const ufv_vit_model* m, const void* pixels, int d
     }
     return UFV_OK;
 }
+
+// ---- STC connector (projector.py:133-250: RegStage x depth -> Conv3d | AvgPool3d sampler -> RegStage x depth -> readout MLP) -------------
+// token-major bf16 [frames * H * W, C] throughout; one video per call
+static size_t stc_rows_out(const ufv_stc_model* m, int T, int HW, int* To, int* Ho, int* Wo) {
+    if (m->avgpool) { *To = T / m->kt; *Ho = HW / m->kh; *Wo = HW / m->kw; }
+    else { *To = (T + 2 * m->pad - m->kt) / m->kt + 1; *Ho = (HW + 2 * m->pad - m->kh) / m->kh + 1; *Wo = (HW + 2 * m->pad - m->kw) / m->kw + 1; }
+    return (size_t)*To * *Ho * *Wo;
+}
+
+static size_t stc_buf_elems(const ufv_stc_model* m, int T, int HW) {
+    int To, Ho, Wo;
+    const size_t M1 = (size_t)T * HW * HW, M2 = stc_rows_out(m, T, HW, &To, &Ho, &Wo);
+    const size_t cmax = m->c_in > m->c_hid ? m->c_in : m->c_hid;
+    size_t e = M1 * cmax;
+    const size_t g = M2 * (size_t)m->kt * m->kh * m->kw * m->c_hid;        // the Conv3d patch matrix
+    if (!m->avgpool && g > e) e = g;
+    if (M2 * cmax > e) e = M2 * cmax;
+    return e;
+}
+
+extern "C" int64_t ufv_stc_forward_ws_bytes(const ufv_stc_model* m, int T, int HW) {
+    if (!m || T <= 0 || HW <= 0) return -1;
+    const size_t fmax = (size_t)T;                                          // frames of the larger stage
+    return (int64_t)(4 * align256(2 * stc_buf_elems(m, T, HW)) + 3 * align256(2 * fmax * m->c_hid));
+}
+
+static int stc_block(const ufv_stc_model* m, const ufv_stc_block& b, char*& X, char*& A, char*& B, char*& C, char* s0, char* s1, char* s2, int F, int H, int W,
+                     void* stream) {
+    const int P = H * W, M = F * P, Ci = b.c_in, Co = b.c_out;
+    UFV_TRY(ufv_gemm(X, Ci, b.w1, Ci, A, Co, 0, M, Co, Ci, nullptr, UFV_ACT_NONE, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+    UFV_TRY(ufv_layernorm(A, UFV_DT_BF16, Co, B, 0, Co, b.n1_w, b.n1_b, M, Co, m->eps, UFV_ACT_SILU, stream));
+    UFV_TRY(ufv_dwconv3x3_ln_silu(B, A, b.w9, b.n2_w, b.n2_b, F, H, W, Co, m->eps, stream));
+    UFV_TRY(ufv_colmean(A, s0, F, P, Co, stream));
+    UFV_TRY(ufv_gemm(s0, Co, b.se1_w, Co, s1, b.se_rd, 0, F, b.se_rd, Co, b.se1_b, UFV_ACT_SILU, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+    UFV_TRY(ufv_gemm(s1, b.se_rd, b.se2_w, b.se_rd, s2, Co, 0, F, Co, b.se_rd, b.se2_b, UFV_ACT_SIGMOID, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+    UFV_TRY(ufv_scale_channels(A, s2, F, P, Co, stream));
+    UFV_TRY(ufv_gemm(A, Co, b.w3, Co, B, Co, 0, M, Co, Co, nullptr, UFV_ACT_NONE, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+    if (b.ds_w) {
+        UFV_TRY(ufv_gemm(X, Ci, b.ds_w, Ci, C, Co, 0, M, Co, Ci, nullptr, UFV_ACT_NONE, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+        UFV_TRY(ufv_ln_add_silu(B, b.n3_w, b.n3_b, C, b.ds_nw, b.ds_nb, A, M, Co, m->eps, stream));
+    } else {
+        UFV_TRY(ufv_ln_add_silu(B, b.n3_w, b.n3_b, X, nullptr, nullptr, A, M, Co, m->eps, stream));
+    }
+    char* t = X; X = A; A = t;               // the block's output becomes the next input
+    return UFV_OK;
+}
+
+extern "C" int ufv_stc_forward(const ufv_stc_model* m, const void* x, int x_dtype, int T, int HW, float* out, void* ws, int64_t ws_bytes, void* stream) {
+    UFV_REQUIRE(m && x && out && ws && T > 0 && HW > 0, "ufv_stc_forward: bad arguments");
+    UFV_REQUIRE(ws_bytes >= ufv_stc_forward_ws_bytes(m, T, HW), "ufv_stc_forward: workspace too small");
+    UFV_REQUIRE(m->mlp_depth >= 1 && (m->depth == 0 || (m->s1 && m->s2)), "ufv_stc_forward: incomplete model description");
+    const size_t be = align256(2 * stc_buf_elems(m, T, HW));
+    char* p = reinterpret_cast<char*>(ws);
+    char *X = p, *A = p + be, *B = p + 2 * be, *C = p + 3 * be;
+    char* s0 = p + 4 * be; char* s1 = s0 + align256(2 * (size_t)T * m->c_hid); char* s2 = s1 + align256(2 * (size_t)T * m->c_hid);
+    const size_t M1 = (size_t)T * HW * HW;
+    UFV_TRY(ufv_convert(x, x_dtype, X, UFV_DT_BF16, (int64_t)(M1 * m->c_in), stream));
+    for (int i = 0; i < m->depth; ++i) UFV_TRY(stc_block(m, m->s1[i], X, A, B, C, s0, s1, s2, T, HW, HW, stream));
+    const int Cm = m->depth ? m->c_hid : m->c_in;
+    int To, Ho, Wo;
+    const size_t M2 = stc_rows_out(m, T, HW, &To, &Ho, &Wo);
+    UFV_REQUIRE(M2 > 0, "ufv_stc_forward: %d frames of %dx%d give no output token", T, HW, HW);
+    if (m->avgpool) {
+        UFV_TRY(ufv_avgpool3d_silu(X, A, T, HW, HW, Cm, m->kt, m->kh, m->kw, stream));
+        char* t = X; X = A; A = t;
+    } else {
+        const int Kc = m->kt * m->kh * m->kw * Cm;
+        UFV_TRY(ufv_conv3d_gather(X, A, T, HW, HW, Cm, m->kt, m->kh, m->kw, m->pad, stream));
+        UFV_TRY(ufv_gemm(A, Kc, m->samp_w, Kc, X, m->c_hid, 0, (int)M2, m->c_hid, Kc, m->samp_b, UFV_ACT_SILU, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+    }
+    for (int i = 0; i < m->depth; ++i) UFV_TRY(stc_block(m, m->s2[i], X, A, B, C, s0, s1, s2, To, Ho, Wo, stream));
+    for (int i = 0; i < m->mlp_depth; ++i) {
+        const bool last = i == m->mlp_depth - 1;
+        UFV_TRY(ufv_gemm(X, m->c_hid, m->readout_w[i], m->c_hid, last ? (void*)out : (void*)A, m->c_hid, last ? 1 : 0, (int)M2, m->c_hid, m->c_hid, m->readout_b[i],
+                         last ? UFV_ACT_NONE : UFV_ACT_GELU_ERF, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+        char* t = X; X = A; A = t;
+    }
+    return UFV_OK;
+}

@@ -146,9 +146,55 @@ class STCConnector(PackedModule):
             return ops.ln_add_silu(z, blk["n3"][0], blk["n3"][1], sc, blk["ds"][1], blk["ds"][2], eps)
         return ops.ln_add_silu(z, blk["n3"][0], blk["n3"][1], x, None, None, eps)
 
+    def c_model(self):
+        """ctypes view (include/ufv.h ufv_stc_model) of the packed connector -> (struct, objects to keep alive)"""
+        import ctypes
+        from .. import _lib
+        pk = self.packed()
+        keep = []
+
+        def stage(blocks):
+            arr = (_lib.StcBlock * max(len(blocks), 1))()
+            for i, b in enumerate(blocks):
+                ds = b["ds"]
+                arr[i] = _lib.StcBlock(b["w1"].shape[1], b["w1"].shape[0], b["se1"][0].shape[0], 0, b["w1"].data_ptr(), b["n1"][0].data_ptr(), b["n1"][1].data_ptr(),
+                                       b["w9"].data_ptr(), b["n2"][0].data_ptr(), b["n2"][1].data_ptr(), b["se1"][0].data_ptr(), b["se1"][1].data_ptr(),
+                                       b["se2"][0].data_ptr(), b["se2"][1].data_ptr(), b["w3"].data_ptr(), b["n3"][0].data_ptr(), b["n3"][1].data_ptr(),
+                                       ds[0].data_ptr() if ds else None, ds[1].data_ptr() if ds else None, ds[2].data_ptr() if ds else None)
+            keep.append(arr)
+            return arr
+        n = len(pk["readout"])
+        rw = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _ in pk["readout"]])
+        rb = (ctypes.c_void_p * n)(*[b.data_ptr() for _, b in pk["readout"]])
+        keep += [rw, rb]
+        m = _lib.StcModel(depth=self.depth, mlp_depth=n, kt=self.downsample[0], kh=self.downsample[1], kw=self.downsample[2], pad=self.PADDING,
+                          avgpool=int(self.AVGPOOL), c_in=self.encoder_hidden_size, c_hid=self.hidden_size, eps=self.ln_eps,
+                          s1=stage(pk["s1"]) if self.depth else None, s2=stage(pk["s2"]) if self.depth else None,
+                          samp_w=pk["samp_w"].data_ptr() if not self.AVGPOOL else None, samp_b=pk["samp_b"].data_ptr() if not self.AVGPOOL else None,
+                          readout_w=rw, readout_b=rb)
+        return m, keep
+
+    def _stage_call_ok(self, pk):
+        ws = [w for w, _ in pk["readout"]] + ([] if self.AVGPOOL else [pk["samp_w"]]) + ([b["w1"] for b in pk["s1"] + pk["s2"]] if self.depth else [])
+        return not any(isinstance(w, ops.Fp8Weight) for w in ws) and os.environ.get("UFV_STAGE_CALLS", "1") != "0"
+
     def forward_one(self, x, t, hw):
         """x: [t*hw*hw, C_in] any float dtype (one video, token-major) -> fp32 [tokens, hidden]"""
         pk = self.packed()
+        if self._stage_call_ok(pk):
+            # the whole connector as ONE C call (ufv_stc_forward, csrc/stages.hip): the same launches in the same order, bit-identical
+            import ctypes
+            from .. import _lib
+            m, keep = self.c_model()
+            x = x.contiguous()
+            nbytes = _lib.load().ufv_stc_forward_ws_bytes(ctypes.byref(m), t, hw)
+            ws = torch.empty((nbytes,), device=x.device, dtype=torch.uint8)
+            k, p = self.downsample, (0 if self.AVGPOOL else self.PADDING)
+            To, Ho, Wo = [(n_ // k_) if self.AVGPOOL else ((n_ + 2 * p - k_) // k_ + 1) for n_, k_ in zip((t, hw, hw), k)]
+            out = torch.empty((To * Ho * Wo, self.hidden_size), device=x.device, dtype=torch.float32)
+            _lib.call("ufv_stc_forward", ctypes.byref(m), x.data_ptr(), ops._DT[x.dtype], t, hw, out.data_ptr(), ws.data_ptr(), nbytes,
+                      torch.cuda.current_stream().cuda_stream)
+            return out
         h = ops.convert(x.contiguous(), torch.bfloat16)
         if self.depth:
             for blk in pk["s1"]:
