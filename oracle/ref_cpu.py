@@ -690,6 +690,19 @@ def make_siglip_weights(cfg: dict, seed: int = 0, prefix: str = "", std: float =
     return sd
 
 
+def make_clip_weights(cfg: dict, seed: int = 0, prefix: str = "", std: float = 0.02) -> SD:
+    """seeded CLIPVisionModel weights under HF's names (no patch bias, class embedding, n + 1 positions, pre_layrnorm)"""
+    sd = make_siglip_weights(cfg, seed=seed, prefix=prefix, std=std)
+    g = torch.Generator().manual_seed(seed + 1000)
+    D, n = cfg["hidden_size"], (cfg["image_size"] // cfg["patch_size"]) ** 2
+    del sd[prefix + "embeddings.patch_embedding.bias"]
+    sd[prefix + "embeddings.class_embedding"] = _randn(g, D, std=std)
+    sd[prefix + "embeddings.position_embedding.weight"] = _randn(g, n + 1, D, std=std)
+    sd[prefix + "pre_layrnorm.weight"] = 1.0 + _randn(g, D, std=std)
+    sd[prefix + "pre_layrnorm.bias"] = _randn(g, D, std=std)
+    return sd
+
+
 def make_regstage_weights(sd: SD, g, p: str, depth: int, cin: int, cout: int, std: float):
     for i in range(depth):
         b = f"{p}b{i + 1}."

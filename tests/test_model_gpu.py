@@ -286,6 +286,25 @@ def test_fulldim_siglip_layers_vs_oracle():
     assert rel_err(y.cpu(), ref) < 1e-2
 
 
+def test_fulldim_clip_l_layers_vs_oracle():
+    """The reference's secondary tower at its real dimensions: CLIP ViT-L/14-336 (1024, 16 x 64, 4096, quick_gelu, [CLS] + 576 patches = 577
+    tokens -- a sequence length that is no multiple of the attention tile --, pre_layrnorm, hidden_states[-2], CLS dropped; encoder.py:12-93)."""
+    cfg = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=3, num_attention_heads=16, image_size=336, patch_size=14,
+               hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    sd = O.make_clip_weights(cfg, seed=21)
+    tower = CLIPVisionTower("clip-vit-large-patch14-336", Args(), vision_config=cfg)
+    tower.load_hf_state_dict(sd); tower = tower.to(DEV)
+    x = torch.randn(2, 3, 336, 336, generator=torch.Generator().manual_seed(23))
+    y = tower(x.to(DEV))
+    ref = O.clip_tower(sd, cfg, x)
+    assert y.shape == ref.shape == (2, 576, 1024)
+    e = rel_err(y.cpu(), ref)
+    with O.bf16_mirror():
+        em = rel_err(y.cpu(), O.clip_tower(sd, cfg, x))
+    print(f"CLIP-L/14-336 2 layers vs fp32 oracle {e:.2e}, vs bf16 mirror {em:.2e}")
+    assert e < 1e-2 and em < 3e-3                  # measured 4.4e-3 / 1.2e-3
+
+
 def test_fulldim_qwen2_layer_vs_oracle():
     cfg = dict(vocab_size=512, hidden_size=3584, intermediate_size=18944, num_hidden_layers=1, num_attention_heads=28,
                num_key_value_heads=4, rope_theta=1e6, rms_norm_eps=1e-6)
