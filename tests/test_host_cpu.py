@@ -269,3 +269,94 @@ def test_packed_module_refuses_repacking_while_a_trainer_owns_it():
             f()
     m._owner = None
     m.invalidate()
+
+
+def _tiny_tokenizer_dir(path, n_vocab=40):
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {f"t{i}": i for i in range(n_vocab - 3)}
+    vocab.update({"<unk>": n_vocab - 3, "<eos>": n_vocab - 2, "<pad>": n_vocab - 1})
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", eos_token="<eos>", pad_token="<pad>").save_pretrained(path)
+
+
+def test_lora_and_base_model_loading_forms(tmp_path):
+    """The reference's other two loading forms (ufvideo/model/__init__.py:82-125): (i) lora=True -- base model, initialize_MM_tokenizer,
+    non_lora_trainables.bin (with peft's key prefixes), adapter merged as W + (alpha / r) B A, incl. rank / alpha patterns, rsLoRA and
+    modules_to_save; (ii) base + mm_projector.bin.  peft is not in the image: the merge is checked against its definition."""
+    import json
+    import torch
+    from safetensors.torch import save_file
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM, load_pretrained_model
+    from ufvideo_amd.model.lora import merge_lora
+    llm = dict(vocab_size=40, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1)
+    mmk = dict(mm_vision_tower="siglip", mm_vision_select_layer=-2, mm_vision_select_feature="patch", mm_projector_type="spatial_conv", mm_hidden_size=16,
+               mm_region_encoder_type="pooling", image_aspect_ratio="square", num_frames=2, seg_token_id=39, sam2_trunk=None,
+               vision_config=dict(hidden_size=16, intermediate_size=32, num_hidden_layers=2, num_attention_heads=2, image_size=28, patch_size=14))
+    full = VideoReferQwen2ForCausalLM(VideoReferQwen2Config(**llm, **mmk, train_mask_decoder=True), seed=3)
+    sd = {k: v.clone() for k, v in full.state_dict().items()}
+    base, adir, pdir = tmp_path / "base", tmp_path / "adapter", tmp_path / "pretrain"
+    for d in (base, adir, pdir):
+        d.mkdir()
+    # a plain language-model base: no multimodal modules
+    lm_keys = [k for k in sd if not k.startswith(("model.mm_projector.", "model.region_encoder.", "model.text_hidden_fcs.", "model.vision_tower."))]
+    save_file({k: sd[k].contiguous() for k in lm_keys}, str(base / "model.safetensors"))
+    (base / "config.json").write_text(json.dumps(dict(llm, model_type="qwen2")))
+    _tiny_tokenizer_dir(str(base))
+    # ---- (i) the adapter directory
+    (adir / "config.json").write_text(json.dumps(dict(llm, **mmk, model_type="videorefer_qwen2")))
+    _tiny_tokenizer_dir(str(adir))
+    g = torch.Generator().manual_seed(5)
+    r, alpha = 4, 8
+    targets = {"model.layers.0.self_attn.q_proj": (r, alpha), "model.layers.1.self_attn.v_proj": (r, alpha), "model.layers.1.mlp.down_proj": (2, 6)}
+    asd = {}
+    for mod, (rr, _) in targets.items():
+        out_f, in_f = sd[mod + ".weight"].shape
+        asd[f"base_model.model.{mod}.lora_A.weight"] = torch.randn(rr, in_f, generator=g) * 0.3
+        asd[f"base_model.model.{mod}.lora_B.weight"] = torch.randn(out_f, rr, generator=g) * 0.3
+    new_norm = torch.randn(32, generator=g)
+    asd["base_model.model.model.norm.modules_to_save.weight"] = new_norm
+    save_file({k: v.contiguous() for k, v in asd.items()}, str(adir / "adapter_model.safetensors"))
+    acfg = dict(peft_type="LORA", r=r, lora_alpha=alpha, target_modules=["q_proj", "v_proj", "down_proj"], fan_in_fan_out=False,
+                rank_pattern={"down_proj": 2}, alpha_pattern={"down_proj": 6}, modules_to_save=["norm"])
+    (adir / "adapter_config.json").write_text(json.dumps(acfg))
+    proj = {k: torch.randn(v.shape, generator=g) * 0.1 for k, v in sd.items() if k.startswith("model.mm_projector.")}
+    torch.save({"base_model.model." + k: v for k, v in proj.items()}, str(adir / "non_lora_trainables.bin"))
+    tok, m, processor, ctx = load_pretrained_model(str(adir), str(base), "videorefer_qwen2", device="cpu", lora=True)
+    n_tok = len(tok)
+    assert n_tok == 40 + 102 and m.lm_head.weight.shape[0] == n_tok and m.config.vocab_size == n_tok       # <region>, 100 x <TEMP-..>, [SEG]
+    got = dict(m.state_dict())
+    for mod, (rr, al) in targets.items():
+        want = sd[mod + ".weight"].float() + (al / rr) * (asd[f"base_model.model.{mod}.lora_B.weight"] @ asd[f"base_model.model.{mod}.lora_A.weight"])
+        assert torch.allclose(got[mod + ".weight"].float(), want.to(torch.bfloat16).float(), atol=1e-6), mod
+        assert not torch.equal(got[mod + ".weight"], sd[mod + ".weight"])
+    assert torch.equal(got["model.norm.weight"], new_norm.to(torch.bfloat16))
+    assert torch.equal(got["model.layers.0.self_attn.k_proj.weight"], sd["model.layers.0.self_attn.k_proj.weight"])          # untouched
+    for k, v in proj.items():
+        assert torch.equal(got[k], v.to(torch.bfloat16)), k
+    assert torch.equal(got["model.embed_tokens.weight"][:40], sd["model.embed_tokens.weight"])
+    # the merge itself: rsLoRA scaling, fan_in_fan_out, refusals
+    p = {"x.weight": torch.zeros(6, 5)}
+    A, B = torch.randn(3, 5, generator=g), torch.randn(6, 3, generator=g)
+    merge_lora(p, dict(r=3, lora_alpha=6, use_rslora=True), {"base_model.model.x.lora_A.default.weight": A, "base_model.model.x.lora_B.default.weight": B})
+    assert torch.allclose(p["x.weight"], (6 / 3 ** 0.5) * (B @ A), atol=1e-6)
+    p = {"x.weight": torch.zeros(5, 6)}
+    merge_lora(p, dict(r=3, lora_alpha=3, fan_in_fan_out=True), {"x.lora_A.weight": A, "x.lora_B.weight": B})
+    assert torch.allclose(p["x.weight"], (B @ A).t(), atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        merge_lora(p, dict(r=3, lora_alpha=3, use_dora=True), {})
+    with pytest.raises(KeyError, match="does not have"):
+        merge_lora({}, dict(r=3, lora_alpha=3), {"y.lora_A.weight": A, "y.lora_B.weight": B})
+    with pytest.raises(ValueError, match="model_base"):
+        load_pretrained_model(str(adir), None, "videorefer_qwen2", device="cpu", lora=True)
+    # ---- (ii) base + mm_projector.bin (the reference's pre-training form)
+    (pdir / "config.json").write_text(json.dumps(dict(llm, **mmk, model_type="videorefer_qwen2", tune_mm_mlp_adapter=True)))
+    torch.save(proj, str(pdir / "mm_projector.bin"))
+    tok2, m2, _, _ = load_pretrained_model(str(pdir), str(base), "videorefer_qwen2", device="cpu")
+    got2 = dict(m2.state_dict())
+    for k, v in proj.items():
+        assert torch.equal(got2[k], v.to(torch.float16).to(torch.bfloat16)), k
+    assert torch.equal(got2["model.layers.1.mlp.down_proj.weight"], sd["model.layers.1.mlp.down_proj.weight"]) and len(tok2) == 40
+    with pytest.raises(NotImplementedError):
+        load_pretrained_model(str(pdir), str(base), "videorefer_qwen2", device="cpu", load_4bit=True)

@@ -683,8 +683,9 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         return _inputs
 
     @classmethod
-    def from_pretrained(cls, path, config=None, device=None, dtype=torch.bfloat16, **kw):
-        """Loads config.json + *.safetensors from a local directory (no network)."""
+    def from_pretrained(cls, path, config=None, device=None, dtype=torch.bfloat16, allow_missing=(), **kw):
+        """Loads config.json + *.safetensors from a local directory (no network).  allow_missing: key prefixes that may be absent (a plain
+        language-model base has no multimodal modules; the caller loads them next)."""
         config = config or VideoReferQwen2Config.from_pretrained(path)
         model = cls(config, device=device, dtype=dtype)
         from safetensors.torch import load_file
@@ -703,7 +704,8 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         # a weight that stays at its random initialisation makes the model emit garbage without any error: refuse, unless it is the
         # vision tower and the tower was just loaded from its own directory (the reference's checkpoints may or may not carry it)
         tower_loaded_separately = getattr(model.get_vision_tower(), "_local_path", lambda: None)() is not None
-        missing = [k for k in res.missing_keys if not (k.startswith("model.vision_tower.") and not tower_in_ckpt and tower_loaded_separately)]
+        missing = [k for k in res.missing_keys if not (k.startswith("model.vision_tower.") and not tower_in_ckpt and tower_loaded_separately)
+                   and not k.startswith(tuple(allow_missing))]
         if missing:
             raise KeyError(f"{path}: {len(missing)} weights of the model are not in the checkpoint (they would keep their random "
                            f"initialisation): {missing[:6]}{' ...' if len(missing) > 6 else ''}")
