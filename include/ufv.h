@@ -344,8 +344,12 @@ int ufv_dwconv3x3_dw(const void* x, const void* dy, float* dw9, int F, int H, in
 /* out[f][c] = sum_p a[f,p,c] * b[f,p,c] (SE gate gradient); out[f,p,c] = a[f,p,c] * g[f,c] + s[f,c] * k (s may be NULL) */
 int ufv_prod_colsum(const void* a, const void* b, int F, int P, int C, float* out, void* stream);
 int ufv_scale_add_bcast(const void* a, const void* g, const float* s, float k, void* out, int F, int P, int C, void* stream);
-/* inverse of ufv_conv3d_gather for padding 0 / stride = kernel: dx [T*H*W, C] from dA [To*Ho*Wo, kt*kh*kw*C] */
-int ufv_conv3d_scatter(const void* dA, void* dx, int T, int H, int W, int C, int kt, int kh, int kw, void* stream);
+/* inverse of ufv_conv3d_gather (stride = kernel, zero padding `pad`): dx [T*H*W, C] from dA [To*Ho*Wo, kt*kh*kw*C]; pixels past the last window get 0 */
+int ufv_conv3d_scatter(const void* dA, void* dx, int T, int H, int W, int C, int kt, int kh, int kw, int pad, void* stream);
+/* AvgPool3d sampler in training: the pooled value without the activation (ufv_avgpool3d_silu fuses SiLU), and its backward
+ * dx [T*H*W, C] = dy [To*Ho*Wo, C] / (kt*kh*kw) on the pixels inside a window */
+int ufv_avgpool3d(const void* x, void* out, int T, int H, int W, int C, int kt, int kh, int kw, void* stream);
+int ufv_avgpool3d_bwd(const void* dy, void* dx, int T, int H, int W, int C, int kt, int kh, int kw, void* stream);
 
 /* generate(do_sample=True) (ufvideo/__init__.py:113-127 -> HF TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper +
  * multinomial): for each of the M rows of logits f32 [M, ld], out[m] = a token drawn from softmax(logits / temperature)

@@ -525,6 +525,47 @@ def test_projector_grad_vs_oracle_autograd(cin, hid, t, hw, depth):
     assert rel_err(dx.float().cpu(), xr.grad) < 6e-2
 
 
+@pytest.mark.parametrize("kind,cin,hid,t,hw,depth", [("stc_connector", 64, 64, 4, 4, 2), ("stc_connector", 128, 256, 3, 5, 1), ("spatial_conv", 64, 64, 3, 6, 0),
+                                                     ("stp_connector", 64, 64, 4, 6, 2), ("stp_connector", 64, 128, 5, 5, 1), ("spatial_pool", 64, 64, 3, 5, 0)])
+def test_projector_grad_other_connectors_vs_oracle_autograd(kind, cin, hid, t, hw, depth):
+    """the rest of the STC family in training (VERDICT r1 missing #4): Conv3d with padding 1 (windows straddle the zero border: stc_connector,
+    spatial_conv) and the AvgPool3d samplers (stp_connector, spatial_pool; odd sizes floor, so the last frame / row / column gets no gradient)
+    against torch autograd over the oracle restatement of the reference's forward (projector.py:133-250)"""
+    from ufvideo_amd.model.projector import STCConnector, STPConnector, SpatialConv, SpatialPool
+    from ufvideo_amd.train_projector import ProjectorGrad
+    cls, ds, pad, avg = {"stc_connector": (STCConnector, (2, 2, 2), 1, False), "spatial_conv": (SpatialConv, (1, 2, 2), 1, False),
+                         "stp_connector": (STPConnector, (2, 2, 2), 0, True), "spatial_pool": (SpatialPool, (1, 2, 2), 0, True)}[kind]
+    sd = O.make_stc_weights(cin, hid, seed=41, depth=depth, downsample=ds)
+    if avg:
+        sd = {k: v for k, v in sd.items() if not k.startswith("sampler.")}
+    sd = {k: bfr(v * (3.0 if v.ndim >= 2 else 1.0)) for k, v in sd.items()}
+    pj = cls(_PCfg(cin, hid), depth=depth) if kind in ("stc_connector", "stp_connector") else cls(_PCfg(cin, hid))
+    pj.load_state_dict(sd)
+    pj = pj.to(DEV)
+    g_ = torch.Generator().manual_seed(42)
+    x = bfr(torch.randn(t * hw * hw, cin, generator=g_))
+    with torch.enable_grad():
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        y = O.stc_connector(p, xr.view(1, t, hw * hw, cin), downsample=ds, padding=pad, depth=depth, avgpool=avg)
+        dout = torch.randn(y.shape[1:], generator=g_)
+        y[0].backward(dout)
+    pg = ProjectorGrad(pj)
+    out, st = pg.forward(x.to(DEV), t, hw)
+    assert out.shape == y.shape[1:] and rel_err(out.cpu(), y[0].detach()) < 3e-2
+    with torch.no_grad():
+        assert rel_err(pj(x.view(1, t, hw * hw, cin).to(DEV))[0].cpu(), y[0].detach()) < 3e-2          # and the inference path of the same module
+    grads, dx = pg.backward(dout.to(DEV), st)
+    assert set(grads) == set(sd), set(sd) ^ set(grads)
+    worst = max((rel_err(grads[k].cpu().reshape(p[k].shape), p[k].grad), k) for k in sd)
+    assert worst[0] < 6e-2, worst
+    assert rel_err(dx.float().cpu(), xr.grad) < 6e-2
+    if avg and depth == 0 and (t % ds[0] or hw % ds[1]):       # floor: pixels past the last window carry exactly no gradient (no RegStage in front)
+        d4 = dx.float().cpu().view(t, hw, hw, cin)
+        assert float(d4[:, (hw // ds[1]) * ds[1]:].abs().max() if hw % ds[1] else 0.0) == 0.0
+        assert float(d4[(t // ds[0]) * ds[0]:].abs().max() if t % ds[0] else 0.0) == 0.0
+
+
 def _mm_tiny_model():
     """tiny tower + STC-v35 connector + decoder with a one-video sample (weights from the oracle's generators)"""
     from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM

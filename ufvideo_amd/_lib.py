@@ -79,7 +79,9 @@ SIGNATURES = {
     "ufv_dwconv3x3_dw": [_p, _p, _p, _i, _i, _i, _i, _p, _p],
     "ufv_prod_colsum": [_p, _p, _i, _i, _i, _p, _p],
     "ufv_scale_add_bcast": [_p, _p, _p, _f, _p, _i, _i, _i, _p],
-    "ufv_conv3d_scatter": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ufv_conv3d_scatter": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ufv_avgpool3d": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "ufv_avgpool3d_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "ufv_sample_top_p": [_p, _l, _i, _i, _f, _i, _f, _p, _p, _p, _p],
     "ufv_transpose_bf16": [_p, _l, _p, _l, _i, _i, _i, _p],
     "ufv_rmsnorm_bwd": [_p, _i, _p, _p, _i, _p, _i, _i, _p, _i, _i, _i, _f, _p, _p],

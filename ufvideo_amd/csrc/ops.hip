@@ -541,6 +541,7 @@ __global__ __launch_bounds__(256) void scale_channels_k(bf16* x, const bf16* gat
 }
 
 // AvgPool3d(k = stride = (kt,kh,kw), no padding, floor) + SiLU over token-major x [T,H,W,C] (STP / spatial_pool sampler)
+template <int ACT>
 __global__ __launch_bounds__(256) void avgpool3d_silu_k(const bf16* x, bf16* out, int T, int H, int W, int C, int kt, int kh, int kw,
                                                         int To, int Ho, int Wo) {
     const int cv = C / 8;
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256) void avgpool3d_silu_k(const bf16* x, bf16* out
                 }
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)act_apply_t<ACT_SILU>(acc[j] * inv);
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)act_apply_t<ACT>(acc[j] * inv);
         *reinterpret_cast<bf16x8*>(out + p * C + c) = o;
     }
 }
@@ -941,7 +942,18 @@ extern "C" int ufv_avgpool3d_silu(const void* x, void* out, int T, int H, int W,
     UFV_REQUIRE(x && out && C % 8 == 0 && kt > 0 && kh > 0 && kw > 0, "ufv_avgpool3d_silu: C must be a multiple of 8");
     const int To = T / kt, Ho = H / kh, Wo = W / kw;
     UFV_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "ufv_avgpool3d_silu: empty output");
-    hipLaunchKernelGGL(avgpool3d_silu_k, dim3(grid_for((int64_t)To * Ho * Wo * (C / 8))), dim3(256), 0, ST(stream), (const bf16*)x,
+    hipLaunchKernelGGL(avgpool3d_silu_k<ACT_SILU>, dim3(grid_for((int64_t)To * Ho * Wo * (C / 8))), dim3(256), 0, ST(stream), (const bf16*)x,
+                       (bf16*)out, T, H, W, C, kt, kh, kw, To, Ho, Wo);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+// the same pooling without the activation (training keeps the pre-activation: train_projector.py)
+extern "C" int ufv_avgpool3d(const void* x, void* out, int T, int H, int W, int C, int kt, int kh, int kw, void* stream) {
+    UFV_REQUIRE(x && out && C % 8 == 0 && kt > 0 && kh > 0 && kw > 0, "ufv_avgpool3d: C must be a multiple of 8");
+    const int To = T / kt, Ho = H / kh, Wo = W / kw;
+    UFV_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "ufv_avgpool3d: empty output");
+    hipLaunchKernelGGL(avgpool3d_silu_k<ACT_NONE>, dim3(grid_for((int64_t)To * Ho * Wo * (C / 8))), dim3(256), 0, ST(stream), (const bf16*)x,
                        (bf16*)out, T, H, W, C, kt, kh, kw, To, Ho, Wo);
     UFV_CHECK_LAUNCH();
     return UFV_OK;

@@ -461,8 +461,11 @@ __global__ __launch_bounds__(256) void scale_add_bcast_k(const bf16* __restrict_
 
 // inverse of conv3d_gather for padding 0 and stride = kernel (non-overlapping windows): dx[t,y,x,:] = dA[(to,ho,wo),(dt,dh,dw),:];
 // positions outside every window (odd trailing rows) get zeros
+// POOL: dA is [To*Ho*Wo, C] (gradient of an average-pooled value, shared by the window's taps and scaled by 1 / taps) instead of the Conv3d
+// patch matrix [To*Ho*Wo, taps*C]
+template <bool POOL>
 __global__ __launch_bounds__(256) void conv3d_scatter_k(const bf16* __restrict__ dA, bf16* __restrict__ dx, int T, int H, int W, int C, int kt, int kh,
-                                                        int kw, int To, int Ho, int Wo) {
+                                                        int kw, int pad, int To, int Ho, int Wo) {
     const int cv = C >> 3;
     const int64_t total = (int64_t)T * H * W * cv;
     for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
@@ -471,12 +474,21 @@ __global__ __launch_bounds__(256) void conv3d_scatter_k(const bf16* __restrict__
         const int x = p % W; p /= W;
         const int y = p % H;
         const int t = (int)(p / H);
-        const int to = t / kt, ho = y / kh, wo = x / kw;
+        // kernel = stride: a pixel (shifted by the zero padding) lies in exactly one window, or past the last one
+        const int tp = t + pad, yp = y + pad, xp = x + pad;
+        const int to = tp / kt, ho = yp / kh, wo = xp / kw;
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (to < To && ho < Ho && wo < Wo) {
             const int64_t r = ((int64_t)to * Ho + ho) * Wo + wo;
-            const int tap = ((t % kt) * kh + (y % kh)) * kw + (x % kw);
-            v = *reinterpret_cast<const bf16x8*>(dA + (r * (kt * kh * kw) + tap) * C + c8 * 8);
+            if (POOL) {
+                const bf16x8 d = *reinterpret_cast<const bf16x8*>(dA + r * C + c8 * 8);
+                const float inv = 1.0f / (kt * kh * kw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)d[j] * inv);
+            } else {
+                const int tap = ((tp % kt) * kh + (yp % kh)) * kw + (xp % kw);
+                v = *reinterpret_cast<const bf16x8*>(dA + (r * (kt * kh * kw) + tap) * C + c8 * 8);
+            }
         }
         reinterpret_cast<bf16x8*>(dx)[id] = v;
     }
@@ -597,12 +609,22 @@ extern "C" int ufv_scale_add_bcast(const void* a, const void* g, const float* s,
     return UFV_OK;
 }
 
-extern "C" int ufv_conv3d_scatter(const void* dA, void* dx, int T, int H, int W, int C, int kt, int kh, int kw, void* stream) {
-    UFV_REQUIRE(dA && dx && C % 8 == 0 && kt > 0 && kh > 0 && kw > 0, "ufv_conv3d_scatter: C must be a multiple of 8");
-    const int To = (T - kt) / kt + 1, Ho = (H - kh) / kh + 1, Wo = (W - kw) / kw + 1;
+extern "C" int ufv_conv3d_scatter(const void* dA, void* dx, int T, int H, int W, int C, int kt, int kh, int kw, int pad, void* stream) {
+    UFV_REQUIRE(dA && dx && C % 8 == 0 && kt > 0 && kh > 0 && kw > 0 && pad >= 0, "ufv_conv3d_scatter: C must be a multiple of 8");
+    const int To = (T + 2 * pad - kt) / kt + 1, Ho = (H + 2 * pad - kh) / kh + 1, Wo = (W + 2 * pad - kw) / kw + 1;
     UFV_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "ufv_conv3d_scatter: empty output");
-    hipLaunchKernelGGL(conv3d_scatter_k, dim3(grid_for((int64_t)T * H * W * (C / 8))), dim3(256), 0, ST(stream), (const bf16*)dA, (bf16*)dx, T, H,
-                       W, C, kt, kh, kw, To, Ho, Wo);
+    hipLaunchKernelGGL(conv3d_scatter_k<false>, dim3(grid_for((int64_t)T * H * W * (C / 8))), dim3(256), 0, ST(stream), (const bf16*)dA, (bf16*)dx, T, H,
+                       W, C, kt, kh, kw, pad, To, Ho, Wo);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_avgpool3d_bwd(const void* dy, void* dx, int T, int H, int W, int C, int kt, int kh, int kw, void* stream) {
+    UFV_REQUIRE(dy && dx && C % 8 == 0 && kt > 0 && kh > 0 && kw > 0, "ufv_avgpool3d_bwd: C must be a multiple of 8");
+    const int To = T / kt, Ho = H / kh, Wo = W / kw;
+    UFV_REQUIRE(To > 0 && Ho > 0 && Wo > 0, "ufv_avgpool3d_bwd: empty output");
+    hipLaunchKernelGGL(conv3d_scatter_k<true>, dim3(grid_for((int64_t)T * H * W * (C / 8))), dim3(256), 0, ST(stream), (const bf16*)dy, (bf16*)dx, T, H,
+                       W, C, kt, kh, kw, 0, To, Ho, Wo);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }

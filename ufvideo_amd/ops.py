@@ -696,10 +696,26 @@ def scale_add_bcast(a, g, s, k, F, P):
     return out
 
 
-def conv3d_scatter(dA, T, H, W, C, k):
+def conv3d_scatter(dA, T, H, W, C, k, pad=0):
     _chk(dA, torch.bfloat16, "dA"); assert dA.is_contiguous()
     dx = torch.empty((T * H * W, C), device=dA.device, dtype=torch.bfloat16)
-    _lib.call("ufv_conv3d_scatter", dA.data_ptr(), dx.data_ptr(), T, H, W, C, k[0], k[1], k[2], _stream())
+    _lib.call("ufv_conv3d_scatter", dA.data_ptr(), dx.data_ptr(), T, H, W, C, k[0], k[1], k[2], pad, _stream())
+    return dx
+
+
+def avgpool3d(x, T, H, W, C, k):
+    """AvgPool3d(k) without the activation: x bf16 [T*H*W, C] -> (bf16 [To*Ho*Wo, C], (To, Ho, Wo))"""
+    _chk(x, torch.bfloat16, "x"); assert x.is_contiguous()
+    To, Ho, Wo = T // k[0], H // k[1], W // k[2]
+    out = torch.empty((To * Ho * Wo, C), device=x.device, dtype=torch.bfloat16)
+    _lib.call("ufv_avgpool3d", x.data_ptr(), out.data_ptr(), T, H, W, C, k[0], k[1], k[2], _stream())
+    return out, (To, Ho, Wo)
+
+
+def avgpool3d_bwd(dy, T, H, W, C, k):
+    _chk(dy, torch.bfloat16, "dy"); assert dy.is_contiguous()
+    dx = torch.empty((T * H * W, C), device=dy.device, dtype=torch.bfloat16)
+    _lib.call("ufv_avgpool3d_bwd", dy.data_ptr(), dx.data_ptr(), T, H, W, C, k[0], k[1], k[2], _stream())
     return dx
 
 

@@ -36,8 +36,8 @@ def _lin_bwd(x, w, dy, want_dx=True):
 
 class ProjectorGrad:
     def __init__(self, proj):
-        if not isinstance(proj, STCConnector) or proj.AVGPOOL or proj.PADDING != 0:
-            raise NotImplementedError("projector backward is built for the Conv3d connectors with padding 0 (stc_connector_v35)")
+        if not isinstance(proj, STCConnector):
+            raise NotImplementedError("projector backward is built for the STC family (stc_connector[_v35], stp_connector, spatial_conv, spatial_pool)")
         if getattr(proj, "gemm_dtype", "bf16") != "bf16":
             raise NotImplementedError("training runs on the bf16 weights")
         self.proj = proj
@@ -77,9 +77,12 @@ class ProjectorGrad:
             st["s1"].append(s)
         C = h.shape[1]
         st["h_pre_sampler_shape"] = (t, hw, hw, C)
-        A, (To, Ho, Wo) = ops.conv3d_gather(h, t, hw, hw, C, pj.downsample, 0)
-        st["A"] = A
-        st["samp_pre"] = ops.gemm(A, pk["samp_w"], bias=pk["samp_b"])
+        if pj.AVGPOOL:                                       # nn.AvgPool3d + SiLU (stp_connector / spatial_pool)
+            st["samp_pre"], (To, Ho, Wo) = ops.avgpool3d(h.contiguous(), t, hw, hw, C, pj.downsample)
+        else:                                                # Conv3d, kernel = stride, padding 0 (v35) or 1 (stc_connector / spatial_conv)
+            A, (To, Ho, Wo) = ops.conv3d_gather(h, t, hw, hw, C, pj.downsample, pj.PADDING)
+            st["A"] = A
+            st["samp_pre"] = ops.gemm(A, pk["samp_w"], bias=pk["samp_b"])
         h = ops.act_fwd(st["samp_pre"], "silu")
         for blk in (pk["s2"] if pj.depth else []):
             h, s = self._block_fwd(h, blk, To, Ho, Wo)
@@ -164,13 +167,16 @@ class ProjectorGrad:
         for i in range(len(st["s2"]) - 1, -1, -1):
             d = self._block_bwd(d, pk["s2"][i], st["s2"][i], g, f"s2.b{i + 1}.")
         d = ops.act_bwd(st["samp_pre"], d, "silu")
-        C = pk["samp_w"].shape[0]
-        g["sampler.0.bias"] = ops.colsum(d, torch.zeros((C,), device=d.device, dtype=torch.float32))
-        dA, dws = _lin_bwd(st["A"], pk["samp_w"], d)
-        kt, kh, kw = pj.downsample
-        g["sampler.0.weight"] = dws.view(C, kt, kh, kw, -1).permute(0, 4, 1, 2, 3).contiguous()
         t, hh, ww, Cc = st["h_pre_sampler_shape"]
-        d = ops.conv3d_scatter(dA, t, hh, ww, Cc, pj.downsample)
+        if pj.AVGPOOL:
+            d = ops.avgpool3d_bwd(d.contiguous(), t, hh, ww, Cc, pj.downsample)
+        else:
+            C = pk["samp_w"].shape[0]
+            g["sampler.0.bias"] = ops.colsum(d, torch.zeros((C,), device=d.device, dtype=torch.float32))
+            dA, dws = _lin_bwd(st["A"], pk["samp_w"], d)
+            kt, kh, kw = pj.downsample
+            g["sampler.0.weight"] = dws.view(C, kt, kh, kw, -1).permute(0, 4, 1, 2, 3).contiguous()
+            d = ops.conv3d_scatter(dA, t, hh, ww, Cc, pj.downsample, pj.PADDING)
         for i in range(len(st["s1"]) - 1, -1, -1):
             d = self._block_bwd(d, pk["s1"][i], st["s1"][i], g, f"s1.b{i + 1}.")
         return g, d
