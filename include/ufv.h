@@ -43,7 +43,9 @@ extern "C" {
 #define UFV_GEMM_FAST256 4 /* 8-wave ping-pong MFMA kernel, 256x256x64 tile (large M) */
 #define UFV_GEMM_PP(shape) (4 | ((shape) << 8)) /* the ping-pong kernel at a named tile shape, 1000 + MA0 MA1 NB1 as decimal digits:
                                                 1442 = 256x256 (= UFV_GEMM_FAST256), 1432 = 224x256, 1332 = 192x256, 1322 = 160x256,
-                                                1441 = 256x192, 1431 = 224x192, 1331 = 192x192; N % tile width must be 0 or 128 */
+                                                1441 = 256x192, 1431 = 224x192, 1331 = 192x192; N % tile width must be 0 or 128.
+                                                + 10000 * parts: the aligned split-K form (fp32 output, no activation): the parts of a tile add into the
+                                                output in turn order, e.g. 41441 = 256x192 tiles, K in 4 parts */
 #define UFV_GEMM_STREAMK 5 /* the same kernel with stream-K work split: every CU gets the same number of K-tile iterations */
 
 /* dtype ids for inputs that may arrive in several formats */

@@ -352,13 +352,50 @@ def test_gemm_pingpong_tile_shapes_bitwise_equal_128_kernel(shape):
             ops.gemm(bf(g(256, 64, seed=1)), bf(g(512, 64, seed=2)), swiglu=True, kernel=kern)
 
 
+@pytest.mark.parametrize("shape,parts", [(1441, 4), (1442, 5), (1442, 2), (1432, 3), (1332, 7), (1322, 8), (1431, 6), (1331, 5)])
+def test_gemm_split_k_turn_ordered_sum(shape, parts):
+    """Aligned split-K of the ping-pong kernel (UFV_GEMM_PP(shape + 10000 * parts)): the parts of a tile add into the fp32 output in turn order,
+    so the result is deterministic (repeated launches bit-equal) and equals the unsplit product up to the different summation tree (parts partial
+    sums instead of one chain: <= 4e-6 of the output range); in place on the residual stream and with a separate residual + bias; ragged M,
+    an N ending on a half tile, more items than CUs (several rounds) and fewer; refused with an activation, a bf16 output or empty parts."""
+    bm, bn = PP_SHAPES[shape]
+    kern = ops.GEMM_FAST256 | ((shape + 10000 * parts) << 8)
+    full, ragged = (768, 640) if bn == 256 else (1152, 512)
+    for M, N, K in ((2399, full, 64 * parts * 3), (bm * 2 + 5, ragged, 64 * (parts * 3 - 1)), (300, full * 3, 64 * parts * 2)):
+        a, w = bf(g(M, K, seed=shape + parts)), bf(g(N, K, seed=shape + 2, scale=0.05))
+        bias, resid = g(N, seed=3), g(M, N, seed=4)
+        ref = ops.gemm(a, w, bias=bias, resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST)
+        outs = []
+        for _ in range(3):
+            x = resid.clone()
+            ops.gemm(a, w, bias=bias, resid=x, out=x, kernel=kern)                  # in place, as the decoder calls it
+            outs.append(x)
+        assert rel(outs[0], ref) < 4e-6, (shape, parts, M, N, K, rel(outs[0], ref))
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        y = torch.full((M, N), float("nan"), device=DEV)                              # out of place: every element is written by part 0
+        ops.gemm(a, w, bias=bias, resid=resid, out=y, kernel=kern)
+        assert torch.equal(y, outs[0])
+        assert torch.equal(ops.gemm(a, w, out_dtype=torch.float32, kernel=kern), ops.gemm(a, w, out_dtype=torch.float32, kernel=kern))
+    a, w = bf(g(512, 64 * parts * 2, seed=1)), bf(g(full, 64 * parts * 2, seed=2))
+    with pytest.raises(_lib.UfvError, match="split-K"):
+        ops.gemm(a, w, act="gelu", out_dtype=torch.float32, kernel=kern)
+    with pytest.raises(_lib.UfvError, match="split-K"):
+        ops.gemm(a, w, kernel=kern)                                                   # bf16 output
+    with pytest.raises(_lib.UfvError, match="non-empty"):
+        ops.gemm(bf(g(512, 64 * (parts - 1), seed=1)), bf(g(full, 64 * (parts - 1), seed=2)), out_dtype=torch.float32, kernel=kern)
+
+
 def test_gemm_auto_choice_matches_every_kernel_it_can_pick():
     """GEMM_AUTO routes by a cost model (csrc/gemm.hip choose_kernel); whatever it picks at the config-#2 shapes and around them, the
     result is the 128-wide kernel's, bit for bit."""
     for M, N, K, f32 in ((2399, 3584, 512, True), (2399, 4608, 256, False), (18432, 1152, 128, True), (4703, 3584, 192, True), (2304, 3584, 128, False),
-                         (1000, 1152, 1152, True), (257, 128, 64, False)):
+                         (1000, 1152, 1152, True), (257, 128, 64, False), (2399, 3584, 18944, True), (300, 3584, 18944, True)):
         a, w = bf(g(M, K, seed=M % 97)), bf(g(N, K, seed=N % 89, scale=0.05))
-        if f32:
+        if f32 and K >= 4096:                        # long K with few tiles: the model may take a split-K form (a different summation tree)
+            resid = g(M, N, seed=5)
+            got, want = ops.gemm(a, w, resid=resid, out_dtype=torch.float32), ops.gemm(a, w, resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST)
+            assert rel(got, want) < 4e-6 and torch.equal(got, ops.gemm(a, w, resid=resid, out_dtype=torch.float32))
+        elif f32:
             resid = g(M, N, seed=5)
             assert torch.equal(ops.gemm(a, w, resid=resid, out_dtype=torch.float32), ops.gemm(a, w, resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST))
         else:

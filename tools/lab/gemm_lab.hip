@@ -21,6 +21,7 @@ void ufv_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprin
 extern "C" const char* ufv_last_error(void) { return ""; }
 #include "../../ufvideo_amd/csrc/gemm256.hip"
 #include "../../ufvideo_amd/csrc/gemm256_b.hip"
+#include "../../ufvideo_amd/csrc/gemm256_s.hip"
 int ufv_launch_pp_shape_fp8(const void*, const void*, const Epi&, int, int, int, int, int, bool, int, hipStream_t) { return 1; }
 
 static inline uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }

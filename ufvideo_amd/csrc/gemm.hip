@@ -14,6 +14,7 @@
 // Generic kernel: any shape/alignment, one thread per output, used for tiny problems
 // (region encoder, SE gates, tiny test models).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/ufv.h"
 #include "gemm_epi.h"
 
@@ -546,7 +547,10 @@ inline int pick_mt(int M, int N) {
 struct PPShape { int code, ma0, ma1, nb1; };
 constexpr PPShape PP_SHAPES[] = {{1442, 4, 4, 2}, {1432, 4, 3, 2}, {1332, 3, 3, 2}, {1322, 3, 2, 2}, {1441, 4, 4, 1}, {1431, 4, 3, 1}, {1331, 3, 3, 1}};
 
-inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu) {
+// split-K forms (aligned split, gemm256_kernel.h KSPL; fp32 output without activation only): items = tiles x parts in rounds of 256, a part's seam
+// carries the turn-ordered read-modify-write of its tile (+12000 ticks); taken when the model sees at least 5 % over the best unsplit kernel --
+// in practice the decoder's `down` projection (M = 2399: 140 tiles of 256x256 for 296 K-tiles; 348 -> ~270 us) and its 64-frame form.
+inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool can_split = false) {
     const double nk = K / 64.0, c_out = out_f32 ? 0.33 : 0.183;
     double best = 1e30;
     int pick = 0;
@@ -566,6 +570,25 @@ inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu) {
         const double tk = 2.0 * ((pa > 500 ? pa : 500) + (pb > 500 ? pb : 500));
         const double c = (double)((t + 255) / 256) * (nk * tk + 2500.0 + (double)bm * bn * c_out);
         if (c < best) { best = c; pick = s.code; }
+    }
+    if (can_split && out_f32 && !swiglu && K % 64 == 0) {
+        // regression over 31 measured (shape, parts) runs of tools/gemm_splitk.py (within 5 % of all but the 3-part splits, which it flatters
+        // by 16 %: parts >= 4 only): us = rounds * (K-tiles per part * (1.114 a + 0.328 r) + 2.73 a + 14.63), a = tile area / 256^2, r = operand
+        // rows staged per K-tile / 512 (a 96-row half is staged as 128); 1389 ticks per us on the box the unsplit model's ticks were fitted on
+        const int nkt = K / 64;
+        double best_split = best * 0.95;
+        for (const PPShape& s : PP_SHAPES) {
+            const int bm = 32 * (s.ma0 + s.ma1), bn = 128 + 64 * s.nb1;
+            if (N % bn != 0 && N % bn != 128) continue;
+            const long t = (long)cdiv(M, bm) * cdiv(N, bn);
+            const double a = (double)bm * bn / 65536.0, r = ((s.ma0 > 2 ? 128 : 64) + (s.ma1 > 2 ? 128 : 64) + 128 + 64 * s.nb1) / 512.0;
+            for (int parts = 4; parts <= 8; ++parts) {
+                const int per = cdiv(nkt, parts);
+                if ((parts - 1) * per >= nkt || per < 24) continue;
+                const double c = 1389.0 * (double)((t * parts + 255) / 256) * (per * (1.114 * a + 0.328 * r) + 2.73 * a + 14.63);
+                if (c < best_split) { best_split = c; pick = s.code + 10000 * parts; }
+            }
+        }
     }
     return pick;
 }
@@ -623,7 +646,7 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
     if (force == UFV_GEMM_STREAMK) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, true, 0, st);
     if (force == UFV_GEMM_FAST256) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, shape, st);
     if (force == UFV_GEMM_AUTO && big_ok) {
-        const int pick = choose_kernel(M, N, Q ? K / 2 : K, F, S);
+        const int pick = choose_kernel(M, N, Q ? K / 2 : K, F, S, !Q && e.act == ACT_NONE && e.resid_rows == 0 && getenv("UFV_GEMM_NO_SPLITK") == nullptr);
         if (pick) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, pick, st);
     }
     if ((force == UFV_GEMM_AUTO && fast_ok && M > 64) || force == UFV_GEMM_FAST)

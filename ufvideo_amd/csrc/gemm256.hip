@@ -26,7 +26,15 @@ static int streamk_state(int grid, StreamK* out) {
 
 template <bool F, bool S, bool Q>
 static int launch256_t(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool streamk, int shape, hipStream_t st) {
-    // shape: 0 / 1442 = the 256x256 tile; other codes (1000 + MA0 MA1 NB1, plain epilogues only) are built in gemm256_b.hip / gemm256_q.hip
+    // shape: 0 / 1442 = the 256x256 tile; other codes (1000 + MA0 MA1 NB1, plain epilogues only) are built in gemm256_b.hip / gemm256_q.hip;
+    // + 10000 * parts = the split-K form of that shape (gemm256_s.hip)
+    if (shape >= 10000) {
+        if (!F || S || Q) {
+            ufv_set_error("ufv_gemm: split-K is built for bf16 operands with an fp32 output (no SwiGLU)");
+            return UFV_EUNSUPPORTED;
+        }
+        return ufv_launch_pp_split(A, W, e, M, N, K, lda, ldw, shape % 10000, shape / 10000, st);
+    }
     if (shape != 0 && shape != 1442) {
         if constexpr (S) {
             ufv_set_error("ufv_gemm: the SwiGLU epilogue is built for the 256x256 tile only");
@@ -51,7 +59,7 @@ static int launch256_t(const void* A, const void* W, const Epi& e, int M, int N,
         const int tiles = cdiv(M, 256) * cdiv(N, 256);
         const int nk = K / (Q ? 128 : 64);
         if ((long long)tiles * nk < n_cu) return launch_pp<F, S, Q, 4, 4, 2, true>(A, W, e, M, N, K, lda, ldw, st);
-        StreamK sk = {nullptr, nullptr, 0, pp_group(cdiv(M, 256))};
+        StreamK sk = {nullptr, nullptr, 0, pp_group(cdiv(M, 256)), 1};
         const int rc = streamk_state(n_cu, &sk);
         if (rc != UFV_OK) return rc;
         hipLaunchKernelGGL((gemm_nt_256<F, S, Q, true>), dim3(n_cu), dim3(512), SMEM256, st, A, W, e, M, N, K, lda, ldw, sk);

@@ -86,6 +86,85 @@ __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2 + NB1][MA0 + MA
     }
 }
 
+// Split-K part of a tile (KSPL kernels): out (+)= acc in TURN order part 0, 1, ... (deterministic sum).  Part 0 stores acc + bias + residual;
+// a later part adds its accumulators to what the earlier parts left in `out`.  The parts of a tile run on different XCDs, whose L2s are not
+// coherent: the tile is read and written with system-scope (sc0 sc1) accesses, two accumulator rows per round trip.
+template <int MA0, int MA1, int NB1>
+__device__ __forceinline__ void epilogue_split(const f32x4 (&acc)[2 + NB1][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc, int frow,
+                                               int fq, const f32x4 (&bias)[2 + NB1], bool first) {
+    constexpr int MT = MA0 + MA1, NT = 2 + NB1;
+    float* out = reinterpret_cast<float*>(e.out);
+    int ncol[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ncol[nt] = n0 + (nt < 2 ? wc * 32 + nt * 16 : 128 + wc * 16 * NB1 + (nt - 2) * 16) + fq * 4;
+        nok[nt] = n0 + (nt < 2 ? 0 : 128) < N;
+    }
+    auto row_of = [&](int mt) { return m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow; };
+    auto store_row = [&](int m, const f32x4 (&v)[NT]) {
+        if (m < M) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (nok[nt]) {
+                    float* pp = out + (size_t)m * e.ldc + ncol[nt];
+                    // (s_nop: a store wider than 64 bits still reads its data registers for a cycle after issue; inside inline asm the
+                    //  compiler cannot see that and re-used them for the next address at once -- corrupted rows on hardware)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(pp), "v"(v[nt]) : "memory");
+                }
+        }
+    };
+    if (first) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = row_of(mt);
+            f32x4 v[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                v[nt] = acc[nt][mt] + bias[nt];
+                if (e.resid && m < M && nok[nt]) {
+                    const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
+                    v[nt] += *reinterpret_cast<const f32x4*>(e.resid + (size_t)mr * e.ldr + ncol[nt]);
+                }
+            }
+            store_row(m, v);
+        }
+        return;
+    }
+    // later parts: read-modify-write, TWO accumulator rows per memory round trip (clamped rows / half-tiles past the edge are loaded, never stored)
+    const int c2 = min(ncol[2], N - 4), c3 = NT == 4 ? min(ncol[NT - 1], N - 4) : 0;
+#pragma unroll
+    for (int mp = 0; mp < MT; mp += 2) {
+        const int ma = row_of(mp), mb = mp + 1 < MT ? row_of(mp + 1) : ma;
+        const float* ra = out + (size_t)min(ma, M - 1) * e.ldc;
+        const float* rb = out + (size_t)min(mb, M - 1) * e.ldc;
+        f32x4 a0, a1, a2, a3 = {0, 0, 0, 0}, b0, b1, b2, b3 = {0, 0, 0, 0};
+        if constexpr (NT == 4)
+            asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+                         : "v"(ra + ncol[0]), "v"(ra + ncol[1]), "v"(ra + c2), "v"(ra + c3), "v"(rb + ncol[0]), "v"(rb + ncol[1]), "v"(rb + c2), "v"(rb + c3)
+                         : "memory");
+        else
+            asm volatile("global_load_dwordx4 %0, %6, off sc0 sc1\n\tglobal_load_dwordx4 %1, %7, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %2, %8, off sc0 sc1\n\tglobal_load_dwordx4 %3, %9, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %4, %10, off sc0 sc1\n\tglobal_load_dwordx4 %5, %11, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(b0), "=&v"(b1), "=&v"(b2)
+                         : "v"(ra + ncol[0]), "v"(ra + ncol[1]), "v"(ra + c2), "v"(rb + ncol[0]), "v"(rb + ncol[1]), "v"(rb + c2) : "memory");
+        f32x4 va[NT], vb[NT];
+        va[0] = acc[0][mp] + a0; va[1] = acc[1][mp] + a1; va[2] = acc[2][mp] + a2;
+        if constexpr (NT == 4) va[3] = acc[3][mp] + a3;
+        store_row(ma, va);
+        if (mp + 1 < MT) {
+            vb[0] = acc[0][mp + 1] + b0; vb[1] = acc[1][mp + 1] + b1; vb[2] = acc[2][mp + 1] + b2;
+            if constexpr (NT == 4) vb[3] = acc[3][mp + 1] + b3;
+            store_row(mb, vb);
+        }
+    }
+}
+
 // FP8: e4m3 operands, K-tile = 128 elements (the same 128-byte LDS rows and DMA pattern), 8 x v_mfma_f32_16x16x128_f8f6f4
 // per phase instead of 16 x 16x16x32_bf16; accumulators are scaled by scale_m[row] * scale_n[col] before the epilogue.
 //
@@ -101,6 +180,7 @@ struct StreamK {
     int* flags;         // [grid]
     int epoch;          // value that marks "slot written during THIS launch"
     int gm;             // row-tiles per group of the tile order (concurrent tiles of a group share A / W panels in L2)
+    int ksplit;         // KSPL kernels: K parts per tile (items = tiles x parts, part-major), turn flags in `flags`, `epoch` = this launch's flag base
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -109,7 +189,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // reads A1 and multiplies the bottom half with the B fragments still in registers.  Half as many barrier steps per K-tile, each twice
 // as long; staging: A1[t+1] in phase A of K-tile t, A0 / B0 / B1 [t+2] in phase B (every half-tile is re-staged two barrier steps after its
 // last reader and lands six steps = 1.5 K-tiles before its first).
-template <bool OUT_F32, bool SWIGLU, bool FP8, bool SKT, int MA0 = 4, int MA1 = 4, int NB1 = 2, bool PH2 = false>
+// KSPL: aligned split-K for outputs with few tiles and a long K (the decoder's `down` projection: 140 tiles of 256x256 on 256 CUs).  Items
+// are (part, tile) in part-major order, every part a contiguous range of K-tiles, so the blocks of a round run the SAME K range of
+// neighbouring tiles and keep sharing A / W panels in L2 (free-running stream-K ranges do not: they re-read every panel from HBM).  The parts of
+// a tile add into the fp32 output in turn order (epilogue_split) -- deterministic, no workspace; needs act == none and one block per CU.
+template <bool OUT_F32, bool SWIGLU, bool FP8, bool SKT, int MA0 = 4, int MA1 = 4, int NB1 = 2, bool PH2 = false, bool KSPL = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ Av, const void* __restrict__ Wv, Epi e, int M,
                                                        int N, int K, int lda, int ldw, StreamK sk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -117,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     using T = PP<MA0, MA1, NB1>;
     constexpr int MT = T::MT, NT = T::NT, BM = T::BM, BN = T::BN;
     static_assert(!SKT || (MA0 == 4 && MA1 == 4 && NB1 == 2), "the stream-K fix-up is written for the 256x256 tile image");
+    static_assert(!KSPL || (OUT_F32 && !SWIGLU && !FP8 && !SKT && PH2), "split-K parts accumulate into an fp32 output");
     const char* A = reinterpret_cast<const char*>(Av);
     const char* W = reinterpret_cast<const char*>(Wv);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -145,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     long long cur = SK ? range_lo(pos) : 0;
     const long long hi = SK ? range_lo(pos + 1) : 0;
     int round = 0;
+    int item_part = 0, item_tile = 0;          // KSPL: the item next_item() handed out last
     // next work item: tile (m0_, n0_) and its K-tile range [k0_, k1_)
     auto next_item = [&](int& m0_, int& n0_, int& k0_, int& k1_) -> bool {
         if (SK) {
@@ -156,13 +242,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             tile_coords(tile, m0_, n0_);
             return true;
         }
+        const int items = KSPL ? nwg * sk.ksplit : nwg;
         const int base = round * G;
-        const int cnt = min(G, nwg - base);          // tiles in this round
+        const int cnt = min(G, items - base);        // items in this round
         const int bid = blockIdx.x;
         ++round;
         if (bid >= cnt) return false;
         const int q = cnt >> 3, r = cnt & 7, x = bid & 7;
-        tile_coords(base + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3), m0_, n0_);
+        const int id = base + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+        if constexpr (KSPL) {
+            const int per = (nk + sk.ksplit - 1) / sk.ksplit;
+            item_part = id / nwg; item_tile = id - item_part * nwg;
+            tile_coords(item_tile, m0_, n0_);
+            k0_ = item_part * per; k1_ = min(nk, k0_ + per);
+            return true;
+        }
+        tile_coords(id, m0_, n0_);
         k0_ = 0; k1_ = nk;
         return true;
     };
@@ -359,12 +454,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     f32x4 bias[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bias[nt] = f32x4{0, 0, 0, 0};
-    if (!part_tail && !SWIGLU && e.bias) {
+    if (!part_tail && !SWIGLU && e.bias && (!KSPL || item_part == 0)) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(e.bias + col_of(nt));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const int cm0 = m0, cn0 = n0;
+    const int cm0 = m0, cn0 = n0, cpart = item_part, ctile = item_tile, clen = len;
     have = next_item(m0, n0, k0, k1);
     if (have) { set_src(m0, n0); kbeg = k0; kend = k1; prologue_loads(); }
     if constexpr (SK) if (part_head) {
@@ -406,6 +501,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             __syncthreads();                                        // ... before one thread publishes the slot
             if (tid == 0) __hip_atomic_store(sk.flags + pos, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    } else if constexpr (KSPL) {
+        // turn order: part p of a tile stores after part p - 1 has (flag = base + p); a part with an empty K range only passes the turn on
+        if (cpart > 0) {
+            if (tid == 0)
+                while (__hip_atomic_load(sk.flags + ctile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch + cpart) __builtin_amdgcn_s_sleep(2);
+            __syncthreads();
+        }
+        if (clen > 0 || cpart == 0) epilogue_split<MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias, cpart == 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave's write-through stores are acknowledged ...
+        __syncthreads();                                            // ... before one thread passes the turn on
+        if (tid == 0) __hip_atomic_store(sk.flags + ctile, sk.epoch + cpart + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_, false, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias)))
     }
@@ -431,11 +537,30 @@ static inline int pp_n_cu() {
 // made its XCDs fetch 16 W panels per round instead of 4; 1203 -> 1244 TF/s on gate/up), else ~8 in equal groups
 static inline int pp_group(int tiles_m) { return tiles_m <= 16 ? tiles_m : cdiv(tiles_m, cdiv(tiles_m, 8)); }
 
-template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false>
-static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
+// turn flags of the split-K kernels: one int per tile, grow-only; every launch takes a fresh base so that nothing needs clearing
+static inline int splitk_flags(int tiles, int** flags, int* base) {
+    static int* buf = nullptr;
+    static int cap = 0, epoch = 0;
+    if (tiles > cap || epoch > (1 << 30)) {
+        if (buf) (void)hipFree(buf);
+        buf = nullptr; cap = 0;
+        const int n = tiles > 4096 ? tiles : 4096;
+        if (hipMalloc(&buf, (size_t)n * sizeof(int)) != hipSuccess || hipMemset(buf, 0, (size_t)n * sizeof(int)) != hipSuccess) {
+            ufv_set_error("ufv_gemm: could not allocate the split-K turn flags (%d tiles)", tiles);
+            return UFV_EHIP;
+        }
+        cap = n; epoch = 0;
+    }
+    epoch += 64;
+    *flags = buf; *base = epoch;
+    return UFV_OK;
+}
+
+template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false>
+static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st, int ksplit = 1) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM256);
         attr_set = true;
     }
@@ -446,8 +571,20 @@ static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, i
         return UFV_EUNSUPPORTED;
     }
     const int tiles_m = cdiv(M, T::BM), tiles = tiles_m * cdiv(N, T::BN), n_cu = pp_n_cu();
-    StreamK sk = {nullptr, nullptr, 0, pp_group(tiles_m)};
-    hipLaunchKernelGGL((gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), SMEM256, st, A, W, e, M, N, K,
+    StreamK sk = {nullptr, nullptr, 0, pp_group(tiles_m), 1};
+    int items = tiles;
+    if constexpr (KSPL) {
+        const int nk = K / 64;
+        if (e.act != ACT_NONE || ksplit < 2 || ksplit > 32 || (ksplit - 1) * cdiv(nk, ksplit) >= nk) {
+            ufv_set_error("ufv_gemm: split-K needs an activation-free epilogue and 2 <= parts <= 32 non-empty K ranges (parts=%d, K-tiles=%d)", ksplit, nk);
+            return UFV_EUNSUPPORTED;
+        }
+        const int rc = splitk_flags(tiles, &sk.flags, &sk.epoch);
+        if (rc != UFV_OK) return rc;
+        sk.ksplit = ksplit;
+        items = tiles * ksplit;
+    }
+    hipLaunchKernelGGL((gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL>), dim3(items < n_cu ? items : n_cu), dim3(512), SMEM256, st, A, W, e, M, N, K,
                        lda, ldw, sk);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
@@ -456,6 +593,8 @@ static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, i
 // the named tile shapes live in their own translation units (gemm256_b.hip: bf16 operands, gemm256_q.hip: e4m3), one build job each
 int ufv_launch_pp_shape_bf16(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32, int shape, hipStream_t st);
 int ufv_launch_pp_shape_fp8(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32, int shape, hipStream_t st);
+// gemm256_s.hip: the split-K instantiations (bf16 operands, fp32 output)
+int ufv_launch_pp_split(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int shape, int ksplit, hipStream_t st);
 
 template <bool F, bool Q>
 static int launch_pp_shape(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int shape, hipStream_t st) {

@@ -54,7 +54,7 @@ __device__ __forceinline__ void epi_store4b(const Epi& e, int m, int n, float v0
         // ours; sc0 sc1 makes the line visible in memory when the store is acknowledged -- no L2 write-back fence needed.
         f32x4 o = {v0, v1, v2, v3};
         float* p = reinterpret_cast<float*>(e.out) + (size_t)m * e.ldc + n;
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(o) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(p), "v"(o) : "memory");       // s_nop: store-data hazard the compiler cannot see inside asm
         return;
     }
     float v[4] = {v0, v1, v2, v3};      // b = bias already in registers (zeros when there is none)
