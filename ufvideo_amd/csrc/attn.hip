@@ -193,45 +193,12 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 ? 3 : 2)) void attn_fwd_mfma(Att
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-        // PIPE (head_dim 128: 256 registers at two waves per SIMD): all K fragments of the tile are requested before the first score
-        // MFMA, and the V^T fragments of the first two d-tiles behind the last one, so that the LDS latency (one exposed read per MFMA
-        // in the compiler's own schedule: `ds_read; s_waitcnt lgkmcnt(0); v_mfma` 16 + 16 times per tile) runs under the MFMAs and the
-        // softmax arithmetic; the remaining V^T reads are issued between the d-tiles of the second product.
-        constexpr bool PIPE = (HD == 128);
-        bf16x8 vf[PIPE ? DT : 1][4];
-        auto read_vt = [&](int dt) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const char* vp = vb + (16 * c) * PV + v_off + dt * 64;
-                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp));
-                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp + 8 * PV));
-                vf[PIPE ? dt : 0][c] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-        };
-        if constexpr (PIPE) {
-            bf16x8 kf[2 * KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                kf[2 * ks] = *reinterpret_cast<const bf16x8*>(kb + k_off + ks * 32);
-                kf[2 * ks + 1] = *reinterpret_cast<const bf16x8*>(kb + 32 * PK + k_off + ks * 32);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * ks], qf[ks], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * ks + 1], qf[ks], s1, 0, 0, 0);
-            }
-            read_vt(0);
-            read_vt(1);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kb + k_off + ks * 32);
             const bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kb + 32 * PK + k_off + ks * 32);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
-        }
         }
         // ---- masking only where a tile can contain invalid keys (sequence end / causal diagonal): wave-uniform
         bool need_mask = kbase_idx + 64 > a.Sk;
@@ -278,23 +245,16 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 ? 3 : 2)) void attn_fwd_mfma(Att
         pf[2] = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
         pf[3] = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
         // ---- O^T[d][q] += sum_key V[key][d] P[key][q]; V^T fragments via transposed LDS reads
-        if constexpr (PIPE) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][c], pf[c], oacc[dt], 0, 0, 0);
-                if (dt + 2 < DT) read_vt(dt + 2);                  // two d-tiles ahead, issued while this d-tile's MFMAs run
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            read_vt(dt);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)             // c = hh*2 + sp : 16-key chunk
-                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][c], pf[c], oacc[dt], 0, 0, 0);
-        }
+            for (int c = 0; c < 4; ++c) {           // c = hh*2 + sp : 16-key chunk
+                const char* vp = vb + (16 * c) * PV + v_off + dt * 64;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vp + 8 * PV));
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], oacc[dt], 0, 0, 0);
+            }
         }
         if (t + 1 < ntiles) write_lds((t + 1) & 1);
         __syncthreads();
