@@ -165,7 +165,11 @@ def attn_ref(q, k, v, causal, q_pos0=0):
     (72, 2, 2, 200, 200, True, 1), (72, 2, 1, 70, 300, True, 1), (72, 3, 3, 192, 192, False, 1), (72, 2, 2, 64, 64, False, 1),
     (72, 4, 4, 576, 576, False, 3), (72, 16, 16, 130, 130, False, 1), (72, 4, 4, 576, 576, False, 7), (72, 6, 6, 384, 500, False, 8),
     (72, 16, 16, 576, 576, False, 1), (72, 3, 3, 300, 100, False, 1), (72, 5, 5, 288, 576, False, 9),
-    (72, 16, 16, 576, 576, False, 11), (72, 3, 3, 288, 300, False, 11), (72, 2, 2, 864, 70, False, 11), (72, 4, 2, 288, 288, False, 0)])
+    (72, 16, 16, 576, 576, False, 11), (72, 3, 3, 288, 300, False, 11), (72, 2, 2, 864, 70, False, 11), (72, 4, 2, 288, 288, False, 0),
+    # head_dim 128 causal with the key split over two wave groups (kernel 12; 13 = the plain kernel; 0 picks by block count): odd tile counts, a
+    # single tile (group 1 idle), a cached prefix (q_pos0 > 0), GQA
+    (128, 8, 2, 300, 300, True, 12), (128, 4, 4, 257, 257, True, 12), (128, 8, 2, 40, 140, True, 12), (128, 4, 2, 50, 50, True, 12),
+    (128, 28, 4, 1300, 1300, True, 12), (128, 28, 4, 1300, 1300, True, 13), (128, 28, 4, 700, 1500, True, 0), (128, 4, 1, 129, 640, True, 12)])
 def test_attention(hd, Hq, Hkv, Sq, Sk, causal, kernel):
     B = 2
     # fused qkv buffer like the real path: [B*S, (Hq + 2 Hkv) * hd]

@@ -90,16 +90,23 @@ struct Cfg {
     static constexpr int STAGE = 64 * PK + 64 * PV;
 };
 
-template <int HD, int NW, bool CAUSAL>
-__global__ __launch_bounds__(NW * 64, (HD <= 96 ? 3 : 2)) void attn_fwd_mfma(AttnArgs a) {
+// NG = 2 (key split): the block holds TWO groups of NW waves over the same 32*NW queries; group g takes the key tiles t = g, g + 2, ... with its
+// own K/V staging buffers, and the groups' (m, l, O) are merged through LDS at the end (lane to lane: the same lane of the same wave holds the same
+// query and output columns in both groups).  A causal launch is as long as its last q-tile's walk over all keys (38 tiles at S = 2399, with 532
+// blocks for 512 slots the light blocks cannot fill the time the heavy ones need); the split halves that walk.
+template <int HD, int NW, bool CAUSAL, int NG = 1>
+__global__ __launch_bounds__(NW * NG * 64, (NG > 1 ? 1 : (HD <= 96 ? 3 : 2))) void attn_fwd_mfma(AttnArgs a) {
     using C = Cfg<HD>;
     constexpr int KS = C::KS, DT = C::DT, KC = C::KC, VC = C::VC, PK = C::PK, PV = C::PV, STAGE = C::STAGE;
     constexpr int NT = NW * 64;
     constexpr int CK = (64 * KC + NT - 1) / NT, CV = (64 * VC + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = NG > 1 ? wave_all / NW : 0, wave = NG > 1 ? wave_all % NW : wave_all;
+    const int tid = wave * 64 + lane;                           // thread index inside the group: staging work is split per group
+    char* smem = smem_all + grp * (2 * STAGE);
     const int h = lane >> 5, l31 = lane & 31;
     int qt = blockIdx.x, hq = blockIdx.y, b = blockIdx.z;
     if (CAUSAL) {
@@ -181,12 +188,13 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 ? 3 : 2)) void attn_fwd_mfma(Att
     const int k_off = l31 * PK + h * 16;                                  // + hh*32*PK + ks*32
     const int v_off = (4 * h + ((lane & 15) >> 2)) * PV + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;   // + (hh*32+16s(+8))*PV + dt*64
 
-    issue_loads(0);
-    write_lds(0);
+    if (grp < ntiles) { issue_loads(grp); write_lds(0); }
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) issue_loads(t + 1);
-        const char* kb = smem + (t & 1) * STAGE;
+    for (int it = 0; it * NG < ntiles; ++it) {
+        const int t = it * NG + grp;
+        if (t < ntiles) {                                          // (wave-uniform; the last round of a key split may leave a group without a tile)
+        if (t + NG < ntiles) issue_loads(t + NG);
+        const char* kb = smem + (it & 1) * STAGE;
         const char* vb = kb + 64 * PK;
         const int kbase_idx = t * 64;
         // ---- S^T[key][q] for 64 keys: two 32x32 tiles
@@ -256,8 +264,33 @@ __global__ __launch_bounds__(NW * 64, (HD <= 96 ? 3 : 2)) void attn_fwd_mfma(Att
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c], oacc[dt], 0, 0, 0);
             }
         }
-        if (t + 1 < ntiles) write_lds((t + 1) & 1);
+        if (t + NG < ntiles) write_lds((it + 1) & 1);
+        }
         __syncthreads();
+    }
+
+    if constexpr (NG > 1) {
+        // ---- merge the groups: group 1 parks (m, l, O) in LDS (its K/V buffers are idle now), group 0 folds them into its own
+        float* mb = reinterpret_cast<float*>(smem_all) + (size_t)(wave * 64 + lane) * (DT * 16 + 2);
+        if (grp == 1) {
+            mb[0] = m_run; mb[1] = l_run;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mb[2 + i * 16 + r] = oacc[i][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m1 = mb[0], l1 = mb[1];
+        const float mnew = fmaxf(m_run, m1);
+        const float a0 = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - mnew);
+        const float a1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m1 - mnew);
+        l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] = oacc[i][r] * a0 + mb[2 + i * 16 + r] * a1;
+        m_run = mnew;
     }
 
     // ---- normalise and store O[q][d], d = 32dt + (r&3) + 8(r>>2) + 4h  (4 consecutive d per register quad)
@@ -1038,6 +1071,22 @@ __global__ __launch_bounds__(256) void attn_fewkeys(AttnArgs a) {
         *reinterpret_cast<bf16x4*>(op + d) = (bf16x4){(bf16)(acc[d] * inv), (bf16)(acc[d + 1] * inv), (bf16)(acc[d + 2] * inv), (bf16)(acc[d + 3] * inv)};
 }
 
+// causal head_dim 128 with a key split over two wave groups per block (see attn_fwd_mfma NG)
+template <int NW>
+int launch_mfma_split2(const AttnArgs& a, hipStream_t st) {
+    constexpr int smem = 4 * Cfg<128>::STAGE;
+    static_assert((size_t)NW * 64 * (Cfg<128>::DT * 16 + 2) * 4 <= (size_t)smem, "merge buffer must fit in the staging area");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<128, NW, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    dim3 grid(cdiv(a.Sq, 32 * NW), a.Hq, a.B);
+    hipLaunchKernelGGL((attn_fwd_mfma<128, NW, true, 2>), grid, dim3(NW * 128), smem, st, a);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
 template <int HD, int NW>
 int launch_mfma(const AttnArgs& a, int causal, hipStream_t st) {
     constexpr int smem = 2 * Cfg<HD>::STAGE;
@@ -1112,7 +1161,8 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
     }
-    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || kernel == 10 || kernel == 11 || (kernel == 0 && mfma_ok && Sq >= 16)) {
+    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || kernel == 10 || kernel == 11 || ((kernel == 12 || kernel == 13) && mfma_ok) ||
+        (kernel == 0 && mfma_ok && Sq >= 16)) {
         const bool six = (Sq % 192 == 0) && (Sq % 128 != 0);     // e.g. 576 ViT tokens: 3 blocks of 6 waves, no idle wave
         switch (hd) {
             case 64: return launch_mfma<64, 4>(a, causal, st);
@@ -1128,7 +1178,16 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
                      return six ? launch_mfma_dma<72, 6, false>(a, causal, st) : launch_mfma_dma<72, 4, false>(a, causal, st);
             case 80: return launch_mfma<80, 4>(a, causal, st);
             case 96: return launch_mfma<96, 4>(a, causal, st);
-            case 128: return launch_mfma<128, 4>(a, causal, st);
+            case 128:
+                // kernel 12: key split over two wave groups per block; kernel 13: never.  Default when the launch has few blocks for the chip
+                // (<= ~2.3 per CU: the causal S = 2399 prefill has 532 for 512 slots and ends with its heaviest blocks alone; measured 88 -> 82 us
+                // there, 41 -> 31 us at S = 1200; with many blocks -- S = 4703: 1036 -- the plain kernel's two blocks per CU retire more tiles: 232 vs 254 us)
+                {
+                    const int64_t blocks = (int64_t)cdiv(Sq, 128) * Hq * B;
+                    if (causal && kernel != 13 && (kernel == 12 || (kernel == 0 && Sq + q_pos0 >= 512 && blocks <= 600)))
+                        return launch_mfma_split2<4>(a, st);
+                }
+                return launch_mfma<128, 4>(a, causal, st);
         }
     }
     const bool few_ok = aligned && !causal && Sk <= 64 && (hd == 16 || hd == 32) && (size_t)Sk * Hkv * hd * 8 <= 64 * 1024;
