@@ -142,6 +142,38 @@ def test_decoder_fulldim_layer_logits_and_cached_step():
     check("decoder full-dim layer: cached decode step", l1, rm1["logits"], r321["logits"], 1e-2, bound_mirror=4.5e-3)   # 2.3e-3 / 5.0e-3
 
 
+def test_tower_and_decoder_at_production_depth_and_dimensions():
+    """The two long chains of config #2 at their real depth AND their real dimensions: the SigLIP-so400m tower to hidden_states[-2] (26 layers, d 1152,
+    16 x 72, 4304, one 336^2 frame = 576 tokens) and the Qwen2-7B decoder (28 layers, 3584, 28 / 4 x 128, 18944) on S = 383 positions (4 frames' 288 visual
+    tokens + 95 text tokens).  The decoder's 28 layers share ONE set of seeded weights (the oracle's state dict aliases them, the HIP model holds 28 copies):
+    the depth of the chain is what is tested, 30 GB of distinct fp32 weights on the CPU are not needed for that."""
+    vit = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16, image_size=336, patch_size=14)
+    sd = O.make_siglip_weights(vit, seed=61)
+    tower = SiglipVisionTower("siglip", Args(), vision_config=vit)
+    tower.load_hf_state_dict(sd); tower = tower.to(DEV)
+    x = torch.randn(1, 3, 336, 336, generator=torch.Generator().manual_seed(62))
+    ym, y32 = both(lambda: O.siglip_tower(sd, vit, x))
+    check("tower production depth + dims (26 L, d 1152, hd 72)", tower.encode(x.to(DEV)), ym, y32, 1.5e-2, bound_mirror=1.1e-2)    # measured 5.2e-3 / 7.4e-3 (mirror vs fp32 7.4e-3)
+    del tower, sd
+    cfg1 = dict(vocab_size=512, hidden_size=3584, intermediate_size=18944, num_hidden_layers=1, num_attention_heads=28, num_key_value_heads=4,
+                rope_theta=1e6, rms_norm_eps=1e-6)
+    one = O.make_qwen2_weights(cfg1, seed=63)
+    cfg = dict(cfg1, num_hidden_layers=28)
+    full = {k: v for k, v in one.items() if not k.startswith("model.layers.")}
+    for i in range(28):
+        full.update({k.replace("model.layers.0.", f"model.layers.{i}."): v for k, v in one.items() if k.startswith("model.layers.0.")})
+    m = VideoReferQwen2ForCausalLM(VideoReferQwen2Config(**cfg, train_mask_decoder=True))
+    m.load_state_dict(full, strict=True); m = m.to(DEV)
+    xe = torch.randn(1, 383, 3584, generator=torch.Generator().manual_seed(64)) * 0.5
+    logits, cache, hs, normed = m._decode_batch(xe.to(DEV), None, None, True, 0)
+    rm, r32 = both(lambda: O.qwen2_forward(full, cfg, xe))
+    check("decoder production depth + dims (28 L, S 383): hidden", normed, rm["hidden_states"][-1][0], r32["hidden_states"][-1][0], 9e-2, bound_mirror=3.3e-2)   # measured 1.6e-2 / 4.3e-2 (mirror vs fp32 4.5e-2: bf16 storage itself, 28 layers deep)
+    check("decoder production depth + dims (28 L, S 383): logits", logits, rm["logits"], r32["logits"], 8e-2, bound_mirror=3.5e-2)      # 1.7e-2 / 3.9e-2 (4.0e-2)
+    mid = hs[14]                                               # HF hidden_states[14] = the stream after 14 layers
+    check("decoder production depth + dims: stream after 14 layers", mid[0] if mid.dim() == 3 else mid, rm["hidden_states"][14][0], r32["hidden_states"][14][0], 5.4e-2,
+          bound_mirror=2.1e-2)                                                                 # 1.0e-2 / 2.7e-2 (2.6e-2)
+
+
 def _oracle_pipeline(w, a):
     """tiny end-to-end on the CPU oracle: tower -> connector -> region encoder -> splice -> decoder"""
     vt = "model.vision_tower.vision_tower."
