@@ -1087,6 +1087,10 @@ int launch_mfma_split2(const AttnArgs& a, hipStream_t st) {
     return UFV_OK;
 }
 
+static inline bool split2_pays(int Sq, int Hq, int B, int q_pos0) {
+    return Sq + q_pos0 >= 512 && (int64_t)cdiv(Sq, 128) * Hq * B <= 600;
+}
+
 template <int HD, int NW>
 int launch_mfma(const AttnArgs& a, int causal, hipStream_t st) {
     constexpr int smem = 2 * Cfg<HD>::STAGE;
@@ -1182,11 +1186,7 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
                 // kernel 12: key split over two wave groups per block; kernel 13: never.  Default when the launch has few blocks for the chip
                 // (<= ~2.3 per CU: the causal S = 2399 prefill has 532 for 512 slots and ends with its heaviest blocks alone; measured 88 -> 82 us
                 // there, 41 -> 31 us at S = 1200; with many blocks -- S = 4703: 1036 -- the plain kernel's two blocks per CU retire more tiles: 232 vs 254 us)
-                {
-                    const int64_t blocks = (int64_t)cdiv(Sq, 128) * Hq * B;
-                    if (causal && kernel != 13 && (kernel == 12 || (kernel == 0 && Sq + q_pos0 >= 512 && blocks <= 600)))
-                        return launch_mfma_split2<4>(a, st);
-                }
+                if (causal && kernel != 13 && (kernel == 12 || (kernel == 0 && split2_pays(Sq, Hq, B, q_pos0)))) return launch_mfma_split2<4>(a, st);
                 return launch_mfma<128, 4>(a, causal, st);
         }
     }
@@ -1221,6 +1221,8 @@ extern "C" int ufv_attention_causal_lse(const void* q, int64_t q_ss, const void*
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
     a.q_bs = 0; a.q_ss = q_ss; a.k_bs = 0; a.k_ss = k_ss; a.v_bs = 0; a.v_ss = v_ss; a.o_bs = 0; a.o_ss = o_ss;
     a.B = 1; a.Hq = Hq; a.Hkv = Hkv; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = scale; a.q_pos0 = 0; a.lse = lse;
+    // the same kernel choice as ufv_attention's causal hd-128 path: the training forward and the inference path return the same bits
+    if (split2_pays(S, Hq, 1, 0)) return launch_mfma_split2<4>(a, reinterpret_cast<hipStream_t>(stream));
     return launch_mfma<128, 4>(a, 1, reinterpret_cast<hipStream_t>(stream));
 }
 
