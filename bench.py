@@ -69,45 +69,37 @@ def synthetic_inputs(device, frames=T_FRAMES):
 
 
 class KernelTimer:
-    """HIP-event timing of one kernel family on the launch stream (torch's current stream)."""
+    """HIP-event timing of the dominant kernel (the gate/up GEMM) on its launch stream, recorded inside the library (ufv_gemm_timing), so the
+    launches are timed wherever they are issued from -- the op-level loops or the whole-stage C calls the product path uses."""
 
     def __init__(self):
-        self.pairs = []
-        self.on = False
+        self._on = False
 
     def wrap(self, ops_mod):
-        orig = ops_mod.gemm
-        timer = self
+        pass
 
-        def gemm(a, w, *args, **kw):
-            if timer.on and kw.get("swiglu") and a.shape[0] > 64 and not isinstance(w, ops_mod.Fp8Weight):
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                out = orig(a, w, *args, **kw)
-                e.record()
-                timer.pairs.append((s, e, a.shape[0], w.shape[0], a.shape[1]))
-                return out
-            return orig(a, w, *args, **kw)
-        ops_mod.gemm = gemm
-        orig8 = ops_mod.gemm_fp8
+    @property
+    def on(self):
+        return self._on
 
-        def gemm_fp8(aq, sa, w, *args, **kw):       # fp8 mode: the GEMM alone (the activation quantisation is its own kernel)
-            if timer.on and kw.get("swiglu") and aq.shape[0] > 64:
-                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                out = orig8(aq, sa, w, *args, **kw)
-                e.record()
-                timer.pairs.append((s, e, aq.shape[0], w.shape[0], aq.shape[1]))
-                return out
-            return orig8(aq, sa, w, *args, **kw)
-        ops_mod.gemm_fp8 = gemm_fp8
+    @on.setter
+    def on(self, v):
+        from ufvideo_amd import _lib
+        self._on = bool(v)
+        _lib.call("ufv_gemm_timing", int(self._on))
 
     def summary(self):
-        if not self.pairs:
+        import ctypes
+        from ufvideo_amd import _lib
+        cap = 1 << 16
+        ms = (ctypes.c_float * cap)()
+        mnk = (ctypes.c_int32 * (3 * cap))()
+        n = _lib.load().ufv_gemm_timing_read(ms, mnk, cap)
+        if n <= 0:
             return None
-        ms = [s.elapsed_time(e) for s, e, *_ in self.pairs]
-        M, N, K = self.pairs[0][2:]
-        return dict(mean_ms=float(np.mean(ms)), launches=len(ms), M=M, N=N, K=K, flops=2.0 * M * N * K)
+        n = min(n, cap)
+        M, N, K = mnk[0], mnk[1], mnk[2]
+        return dict(mean_ms=float(np.mean(ms[:n])), launches=n, M=M, N=N, K=K, flops=2.0 * M * N * K)
 
 
 def one_step(model, video, ids, am, cache, frameshard=False):

@@ -398,6 +398,13 @@ int ufv_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_
  * (head h at column h*hd, RoPE applied), k / v bf16 [>= round_up(S,128) rows, ldkv] (kv-head g at column g*hd), dO bf16 [S, lddo]
  * -> dq [S, lddq], dk / dv [S, lddkv] bf16.  ws = ufv_attention_bwd_ws_bytes(S, Hq, Hkv, hd). */
 int64_t ufv_attention_bwd_ws_bytes(int S, int Hq, int Hkv, int hd);
+/* Measurement aid (bench.py's roofline entry): while enabled, every ufv_gemm / ufv_gemm_fp8 launch with the SwiGLU epilogue and M > 64 -- the
+ * decoder's gate/up projection, the dominant kernel -- is bracketed by a HIP event pair on its own stream, whether it is issued op by op or
+ * inside a stage call.  ufv_gemm_timing_read waits for the recorded launches, returns their count, copies up to `cap` durations (ms) and
+ * shapes (M, N, K per launch) and forgets them.  Not thread-safe; off by default. */
+int ufv_gemm_timing(int enable);
+int ufv_gemm_timing_read(float* ms, int32_t* mnk, int cap);
+
 /* C[M,N] (+)= A[M,K] * W[N,K]^T with K split over up to nsplit blocks per output tile (thin outputs over a long K: dV = P^T dO,
  * dK = dS^T Q); partial tiles go to ws (fp32 [nsplit][M][N]) and are summed in order; C fp32 (optionally accumulated) or bf16 */
 int ufv_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int out_f32, int accumulate, int M, int N, int K,

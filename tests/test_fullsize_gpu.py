@@ -32,6 +32,27 @@ def test_token_counts_and_bit_reproducibility(full):
     assert torch.isfinite(outs[0][1]).all() and outs[0][1].shape == (1, 1, model.config.vocab_size)
 
 
+def test_bench_roofline_timer_sees_the_gate_up_launches_of_the_product_path(full):
+    """bench.py's roofline entry times the dominant kernel inside the library (ufv_gemm_timing), so it keeps working when the prefill runs as ONE
+    stage call: one step = 28 gate/up launches of M = 2399, N = 37888, K = 3584 with plausible durations; nothing is recorded while it is off"""
+    import bench
+    from ufvideo_amd.model import KVCache
+    model, video, ids, am = full
+    cfg = model.config
+    cache = KVCache(cfg.num_hidden_layers, 2304 + 128, 2 * cfg.num_key_value_heads * cfg.head_dim, video.device)
+    timer = bench.KernelTimer()
+    with torch.no_grad():
+        bench.one_step(model, video, ids, am, cache)
+        assert timer.summary() is None
+        timer.on = True
+        bench.one_step(model, video, ids, am, cache)
+        timer.on = False
+        bench.one_step(model, video, ids, am, cache)
+    ks = timer.summary()
+    assert ks is not None and ks["launches"] == 28 and (ks["M"], ks["N"], ks["K"]) == (2399, 37888, 3584)
+    assert 0.2 < ks["mean_ms"] < 2.0 and timer.summary() is None
+
+
 def test_encoder_is_independent_per_aligned_frame_chunk(full):
     """tower + STC-v35 on frames [0:16] and [16:32] separately == the 32-frame pass, bit for bit (even-length chunks: the
     k2/s2 temporal conv never straddles a chunk boundary) -- the property encode_frame_sharded builds on."""

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ufv_attention_decode": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _i, _i, _f, _p, _i, _p],
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
     "ufv_qwen2_prefill": [_p, _p, _i, _i, _p, _l, _p, _p, _p, _p],
+    "ufv_gemm_timing": [_i],
     "ufv_vit_forward": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _l, _p],
     "ufv_stc_forward": [_p, _p, _i, _i, _i, _p, _p, _l, _p],
     "ufv_qwen2_decode_step_dev": [_p, _p, _p, _p, _l, _p, _p, _p, _p],
@@ -99,7 +100,7 @@ SIGNATURES = {
     "ufv_attention_bwd_fused": [_p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p],
 }
 # entry points that return a size instead of a status
-SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l),
+SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l), "ufv_gemm_timing_read": ([_p, _p, _i], _i),
               "ufv_qwen2_prefill_ws_bytes": ([_p, _i], _l), "ufv_vit_forward_ws_bytes": ([_p, _i], _l), "ufv_stc_forward_ws_bytes": ([_p, _i, _i], _l),
               "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l), "ufv_attention_bwd_fused_ws_bytes": ([_i, _i], _l),
               "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l), "ufv_mask_dot_bwd_ws_bytes": ([_i, _i], _l)}

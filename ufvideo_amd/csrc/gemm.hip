@@ -14,6 +14,7 @@
 // Generic kernel: any shape/alignment, one thread per output, used for tiny problems
 // (region encoder, SE gates, tiny test models).
 #include "common.h"
+#include <vector>
 #include <cstdlib>
 #include "../../include/ufv.h"
 #include "gemm_epi.h"
@@ -667,6 +668,12 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
     }
 }
 
+// Launch timing of the dominant kernel for bench.py's roofline entry (ufv_gemm_timing): while enabled, every tile-kernel GEMM with the SwiGLU
+// epilogue (the decoder's gate/up projection) is bracketed by a HIP event pair on ITS stream, wherever the call comes from (op-level or a stage call).
+struct TimedLaunch { hipEvent_t s, e; int M, N, K; };
+static bool g_timing = false;
+static std::vector<TimedLaunch>& timed_launches() { static std::vector<TimedLaunch> v; return v; }
+
 template <bool Q>
 int gemm_entry(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, void* C, int ldc, int out_f32,
                int M, int N, int K, const float* bias, int act, const float* resid, int ldr, int resid_rows, int swiglu, int kernel,
@@ -675,14 +682,48 @@ int gemm_entry(const void* A, int lda, const float* a_scale, const void* W, int 
     e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = resid_rows;
     e.scale_m = a_scale; e.scale_n = w_scale; e.dump_f32 = 0; e.ksplit = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    TimedLaunch tl{};
+    const bool timed = g_timing && swiglu && M > 64 && hipEventCreate(&tl.s) == hipSuccess && hipEventCreate(&tl.e) == hipSuccess;
+    if (timed) (void)hipEventRecord(tl.s, st);
+    int rc;
     if (out_f32)
-        return swiglu ? launch_any<true, true, Q>(A, W, e, M, N, K, lda, ldw, kernel, st)
-                      : launch_any<true, false, Q>(A, W, e, M, N, K, lda, ldw, kernel, st);
-    return swiglu ? launch_any<false, true, Q>(A, W, e, M, N, K, lda, ldw, kernel, st)
-                  : launch_any<false, false, Q>(A, W, e, M, N, K, lda, ldw, kernel, st);
+        rc = swiglu ? launch_any<true, true, Q>(A, W, e, M, N, K, lda, ldw, kernel, st)
+                    : launch_any<true, false, Q>(A, W, e, M, N, K, lda, ldw, kernel, st);
+    else
+        rc = swiglu ? launch_any<false, true, Q>(A, W, e, M, N, K, lda, ldw, kernel, st)
+                    : launch_any<false, false, Q>(A, W, e, M, N, K, lda, ldw, kernel, st);
+    if (timed) {
+        (void)hipEventRecord(tl.e, st);
+        tl.M = M; tl.N = N; tl.K = K;
+        timed_launches().push_back(tl);
+    }
+    return rc;
 }
 
 }  // namespace
+
+extern "C" int ufv_gemm_timing(int enable) {
+    g_timing = enable != 0;
+    return UFV_OK;
+}
+
+// waits for the recorded launches, writes up to `cap` durations (ms) and shapes (M, N, K per launch), forgets them; returns how many there were
+extern "C" int ufv_gemm_timing_read(float* ms, int32_t* mnk, int cap) {
+    std::vector<TimedLaunch>& v = timed_launches();
+    const int n = (int)v.size();
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        (void)hipEventSynchronize(v[i].e);
+        (void)hipEventElapsedTime(&t, v[i].s, v[i].e);
+        if (i < cap) {
+            if (ms) ms[i] = t;
+            if (mnk) { mnk[3 * i] = v[i].M; mnk[3 * i + 1] = v[i].N; mnk[3 * i + 2] = v[i].K; }
+        }
+        (void)hipEventDestroy(v[i].s); (void)hipEventDestroy(v[i].e);
+    }
+    v.clear();
+    return n;
+}
 
 extern "C" int ufv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int out_f32, int M, int N, int K,
                         const float* bias, int act, const float* resid, int ldr, int resid_rows, int swiglu, int kernel,
