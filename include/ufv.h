@@ -201,6 +201,7 @@ typedef struct {
     const ufv_qwen2_layer* layers;
 } ufv_qwen2_model;
 
+/* the workspace must be ZERO-filled once before the first step (it holds the arrival counters of the fused decode attention) */
 int64_t ufv_qwen2_decode_ws_bytes(const ufv_qwen2_model* m);
 /* token_dev: previous token id (device int64[1]); pos: its position (= number of cached tokens); writes logits f32
  * [vocab], optional hidden_out f32 [d] (final-norm hidden state), next_token_dev = argmax. */
@@ -277,6 +278,13 @@ int ufv_attention_decode_dev(const void* q, int64_t q_bs, const void* k, int64_t
                              int64_t v_ss, void* o, int64_t o_bs, int B, int Hq, int Hkv, const int* pos_dev, int max_keys, int hd,
                              float scale, void* ws, int nsplit, void* stream);
 int ufv_add_int(int* p, int v, void* stream);
+/* the three of them in ONE launch (RoPE of the new token's q / k, KV-cache append at `pos`, split attention over pos + 1 keys, merge): qkv bf16
+ * [(Hq + 2 Hkv) * hd] = the raw projections of the new token (left untouched), kv_cache row = [Hkv*hd k | Hkv*hd v]; pos from the host or
+ * *pos_dev; o bf16 [Hq * hd].  ws: ufv_attention_decode_fused_ws_bytes(...) bytes whose trailing Hq ints (arrival counters) are ZERO before the
+ * first call -- they return to zero by themselves.  head_dim 64 / 128.  Bit-identical to the three calls. */
+int64_t ufv_attention_decode_fused_ws_bytes(int Hq, int hd, int nsplit);
+int ufv_attention_decode_fused(const void* qkv, int Hq, int Hkv, int hd, const float* inv_freq, int pos, const int* pos_dev, void* kv_cache, int ldkv,
+                               int max_keys, void* o, float scale, void* ws, int nsplit, void* stream);
 /* HIP-graph capture of a launch-bound call sequence: begin; ufv_* calls on `stream` (a created stream, not the legacy default
  * one) are recorded instead of executed; end returns an executable graph; launch replays it on a stream */
 int ufv_graph_begin(void* stream);

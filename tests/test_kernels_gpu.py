@@ -435,6 +435,41 @@ def test_rope_kv_scalar_path():
     assert torch.equal(cache[pos0:pos0 + S, Hkv * hd:], bf(ref_in[:, (Hq + Hkv) * hd:]))
 
 
+@pytest.mark.parametrize("hd,Hq,Hkv,pos,nsplit", [(128, 28, 4, 2399, 16), (128, 4, 2, 4, 16), (128, 4, 4, 0, 16), (64, 8, 2, 700, 7), (64, 4, 4, 63, 1), (128, 14, 2, 300, 16)])
+def test_attention_decode_fused_bit_identical_to_the_three_calls(hd, Hq, Hkv, pos, nsplit):
+    """`ufv_attention_decode_fused` (RoPE of q / k, KV append, split attention, merge in one launch) == ufv_rope_kv1_dev -> ufv_attention_decode_dev (split +
+    combine): the output row and the appended cache row bit for bit, position from the host and from device memory, twice in a row on the same workspace
+    (the arrival counters return to zero), splits without keys (pos < nsplit), one split, GQA"""
+    import ctypes
+    W = (Hq + 2 * Hkv) * hd
+    qkv = bf(g(1, W, seed=hd + pos))
+    cache = bf(g(pos + 9, 2 * Hkv * hd, seed=pos + 1))
+    inv_freq = (1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    scale = hd ** -0.5
+    # the three-call sequence
+    q1, c1 = qkv.clone(), cache.clone()
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device=DEV)
+    ws1 = torch.empty(_lib.load().ufv_attention_decode_ws_bytes(1, Hq, hd, nsplit), device=DEV, dtype=torch.uint8)
+    o1 = torch.empty(1, Hq * hd, device=DEV, dtype=torch.bfloat16)
+    _lib.call("ufv_rope_kv1_dev", q1.data_ptr(), Hq, Hkv, hd, inv_freq.data_ptr(), pos_dev.data_ptr(), c1.data_ptr(), c1.stride(0), st)
+    _lib.call("ufv_attention_decode_dev", q1.data_ptr(), 0, c1.data_ptr(), 0, c1.stride(0), c1[:, Hkv * hd:].data_ptr(), 0, c1.stride(0), o1.data_ptr(), 0, 1,
+              Hq, Hkv, pos_dev.data_ptr(), c1.shape[0], hd, scale, ws1.data_ptr(), nsplit, st)
+    nb = _lib.load().ufv_attention_decode_fused_ws_bytes(Hq, hd, nsplit)
+    ws2 = torch.zeros(nb, device=DEV, dtype=torch.uint8)
+    for use_dev in (False, True, False):
+        q2, c2 = qkv.clone(), cache.clone()
+        o2 = torch.full((1, Hq * hd), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _lib.call("ufv_attention_decode_fused", q2.data_ptr(), Hq, Hkv, hd, inv_freq.data_ptr(), pos, pos_dev.data_ptr() if use_dev else None, c2.data_ptr(),
+                  c2.stride(0), c2.shape[0], o2.data_ptr(), scale, ws2.data_ptr(), nsplit, st)
+        assert torch.equal(o2, o1), (use_dev, rel(o2, o1.float()))
+        assert torch.equal(c2, c1) and torch.equal(q2, qkv)              # the row appended at `pos`; qkv untouched
+        assert int(ws2.view(torch.int32)[-Hq:].abs().max()) == 0          # counters back at zero
+    with pytest.raises(_lib.UfvError, match="head_dim"):
+        _lib.call("ufv_attention_decode_fused", qkv.data_ptr(), Hq, Hkv, 72, inv_freq.data_ptr(), pos, None, cache.data_ptr(), cache.stride(0), cache.shape[0],
+                  o1.data_ptr(), scale, ws2.data_ptr(), nsplit, st)
+
+
 @pytest.mark.parametrize("hd,Hq,Hkv,Sk,nsplit", [(128, 28, 4, 2400, 16), (128, 4, 2, 5, 16), (16, 4, 2, 61, 3), (64, 8, 8, 700, 1)])
 def test_attention_decode(hd, Hq, Hkv, Sk, nsplit):
     q = bf(g(1, 1, Hq, hd, seed=70))

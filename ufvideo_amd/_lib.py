@@ -67,6 +67,7 @@ SIGNATURES = {
     "ufv_rope_kv1_dev": [_p, _i, _i, _i, _p, _p, _p, _i, _p],
     "ufv_attention_decode_dev": [_p, _l, _p, _l, _l, _p, _l, _l, _p, _l, _i, _i, _i, _p, _i, _i, _f, _p, _i, _p],
     "ufv_add_int": [_p, _i, _p],
+    "ufv_attention_decode_fused": [_p, _i, _i, _i, _p, _i, _p, _p, _i, _i, _p, _f, _p, _i, _p],
     "ufv_graph_begin": [_p],
     "ufv_graph_end": [_p, _p],
     "ufv_graph_launch": [_p, _p],
@@ -100,7 +101,7 @@ SIGNATURES = {
     "ufv_attention_bwd_fused": [_p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p],
 }
 # entry points that return a size instead of a status
-SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l), "ufv_gemm_timing_read": ([_p, _p, _i], _i),
+SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l), "ufv_attention_decode_fused_ws_bytes": ([_i, _i, _i], _l), "ufv_gemm_timing_read": ([_p, _p, _i], _i),
               "ufv_qwen2_prefill_ws_bytes": ([_p, _i], _l), "ufv_vit_forward_ws_bytes": ([_p, _i], _l), "ufv_stc_forward_ws_bytes": ([_p, _i, _i], _l),
               "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l), "ufv_attention_bwd_fused_ws_bytes": ([_i, _i], _l),
               "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l), "ufv_mask_dot_bwd_ws_bytes": ([_i, _i], _l)}

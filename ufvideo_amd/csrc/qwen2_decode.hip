@@ -4,6 +4,7 @@
 // entry points in include/ufv.h on one stream (no allocation, no synchronisation): it exists so that the host pays
 // one FFI call per token instead of ~340.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/ufv.h"
 
 #define UFV_TRY(expr)            \
@@ -24,7 +25,9 @@ extern "C" int64_t ufv_qwen2_decode_ws_bytes(const ufv_qwen2_model* m) {
     b += align256(2 * qkv);                         // qkv
     b += align256(2 * (size_t)m->n_q * m->hd);      // o
     b += align256(2 * (size_t)m->d_ff);             // act
-    b += align256(ufv_attention_decode_ws_bytes(1, m->n_q, m->hd, m->attn_splits));
+    const int64_t fused = (m->hd == 64 || m->hd == 128) ? ufv_attention_decode_fused_ws_bytes(m->n_q, m->hd, m->attn_splits) : 0;
+    const int64_t plain = ufv_attention_decode_ws_bytes(1, m->n_q, m->hd, m->attn_splits);
+    b += align256((size_t)(fused > plain ? fused : plain));
     return (int64_t)b;
 }
 
@@ -47,6 +50,9 @@ static int decode_step_impl(const ufv_qwen2_model* m, const int64_t* token_dev, 
     void* act = p; p += align256(2 * (size_t)I);
     void* aws = p;
     const float scale = 1.0f / sqrtf((float)hd);
+    // the workspace's arrival counters must be zero before the first step (the caller zero-fills `ws` once); UFV_DECODE_FUSED_ATTN=0: three launches
+    static const bool fused_env = getenv("UFV_DECODE_FUSED_ATTN") == nullptr || getenv("UFV_DECODE_FUSED_ATTN")[0] != '0';
+    const bool fused_attn = fused_env && (hd == 64 || hd == 128) && (m->ldkv % 8 == 0);
 
     UFV_TRY(ufv_gather_rows(m->embed, UFV_DT_BF16, D, token_dev, x, UFV_DT_F32, D, nullptr, 1, D, stream));
     for (int l = 0; l < m->n_layers; ++l) {
@@ -56,7 +62,10 @@ static int decode_step_impl(const ufv_qwen2_model* m, const int64_t* token_dev, 
         const bool q8 = L.wqkv8 && L.wo8 && L.wgu8 && L.wd8;      // W8A8 decode: e4m3 weights, rows quantised inside the GEMV
         UFV_TRY(ufv_gemv1(nullptr, x, L.ln1, m->eps, q8 ? L.wqkv8 : L.wqkv, D, q8 ? L.sqkv : nullptr, qkv, 0, qkv_n, D, L.bqkv, UFV_ACT_NONE,
                           nullptr, 0, stream));
-        if (pos_dev) {
+        if (fused_attn) {
+            // RoPE + KV append + split attention + merge in ONE launch (csrc/attn.hip attn_decode_fused; bit-identical to the three calls below)
+            UFV_TRY(ufv_attention_decode_fused(qkv, H, KV, hd, m->inv_freq, pos, pos_dev, kv, m->ldkv, m->max_len, o, scale, aws, m->attn_splits, stream));
+        } else if (pos_dev) {
             UFV_TRY(ufv_rope_kv1_dev(qkv, H, KV, hd, m->inv_freq, pos_dev, kv, m->ldkv, stream));
             UFV_TRY(ufv_attention_decode_dev(qkv, 0, kv, 0, m->ldkv, kv + 2 * (size_t)KV * hd, 0, m->ldkv, o, 0, 1, H, KV, pos_dev, m->max_len,
                                              hd, scale, aws, m->attn_splits, stream));

@@ -672,7 +672,7 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         m, layers = self.model.c_model(cache, lm_head=head["lm_head"], vocab=head["V"])
         nbytes = _lib.load().ufv_qwen2_decode_ws_bytes(ctypes.byref(m))
         dev = cache.buf[0].device
-        return {"model": m, "layers": layers, "ws": torch.empty((nbytes,), device=dev, dtype=torch.uint8),
+        return {"model": m, "layers": layers, "ws": torch.zeros((nbytes,), device=dev, dtype=torch.uint8),      # zero: arrival counters of the fused attention
                 "logits": torch.empty((head["V"],), device=dev, dtype=torch.float32)}
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
