@@ -411,6 +411,9 @@ int64_t ufv_attention_bwd_ws_bytes(int S, int Hq, int Hkv, int hd);
  * inside a stage call.  ufv_gemm_timing_read waits for the recorded launches, returns their count, copies up to `cap` durations (ms) and
  * shapes (M, N, K per launch) and forgets them.  Not thread-safe; off by default. */
 int ufv_gemm_timing(int enable);
+/* which kernel UFV_GEMM_AUTO takes for a bf16 GEMM of this shape (host arithmetic, no launch): 0 = the 128-wide / small-shape kernels, else the
+ * UFV_GEMM_PP shape code (+ 10000 * parts for the split-K form; act_none = no activation in the epilogue) */
+int ufv_gemm_choice(int M, int N, int K, int out_f32, int swiglu, int act_none);
 int ufv_gemm_timing_read(float* ms, int32_t* mnk, int cap);
 
 /* C[M,N] (+)= A[M,K] * W[N,K]^T with K split over up to nsplit blocks per output tile (thin outputs over a long K: dV = P^T dO,

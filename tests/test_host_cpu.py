@@ -360,3 +360,20 @@ def test_lora_and_base_model_loading_forms(tmp_path):
     assert torch.equal(got2["model.layers.1.mlp.down_proj.weight"], sd["model.layers.1.mlp.down_proj.weight"]) and len(tok2) == 40
     with pytest.raises(NotImplementedError):
         load_pretrained_model(str(pdir), str(base), "videorefer_qwen2", device="cpu", load_4bit=True)
+
+
+def test_gemm_kernel_choice_at_the_config2_shapes():
+    """The cost model behind UFV_GEMM_AUTO (csrc/gemm.hip choose_kernel) is host arithmetic: pin what it picks at the shapes of the headline clip
+    (measured best or within a few % of it on MI355X: tools/gemm_shapes.py, tools/gemm_splitk.py) so that a change of its constants shows up here."""
+    from ufvideo_amd import _lib
+    pick = _lib.load().ufv_gemm_choice
+    assert pick(2399, 37888, 3584, 0, 1, 1) == 1442                      # gate/up (SwiGLU): 256x256
+    assert pick(18432, 3456, 1152, 0, 0, 1) == 1442 and pick(18432, 4352, 1152, 0, 0, 0) == 1442     # ViT qkv, fc1 (GELU)
+    assert pick(18432, 1152, 1152, 1, 0, 1) == 1431 and pick(18432, 1152, 4352, 1, 0, 1) == 1431     # ViT out_proj, fc2: 224x192, 498 tiles = 1.95 rounds
+    assert pick(2399, 3584, 3584, 1, 0, 1) == 1331                        # LLM o_proj: 192x192, 247 tiles = one round
+    assert pick(2399, 4608, 3584, 0, 0, 1) in (1332, 1441)                # LLM qkv
+    assert pick(2399, 3584, 18944, 1, 0, 1) == 41441                      # LLM down: 256x192 tiles x 4 K parts
+    assert pick(2399, 3584, 18944, 1, 0, 0) < 10000                       # ... never split under an activation
+    assert pick(2399, 3584, 18944, 0, 0, 1) < 10000                       # ... or into a bf16 output
+    assert pick(4703, 3584, 18944, 1, 0, 1) // 10000 >= 4                 # 64 frames: split as well
+    assert pick(100, 3584, 3584, 1, 0, 1) == 0 and pick(2399, 3500, 3584, 1, 0, 1) == 0      # small / unaligned shapes: not the ping-pong kernel

@@ -702,6 +702,13 @@ int gemm_entry(const void* A, int lda, const float* a_scale, const void* W, int 
 
 }  // namespace
 
+// what UFV_GEMM_AUTO would launch for a bf16 GEMM of this shape: 0 = the 128-wide kernel (or GEMV / generic for tiny shapes), else the ping-pong
+// kernel's shape code as in UFV_GEMM_PP (1442, 1431, ..., + 10000 * parts for the split-K form).  Host arithmetic only (no GPU needed).
+extern "C" int ufv_gemm_choice(int M, int N, int K, int out_f32, int swiglu, int act_none) {
+    if (M < 256 || N % BN != 0 || K % BK != 0) return 0;
+    return choose_kernel(M, N, K, out_f32 != 0, swiglu != 0, act_none != 0 && getenv("UFV_GEMM_NO_SPLITK") == nullptr);
+}
+
 extern "C" int ufv_gemm_timing(int enable) {
     g_timing = enable != 0;
     return UFV_OK;
