@@ -225,6 +225,10 @@ class DecoderTrainer:
         self._fresh = True
         self._last_micro = False
         self.comm_stream = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        if self.world > 1:
+            # RCCL kernels on the side stream hold CUs while GEMMs run: the split-K GEMM form spins on turn flags and assumes that its <= 256 blocks all
+            # become resident -- keep ufv_gemm on the unsplit kernels in a process that overlaps collectives with compute (threading)
+            os.environ["UFV_GEMM_NO_SPLITK"] = "1"
         # the decoder's packed weights now ARE this trainer's buffers: anything that would re-pack them from the (stale) nn.Parameters
         # -- .to(), load_state_dict, set_gemm_dtype, resize_token_embeddings, invalidate() -- raises until detach()
         model.get_model()._owner = self
