@@ -544,7 +544,7 @@ static inline int splitk_flags(int tiles, int** flags, int* base) {
     if (tiles > cap || epoch > (1 << 30)) {
         if (buf) (void)hipFree(buf);
         buf = nullptr; cap = 0;
-        const int n = tiles > 4096 ? tiles : 4096;
+        const int n = tiles > 65536 ? tiles : 65536;            // 256 KiB: regrowth (an implicit device sync in hipFree) practically never happens
         if (hipMalloc(&buf, (size_t)n * sizeof(int)) != hipSuccess || hipMemset(buf, 0, (size_t)n * sizeof(int)) != hipSuccess) {
             ufv_set_error("ufv_gemm: could not allocate the split-K turn flags (%d tiles)", tiles);
             return UFV_EHIP;
