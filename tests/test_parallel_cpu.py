@@ -172,6 +172,36 @@ def test_bench_run_protocol_world2_gloo():
     assert o0["config"]["parallelism"] == "clip-dp2" and "cpu_baseline" not in o0 and "roofline" not in o0     # stub: no kernel was timed
 
 
+def test_bench_main_gpus2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's command form): main() starts the two ranks itself as a
+    torch.distributed.run child, rank 0 prints ONE JSON line with n_gpus = 2, exit code 0.  (--stub: gloo on the CPU, sleeping step.)"""
+    import json, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    bench_py = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, bench_py, "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["config"]["parallelism"] == "clip-dp2"
+    assert out["ms_per_step"] >= 20.0                                 # the slow rank's 2 x 10 ms
+    assert abs(out["value"] - 2 * 4 * 2304 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-3
+
+
+def test_bench_main_refuses_more_gpus_than_visible_and_a_disagreeing_launcher():
+    """No silent n_gpus = 1: without N visible GPUs `--gpus N` exits non-zero and prints no JSON line; under a launcher whose
+    WORLD_SIZE differs from --gpus likewise."""
+    import subprocess, sys
+    bench_py = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    have = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, bench_py, "--gpus", str(have + 1 if have else 2)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, bench_py, "--gpus", "2", "--stub"], env=dict(env, WORLD_SIZE="4", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "disagrees" in r.stderr and "{" not in r.stdout
+
+
 # ---- ZeRO-2 exchange of the training step (ufvideo_amd/train.py) ---------------------------------------------------
 
 def _zero2_worker(rank, world, port, q):

@@ -53,3 +53,15 @@ def test_collectives_on_rccl_world_size_one():
     env = dict(os.environ, UFV_ROOT=root, UFV_PORT="29517", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_gpus2_on_a_one_gpu_box_fails_loudly():
+    """The driver's command form `python3 bench.py --gpus N` on a host with fewer than N GPUs must not report a line at all (round 2's
+    bench ignored --gpus and printed n_gpus: 1)."""
+    import torch
+    have = torch.cuda.device_count()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible" in r.stderr and "{" not in r.stdout
