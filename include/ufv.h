@@ -7,13 +7,26 @@
  *
  * Conventions
  *  - plain C: raw device pointers + sizes; no C++/torch types cross the boundary.
- *  - all buffers are caller-owned device memory on the current HIP device; nothing is allocated,
- *    freed or synchronised inside; every call is enqueued on `stream` (a hipStream_t; NULL = the
- *    default stream) and returns immediately.
+ *  - all buffers are caller-owned device memory on the current HIP device; every call is enqueued on
+ *    `stream` (a hipStream_t; NULL = the default stream) and returns immediately; nothing is allocated,
+ *    freed or synchronised inside, with ONE exception: the split-K form of ufv_gemm (what
+ *    UFV_GEMM_AUTO takes for few-tile / long-K fp32 products, and the opt-in UFV_GEMM_STREAMK) keeps a
+ *    per-device record inside the library -- a 4 MiB ring of turn flags and a pinned error word,
+ *    allocated under a mutex on the first such launch on a device or by ufv_gemm_prepare() (call it
+ *    before stream capture).  Every launch gets a private slice of the ring and its own ticket base,
+ *    so split-K GEMMs may be in flight on several streams and devices at once.
  *  - return value: 0 = ok, <0 = error (UFV_E*); `ufv_last_error()` returns a thread-local message.
  *  - bf16 = bfloat16 storage (uint16_t bit pattern), activations bf16, accumulation fp32, the
  *    residual streams fp32.  "ld*" arguments are row pitches in ELEMENTS.
- *  - thread-compatible: no global state except the thread-local error string.
+ *  - thread-safe: the only process-wide state is that per-device record (mutex-guarded), the
+ *    split-K on/off switch (an atomic, ufv_gemm_set_splitk) and the measurement aid ufv_gemm_timing
+ *    (not thread-safe, off by default); the error string is thread-local.
+ *  - forward progress of the split-K form: a tile's K parts add into the output in turn order and a
+ *    part waits for its predecessor's flag -- BOUNDED: if a predecessor is not scheduled within ~2^21
+ *    polls (seconds; only possible when the launch's <= 256 blocks cannot all become resident beside
+ *    another long-running kernel) the waiter sets the device's error word and goes on; that launch's
+ *    tile is wrong, nothing hangs, and the next ufv_gemm on the device returns UFV_EHIP
+ *    (ufv_gemm_error_state / ufv_gemm_clear_error).
  */
 #ifndef UFV_H_
 #define UFV_H_
@@ -24,7 +37,9 @@
 extern "C" {
 #endif
 
-#define UFV_ABI_VERSION 1
+/* 2: ufv_conv3d_scatter gained `pad`; ufv_qwen2_decode_step needs a zero-filled workspace; ufv_gemm_prepare / _set_splitk / _error_state /
+ *    _clear_error added.  A binder checks ufv_abi_version() == UFV_ABI_VERSION at load (ufvideo_amd/_lib.py does). */
+#define UFV_ABI_VERSION 2
 
 /* activation ids (ufv_gemm `act`, ufv_layernorm `act`) */
 #define UFV_ACT_NONE 0
@@ -415,6 +430,15 @@ int ufv_gemm_timing(int enable);
  * UFV_GEMM_PP shape code (+ 10000 * parts for the split-K form; act_none = no activation in the epilogue) */
 int ufv_gemm_choice(int M, int N, int K, int out_f32, int swiglu, int act_none);
 int ufv_gemm_timing_read(float* ms, int32_t* mnk, int cap);
+/* Split-K housekeeping (see Conventions).  ufv_gemm_prepare: create the current device's flag ring now (allocates; returns 0 / UFV_EHIP).
+ * ufv_gemm_set_splitk(0 | 1): whether UFV_GEMM_AUTO may take the split-K form; returns the previous setting (initial value 1, or 0 when the
+ * environment variable UFV_GEMM_NO_SPLITK is set at load time).  The split and unsplit forms sum K in different orders: fp32 outputs differ in
+ * the last bits (<= 4e-6 of the largest element).  ufv_gemm_error_state: 0, or the code a timed-out turn wait left on the current device;
+ * ufv_gemm_clear_error resets it. */
+int ufv_gemm_prepare(void);
+int ufv_gemm_set_splitk(int enable);
+int ufv_gemm_error_state(void);
+int ufv_gemm_clear_error(void);
 
 /* C[M,N] (+)= A[M,K] * W[N,K]^T with K split over up to nsplit blocks per output tile (thin outputs over a long K: dV = P^T dO,
  * dK = dS^T Q); partial tiles go to ws (fp32 [nsplit][M][N]) and are summed in order; C fp32 (optionally accumulated) or bf16 */

@@ -3,7 +3,7 @@ result against the unsplit kernel (same products, a different summation tree: <=
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ufvideo_amd import ops
+from ufvideo_amd import ops, _lib
 
 def timeit(fn, iters=20, warm=3):
     for _ in range(warm): fn()
@@ -24,9 +24,9 @@ for name, M, N, K in cases:
     res0 = torch.randn(M, N, device="cuda")
     ref = ops.gemm(a, w, resid=res0, out_dtype=torch.float32, kernel=ops.GEMM_FAST)
     line = f"{name:9s} M={M:6d} N={N:6d} K={K:6d}:"
-    os.environ["UFV_GEMM_NO_SPLITK"] = "1"
+    prev = _lib.load().ufv_gemm_set_splitk(0)
     t0 = timeit(lambda: ops.gemm(a, w, resid=res0, out=torch.empty_like(res0)))
-    del os.environ["UFV_GEMM_NO_SPLITK"]
+    _lib.load().ufv_gemm_set_splitk(prev)
     xa = res0.clone(); ops.gemm(a, w, resid=xa, out=xa)
     assert float((xa - ref).abs().max() / ref.abs().max()) < 4e-6
     t = timeit(lambda: ops.gemm(a, w, resid=res0, out=torch.empty_like(res0)))

@@ -61,6 +61,8 @@ SIGNATURES = {
     "ufv_qwen2_decode_step": [_p, _p, _i, _p, _l, _p, _p, _p, _p],
     "ufv_qwen2_prefill": [_p, _p, _i, _i, _p, _l, _p, _p, _p, _p],
     "ufv_gemm_timing": [_i],
+    "ufv_gemm_prepare": [],
+    "ufv_gemm_clear_error": [],
     "ufv_vit_forward": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _l, _p],
     "ufv_stc_forward": [_p, _p, _i, _i, _i, _p, _p, _l, _p],
     "ufv_qwen2_decode_step_dev": [_p, _p, _p, _p, _l, _p, _p, _p, _p],
@@ -101,7 +103,7 @@ SIGNATURES = {
     "ufv_attention_bwd_fused": [_p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p],
 }
 # entry points that return a size instead of a status
-SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l), "ufv_attention_decode_fused_ws_bytes": ([_i, _i, _i], _l), "ufv_gemm_timing_read": ([_p, _p, _i], _i), "ufv_gemm_choice": ([_i, _i, _i, _i, _i, _i], _i),
+SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l), "ufv_attention_decode_fused_ws_bytes": ([_i, _i, _i], _l), "ufv_gemm_timing_read": ([_p, _p, _i], _i), "ufv_gemm_choice": ([_i, _i, _i, _i, _i, _i], _i), "ufv_gemm_set_splitk": ([_i], _i), "ufv_gemm_error_state": ([], _i),
               "ufv_qwen2_prefill_ws_bytes": ([_p, _i], _l), "ufv_vit_forward_ws_bytes": ([_p, _i], _l), "ufv_stc_forward_ws_bytes": ([_p, _i, _i], _l),
               "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l), "ufv_attention_bwd_fused_ws_bytes": ([_i, _i], _l),
               "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l), "ufv_mask_dot_bwd_ws_bytes": ([_i, _i], _l)}
@@ -138,6 +140,7 @@ class StcModel(C.Structure):
                [("eps", _f), ("_padf", _f), ("s1", C.POINTER(StcBlock)), ("s2", C.POINTER(StcBlock)), ("samp_w", _p), ("samp_b", _p),
                 ("readout_w", C.POINTER(_p)), ("readout_b", C.POINTER(_p))]
 
+ABI_VERSION = 2          # include/ufv.h UFV_ABI_VERSION
 _lib = None
 
 
@@ -158,6 +161,8 @@ def load():
     lib.ufv_last_error.argtypes = []
     lib.ufv_abi_version.restype = _i
     lib.ufv_abi_version.argtypes = []
+    if lib.ufv_abi_version() != ABI_VERSION:
+        raise UfvError(f"{LIB_PATH} has ABI version {lib.ufv_abi_version()}, this binding was written for {ABI_VERSION}: rebuild (make)")
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args

@@ -1405,8 +1405,10 @@ extern "C" int ufv_attention_decode_fused(const void* qkv, int Hq, int Hkv, int 
     UFV_REQUIRE(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)kv_cache % 16 == 0) && ldkv % 8 == 0, "ufv_attention_decode_fused: rows must be 16-byte aligned");
     const int keys = pos_dev ? max_keys : pos + 1;
     UFV_REQUIRE(keys > 0 && (pos_dev || pos < max_keys), "ufv_attention_decode_fused: position %d outside the cache (%d rows)", pos, max_keys);
-    UFV_REQUIRE(cdiv(keys, nsplit) * sizeof(float) <= 48 * 1024, "ufv_attention_decode_fused: too many keys per split (%d / %d)", keys, nsplit);
-    const size_t sm = (size_t)cdiv(keys, nsplit) * sizeof(float);
+    UFV_REQUIRE(cdiv(keys, nsplit) * sizeof(float) <= 48 * 1024 && nsplit <= 4096, "ufv_attention_decode_fused: too many keys per split (%d / %d)", keys, nsplit);
+    // dynamic LDS: the scores of one split, re-used by the merging block as ml[nsplit][2] -- sized for whichever is larger (a short prompt has
+    // fewer keys per split than 2 * nsplit merge words)
+    const size_t sm = (size_t)(cdiv(keys, nsplit) > 2 * nsplit ? cdiv(keys, nsplit) : 2 * nsplit) * sizeof(float);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (hd == 64)
         hipLaunchKernelGGL((attn_decode_fused<64>), dim3(nsplit, Hq), dim3(256), sm, st, (const bf16*)qkv, Hq, Hkv, inv_freq, pos, pos_dev, (bf16*)kv_cache, ldkv,

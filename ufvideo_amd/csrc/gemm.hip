@@ -14,6 +14,7 @@
 // Generic kernel: any shape/alignment, one thread per output, used for tiny problems
 // (region encoder, SE gates, tiny test models).
 #include "common.h"
+#include <atomic>
 #include <vector>
 #include <cstdlib>
 #include "../../include/ufv.h"
@@ -594,6 +595,11 @@ inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool ca
     return pick;
 }
 
+// Whether UFV_GEMM_AUTO may pick the split-K form (ufv_gemm_set_splitk).  The environment variable UFV_GEMM_NO_SPLITK is read ONCE, when the
+// library is loaded, as the initial value; after that only the setter changes it (an atomic: no getenv on the launch path).
+static std::atomic<int> g_splitk{getenv("UFV_GEMM_NO_SPLITK") == nullptr ? 1 : 0};
+static inline bool splitk_enabled() { return g_splitk.load(std::memory_order_relaxed) != 0; }
+
 template <bool F, bool S, bool Q>
 int launch_fast(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
     if (!S) {
@@ -647,7 +653,7 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
     if (force == UFV_GEMM_STREAMK) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, true, 0, st);
     if (force == UFV_GEMM_FAST256) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, shape, st);
     if (force == UFV_GEMM_AUTO && big_ok) {
-        const int pick = choose_kernel(M, N, Q ? K / 2 : K, F, S, !Q && e.act == ACT_NONE && e.resid_rows == 0 && getenv("UFV_GEMM_NO_SPLITK") == nullptr);
+        const int pick = choose_kernel(M, N, Q ? K / 2 : K, F, S, !Q && e.act == ACT_NONE && e.resid_rows == 0 && splitk_enabled());
         if (pick) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, pick, st);
     }
     if ((force == UFV_GEMM_AUTO && fast_ok && M > 64) || force == UFV_GEMM_FAST)
@@ -706,8 +712,10 @@ int gemm_entry(const void* A, int lda, const float* a_scale, const void* W, int 
 // kernel's shape code as in UFV_GEMM_PP (1442, 1431, ..., + 10000 * parts for the split-K form).  Host arithmetic only (no GPU needed).
 extern "C" int ufv_gemm_choice(int M, int N, int K, int out_f32, int swiglu, int act_none) {
     if (M < 256 || N % BN != 0 || K % BK != 0) return 0;
-    return choose_kernel(M, N, K, out_f32 != 0, swiglu != 0, act_none != 0 && getenv("UFV_GEMM_NO_SPLITK") == nullptr);
+    return choose_kernel(M, N, K, out_f32 != 0, swiglu != 0, act_none != 0 && splitk_enabled());
 }
+
+extern "C" int ufv_gemm_set_splitk(int enable) { return g_splitk.exchange(enable != 0 ? 1 : 0); }
 
 extern "C" int ufv_gemm_timing(int enable) {
     g_timing = enable != 0;

@@ -3,27 +3,6 @@
 #include "gemm256_kernel.h"
 #include <cstdlib>
 
-// stream-K workspace: one 256 KiB accumulator slot + one flag per block, allocated on first use and kept (grow-only).
-// One GEMM at a time may use it (launches are ordered on the caller's stream).
-static int streamk_state(int grid, StreamK* out) {
-    static float* ws = nullptr;
-    static int* flags = nullptr;
-    static int cap = 0, epoch = 0;
-    if (grid > cap) {
-        if (ws) (void)hipFree(ws);
-        if (flags) (void)hipFree(flags);
-        ws = nullptr; flags = nullptr; cap = 0;
-        if (hipMalloc(&ws, (size_t)grid * 262144) != hipSuccess || hipMalloc(&flags, (size_t)grid * sizeof(int)) != hipSuccess) {
-            ufv_set_error("ufv_gemm: could not allocate the stream-K workspace (%d x 256 KiB)", grid);
-            return UFV_EHIP;
-        }
-        if (hipMemset(flags, 0, (size_t)grid * sizeof(int)) != hipSuccess) return UFV_EHIP;
-        cap = grid; epoch = 0;
-    }
-    out->ws = ws; out->flags = flags; out->epoch = ++epoch;
-    return UFV_OK;
-}
-
 template <bool F, bool S, bool Q>
 static int launch256_t(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool streamk, int shape, hipStream_t st) {
     // shape: 0 / 1442 = the 256x256 tile; other codes (1000 + MA0 MA1 NB1, plain epilogues only) are built in gemm256_b.hip / gemm256_q.hip;
@@ -59,8 +38,8 @@ static int launch256_t(const void* A, const void* W, const Epi& e, int M, int N,
         const int tiles = cdiv(M, 256) * cdiv(N, 256);
         const int nk = K / (Q ? 128 : 64);
         if ((long long)tiles * nk < n_cu) return launch_pp<F, S, Q, 4, 4, 2, true>(A, W, e, M, N, K, lda, ldw, st);
-        StreamK sk = {nullptr, nullptr, 0, pp_group(cdiv(M, 256)), 1};
-        const int rc = streamk_state(n_cu, &sk);
+        StreamK sk = {nullptr, nullptr, 0, pp_group(cdiv(M, 256)), 1, nullptr};
+        const int rc = ufv_streamk_acquire(n_cu, &sk.ws, &sk.flags, &sk.epoch, &sk.err);     // one stream-K launch at a time per device (opt-in form)
         if (rc != UFV_OK) return rc;
         hipLaunchKernelGGL((gemm_nt_256<F, S, Q, true>), dim3(n_cu), dim3(512), SMEM256, st, A, W, e, M, N, K, lda, ldw, sk);
         UFV_CHECK_LAUNCH();

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "../../include/ufv.h"
 #include "gemm_epi.h"
+#include "gemm_state.h"
 #include <type_traits>
 
 #ifndef UFV_GSTAMP
@@ -180,8 +181,27 @@ struct StreamK {
     int* flags;         // [grid]
     int epoch;          // value that marks "slot written during THIS launch"
     int gm;             // row-tiles per group of the tile order (concurrent tiles of a group share A / W panels in L2)
-    int ksplit;         // KSPL kernels: K parts per tile (items = tiles x parts, part-major), turn flags in `flags`, `epoch` = this launch's flag base
+    int ksplit;         // KSPL kernels: K parts per tile (items = tiles x parts, part-major), turn flags in `flags` (this launch's own slice), `epoch` = this launch's ticket base
+    int* err;           // pinned host word: set when a bounded turn wait expires (gemm_state.hip)
 };
+
+// Bounded waits on another block's flag.  A turn can only fail to come when the launch's blocks are not all resident (some other kernel
+// holds CUs for seconds); instead of hanging the device the waiter gives up after ~2^21 polls (seconds), reports through `err` and goes
+// on -- that launch's tile is then wrong and the next ufv_gemm call on the device returns an error (gemm_state.hip).
+__device__ __forceinline__ void turn_wait_ge(const int* flag, int target, int* err) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 21)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+}
+__device__ __forceinline__ void turn_wait_eq(const int* flag, int value, int* err) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != value) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 21)) { __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -466,8 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         // this block's range ended inside the tile: the following blocks hold the rest, in order
         int covered = len;                          // K-tiles of the tile accounted for so far (this block's k0 was 0)
         for (int q = pos + 1; covered < nk; ++q) {
-            if (tid == 0)
-                while (__hip_atomic_load(sk.flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(2);
+            if (tid == 0) turn_wait_eq(sk.flags + q, sk.epoch, sk.err);
             __syncthreads();
             const float* img = sk.ws + (size_t)q * 65536;          // 256x256 fp32 tile image written by block q's epilogue
 #pragma unroll
@@ -504,8 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     } else if constexpr (KSPL) {
         // turn order: part p of a tile stores after part p - 1 has (flag = base + p); a part with an empty K range only passes the turn on
         if (cpart > 0) {
-            if (tid == 0)
-                while (__hip_atomic_load(sk.flags + ctile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch + cpart) __builtin_amdgcn_s_sleep(2);
+            if (tid == 0) turn_wait_ge(sk.flags + ctile, sk.epoch + cpart, sk.err);
             __syncthreads();
         }
         if (clen > 0 || cpart == 0) epilogue_split<MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias, cpart == 0);
@@ -522,39 +540,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
 }  // namespace
 
 
-static inline int pp_n_cu() {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    return n_cu;
-}
+static inline int pp_n_cu() { return ufv_dev_n_cu(); }
 
 // row-tiles per tile-order group: all of them when there are few (M = 2399 -> 10 row tiles: a ragged second group of 2 rows
 // made its XCDs fetch 16 W panels per round instead of 4; 1203 -> 1244 TF/s on gate/up), else ~8 in equal groups
 static inline int pp_group(int tiles_m) { return tiles_m <= 16 ? tiles_m : cdiv(tiles_m, cdiv(tiles_m, 8)); }
-
-// turn flags of the split-K kernels: one int per tile, grow-only; every launch takes a fresh base so that nothing needs clearing
-static inline int splitk_flags(int tiles, int** flags, int* base) {
-    static int* buf = nullptr;
-    static int cap = 0, epoch = 0;
-    if (tiles > cap || epoch > (1 << 30)) {
-        if (buf) (void)hipFree(buf);
-        buf = nullptr; cap = 0;
-        const int n = tiles > 65536 ? tiles : 65536;            // 256 KiB: regrowth (an implicit device sync in hipFree) practically never happens
-        if (hipMalloc(&buf, (size_t)n * sizeof(int)) != hipSuccess || hipMemset(buf, 0, (size_t)n * sizeof(int)) != hipSuccess) {
-            ufv_set_error("ufv_gemm: could not allocate the split-K turn flags (%d tiles)", tiles);
-            return UFV_EHIP;
-        }
-        cap = n; epoch = 0;
-    }
-    epoch += 64;
-    *flags = buf; *base = epoch;
-    return UFV_OK;
-}
 
 template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false>
 static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st, int ksplit = 1) {
@@ -571,7 +561,7 @@ static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, i
         return UFV_EUNSUPPORTED;
     }
     const int tiles_m = cdiv(M, T::BM), tiles = tiles_m * cdiv(N, T::BN), n_cu = pp_n_cu();
-    StreamK sk = {nullptr, nullptr, 0, pp_group(tiles_m), 1};
+    StreamK sk = {nullptr, nullptr, 0, pp_group(tiles_m), 1, nullptr};
     int items = tiles;
     if constexpr (KSPL) {
         const int nk = K / 64;
@@ -579,7 +569,7 @@ static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, i
             ufv_set_error("ufv_gemm: split-K needs an activation-free epilogue and 2 <= parts <= 32 non-empty K ranges (parts=%d, K-tiles=%d)", ksplit, nk);
             return UFV_EUNSUPPORTED;
         }
-        const int rc = splitk_flags(tiles, &sk.flags, &sk.epoch);
+        const int rc = ufv_splitk_acquire(tiles, ksplit, &sk.flags, &sk.epoch, &sk.err);      // this launch's own flag slice and ticket base
         if (rc != UFV_OK) return rc;
         sk.ksplit = ksplit;
         items = tiles * ksplit;

@@ -228,7 +228,10 @@ class DecoderTrainer:
         if self.world > 1:
             # RCCL kernels on the side stream hold CUs while GEMMs run: the split-K GEMM form spins on turn flags and assumes that its <= 256 blocks all
             # become resident -- keep ufv_gemm on the unsplit kernels in a process that overlaps collectives with compute (threading)
-            os.environ["UFV_GEMM_NO_SPLITK"] = "1"
+            # (ufv_gemm_set_splitk: an atomic in the library, restored by detach().  The unsplit form sums K in one pass instead of in parts, so
+            # fp32 GEMM outputs of this process differ from a world-1 process in the last bits, <= 4e-6 of the largest element.)
+            from . import _lib as _L
+            self._splitk_before = _L.load().ufv_gemm_set_splitk(0)
         # the decoder's packed weights now ARE this trainer's buffers: anything that would re-pack them from the (stale) nn.Parameters
         # -- .to(), load_state_dict, set_gemm_dtype, resize_token_embeddings, invalidate() -- raises until detach()
         model.get_model()._owner = self
@@ -639,6 +642,10 @@ class DecoderTrainer:
     def detach(self):
         """sync_to_model(), then release the model: its packed buffers are rebuilt from the (now current) parameters on next use"""
         self.sync_to_model()
+        if getattr(self, "_splitk_before", None) is not None:
+            from . import _lib as _L
+            _L.load().ufv_gemm_set_splitk(self._splitk_before)
+            self._splitk_before = None
         self.model.get_model()._owner = None
         self.model._owner = None
         self.model.invalidate(); self.model.get_model().invalidate()
