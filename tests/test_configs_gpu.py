@@ -6,6 +6,10 @@
     seconds; every layer has the 7B dimensions), splice bookkeeping exact.
 #3  64 frames 336x336: token count 4608, S = 4703, 8-way aligned frame chunks == the whole clip bit for bit (what the 8-GPU
     frame-sharded encoder relies on).
+#4  the training step at its workload: `DecoderTrainer.train_step(**collator batch)` on a 16-frame 336x336 clip (scripts/train/train_1121v1.sh:34
+    `--num_frames 16`), 7B layer dims, frozen 26-layer tower -> STC-v35 projector (trained) -> splice -> decoder forward / backward (trained) ->
+    clip -> AdamW.  The N > 1 half (ZeRO-2 over 8 GPUs) cannot run on a 1-GPU box: its exchange runs on RCCL at world size 1 in
+    tests/test_parallel_gpu.py and at world size 2 over gloo in tests/test_parallel_cpu.py.
 #5  fp8 GEMMs + the SAM2 segmentation head: SAM2-L (Hiera-L trunk, d_model 256, 64x64 grid) on one 1024x1024 frame against the
     oracle; one fp8 + `[SEG]` run end to end at 32 frames (properties).
 """
@@ -208,3 +212,58 @@ def test_config5_fp8_and_seg_head_end_to_end_32f():
     agree = (outs["fp8"][1] == outs["bf16"][1]).float().mean().item()
     print(f"CONFIG5 fp8 vs bf16 last hidden {d:.2e}   mask agreement {agree:.3f}")
     assert d < 0.3 and agree > 0.9            # measured 0.21 / 0.94: e4m3 carries 3 mantissa bits (the kernels are exact: tests/test_fp8_gpu.py)
+
+
+def _config4_trainer(seed_shift=0):
+    import bench
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM, QWEN2_7B
+    from ufvideo_amd.train import DecoderTrainer
+    dev = torch.device("cuda", 0)
+    cfg = VideoReferQwen2Config(**dict(QWEN2_7B, num_hidden_layers=2), mm_vision_tower="siglip-so400m-patch14-384", mm_vision_select_layer=-2,
+                                mm_vision_select_feature="patch", mm_projector_type="stc_connector_v35", mm_hidden_size=1152,
+                                mm_region_encoder_type="pooling", image_aspect_ratio="square", train_mask_decoder=False,
+                                sam_pretrained=None, sam_out_dim=256, num_frames=16, seg_token_id=151747, sam2_trunk=None,
+                                vision_config=bench.VISION)
+    model = VideoReferQwen2ForCausalLM(cfg, device=dev, seed=0)
+    model.get_vision_tower().load_model(device=dev, seed=7)
+    for m in model.modules():
+        m.tokenizer = bench._Tok()
+    tr = DecoderTrainer(model, lr=2e-5, weight_decay=0.0, max_grad_norm=1.0, train_projector=True, train_decoder=True)
+    video, ids, am = bench.synthetic_inputs(dev, frames=16)
+    labels = ids.clone(); labels[labels < 0] = -100; labels[:, :40] = -100          # the instruction is not supervised (train.py:678-700)
+    return model, tr, dict(input_ids=ids, labels=labels, attention_mask=am, images=[(video, "video")])
+
+
+def test_config4_training_step_16_frames_7b_dims():
+    """Config #4 at its workload through the drop-in call (ufvideo/train.py:678-732 collator keys -> videorefer_qwen2.py:198-352 loss):
+    bookkeeping (16 frames -> 8 x 144 = 1152 visual tokens, S = 1152 + 95), a finite loss at the random-init level, bit-reproducible
+    across two independently built trainers (no atomics on the path), the clipped norm AdamW saw, a loss that falls over three steps on the
+    same batch, and trained weights that reach generate()/forward() (the trainer's buffers ARE the model's packed weights)."""
+    model, tr, batch = _config4_trainer()
+    with torch.no_grad():
+        _, am2, _, emb, lab2, _ = model.prepare_inputs_labels_for_multimodal(batch["input_ids"], batch["attention_mask"], None, batch["labels"],
+                                                                              batch["images"], None, None, None, None)
+    assert emb.shape == (1, 1152 + 95, 3584) and int(am2.sum()) == 1247
+    assert int((lab2 != -100).sum()) == 96 - 40                                       # the video position and the visual tokens carry no label
+    before = tr.proj_bucket.master.clone()
+    losses, norms = [], []
+    for _ in range(3):
+        r = tr.train_step(**batch)
+        losses.append(float(r["loss"])); norms.append(float(r["grad_norm"]))
+    assert all(np.isfinite(losses)) and all(np.isfinite(norms)) and norms[0] > 0
+    assert 11.5 < losses[0] < 13.5                                                    # ln(151748) = 11.93 + the spread of random-init logits
+    assert losses[2] < losses[1] < losses[0]
+    assert float((tr.proj_bucket.master - before).abs().max()) > 0                    # the projector moved
+    for b in tr.layers:
+        assert bool(torch.isfinite(b.g).all()) and torch.equal(b.w, b.master.to(torch.bfloat16))
+    # the model sees the trained weights: the forward loss through the model's own API equals the next step's pre-update loss
+    with torch.no_grad():
+        out = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], images=batch["images"], inference=False)
+    lm = float(out["loss"] if isinstance(out, dict) else out.loss)
+    r4 = tr.train_step(**batch)
+    assert abs(lm - float(r4["loss"])) < 2e-3 * abs(lm)
+    del model, tr, batch
+    torch.cuda.empty_cache()
+    _, tr2, batch2 = _config4_trainer()
+    r = tr2.train_step(**batch2)
+    assert float(r["loss"]) == losses[0] and float(r["grad_norm"]) == norms[0]       # bit-reproducible

@@ -73,7 +73,9 @@ int main(int argc, char** argv) {
         kernel = other; run(); hipDeviceSynchronize(); kernel = keep;
         std::vector<uint16_t> h2(ho.size());
         hipMemcpy(h2.data(), o, h2.size() * 2, hipMemcpyDeviceToHost);
-        int shown = 0; size_t bad = 0;
+        int shown = 0; size_t bad = 0, bits = 0;
+        for (size_t i = 0; i < ho.size(); ++i) bits += ho[i] != h2[i];
+        printf("elements with different BITS from kernel %d: %zu of %zu\n", other, bits, ho.size());
         for (size_t i = 0; i < ho.size(); ++i) { double a_ = bf2f(ho[i]), b_ = bf2f(h2[i]);
             if (fabs(a_ - b_) > 0.02) { ++bad; if (shown++ < 40) { size_t row = i / D; printf("  row(q) %zu head %zu d %zu: this %.4f other %.4f\n", row % S, (i % D) / hd, i % hd, a_, b_); } } }
         printf("elements differing by > 0.02 from kernel %d: %zu of %zu\n", other, bad, ho.size());

@@ -602,6 +602,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
 }
 
 #include "attn_vit.inc"
+#include "attn_vit_p2.inc"
 
 // ---------------------------------------------------------------------------------------------------------
 // Head-pair variant of the LDS-DMA kernel (diagnostic, kernel ids 7 / 8).  With 168 VGPRs a CU holds 3 waves per SIMD, i.e. ONE
@@ -1165,12 +1166,16 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
     }
-    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || kernel == 10 || kernel == 11 || ((kernel == 12 || kernel == 13) && mfma_ok) ||
+    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || kernel == 10 || kernel == 11 || kernel == 14 || ((kernel == 12 || kernel == 13) && mfma_ok) ||
         (kernel == 0 && mfma_ok && Sq >= 16)) {
         const bool six = (Sq % 192 == 0) && (Sq % 128 != 0);     // e.g. 576 ViT tokens: 3 blocks of 6 waves, no idle wave
         switch (hd) {
             case 64: return launch_mfma<64, 4>(a, causal, st);
             case 72: if (kernel == 3) return launch_mfma<72, 4>(a, causal, st);      // register-staged variant (diagnostic)
+                     if (kernel == 14) {
+                         if (causal || !vit72_p2_ok(a)) { ufv_set_error("ufv_attention: kernel 14 is built for non-causal hd 72, S = 576, an even head count and equal q / k / v row pitches"); return UFV_EUNSUPPORTED; }
+                         return launch_vit72_p2(a, st);
+                     }
                      // head-pair variants (diagnostic: measured 10-25 % slower than the 9-wave blocks)
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 7) return launch_pair<72, 6, false>(a, st);
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 8) return launch_pair<72, 6, true>(a, st);
