@@ -21,10 +21,12 @@ import sys
 HD = 72
 PK = 144                  # K / V / Q / O row pitch in LDS (9 chunks of 16 B)
 KT = 64 * PK              # 9216
-VOFF = KT + 128
-STG = VOFF + KT + 128     # 18688 per stage (K | pad | V | pad)
+VOFF = KT                 # V tile right behind the K tile
+KONE_REL = 2 * KT         # 16 bytes {1.0, 0, ...} behind the V tile of EVERY stage (the K fragment of the contraction-padding lanes), + 48 B pad for the
+STG = 2 * KT + 64         # transposed reads of d-tile 2 that run past a row: 18496 per stage
+NSTAGE = 3                # tile j lives in stage j % 3 (9 tiles per pass: the same in every pass, so every LDS offset is an immediate)
 NPIECE = 9                # DMA pieces per wave per tile (a wave loads the K tile or the V tile of its head)
-QPIECES = 14              # 96 rows x 144 B = 13.5 KiB -> 14 pieces
+QPIECES = 9               # staging holds the rows of units 0 and 1 (64 x 144 B = 9 pieces); unit 2's fragments come straight from global memory
 UNIT_BYTES = 32 * PK      # 4608
 NT = 9                    # key tiles per pass (S = 576)
 NPASS = 3
@@ -42,6 +44,7 @@ MRUN = lambda u: 239 + u
 ONES, LANE, QADDR, OWADDR, ORADDR = 242, 243, 244, 245, 246
 VOFFO = lambda i: 247 + i                           # v247..251
 TE, TF, TG, TH = 252, 253, 254, 255
+VQOFF = TH                                           # per-lane source offset of the direct Q loads (row l31, 16 h bytes)
 
 def O(u, dt, r=0): return 48 * u + 16 * dt + r      # a: O^T accumulators
 def KF(ks, half, i=0): return 144 + 8 * ks + 4 * half + i   # a: K fragments
@@ -51,8 +54,13 @@ def VF(dt, c, i=0): return 184 + 16 * dt + 4 * c + i        # a: V^T fragments o
 KVR, QR, ORS = 40, 44, 48
 S_ONR, S_SS, S_OS, S_T64, S_SC, S_RING, S_DST, S_DDST, S_DRD, S_QST, S_QSOFF, S_OSOFF, S_PASS, S_TMP = range(52, 66)
 S_HM, S_ONE, S_RET, S_T2, S_MAGIC, S_KONE, S_T3, S_T4, S_EXLO = 66, 68, 70, 72, 74, 75, 76, 77, 78
-S_ORN = 80          # current num_records word of the O descriptor (0 in pass 0: stores dropped)
+S_Q2OFF = 80        # source offset of unit 2's rows of the next pass (direct Q loads)
 S_ODESC = 84        # s[84:87]: O descriptor actually used by the stores
+
+
+STAMPS = "--stamps" in sys.argv      # lab build: s_memtime at the top of every period -> [wave][128] dwords at %[stp]
+def stamp():
+    return ("GROUP", ["s_memtime s[88:89]", "s_waitcnt lgkmcnt(0)", "s_store_dword s88, s[90:91], 0", "s_add_u32 s90, s90, 4", "s_addc_u32 s91, s91, 0"])
 
 
 class Gen:
@@ -83,13 +91,14 @@ def sr(n, cnt=1):
 
 
 # ---- instruction groups ------------------------------------------------------------------------------------------------------
-def mfma_pv(u):
-    """O[u][dt] += V^T(dt, c) * P[u](c), c = 0..3 in order per dt (the accumulation order of attn_vit.inc)"""
+def mfma_pv(u, zero_c=False):
+    """O[u][dt] (+)= V^T(dt, c) * P[u](c), c = 0..3 in order per dt (the accumulation order of attn_vit.inc); zero_c: the sums start from 0"""
     out = []
     for dt in range(3):
         for c in range(4):
             a = ar(VF(dt, c), 4) if dt < 2 else vr(VD2(c), 4)
-            out.append(f"v_mfma_f32_32x32x16_bf16 {ar(O(u, dt), 16)}, {a}, {vr(P(u, 4 * c), 4)}, {ar(O(u, dt), 16)}")
+            cc = "0" if (zero_c and c == 0) else ar(O(u, dt), 16)
+            out.append(f"v_mfma_f32_32x32x16_bf16 {ar(O(u, dt), 16)}, {a}, {vr(P(u, 4 * c), 4)}, {cc}")
     return out
 
 
@@ -155,24 +164,24 @@ def rescale_o(u):
     return o
 
 
-def k_reads():
-    """K fragments of the tile whose (per-lane) addresses are in KADDR / K4A0 / K4A1"""
+def k_reads(st):
+    """K fragments of the tile in ring stage st (per-lane stage-0 addresses in KADDR / K4A0 / K4A1)"""
     o = []
     for ks in range(4):
         for half in range(2):
-            o.append(f"ds_read_b128 {ar(KF(ks, half), 4)}, {vr(KADDR)} offset:{ks * 32 + half * 32 * PK}")
-    o.append(f"ds_read_b128 {ar(KF(4, 0), 4)}, {vr(K4A0)}")
-    o.append(f"ds_read_b128 {ar(KF(4, 1), 4)}, {vr(K4A1)}")
+            o.append(f"ds_read_b128 {ar(KF(ks, half), 4)}, {vr(KADDR)} offset:{st * STG + ks * 32 + half * 32 * PK}")
+    o.append(f"ds_read_b128 {ar(KF(4, 0), 4)}, {vr(K4A0)} offset:{st * STG}")
+    o.append(f"ds_read_b128 {ar(KF(4, 1), 4)}, {vr(K4A1)} offset:{st * STG}")
     return o
 
 
-def v_reads():
-    """V^T fragments (tr reads); d-tile 2 first (it needs the ones-row substitution afterwards)"""
+def v_reads(st):
+    """V^T fragments (tr reads) of the tile in ring stage st; d-tile 2 first (it needs the ones-row substitution afterwards)"""
     o = []
     for dt in (2, 0, 1):
         for c in range(4):
             for half in range(2):
-                off = dt * 64 + c * 16 * PK + half * 8 * PK
+                off = st * STG + dt * 64 + c * 16 * PK + half * 8 * PK
                 dst = vr(VD2(c, 2 * half), 2) if dt == 2 else ar(VF(dt, c, 2 * half), 2)
                 o.append(f"ds_read_b64_tr_b16 {dst}, {vr(VADDR)} offset:{off}")
     return o
@@ -180,15 +189,6 @@ def v_reads():
 
 def vd2_ones():
     return [f"v_cndmask_b32 {vr(VD2(c, i))}, {vr(VD2(c, i))}, {vr(ONES)}, {sr(S_ONE, 2)}" for c in range(4) for i in range(4)]
-
-
-def addr_flip():
-    """move the K / V fragment read addresses to the other ring stage"""
-    return [f"v_add_u32 {vr(KADDR)}, {sr(S_DRD)}, {vr(KADDR)}", f"v_add_u32 {vr(VADDR)}, {sr(S_DRD)}, {vr(VADDR)}",
-            f"v_add_u32 {vr(TE)}, 128, {vr(KADDR)}", f"v_add_u32 {vr(TF)}, {128 + 32 * PK}, {vr(KADDR)}",
-            f"s_sub_u32 {sr(S_DRD)}, 0, {sr(S_DRD)}",
-            f"v_cndmask_b32 {vr(K4A0)}, {vr(TE)}, {vr(TG)}, {sr(S_HM, 2)}", f"v_cndmask_b32 {vr(K4A1)}, {vr(TF)}, {vr(TG)}, {sr(S_HM, 2)}"]
-    # TG holds the KONE address (set in the prologue and never reused)
 
 
 def dma_piece(rsrc, voff, soff, m0_expr):
@@ -200,26 +200,36 @@ def q_load(u, tmp_bank):
     """Q fragments of unit u from the staging area (rows 32u..32u+31) into Q(u, ks), pre-multiplied by scale*log2e and re-rounded to bf16;
     d >= 72 (ks = 4, h = 1 lanes) zeroed.  tmp_bank: two free VGPRs."""
     a, b = tmp_bank
-    o = [f"ds_read_b128 {vr(Q(u, ks), 4)}, {vr(QADDR)} offset:{u * UNIT_BYTES + ks * 32}" for ks in range(5)]
-    o.append("s_waitcnt lgkmcnt(0)")
+    o = []
+    if u < 2:
+        o = [f"ds_read_b128 {vr(Q(u, ks), 4)}, {vr(QADDR)} offset:{u * UNIT_BYTES + ks * 32}" for ks in range(5)]
+        o.append("s_waitcnt lgkmcnt(0)")
     for ks in range(5):
         for i in range(4):
             r = vr(Q(u, ks, i))
             o += [f"v_lshlrev_b32 {vr(a)}, 16, {r}", f"v_and_b32 {vr(b)}, 0xffff0000, {r}", f"v_mul_f32 {vr(a)}, {sr(S_SC)}, {vr(a)}",
-                  f"v_mul_f32 {vr(b)}, {sr(S_SC)}, {vr(b)}", "s_nop 0", f"v_cvt_pk_bf16_f32 {r}, {vr(a)}, {vr(b)}"]
+                  f"v_mul_f32 {vr(b)}, {sr(S_SC)}, {vr(b)}", f"v_cvt_pk_bf16_f32 {r}, {vr(a)}, {vr(b)}"]
     o += [f"v_cndmask_b32 {vr(Q(u, 4, i))}, {vr(Q(u, 4, i))}, 0, {sr(S_HM, 2)}" for i in range(4)]
     return o
 
 
-def drain(u, bank):
-    """O of unit u (of the pass that just ended) -> normalise -> bf16 -> staging rows -> global; zero the accumulators.
-    bank: base of 32 free VGPRs.  The store offset (rows of the ended pass, unit u) is S_OSOFF + 32 u OS."""
+def q2_fetch():
+    """unit 2's raw Q rows of the NEXT pass straight into its fragment registers: lane (l31, h) loads 16 bytes of row l31 at column chunk 2 ks + h"""
+    return [("VMEM", f"buffer_load_dwordx4 {vr(Q(2, ks), 4)}, {vr(VQOFF)}, {sr(QR, 4)}, {sr(S_Q2OFF)} offen offset:{ks * 32}") for ks in range(5)] + [("TAG", "q2")]
+
+
+def drain(u, bank, bank_b=None):
+    """O of unit u (of the pass that just ended) -> normalise -> bf16 -> staging rows (part A) -> global (part B).  The accumulators are not
+    cleared: the next pass's first PV starts from 0.  bank / bank_b: bases of 16 / 20 free VGPRs for the two parts.  The store offset (rows of
+    the ended pass, unit u) is S_OSOFF + 32 u OS.  Returns (part A, part B)."""
+    bank_b = bank if bank_b is None else bank_b
     x = [bank + i for i in range(4)]
     y = [bank + 4, bank + 5]
     l, l2, inv = bank + 6, bank + 7, bank + 8
     d = [bank + 9 + i for i in range(6)]
-    rows = [bank + 16 + 4 * i for i in range(4)]         # 4 x 4 regs for row chunks (5 chunks: the 5th reuses the first)
-    o = [f"v_accvgpr_read_b32 {vr(l)}, {ar(O(u, 2, 4))}", "s_nop 0", f"v_mov_b32 {vr(l2)}, {vr(l)}", "s_nop 1",
+    rows = [bank_b + 4 * i for i in range(4)]         # 4 x 4 regs for row chunks (5 chunks: the 5th reuses the first)
+    reg = (0 if u == 2 else u) * UNIT_BYTES             # the staging area has two 32-row regions; unit 2's rows leave through region 0 (free again by then)
+    a = [f"v_accvgpr_read_b32 {vr(l)}, {ar(O(u, 2, 4))}", "s_nop 0", f"v_mov_b32 {vr(l2)}, {vr(l)}", "s_nop 1",
          f"v_permlane32_swap_b32 {vr(l)}, {vr(l2)}",
          # inv = 1.0f / l, IEEE (the sequence hipcc emits for the division in attn_vit.inc)
          f"v_div_scale_f32 {vr(d[0])}, {sr(S_T2, 2)}, {vr(l)}, {vr(l)}, 1.0", f"v_rcp_f32 {vr(d[1])}, {vr(d[0])}", "s_nop 0",
@@ -232,26 +242,23 @@ def drain(u, bank):
     groups = [(dt, g4) for dt in range(2) for g4 in range(4)] + [(2, 0)]
     for dt, g4 in groups:
         for i in range(4):
-            o.append(f"v_accvgpr_read_b32 {vr(x[i])}, {ar(O(u, dt, 4 * g4 + i))}")
-        o.append("s_nop 0")
+            a.append(f"v_accvgpr_read_b32 {vr(x[i])}, {ar(O(u, dt, 4 * g4 + i))}")
         for i in range(4):
-            o.append(f"v_mul_f32 {vr(x[i])}, {vr(inv)}, {vr(x[i])}")
-        o += ["s_nop 0", f"v_cvt_pk_bf16_f32 {vr(y[0])}, {vr(x[0])}, {vr(x[1])}", f"v_cvt_pk_bf16_f32 {vr(y[1])}, {vr(x[2])}, {vr(x[3])}", "s_nop 0",
-              f"ds_write_b64 {vr(OWADDR)}, {vr(y[0], 2)} offset:{u * UNIT_BYTES + dt * 64 + g4 * 16}"]
-    o += [f"v_accvgpr_write_b32 {ar(O(u, 0, r))}, 0" for r in range(48)]
-    o += ["s_waitcnt lgkmcnt(0)"]
+            a.append(f"v_mul_f32 {vr(x[i])}, {vr(inv)}, {vr(x[i])}")
+        a += [f"v_cvt_pk_bf16_f32 {vr(y[0])}, {vr(x[0])}, {vr(x[1])}", f"v_cvt_pk_bf16_f32 {vr(y[1])}, {vr(x[2])}, {vr(x[3])}", "s_nop 0",
+              f"ds_write_b64 {vr(OWADDR)}, {vr(y[0], 2)} offset:{reg + dt * 64 + g4 * 16}"]
     # 288 chunks of 16 B: lane c = 64 i + lane; i = 4 covers c = 256..287 (lanes 0..31)
-    o += [f"s_mul_i32 {sr(S_T3)}, {sr(S_OS)}, {32 * u}", f"s_add_u32 {sr(S_T3)}, {sr(S_OSOFF)}, {sr(S_T3)}"]
+    b = ["s_waitcnt lgkmcnt(0)", f"s_mul_i32 {sr(S_T3)}, {sr(S_OS)}, {32 * u}", f"s_add_u32 {sr(S_T3)}, {sr(S_OSOFF)}, {sr(S_T3)}"]
     for i in range(4):
-        o.append(f"ds_read_b128 {vr(rows[i], 4)}, {vr(ORADDR)} offset:{u * UNIT_BYTES + 1024 * i}")
-    o.append("s_waitcnt lgkmcnt(0)")
+        b.append(f"ds_read_b128 {vr(rows[i], 4)}, {vr(ORADDR)} offset:{reg + 1024 * i}")
+    b.append("s_waitcnt lgkmcnt(0)")
     for i in range(4):
-        o.append(("VMEM", f"buffer_store_dwordx4 {vr(rows[i], 4)}, {vr(VOFFO(i))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen"))
-    o += ["s_nop 1", f"ds_read_b128 {vr(rows[0], 4)}, {vr(ORADDR)} offset:{u * UNIT_BYTES + 4096}", "s_waitcnt lgkmcnt(0)",
-          f"s_mov_b64 exec, {sr(S_EXLO, 2)}",
-          ("VMEM", f"buffer_store_dwordx4 {vr(rows[0], 4)}, {vr(VOFFO(4))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen"),
-          "s_mov_b64 exec, -1", "s_nop 1"]
-    return o
+        b.append(("VMEM", f"buffer_store_dwordx4 {vr(rows[i], 4)}, {vr(VOFFO(i))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen"))
+    b += ["s_nop 1", f"ds_read_b128 {vr(rows[0], 4)}, {vr(ORADDR)} offset:{reg + 4096}", "s_waitcnt lgkmcnt(0)",
+          ("GROUP", [f"s_mov_b64 exec, {sr(S_EXLO, 2)}",
+                     ("VMEM", f"buffer_store_dwordx4 {vr(rows[0], 4)}, {vr(VOFFO(4))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen"),
+                     "s_mov_b64 exec, -1"]), "s_nop 1"]
+    return a, b
 
 
 # ---- period scheduler: fillers are (gap, priority, [instrs]) --------------------------------------------------------------
@@ -290,11 +297,14 @@ def emit_ins(G, ins):
             G.vm_log.append(text)
             G.e(text)
         elif kind == "VMWAIT":          # wait until the ops tagged `text` (and everything older) are done: count what was issued after them
-            idx = max(i for i, t in enumerate(G.vm_log) if t.startswith("TAG:" + text))
-            later = sum(1 for t in G.vm_log[idx + 1:] if not t.startswith("TAG:"))
-            G.e(f"s_waitcnt vmcnt({later})")
+            tags = [i for i, t in enumerate(G.vm_log) if t.startswith("TAG:" + text)]
+            later = sum(1 for t in G.vm_log[tags[-1] + 1:] if not t.startswith("TAG:")) if tags else 0
+            G.e(f"s_waitcnt vmcnt({min(later, 63)})")
         elif kind == "TAG":
             G.vm_log.append("TAG:" + text)
+        elif kind == "GROUP":           # instructions that must stay adjacent (m0 set-up + its DMA)
+            for t in text:
+                emit_ins(G, t)
         elif kind == "RAW":
             G.e(text)
     else:
@@ -302,6 +312,10 @@ def emit_ins(G, ins):
 
 
 Gen.emit_ins = emit_ins
+
+
+OPT = set(os.environ.get("UFV_P2_OPT", "").split(","))        # scheduling experiments (results stay correct)
+DROP = set(os.environ.get("UFV_P2_DROP", "").split(","))      # timing experiments only (wrong results): dma, exp, max, seam, barrier, vread, kread
 
 
 def build(simple=False):
@@ -321,22 +335,51 @@ def build(simple=False):
         f"s_lshl_b32 {sr(S_T64)}, {sr(S_SS)}, 6", f"s_mov_b32 {sr(S_MAGIC)}, 0x1c71c71d",
         f"s_mov_b32 {sr(S_HM)}, 0", f"s_mov_b32 {sr(S_HM + 1)}, -1", f"s_mov_b32 {sr(S_ONE)}, 0x100", f"s_mov_b32 {sr(S_ONE + 1)}, 0x100",
         f"s_mov_b32 {sr(S_EXLO)}, -1", f"s_mov_b32 {sr(S_EXLO + 1)}, 0", f"s_mov_b32 {sr(S_PASS)}, 0",
-        f"s_mov_b32 {sr(S_DDST)}, {STG}", f"s_mov_b32 {sr(S_DRD)}, {STG}",
+        "s_mov_b32 s90, %[stp0]", "s_mov_b32 s91, %[stp1]",
         f"v_mbcnt_lo_u32_b32 {vr(LANE)}, -1, 0", f"v_mbcnt_hi_u32_b32 {vr(LANE)}, -1, {vr(LANE)}",
         f"v_mov_b32 {vr(ONES)}, 0x3f803f80",
     ]
+    ins += [f"v_and_b32 {vr(TA)}, 31, {vr(LANE)}", f"v_lshrrev_b32 {vr(TB)}, 5, {vr(LANE)}", f"v_mul_lo_u32 {vr(TC)}, {vr(TA)}, {sr(S_SS)}",
+            f"v_lshl_add_u32 {vr(VQOFF)}, {vr(TB)}, 4, {vr(TC)}"]                     # direct Q loads: row l31, byte 16 h
     for k in range(9):       # DMA source offsets: chunk c = 64 k + lane -> row c / 9, column chunk c % 9
         ins += [f"v_add_u32 {vr(TA)}, {64 * k}, {vr(LANE)}", f"v_mul_hi_u32 {vr(TB)}, {vr(TA)}, {sr(S_MAGIC)}", f"v_mul_u32_u24 {vr(TC)}, 9, {vr(TB)}",
                 f"v_sub_u32 {vr(TC)}, {vr(TA)}, {vr(TC)}", f"v_lshlrev_b32 {vr(TC)}, 4, {vr(TC)}", f"v_mul_lo_u32 {vr(TD)}, {vr(TB)}, {sr(S_SS)}",
                 f"v_add_u32 {vr(VOFFR(k))}, {vr(TD)}, {vr(TC)}"]
         if k < 5:
             ins += [f"v_mul_lo_u32 {vr(TD)}, {vr(TB)}, {sr(S_OS)}", f"v_add_u32 {vr(VOFFO(k))}, {vr(TD)}, {vr(TC)}"]
-    ins += [
+    for i in ins:
+        e(i)
+    if STAMPS:
+        G.emit_ins(stamp())
+    # first in: K/V tile 0, the Q rows of units 0 / 1 (staging) and of unit 2 (straight to its registers); then tile 1 and the first half of tile 2
+    for k in range(NPIECE):
+        for i in dma_piece(KVR, VOFFR(k), "0", [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k}"]):
+            e(i)
+    for k in range(QPIECES):
+        for i in dma_piece(QR, VOFFR(k), sr(S_QSOFF), [f"s_add_u32 m0, {sr(S_QST)}, {1024 * k}"]):
+            e(i)
+    e(f"s_add_u32 {sr(S_Q2OFF)}, {sr(S_QSOFF)}, {sr(S_T64)}")
+    for i in q2_fetch():
+        if i[0] == "VMEM":
+            e(i[1])
+    for k in range(NPIECE):
+        for i in dma_piece(KVR, VOFFR(k), sr(S_T64), [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k + STG}"]):
+            e(i)
+    e(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_T64)}, 1")
+    for k in range(5):
+        for i in dma_piece(KVR, VOFFR(k), sr(S_TMP), [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k + 2 * STG}"]):
+            e(i)
+    e(f"s_mul_i32 {sr(S_T4)}, {sr(S_SS)}, 96")
+    e(f"s_add_u32 {sr(S_QSOFF)}, {sr(S_QSOFF)}, {sr(S_T4)}")            # -> rows of pass 1
+    e(f"s_add_u32 {sr(S_Q2OFF)}, {sr(S_Q2OFF)}, {sr(S_T4)}")
+    # the rest of the per-lane addresses is computed while the first tiles are in flight.  Nothing is zeroed: every accumulator chain of a
+    # pass starts from the constant 0, and what the dummy PV / drain of pass 0 computes from uninitialised registers is never stored
+    ins2 = [
         f"v_and_b32 {vr(TA)}, 31, {vr(LANE)}", f"v_lshrrev_b32 {vr(TB)}, 5, {vr(LANE)}",          # TA = l31, TB = h
         f"v_mul_u32_u24 {vr(TC)}, {PK}, {vr(TA)}",                                                 # TC = l31 * 144
         f"v_lshlrev_b32 {vr(TD)}, 4, {vr(TB)}",                                                    # TD = 16 h
         f"v_add3_u32 {vr(KADDR)}, {vr(TC)}, {vr(TD)}, {sr(S_RING)}",
-        f"v_mov_b32 {vr(TG)}, {sr(S_KONE)}",
+        f"v_mov_b32 {vr(TG)}, {sr(S_RING)}", f"v_add_u32 {vr(TG)}, {KONE_REL}, {vr(TG)}",       # the {1, 0, ...} constant of stage 0 (the stage offset is an immediate)
         f"v_add_u32 {vr(TE)}, 128, {vr(KADDR)}", f"v_add_u32 {vr(TF)}, {128 + 32 * PK}, {vr(KADDR)}",
         f"v_cndmask_b32 {vr(K4A0)}, {vr(TE)}, {vr(TG)}, {sr(S_HM, 2)}", f"v_cndmask_b32 {vr(K4A1)}, {vr(TF)}, {vr(TG)}, {sr(S_HM, 2)}",
         f"v_add3_u32 {vr(QADDR)}, {vr(TC)}, {vr(TD)}, {sr(S_QST)}",
@@ -349,31 +392,14 @@ def build(simple=False):
         f"v_and_b32 {vr(TE)}, 3, {vr(LANE)}", f"v_lshl_add_u32 {vr(TD)}, {vr(TE)}, 3, {vr(TD)}",
         f"v_add3_u32 {vr(VADDR)}, {vr(TC)}, {vr(TD)}, {sr(S_RING)}", f"v_add_u32 {vr(VADDR)}, {VOFF}, {vr(VADDR)}",
     ]
-    ins += [f"v_accvgpr_write_b32 {ar(r)}, 0" for r in range(256)]
-    ins += [f"v_mov_b32 {vr(r)}, 0" for r in list(range(0, 144)) + list(range(204, 220)) + [MRUN(0), MRUN(1), MRUN(2)]]
-    for i in ins:
+    for i in ins2:
         e(i)
-    # Q of pass 0 -> staging; K/V tiles 0 and 1 -> ring stages 0 and 1
-    for k in range(QPIECES):
-        so = sr(S_QSOFF) if k < 9 else sr(S_T3)
-        if k == 9:
-            e(f"s_add_u32 {sr(S_T3)}, {sr(S_QSOFF)}, {sr(S_T64)}")
-        for i in dma_piece(QR, VOFFR(k % 9), so, [f"s_add_u32 m0, {sr(S_QST)}, {1024 * k}"]):
-            e(i)
-    e(f"s_mul_i32 {sr(S_T4)}, {sr(S_SS)}, 96")
-    e(f"s_add_u32 {sr(S_QSOFF)}, {sr(S_QSOFF)}, {sr(S_T4)}")            # -> rows of pass 1
-    for t in range(2):
-        for k in range(NPIECE):
-            so = "0" if t == 0 else sr(S_T64)
-            for i in dma_piece(KVR, VOFFR(k), so, [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k + t * STG}"]):
-                e(i)
-    # next DMA (tile 2) goes to stage 0: S_DST stays; S_DDST = +STG is the toggle applied after each tile's DMA
-    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_waitcnt vmcnt(19) lgkmcnt(0)")      # tile 0 and this wave's staged Q rows are in; unit 2's rows, tile 1 and half of tile 2 (19 ops) may still fly
     e("s_barrier")
-    for u in range(3):
+    for u in range(2):                       # unit 2's fragments are loaded in period (0, 0), as in every pass
         for i in q_load(u, (TA, TB)):
             e(i)
-    for i in k_reads():
+    for i in k_reads(0):
         e(i)
     e("s_waitcnt lgkmcnt(0)")
     for m in mfma_qk(0):
@@ -381,95 +407,134 @@ def build(simple=False):
     # O descriptor of pass 0's (non-existent) predecessor: num_records = 0 -> every store is dropped
     e(f"s_mov_b32 {sr(S_ODESC)}, {sr(ORS)}"); e(f"s_mov_b32 {sr(S_ODESC + 1)}, {sr(ORS + 1)}"); e(f"s_mov_b32 {sr(S_ODESC + 2)}, 0"); e(f"s_mov_b32 {sr(S_ODESC + 3)}, {sr(ORS + 3)}")
     e("s_nop 7"); e("s_nop 7")
+    if STAMPS:
+        G.emit_ins(stamp())
 
     # ================= pass loop =================================================================================================
-    e("PASS_LOOP%=:")
-    G.vm_log = ["TAG:kv_next"]           # at loop entry the pieces of the NEXT tile (tile 1) are already complete (prologue / previous pass)
-    for j in range(NT):
-        for u in range(3):
-            prev_u = (u + 2) % 3
-            next_u = (u + 1) % 3
-            per = Period(mfma_pv(prev_u) + mfma_qk(next_u))
-            free_bank = S((u + 2) % 3, 0)           # 32 VGPRs nobody owns during period (., u)
-            stream_sm = []
-            # ---- softmax of item (j, u)
-            mx = sm_max(u)
-            if j == 0:
-                body = mx + rescale_math(u, True)
-            else:
-                stub, back = G.label("RS"), G.label("BK")
-                body = mx + [f"v_cmp_lt_f32 vcc, 0x{THR:08x}, {vr(T0)}", "s_nop 1", f"s_cbranch_vccnz {stub}", f"{back}:"]
-                G.stubs.append((stub, back, u))
-            ex = sm_exp_cvt(u)
-            if simple:
-                per.put([(22, i) for i in body + ex])
-            else:
-                per.put(spread(body, 3, 8 if j else 11))
-                per.put(spread(ex, 9 if j else 12, 22))
-            # ---- LDS / DMA / address work
-            if u == 0:
-                # V^T fragments of tile j: after the 12 PV MFMAs of the previous tile's last unit have been issued
-                vrd = v_reads()
-                per.put([(22, i) for i in vrd] if simple else spread(vrd, 13, 20))
-                per.put([(22, "s_waitcnt lgkmcnt(0)")])
-                # drain of the previous pass's unit 0 happens in this period when j == 0 (below)
-            if u == 1:
-                per.put([(0, i) for i in vd2_ones()] if simple else spread(vd2_ones(), 1, 6))
-            if u == 2:
-                # barrier B(j+1): my pieces of tile j+1 are in, everybody is done with tile j's LDS image
-                per.put([(0, ("VMWAIT", "kv_next")), (0, "s_barrier")])
-                fl = addr_flip()
-                per.put([(0, i) for i in fl])
-                kr = k_reads()
-                per.put([(1, i) for i in kr] if simple else spread(kr, 1, 6))
-                per.put([(11, "s_waitcnt lgkmcnt(0)")])
-                # DMA of tile j + 2 into the stage everybody just left
-                j2 = (j + 2) % NT
-                dm = [f"s_mul_i32 {sr(S_TMP)}, {sr(S_T64)}, {j2}"]
-                for k in range(NPIECE):
-                    dm += [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k}", "s_nop 0",
-                           ("VMEM", f"buffer_load_dwordx4 {vr(VOFFR(k))}, {sr(KVR, 4)}, {sr(S_TMP)} offen lds")]
-                dm += [("TAG", "kv_next"), f"s_add_u32 {sr(S_DST)}, {sr(S_DST)}, {sr(S_DDST)}", f"s_sub_u32 {sr(S_DDST)}, 0, {sr(S_DDST)}"]
-                per.put([(12, i) for i in dm] if simple else spread(dm, 7, 21))
-            # ---- pass seams
-            if j == 0:
-                dr = drain(u, free_bank)
-                per.put([(22, i) for i in dr])
+    def emit_pass(G, carry):
+        """one pass = 27 periods; `carry`: fillers handed over by the previous pass's last period (the second half of tile 1's DMA pieces)"""
+        e = G.e
+        e("PASS_LOOP%=:")
+        # what was issued before the top of a pass, oldest first: ... tile 1 | unit 2's Q rows | first half of tile 2
+        G.vm_log = ["TAG:kv1"] + ["q2"] * 5 + ["TAG:q2"] + ["kv2a"] * 5
+        for j in range(NT):
+            for u in range(3):
+                prev_u = (u + 2) % 3
+                next_u = (u + 1) % 3
+                pv_first_tile = ((j == 0 and u > 0) or (j == 1 and u == 0)) and "nozc" not in OPT     # the PV of a pass's first key tile starts its sums from 0
+                per = Period(mfma_pv(prev_u, zero_c=pv_first_tile) + mfma_qk(next_u))
+                if STAMPS:
+                    per.put([(0, stamp())])
+                per.put(carry)
+                carry = []
+                free_bank = S((u + 2) % 3, 0)           # 32 VGPRs nobody owns during period (., u)
+                # ---- softmax of item (j, u)
+                mx = sm_max(u)
+                if j == 0:
+                    body = mx + rescale_math(u, True)
+                else:
+                    stub, back = G.label("RS"), G.label("BK")
+                    body = mx + [f"v_cmp_lt_f32 vcc, 0x{THR:08x}, {vr(T0)}", "s_nop 1", f"s_cbranch_vccnz {stub}", f"{back}:"]
+                    G.stubs.append((stub, back, u))
+                ex = sm_exp_cvt(u)
+                if "exp" in DROP:
+                    ex = []
+                if "max" in DROP:
+                    body = []
+                    if j != 0:
+                        G.stubs.pop()
+                if simple:
+                    per.put([(22, i) for i in body + ex])
+                else:
+                    per.put(spread(body, 3 if "sm3" in OPT else 2, (6 if "sm3" in OPT else 5) if j else 9))
+                    per.put(spread(ex, 6 if j else 10, 22))
+                # ---- LDS / DMA / address work
+                if u == 0:
+                    # V^T fragments of tile j: after the 12 PV MFMAs of the previous tile's last unit have been issued
+                    vrd = [] if "vread" in DROP else v_reads(j % NSTAGE)
+                    per.put([(22, i) for i in vrd] if simple else spread(vrd, 13, 20))
+                    per.put([(22, "s_waitcnt lgkmcnt(0)")])
+                if u == 1:
+                    per.put([(0, i) for i in vd2_ones()] if simple else spread(vd2_ones(), 1, 6))
                 if u == 2:
-                    # the O descriptor becomes real after pass 0's drains; the store rows advance by 96 per pass
-                    per.put([(22, f"s_cmp_eq_u32 {sr(S_PASS)}, 0"), (22, f"s_cselect_b32 {sr(S_T3)}, 0, 1"),
-                             (22, f"s_mul_i32 {sr(S_T4)}, {sr(S_OS)}, 96"), (22, f"s_mul_i32 {sr(S_T4)}, {sr(S_T4)}, {sr(S_T3)}"),
-                             (22, f"s_add_u32 {sr(S_OSOFF)}, {sr(S_OSOFF)}, {sr(S_T4)}"), (22, f"s_mov_b32 {sr(S_ODESC + 2)}, {sr(ORS + 2)}")])
-            if 2 <= j <= 8 and u == 1:
-                # Q of the next pass: 2 pieces per tile (tiles 2..8 -> 14 pieces)
-                qd = []
-                for k in (2 * (j - 2), 2 * (j - 2) + 1):
-                    if k == 9 or (k > 9 and k % 2 == 0):
-                        qd.append(f"s_add_u32 {sr(S_T3)}, {sr(S_QSOFF)}, {sr(S_T64)}")
-                    so = sr(S_QSOFF) if k < 9 else sr(S_T3)
-                    qd += [f"s_add_u32 m0, {sr(S_QST)}, {1024 * k}", "s_nop 0", ("VMEM", f"buffer_load_dwordx4 {vr(VOFFR(k % 9))}, {sr(QR, 4)}, {so} offen lds")]
-                per.put([(10, i) for i in qd] if simple else spread(qd, 8, 12))
-            if j == 8 and u == 1:
-                # everything DMA'd for the next pass's Q is in before its fragments are read (this wave's own pieces: vmcnt is enough)
-                per.put([(22, "s_waitcnt vmcnt(0)")])
-                per.put([(22, i) for i in q_load(0, (free_bank, free_bank + 1))])
-                G.vm_log = [t for t in G.vm_log if t.startswith("TAG:")][-1:]      # everything older is complete
-                G.vm_log = ["TAG:kv_next"] if not G.vm_log else G.vm_log
-            if j == 8 and u == 2:
-                per.put([(22, i) for i in q_load(1, (free_bank, free_bank + 1))])
-                per.put([(22, f"s_mul_i32 {sr(S_T4)}, {sr(S_SS)}, 96"), (22, f"s_add_u32 {sr(S_QSOFF)}, {sr(S_QSOFF)}, {sr(S_T4)}")])
-            if j == 0 and u == 0:
-                per.put([(21, i) for i in q_load(2, (TE, TF))])      # before this period's drain (same staging rows are NOT shared: unit 2 rows vs unit 0 rows)
-            per.emit(G)
+                    # barrier B(j+1): my pieces of tile j+1 are in, everybody is done with tile j's LDS image
+                    per.put([(0, ("VMWAIT", f"kv{(j + 1) % NT}"))] + ([] if "barrier" in DROP else [(0, "s_barrier")]))
+                    kr = [] if "kread" in DROP else k_reads((j + 1) % NSTAGE)
+                    per.put([(1, i) for i in kr] if simple else spread(kr, 1, 5))
+                    per.put([(11, "s_waitcnt lgkmcnt(0)")])
+                    # DMA of tile j + 3 into the stage everybody just left (stage j % 3): 5 pieces in this period, 4 in the next
+                    j3 = (j + 3) % NT
+                    dm = [f"s_mul_i32 {sr(S_TMP)}, {sr(S_T64)}, {j3}"]
+                    dm2 = []
+                    for k in range(NPIECE):
+                        pc = [f"s_add_u32 m0, {sr(S_DST)}, {(j % NSTAGE) * STG + 1024 * k}", "s_nop 0",
+                              ("VMEM", f"buffer_load_dwordx4 {vr(VOFFR(k))}, {sr(KVR, 4)}, {sr(S_TMP)} offen lds")]
+                        if "dma" in DROP:
+                            pc = pc[:2]
+                        (dm if k < 5 else dm2).append(("GROUP", pc))
+                    dm2 += [("TAG", f"kv{j3}")]
+                    if simple:
+                        per.put([(12, i) for i in dm]); carry += [(1, i) for i in dm2]
+                    else:
+                        per.put(spread(dm, 6, 21)); carry += spread(dm2, 1, 12)
+                # ---- pass seams
+                if j == 0 and "seam" not in DROP:
+                    dra, drb = drain(u, free_bank, S(u, 16))        # part B runs in the next period, whose free bank is S[u]; its part A takes S[u][0..15]
+                    if "nozc" in OPT:
+                        dra = dra + [f"v_accvgpr_write_b32 {ar(O(u, 0, r))}, 0" for r in range(48)]
+                    per.put([(22, i) for i in dra] if simple or "dr22" in OPT else spread(dra, 1, 22))
+                    carry += [(2, i) for i in drb] if simple else spread(drb, 2, 10)
+                if j == 0 and u == 2:
+                    # the O descriptor becomes real after pass 0's drains; the store rows advance by 96 per pass (applied after the last drain's stores: next period)
+                    carry += [(11, ("GROUP", [f"s_cmp_eq_u32 {sr(S_PASS)}, 0", f"s_cselect_b32 {sr(S_T3)}, 0, 1",      # (SCC: nothing may come between)
+                                              f"s_mul_i32 {sr(S_T4)}, {sr(S_OS)}, 96", f"s_mul_i32 {sr(S_T4)}, {sr(S_T4)}, {sr(S_T3)}",
+                                              f"s_add_u32 {sr(S_OSOFF)}, {sr(S_OSOFF)}, {sr(S_T4)}", f"s_mov_b32 {sr(S_ODESC + 2)}, {sr(ORS + 2)}"]))]
+                if 1 <= j <= 5 and u == 1:
+                    # Q rows of units 0 / 1 of the next pass -> staging: 2 pieces per tile (tiles 1..5 -> 9 pieces); the O rows that left through
+                    # the staging regions are out by then (region 0 is read last, in period (1, 0))
+                    qd = []
+                    for k in [k for k in (2 * (j - 1), 2 * (j - 1) + 1) if k < QPIECES]:
+                        qd.append(("GROUP", [f"s_add_u32 m0, {sr(S_QST)}, {1024 * k}", "s_nop 0",
+                                             ("VMEM", f"buffer_load_dwordx4 {vr(VOFFR(k))}, {sr(QR, 4)}, {sr(S_QSOFF)} offen lds")]))
+                    if j == 5:
+                        qd.append(("TAG", "q_done"))
+                    per.put([(10, i) for i in qd] if simple else spread(qd, 13, 18))
+                if "seam" not in DROP:
+                    if j == 8 and u == 1:
+                        per.put([(0, ("VMWAIT", "q_done"))])
+                        ql = q_load(0, (free_bank, free_bank + 1))
+                        per.put([(22, i) for i in ql] if simple else spread(ql, 1, 22))
+                    if j == 8 and u == 2:
+                        ql = q_load(1, (free_bank, free_bank + 1))
+                        per.put([(22, i) for i in ql] if simple else spread(ql, 1, 22))
+                        # unit 2's last QK^T of the pass was issued in the period before: its registers take the next pass's raw rows
+                        per.put([(1, i) for i in q2_fetch()] if simple else spread(q2_fetch(), 1, 4))
+                    if j == 0 and u == 0:
+                        per.put([(0, ("VMWAIT", "q2"))])
+                        ql = q_load(2, (TE, TF))
+                        per.put([(21, i) for i in ql] if simple else spread(ql, 1, 21))
+                if j == 8 and u == 2:
+                    per.put([(22, f"s_mul_i32 {sr(S_T4)}, {sr(S_SS)}, 96"), (22, f"s_add_u32 {sr(S_QSOFF)}, {sr(S_QSOFF)}, {sr(S_T4)}"),
+                             (22, f"s_add_u32 {sr(S_Q2OFF)}, {sr(S_Q2OFF)}, {sr(S_T4)}")])
+                per.emit(G)
+        return carry
+
+    scratch = Gen()
+    loop_carry = emit_pass(scratch, [])          # first run: only to learn what the last period hands over to period (0, 0)
+    last = emit_pass(G, loop_carry)
+    assert [str(x) for x in last] == [str(x) for x in loop_carry]
     e(f"s_add_u32 {sr(S_PASS)}, {sr(S_PASS)}, 1")
     e(f"s_cmp_lt_u32 {sr(S_PASS)}, {NPASS}")
     e("s_cbranch_scc1 PASS_LOOP%=")
+    if STAMPS:
+        G.emit_ins(stamp())
     # ================= epilogue: the last PV and the three drains ===============================================================
     for m in mfma_pv(2):
         e(m)
     e("s_nop 7"); e("s_nop 7")
     for u in range(3):
-        for i in drain(u, S(1, 0) if u != 1 else S(0, 0)):
+        da, db = drain(u, S(1, 0) if u != 1 else S(0, 0))
+        for i in da + db:
             G.emit_ins(i)
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e("s_branch END%=")
@@ -480,6 +545,9 @@ def build(simple=False):
             e(i)
         e(f"s_branch {back}")
     e("END%=:")
+    if STAMPS:
+        G.emit_ins(stamp())
+        e("s_dcache_wb")
     return G.lines
 
 
@@ -491,6 +559,8 @@ def main():
     clob = [f"v{i}" for i in range(256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(40, 100)] + ["vcc", "memory"]
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_p2.py%s -- do not edit.  %d instructions.\n" % (" --simple" if simple else "", len(lines)))
+        if STAMPS:
+            f.write("#define UFV_VIT_P2_STAMPS 1\n")
         f.write("#define UFV_VIT_P2_ASM \\\n")
         for l in lines:
             f.write('    "%s\\n\\t" \\\n' % l)

@@ -83,6 +83,25 @@ int main(int argc, char** argv) {
         for (size_t r = 0; r < ho.size() / D; ++r) { int nb = 0; for (int c = 0; c < D; ++c) nb += fabs(bf2f(ho[r * D + c]) - bf2f(h2[r * D + c])) > 0.02; if (nb) printf(" %zu(%d)", r, nb); }
         printf("\n");
     }
+    if (kernel == 14 && getenv("LAB_P2_STAMPS")) {       // per-period cycle anatomy of the generated kernel (built with gen_attn_p2.py --stamps)
+        const int nw = B * H / 2 * 4;
+        unsigned* sb; hipMalloc(&sb, (size_t)nw * 512); hipMemset(sb, 0, (size_t)nw * 512);
+        AttnArgs a;
+        a.q = (const bf16*)qkv; a.k = (const bf16*)(qkv + H * hd); a.v = (const bf16*)(qkv + (H + Hkv) * hd); a.o = (bf16*)o;
+        a.q_bs = a.k_bs = a.v_bs = (int64_t)S * W; a.q_ss = a.k_ss = a.v_ss = W; a.o_bs = (int64_t)S * D; a.o_ss = D;
+        a.B = B; a.Hq = H; a.Hkv = Hkv; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd); a.q_pos0 = 0; a.lse = (float*)sb;
+        for (int i = 0; i < 20; ++i) launch_vit72_p2(a, nullptr);
+        hipDeviceSynchronize();
+        std::vector<unsigned> hsb((size_t)nw * 128);
+        hipMemcpy(hsb.data(), sb, hsb.size() * 4, hipMemcpyDeviceToHost);
+        const int NS = 85;
+        std::vector<double> d(NS, 0.0);
+        for (int w = 0; w < nw; ++w) for (int i = 1; i < NS; ++i) d[i] += (double)(unsigned)(hsb[(size_t)w * 128 + i] - hsb[(size_t)w * 128 + i - 1]);
+        printf("stamps (mean cycles over %d waves): prologue %.0f | ", nw, d[1] / nw);
+        double tot = 0; for (int i = 1; i < NS; ++i) tot += d[i] / nw;
+        for (int p_ = 0; p_ < 3; ++p_) { printf("\n pass %d:", p_); for (int j = 0; j < 9; ++j) { printf("  t%d", j); for (int u = 0; u < 3; ++u) printf(" %4.0f", d[2 + p_ * 27 + j * 3 + u + 1 > NS - 1 ? NS - 1 : 2 + p_ * 27 + j * 3 + u + 1] / nw); } }
+        printf("\n epilogue %.0f ; total %.0f cycles\n", d[NS - 1] / nw, tot);
+    }
     // timeline
     hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &st, sizeof(st));
     run(); hipDeviceSynchronize();

@@ -1179,6 +1179,8 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
                      // head-pair variants (diagnostic: measured 10-25 % slower than the 9-wave blocks)
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 7) return launch_pair<72, 6, false>(a, st);
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 8) return launch_pair<72, 6, true>(a, st);
+                     // third generation (attn_vit_p2.inc): SigLIP at 336 px; bit-identical to the second generation, which stays for other lengths
+                     if (!causal && vit72_p2_ok(a) && (kernel == 0 || kernel == 1)) return launch_vit72_p2(a, st);
                      if (!causal && Sq % 288 == 0 && (int64_t)Sk * (k_ss > v_ss ? k_ss : v_ss) * 2 < (1ll << 31) && (kernel == 0 || kernel == 1 || kernel == 11))
                          return launch_vit72<9>(a, st);   // second-generation ViT kernel (attn_vit.inc)
                      if (Sq % 288 == 0 && kernel == 6) return launch_mfma_dma<72, 9, false>(a, causal, st);   // lockstep variant (diagnostic)
