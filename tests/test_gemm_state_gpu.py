@@ -19,13 +19,13 @@ def _case(M, N, K, seed):
 
 def test_auto_picks_split_k_for_down_and_switch_turns_it_off():
     lib = _lib.load()
-    assert lib.ufv_gemm_choice(2399, 3584, 18944, 1, 0, 1) >= 10000          # the decoder's `down`: split form
+    assert lib.ufv_gemm_choice(1200, 3584, 18944, 1, 0, 1) >= 10000          # the decoder's `down` at a short prompt: split form
     prev = lib.ufv_gemm_set_splitk(0)
     try:
-        assert prev == 1 and lib.ufv_gemm_choice(2399, 3584, 18944, 1, 0, 1) < 10000
+        assert prev == 1 and lib.ufv_gemm_choice(1200, 3584, 18944, 1, 0, 1) < 10000
     finally:
         assert lib.ufv_gemm_set_splitk(prev) == 0
-    assert lib.ufv_gemm_choice(2399, 3584, 18944, 1, 0, 1) >= 10000
+    assert lib.ufv_gemm_choice(1200, 3584, 18944, 1, 0, 1) >= 10000
 
 
 def test_split_k_on_two_streams_at_once_is_bit_equal_to_one_at_a_time():
@@ -33,9 +33,9 @@ def test_split_k_on_two_streams_at_once_is_bit_equal_to_one_at_a_time():
     same launch run alone (deterministic turn order), and the device's error word stays 0."""
     lib = _lib.load()
     _lib.call("ufv_gemm_prepare")
-    A = _case(2399, 3584, 18944, 1)          # `down` at config #2
-    B = _case(1200, 3584, 18944, 2)          # a shorter prompt: other tile count, other parts
-    assert lib.ufv_gemm_choice(1200, 3584, 18944, 1, 0, 1) >= 10000
+    A = _case(1200, 3584, 18944, 1)          # `down` at a short prompt
+    B = _case(600, 3584, 18944, 2)           # a shorter one: other tile count, other parts
+    assert lib.ufv_gemm_choice(1200, 3584, 18944, 1, 0, 1) >= 10000 and lib.ufv_gemm_choice(600, 3584, 18944, 1, 0, 1) >= 10000
     ref = []
     for a, w, r in (A, B):
         o = torch.empty_like(r); ops.gemm(a, w, resid=r, out=o); ref.append(o)

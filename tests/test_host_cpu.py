@@ -372,8 +372,9 @@ def test_gemm_kernel_choice_at_the_config2_shapes():
     assert pick(18432, 1152, 1152, 1, 0, 1) == 1431 and pick(18432, 1152, 4352, 1, 0, 1) == 1431     # ViT out_proj, fc2: 224x192, 498 tiles = 1.95 rounds
     assert pick(2399, 3584, 3584, 1, 0, 1) == 1331                        # LLM o_proj: 192x192, 247 tiles = one round
     assert pick(2399, 4608, 3584, 0, 0, 1) in (1332, 1441)                # LLM qkv
-    assert pick(2399, 3584, 18944, 1, 0, 1) == 41441                      # LLM down: 256x192 tiles x 4 K parts
-    assert pick(2399, 3584, 18944, 1, 0, 0) < 10000                       # ... never split under an activation
-    assert pick(2399, 3584, 18944, 0, 0, 1) < 10000                       # ... or into a bf16 output
-    assert pick(4703, 3584, 18944, 1, 0, 1) // 10000 >= 4                 # 64 frames: split as well
+    # LLM down: since the row-pipelined residual epilogue (round 3) the unsplit 192x192 kernel (247 tiles = one full round) beats the split-K form
+    assert pick(2399, 3584, 18944, 1, 0, 1) == 1331 and pick(4703, 3584, 18944, 1, 0, 1) == 1331
+    assert pick(1200, 3584, 18944, 1, 0, 1) // 10000 >= 4                 # a short prompt leaves CUs idle unsplit: aligned split-K
+    assert pick(1200, 3584, 18944, 1, 0, 0) < 10000                       # ... never split under an activation
+    assert pick(1200, 3584, 18944, 0, 0, 1) < 10000                       # ... or into a bf16 output
     assert pick(100, 3584, 3584, 1, 0, 1) == 0 and pick(2399, 3500, 3584, 1, 0, 1) == 0      # small / unaligned shapes: not the ping-pong kernel

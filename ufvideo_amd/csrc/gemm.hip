@@ -553,7 +553,7 @@ constexpr PPShape PP_SHAPES[] = {{1442, 4, 4, 2}, {1432, 4, 3, 2}, {1332, 3, 3, 
 // carries the turn-ordered read-modify-write of its tile (+12000 ticks); taken when the model sees at least 5 % over the best unsplit kernel --
 // in practice the decoder's `down` projection (M = 2399: 140 tiles of 256x256 for 296 K-tiles; 348 -> ~270 us) and its 64-frame form.
 inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool can_split = false) {
-    const double nk = K / 64.0, c_out = out_f32 ? 0.33 : 0.183;
+    const double nk = K / 64.0, c_out = out_f32 ? 0.21 : 0.183;      // (fp32 + residual: 0.33 before the row-pipelined residual epilogue of round 3)
     double best = 1e30;
     int pick = 0;
     for (int mt = 4; mt <= 6; ++mt) {
@@ -572,6 +572,13 @@ inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool ca
         const double tk = 2.0 * ((pa > 500 ? pa : 500) + (pb > 500 ? pb : 500));
         const double c = (double)((t + 255) / 256) * (nk * tk + 2500.0 + (double)bm * bn * c_out);
         if (c < best) { best = c; pick = s.code; }
+    }
+    // Long-K fp32 products whose 192x192 tiling fills the chip (the decoder's `down` at S = 2399: 247 tiles for 256 CUs; 475 at 64 frames): since the
+    // row-pipelined residual epilogue (round 3) the unsplit 192x192 kernel beats both the split-K form and the 128-wide kernel there (292 us against
+    // 314 / 353, tools/gemm_shapes.py); the tick model above still carries the old epilogue's K-tile floor for small tiles, so this case is decided here.
+    if (out_f32 && !swiglu && K >= 8192 && M >= 256 && (N % 192 == 0 || N % 192 == 128)) {
+        const long t = (long)cdiv(M, 192) * cdiv(N, 192);
+        if ((double)t / (256.0 * ((t + 255) / 256)) >= 0.9) return 1331;
     }
     if (can_split && out_f32 && !swiglu && K % 64 == 0) {
         // regression over 31 measured (shape, parts) runs of tools/gemm_splitk.py (within 5 % of all but the 3-part splits, which it flatters

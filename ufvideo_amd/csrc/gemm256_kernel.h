@@ -50,6 +50,72 @@ template <int MA0, int MA1, int NB1> struct PP {
     static constexpr int LA0 = MA0 > 2 ? 2 : 1, LA1 = MA1 > 2 ? 2 : 1, LB0 = 2, LB1 = NB1;     // DMA instructions per wave per half-tile
 };
 
+
+// Residual epilogue (o_proj / out_proj / fc2 / down / patch-embed: out = acc + bias + resid, no activation), rows pipelined by hand.
+// Written as plain C++ the residual load of every 4-column group is followed by `s_waitcnt vmcnt(0)` and its store (the output may alias
+// the residual -- it IS the residual stream, updated in place -- so the compiler keeps every load behind the previous store): 32 dependent
+// memory round trips per wave and tile, ~16 us of a 35 us out_proj tile.  Here the residual rows of accumulator row mt + 1 are requested
+// before row mt is stored, the loads are inline asm (no compiler-inserted waits) and the waits are counted: one round trip is exposed per
+// tile, the rest run under each other.  Same arithmetic, same element order: bit-identical output.
+template <bool OUT_F32, int MA0, int MA1, int NB1>
+__device__ __forceinline__ void epilogue256_resid(const f32x4 (&acc)[2 + NB1][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc,
+                                                  int frow, int fq, const f32x4 (&bias)[2 + NB1]) {
+    constexpr int MT = MA0 + MA1, NT = 2 + NB1;
+    int ncol[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ncol[nt] = n0 + (nt < 2 ? wc * 32 + nt * 16 : 128 + wc * 16 * NB1 + (nt - 2) * 16) + fq * 4;
+        nok[nt] = n0 + (nt < 2 ? 0 : 128) < N;
+        ncol[nt] = nok[nt] ? ncol[nt] : 0;            // a half-tile past N: loads a valid address, stores nothing
+    }
+    auto row_of = [&](int mt) { return m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow; };
+    f32x4 r[2][NT];
+    auto request = [&](int mt, f32x4 (&dst)[NT]) {
+        const int m = min(row_of(mt), M - 1);
+        const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
+        const float* rp = e.resid + (size_t)mr * e.ldr;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[nt]) : "v"(rp + ncol[nt]) : "memory");
+    };
+    request(0, r[0]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 (&cur)[NT] = r[mt & 1];
+        if (mt + 1 < MT) request(mt + 1, r[(mt + 1) & 1]);
+        // in flight behind row mt's loads: the stores of row mt - 1 (NT, when there was one) and the loads of row mt + 1 (NT, when there is one)
+        if (mt == 0) {
+            if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+            else asm volatile("s_waitcnt vmcnt(3)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2])::"memory");
+        } else if (mt + 1 < MT) {
+            if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+            else asm volatile("s_waitcnt vmcnt(6)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2])::"memory");
+        } else {                                       // last row: only the stores of the row before it are younger
+            if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+            else asm volatile("s_waitcnt vmcnt(3)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2])::"memory");
+        }
+        const int m = row_of(mt);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            // the element order of epi_store4b: (acc + bias) then + resid
+            f32x4 v = acc[nt][mt] + bias[nt];
+            v += cur[nt];
+            // stores are ALWAYS issued (the wait counts above rely on it); rows / half-tiles past the edge go to a clamped address with no lane enabled
+            const bool ok = m < M && nok[nt];
+            if constexpr (OUT_F32) {
+                float* pp = reinterpret_cast<float*>(e.out) + (size_t)min(m, M - 1) * e.ldc + ncol[nt];
+                asm volatile("s_mov_b64 s[2:3], exec\n\ts_and_b64 exec, exec, %2\n\tglobal_store_dwordx4 %0, %1, off\n\ts_mov_b64 exec, s[2:3]\n\ts_nop 1"
+                             ::"v"(pp), "v"(v), "s"(__builtin_amdgcn_ballot_w64(ok)) : "memory", "s2", "s3", "scc");
+            } else {
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                bf16* pp = reinterpret_cast<bf16*>(e.out) + (size_t)min(m, M - 1) * e.ldc + ncol[nt];
+                asm volatile("s_mov_b64 s[2:3], exec\n\ts_and_b64 exec, exec, %2\n\tglobal_store_dwordx2 %0, %1, off\n\ts_mov_b64 exec, s[2:3]\n\ts_nop 1"
+                             ::"v"(pp), "v"(o), "s"(__builtin_amdgcn_ballot_w64(ok)) : "memory", "s2", "s3", "scc");
+            }
+        }
+    }
+}
+
 // acc[nt][mt][j] = C[m0 + row(mt)][n0 + col(nt) + fq*4 + j] with
 //   row(mt) = mt < MA0 ? wr*16*MA0 + mt*16 + frow : 32*MA0 + wr*16*MA1 + (mt-MA0)*16 + frow
 //   col(nt) = nt < 2 ? wc*32 + nt*16 : 128 + wc*16*NB1 + (nt-2)*16
@@ -329,6 +395,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     int m0, n0, k0, k1;
     bool have = next_item(m0, n0, k0, k1);
     if (have) { set_src(m0, n0); kbeg = k0; kend = k1; prologue_loads(); }
+    // Stores of the previous item's epilogue that may still be in flight when this item's first K-tile is consumed.  vmcnt is one in-order
+    // counter: this item's prologue DMA was issued BEFORE those stores, so a wait that must only cover the prologue may leave them (NST more
+    // operations) outstanding -- the first K-tile's two phases then run while the store burst drains instead of behind it.  Exact only when
+    // every store instruction of the epilogue was issued (interior tile); 0 otherwise and for a block's first item.
+    constexpr int NST = SWIGLU ? 2 * MT : MT * NT;
+    constexpr bool RELAX_OK = PH2 && !SKT && !KSPL && (L_ALL + NST <= 63);
+    bool relax = false;
     while (have) {
     const int len = k1 - k0;
     f32x4 acc[NT][MT];   // [nt][mt]
@@ -382,8 +455,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     __builtin_amdgcn_s_barrier();
 
     if constexpr (PH2) {
-        if (len > 1) wait_vmcnt<L_ALL>();              // A0 / B0 / B1 of the first K-tile; its A1 and the second tile's three stay in flight
-        else wait_vmcnt<T::LA1>();
+        if (len > 1) {                                 // A0 / B0 / B1 of the first K-tile; its A1 and the second tile's three stay in flight
+            if (RELAX_OK && relax) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
+            else wait_vmcnt<L_ALL>();
+        } else wait_vmcnt<T::LA1>();
     } else {
         if (len > 1) UFV_WAIT_KEEP_A0_B1();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -402,8 +477,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         read_a(buf, H0{});
         read_b(buf + 49152, H1{});
         stage(d ^ 1, 1, t + 1);
-        if (tt + 1 < len) wait_vmcnt<L_ALL>();        // behind A1[t]: A0/B0/B1[t+1] and A1[t+1]
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tt + 1 < len) {                            // behind A1[t]: A0/B0/B1[t+1] and A1[t+1] (+ at the item's first K-tile the previous epilogue's stores)
+            if (RELAX_OK && relax && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
+            else wait_vmcnt<L_ALL>();
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, 0, MA0, 1, 2, 3)
         // phase B: A1 -> bottom half; prefetch A0 / B0 / B1 [t+2]; retire A0 / B0 / B1 [t+1]
         UFV_GSTAMP(4);
@@ -411,8 +488,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         stage(d, 0, t + 2);
         stage(d, 2, t + 2);
         stage(d, 3, t + 2);
-        if (tt + 2 < len) wait_vmcnt<L_ALL>();        // behind them: A1[t+1] and A0/B0/B1[t+2]
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tt + 2 < len) {                            // behind them: A1[t+1] and A0/B0/B1[t+2]
+            if (RELAX_OK && relax && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
+            else wait_vmcnt<L_ALL>();
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, MA0, MA1, 5, 6, 7)
         UFV_GSTAMP(8);
     }
@@ -531,7 +610,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         __syncthreads();                                            // ... before one thread passes the turn on
         if (tid == 0) __hip_atomic_store(sk.flags + ctile, sk.epoch + cpart + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_, false, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias)))
+        bool by_rows = false;
+        if constexpr (!SWIGLU && !FP8) by_rows = e.resid != nullptr && e.act == ACT_NONE;
+        if (by_rows) {
+            if constexpr (!SWIGLU && !FP8) epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
+            relax = RELAX_OK;                                     // this form issues every store instruction, edge tiles included
+        } else {
+            UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_, false, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias)))
+            relax = RELAX_OK && cm0 + BM <= M && cn0 + BN <= N;      // every one of the NST store instructions was issued
+        }
     }
     }   // persistent tile loop
 #undef UFV_WAIT_KEEP_A0_B1
