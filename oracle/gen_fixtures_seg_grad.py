@@ -74,15 +74,25 @@ def main():
         cap["hidden"], cap["fcs_out"] = inp[0], outp
     fcs_mod.register_forward_hook(fcs_hook)
     out = {"images_sam": sam, "loss_weights": np.array([1.0, 2.0, 0.5]), "sam_seeds": np.array([GS.GH.SEEDS[k] for k in ("trunk", "neck", "heads")])}
+    # "blob" (round 3): a STRUCTURED ground truth -- two discs, one empty and one full mask -- so that d(loss)/d(logit) has one sign over whole
+    # regions and the gradients behind the resizes are sums that add up instead of remainders of cancelling ones (the random masks of the first
+    # two cases amplify bf16 storage noise to 10-30 % per tensor); the test holds this case to 5 % per tensor and 2 % on norms.
     cases = {"two_obj": dict(ids=[[5, 6, -201, 7, 299, 9, 299, 11]], n_obj=2, hw=(40, 50)),
-             "one_obj": dict(ids=[[5, 6, -201, 7, 8, 299, 11]], n_obj=1, hw=(33, 47))}
+             "one_obj": dict(ids=[[5, 6, -201, 7, 8, 299, 11]], n_obj=1, hw=(33, 47)),
+             "blob": dict(ids=[[5, 6, -201, 7, 8, 299, 11]], n_obj=1, hw=(40, 50), structured=True)}
     torch.set_grad_enabled(True)
     params = dict(model.named_parameters())
     for name, c in cases.items():
         model.zero_grad(set_to_none=True)
         ids = torch.tensor(c["ids"], dtype=torch.long)
         labels = ids.clone(); labels[labels < 0] = -100; labels[:, :2] = -100
-        gt = (torch.rand(T * c["n_obj"], *c["hw"], generator=g) > 0.5).float()
+        if c.get("structured"):
+            yy, xx = torch.meshgrid(torch.arange(c["hw"][0]), torch.arange(c["hw"][1]), indexing="ij")
+            disc = lambda cy, cx, r: (((yy - cy) ** 2 + (xx - cx) ** 2) < r * r).float()      # noqa: E731
+            gt = torch.stack([disc(18, 22, 13), disc(24, 30, 9), torch.zeros(*c["hw"]), torch.ones(*c["hw"])])
+            assert gt.shape[0] == T * c["n_obj"]
+        else:
+            gt = (torch.rand(T * c["n_obj"], *c["hw"], generator=g) > 0.5).float()
         r = model(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels, images=[(video, "video")], images_sam=sam,
                   offset=torch.tensor([0, 1]), masks_list=[gt], label_list=[torch.zeros(*c["hw"])], inference=False)
         r["loss"].backward()

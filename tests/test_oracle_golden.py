@@ -425,7 +425,7 @@ def test_mask_loss_grads_vs_reference_backward():
     tab, e1 = w["model.embed_tokens.weight"].float(), t(m["sp_vid_only_nolab_emb"])[0]
     mm = e1[2:-3]
     images_sam = t(a["images_sam"])[0]
-    for name in ("two_obj", "one_obj"):
+    for name in ("two_obj", "one_obj", "blob"):          # "blob": the structured ground truth of round 3 (two discs, an empty and a full mask)
         ws = {k: v.float().clone().requires_grad_(k.startswith(("model.layers.", "model.norm.", "lm_head.", "model.text_hidden_fcs.", "model.embed_tokens.")))
               for k, v in w.items()}
         ss = {k: v.float().clone().requires_grad_(k.startswith("sam_mask_decoder.")) for k, v in sam.items()}
@@ -505,7 +505,12 @@ def test_mask_loss_grad_bf16_storage_noise():
             O.F, O._MIRROR = real_f, False
         r["mask_loss"].backward()
         return {k: v.grad for k, v in {**ss, **ws}.items() if v.grad is not None and float(v.grad.norm()) > 1e-8}
-    for name, fcs0 in (("two_obj", 0.094), ("one_obj", 0.157)):
+    # "blob" (round 3, VERDICT r2 next #4a): a STRUCTURED ground truth (two discs, an empty and a full mask) was expected to remove the
+    # amplification.  It does not: median 7 % (random masks: 10-11 %), text_hidden_fcs.0.0 12 % -- the cancellation sits in the CHANNEL
+    # contraction of the hyper-network product ([pixels x 32] . [32]) and in the token-side MLPs, not in the spatial sign pattern of
+    # d(loss)/d(logit).  So the GPU test holds the blob case to 20 % per tensor (the measured 9-15 % x 1.5), not to 5 %; what a 5 % bound
+    # was meant to catch -- a wrong bilinear tap, a mis-scaled DICE term -- is caught by the per-kernel tests at 1e-5 (test_seg_train_gpu.py).
+    for name, fcs0 in (("two_obj", 0.094), ("one_obj", 0.157), ("blob", 0.118)):
         g0, g1 = grads(False, name), grads(True, name)
         errs = {k: rel_err(g1[k], g0[k]) for k in g0}
         med = sorted(errs.values())[len(errs) // 2]

@@ -28,6 +28,12 @@ DEV = "cuda"
 # same tensors (1 % ... 25 %, text_hidden_fcs 8 % / 15 %).  Noise adds in quadrature, so gradient NORMS are compared at 4 %.  Tensors with
 # a tiny gradient are judged against the decoder's largest gradient norm.
 GRAD_TOL = 0.3
+# The third fixture case ("blob", round 3) has a STRUCTURED ground truth (two discs, an empty and a full mask): d(loss)/d(logit) keeps its sign
+# over whole regions and |d fcs_out| is 10x the random-mask cases'.  Measured on MI355X: 9-15 % per tensor, the same as the random masks, and the
+# oracle's own fp32-vs-bf16-storage experiment gives the same figures for it (7 % median, text_hidden_fcs.0.0 12 %; HIP 12.4 %): the amplification
+# comes from the channel contraction of the hyper-network product and the token-side MLPs, not from the spatial sign pattern.  The case is held to
+# 20 % per tensor / 4 % on norms; the sharp checks (bilinear taps, BCE / DICE scaling: 1e-5 vs autograd) are the per-kernel tests above.
+TOL = {"two_obj": (GRAD_TOL, 0.04), "one_obj": (GRAD_TOL, 0.04), "blob": (0.2, 0.04)}
 
 
 def bfr(x):
@@ -101,7 +107,7 @@ def _seg_model():
     return a, m, arrs, w
 
 
-def _check_sam_grads(a, name, leaves, tol):
+def _check_sam_grads(a, name, leaves, tol, ntol=0.04):
     n_checked = 0
     scale = max(float(a[k][0]) for k in a if k.startswith(name + "_gs::"))           # the largest gradient norm of the decoder
     for key in a:
@@ -113,7 +119,7 @@ def _check_sam_grads(a, name, leaves, tol):
             g = g.float().cpu()
             f = g.reshape(-1)
             samp = f[torch.linspace(0, f.numel() - 1, min(97, f.numel())).long()]
-            assert abs(float(g.norm()) - float(ref[0])) < 0.04 * float(ref[0]) + 2e-3 * scale, (pn, float(g.norm()), float(ref[0]))
+            assert abs(float(g.norm()) - float(ref[0])) < ntol * float(ref[0]) + 2e-3 * scale, (pn, float(g.norm()), float(ref[0]))
             err = float((samp - ref[2:]).norm())
             assert err < tol * float(ref[2:].norm()) + 2e-3 * scale * (samp.numel() / f.numel()) ** 0.5, (pn, err, float(ref[2:].norm()))
             n_checked += 1
@@ -123,8 +129,9 @@ def _check_sam_grads(a, name, leaves, tol):
     assert n_checked >= 100
 
 
-@pytest.mark.parametrize("name", ["two_obj", "one_obj"])
+@pytest.mark.parametrize("name", ["two_obj", "one_obj", "blob"])
 def test_seg_head_forward_backward_vs_reference_backward(name):
+    tol, ntol = TOL[name]
     from ufvideo_amd.train_seg import SegHeadGrad
     a, m, arrs, w = _seg_model()
     seg = SegHeadGrad(m)
@@ -147,12 +154,14 @@ def test_seg_head_forward_backward_vs_reference_backward(name):
     # the reference's d(loss)/d([SEG] embedding) pulled back through text_hidden_fcs (Linear-ReLU-Linear) in fp32
     W0, b0, W2 = (w["model.text_hidden_fcs.0." + k].float() for k in ("0.weight", "0.bias", "2.weight"))
     want = ((t(a[name + "_d_fcs_out"])[0][rows] @ W2) * ((hidden[rows] @ W0.T + b0) > 0).float()) @ W0
-    assert rel_err(hid.grad.cpu(), want) < GRAD_TOL, rel_err(hid.grad.cpu(), want)
+    worst = {"d_hidden": rel_err(hid.grad.cpu(), want)}
     for key in a:
         if key.startswith(name + "_g::model.text_hidden_fcs."):
             pn = key[len(name) + 4 + len("model."):]
-            assert rel_err(leaves[pn].grad.cpu(), t(a[key])) < GRAD_TOL, (pn, rel_err(leaves[pn].grad.cpu(), t(a[key])))
-    _check_sam_grads(a, name, leaves, GRAD_TOL)
+            worst[pn] = rel_err(leaves[pn].grad.cpu(), t(a[key]))
+    print("seg grads", name, {k: round(v, 4) for k, v in worst.items()})
+    assert max(worst.values()) < tol, worst
+    _check_sam_grads(a, name, leaves, tol, ntol)
 
 
 def test_train_step_with_seg_head_vs_reference_backward():
