@@ -116,6 +116,50 @@ __device__ __forceinline__ void epilogue256_resid(const f32x4 (&acc)[2 + NB1][MA
     }
 }
 
+
+// bf16 epilogue with 16-byte stores (no residual): the two 16-column n-tiles of a wave's 32-column run are regrouped across the four 16-lane rows
+// with v_permlane32_swap + v_permlane16_swap (two per register pair), after which lane row r of accumulator row `frow` holds columns 8r .. 8r + 7
+// of the run: one global_store_dwordx4 per (accumulator row, run) -- 16 store instructions per wave and tile instead of 32, 64-byte segments
+// instead of 32-byte ones.  The tile round's store burst is issue-bound: same values, same rounding, bit-identical output.
+template <int ACT, int MA0, int MA1, int NB1>
+__device__ __forceinline__ void epilogue256_wide(const f32x4 (&acc)[2 + NB1][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc,
+                                                 int frow, int fq, const f32x4 (&bias)[2 + NB1]) {
+    constexpr int MT = MA0 + MA1;
+    bf16* out = reinterpret_cast<bf16*>(e.out);
+    auto pack2 = [&](float a, float b) -> unsigned {
+        const bf16x2 p = {(bf16)a, (bf16)b};
+        return __builtin_bit_cast(unsigned, p);
+    };
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow;
+#pragma unroll
+        for (int run = 0; run < 2; ++run) {
+            const int nb = n0 + run * 128;
+            if (nb >= N) continue;
+            if (run == 1 && NB1 == 1) {               // a 16-column second half has no partner n-tile: the 8-byte store
+                if (m < M) {
+                    const f32x4 v = acc[2][mt] + bias[2];
+                    const bf16x4 o = {(bf16)act_apply_t<ACT>(v[0]), (bf16)act_apply_t<ACT>(v[1]), (bf16)act_apply_t<ACT>(v[2]), (bf16)act_apply_t<ACT>(v[3])};
+                    *reinterpret_cast<bf16x4*>(out + (size_t)m * e.ldc + nb + wc * 16 + fq * 4) = o;
+                }
+                continue;
+            }
+            const f32x4 va = acc[2 * run][mt] + bias[2 * run], vb = acc[2 * run + 1][mt] + bias[2 * run + 1];
+            unsigned x0 = pack2(act_apply_t<ACT>(va[0]), act_apply_t<ACT>(va[1])), x1 = pack2(act_apply_t<ACT>(va[2]), act_apply_t<ACT>(va[3]));
+            unsigned y0 = pack2(act_apply_t<ACT>(vb[0]), act_apply_t<ACT>(vb[1])), y1 = pack2(act_apply_t<ACT>(vb[2]), act_apply_t<ACT>(vb[3]));
+            auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            auto t0 = __builtin_amdgcn_permlane16_swap((unsigned)s0[0], (unsigned)s0[1], false, false);
+            auto t1 = __builtin_amdgcn_permlane16_swap((unsigned)s1[0], (unsigned)s1[1], false, false);
+            if (m < M) {
+                const i32x4 o = {(int)t0[0], (int)t1[0], (int)t0[1], (int)t1[1]};       // columns 8 fq .. 8 fq + 7 of the run
+                *reinterpret_cast<i32x4*>(out + (size_t)m * e.ldc + nb + wc * 32 + fq * 8) = o;
+            }
+        }
+    }
+}
+
 // acc[nt][mt][j] = C[m0 + row(mt)][n0 + col(nt) + fq*4 + j] with
 //   row(mt) = mt < MA0 ? wr*16*MA0 + mt*16 + frow : 32*MA0 + wr*16*MA1 + (mt-MA0)*16 + frow
 //   col(nt) = nt < 2 ? wc*32 + nt*16 : 128 + wc*16*NB1 + (nt-2)*16
@@ -399,9 +443,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // counter: this item's prologue DMA was issued BEFORE those stores, so a wait that must only cover the prologue may leave them (NST more
     // operations) outstanding -- the first K-tile's two phases then run while the store burst drains instead of behind it.  Exact only when
     // every store instruction of the epilogue was issued (interior tile); 0 otherwise and for a block's first item.
-    constexpr int NST = SWIGLU ? 2 * MT : MT * NT;
+    constexpr int NST = SWIGLU ? 2 * MT : MT * NT;           // store instructions of the 8-byte / residual epilogues; the 16-byte bf16 epilogue issues 2 * MT
+    constexpr int NSTW = 2 * MT;
     constexpr bool RELAX_OK = PH2 && !SKT && !KSPL && (L_ALL + NST <= 63);
-    bool relax = false;
+    int relax = 0;                                           // 0: strict waits; 1: NST stores may stay in flight; 2: NSTW
     while (have) {
     const int len = k1 - k0;
     f32x4 acc[NT][MT];   // [nt][mt]
@@ -456,7 +501,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
 
     if constexpr (PH2) {
         if (len > 1) {                                 // A0 / B0 / B1 of the first K-tile; its A1 and the second tile's three stay in flight
-            if (RELAX_OK && relax) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
+            if (RELAX_OK && relax == 1) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
+            else if (RELAX_OK && relax == 2) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
             else wait_vmcnt<L_ALL>();
         } else wait_vmcnt<T::LA1>();
     } else {
@@ -478,7 +524,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         read_b(buf + 49152, H1{});
         stage(d ^ 1, 1, t + 1);
         if (tt + 1 < len) {                            // behind A1[t]: A0/B0/B1[t+1] and A1[t+1] (+ at the item's first K-tile the previous epilogue's stores)
-            if (RELAX_OK && relax && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
+            if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
+            else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
             else wait_vmcnt<L_ALL>();
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, 0, MA0, 1, 2, 3)
@@ -489,7 +536,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         stage(d, 2, t + 2);
         stage(d, 3, t + 2);
         if (tt + 2 < len) {                            // behind them: A1[t+1] and A0/B0/B1[t+2]
-            if (RELAX_OK && relax && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
+            if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
+            else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
             else wait_vmcnt<L_ALL>();
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, MA0, MA1, 5, 6, 7)
@@ -612,12 +660,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     } else {
         bool by_rows = false;
         if constexpr (!SWIGLU && !FP8) by_rows = e.resid != nullptr && e.act == ACT_NONE;
+        bool wide = false;
+        if constexpr (!OUT_F32 && !SWIGLU) wide = e.resid == nullptr && e.ldc % 8 == 0 && ((uintptr_t)e.out & 15) == 0;
+        const bool interior = cm0 + BM <= M && cn0 + BN <= N;     // every store instruction of the epilogue is issued
         if (by_rows) {
             if constexpr (!SWIGLU && !FP8) epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
-            relax = RELAX_OK;                                     // this form issues every store instruction, edge tiles included
+            relax = RELAX_OK ? 1 : 0;                             // this form issues every store instruction, edge tiles included
+        } else if (wide) {
+            if constexpr (!OUT_F32 && !SWIGLU) { UFV_ACT_SWITCH(e.act, (epilogue256_wide<ACT_, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias))) }
+            relax = RELAX_OK && interior ? 2 : 0;
         } else {
             UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_, false, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias)))
-            relax = RELAX_OK && cm0 + BM <= M && cn0 + BN <= N;      // every one of the NST store instructions was issued
+            relax = RELAX_OK && interior ? 1 : 0;
         }
     }
     }   // persistent tile loop
