@@ -114,11 +114,13 @@ def mfma_qk(u):
 def sm_max(u):
     """tile max of unit u in T0 (all lanes of a query agree), two interleaved chains"""
     s = lambda r: vr(S(u, r))
-    o = [f"v_max_f32 {vr(T0)}, {s(0)}, {s(16)}", f"v_max_f32 {vr(T1)}, {s(1)}, {s(17)}"]
-    for r in range(2, 16, 2):
-        o.append(f"v_max3_f32 {vr(T0)}, {vr(T0)}, {s(r)}, {s(16 + r)}")
-        o.append(f"v_max3_f32 {vr(T1)}, {vr(T1)}, {s(r + 1)}, {s(17 + r)}")
-    # NOTE: max is exact and order-independent, so the two-chain form gives the bits of the single chain
+    ch = [T0, T1, TE, TF] if "max4" in OPT else [T0, T1]          # independent chains (max is exact and order-independent: same bits as one chain)
+    n = len(ch)
+    o = [f"v_max_f32 {vr(ch[k])}, {s(k)}, {s(16 + k)}" for k in range(n)]
+    for r in range(n, 16):
+        o.append(f"v_max3_f32 {vr(ch[r % n])}, {vr(ch[r % n])}, {s(r)}, {s(16 + r)}")
+    if n == 4:
+        o += [f"v_max_f32 {vr(T0)}, {vr(T0)}, {vr(TE)}", f"v_max_f32 {vr(T1)}, {vr(T1)}, {vr(TF)}"]
     o += [f"v_max_f32 {vr(T0)}, {vr(T0)}, {vr(T1)}", f"v_mov_b32 {vr(T1)}, {vr(T0)}", "s_nop 1",
           f"v_permlane32_swap_b32 {vr(T0)}, {vr(T1)}", f"v_max_f32 {vr(T0)}, {vr(T0)}, {vr(T1)}"]
     return o
@@ -446,8 +448,9 @@ def build(simple=False):
                 if simple:
                     per.put([(22, i) for i in body + ex])
                 else:
-                    per.put(spread(body, 3 if "sm3" in OPT else 2, (6 if "sm3" in OPT else 5) if j else 9))
-                    per.put(spread(ex, 6 if j else 10, 22))
+                    mg = int(os.environ.get("UFV_P2_MAXGAP", "5"))
+                    per.put(spread(body, 2, mg if j else 9))
+                    per.put(spread(ex, (mg + 1) if j else 10, 22))
                 # ---- LDS / DMA / address work
                 if u == 0:
                     # V^T fragments of tile j: after the 12 PV MFMAs of the previous tile's last unit have been issued
@@ -511,7 +514,7 @@ def build(simple=False):
                         per.put([(1, i) for i in q2_fetch()] if simple else spread(q2_fetch(), 1, 4))
                     if j == 0 and u == 0:
                         per.put([(0, ("VMWAIT", "q2"))])
-                        ql = q_load(2, (TE, TF))
+                        ql = q_load(2, (TC, TD))
                         per.put([(21, i) for i in ql] if simple else spread(ql, 1, 21))
                 if j == 8 and u == 2:
                     per.put([(22, f"s_mul_i32 {sr(S_T4)}, {sr(S_SS)}, 96"), (22, f"s_add_u32 {sr(S_QSOFF)}, {sr(S_QSOFF)}, {sr(S_T4)}"),

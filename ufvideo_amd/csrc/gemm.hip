@@ -63,6 +63,83 @@ __device__ __forceinline__ void epilogue128(const f32x4 (&acc)[4][MT], const Epi
     }
 }
 
+
+// The residual epilogue with the rows pipelined by hand and the bf16 epilogue with 16-byte stores: the 128-wide kernel's forms of
+// epilogue256_resid / epilogue256_wide (gemm256_kernel.h, where the reasons are written down).  A wave's 64 columns are contiguous here.
+template <bool OUT_F32, int MT>
+__device__ __forceinline__ void epilogue128_resid(const f32x4 (&acc)[4][MT], const Epi& e, int M, int m0, int n0, int wm, int wn, int frow, int fq) {
+    const int ncol = n0 + wn * 64 + fq * 4;
+    f32x4 bias[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + ncol + 16 * nt) : f32x4{0, 0, 0, 0};
+    f32x4 r[2][4];
+    auto request = [&](int mt, f32x4 (&dst)[4]) {
+        const int m = min(m0 + wm * (16 * MT) + mt * 16 + frow, M - 1);
+        const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
+        const float* rp = e.resid + (size_t)mr * e.ldr + ncol;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[nt]) : "v"(rp + 16 * nt) : "memory");
+    };
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3])::"memory");
+    request(0, r[0]);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f32x4 (&cur)[4] = r[mt & 1];
+        if (mt + 1 < MT) request(mt + 1, r[(mt + 1) & 1]);
+        if (mt == 0 && MT > 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+        else if (mt + 1 < MT) asm volatile("s_waitcnt vmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+        else if (MT > 1) asm volatile("s_waitcnt vmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+        const int m = m0 + wm * (16 * MT) + mt * 16 + frow;
+        const bool ok = m < M;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v = acc[nt][mt] + bias[nt];
+            v += cur[nt];
+            if constexpr (OUT_F32) {
+                float* pp = reinterpret_cast<float*>(e.out) + (size_t)min(m, M - 1) * e.ldc + ncol + 16 * nt;
+                asm volatile("s_mov_b64 s[2:3], exec\n\ts_and_b64 exec, exec, %2\n\tglobal_store_dwordx4 %0, %1, off\n\ts_mov_b64 exec, s[2:3]\n\ts_nop 1"
+                             ::"v"(pp), "v"(v), "s"(__builtin_amdgcn_ballot_w64(ok)) : "memory", "s2", "s3", "scc");
+            } else {
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                bf16* pp = reinterpret_cast<bf16*>(e.out) + (size_t)min(m, M - 1) * e.ldc + ncol + 16 * nt;
+                asm volatile("s_mov_b64 s[2:3], exec\n\ts_and_b64 exec, exec, %2\n\tglobal_store_dwordx2 %0, %1, off\n\ts_mov_b64 exec, s[2:3]\n\ts_nop 1"
+                             ::"v"(pp), "v"(o), "s"(__builtin_amdgcn_ballot_w64(ok)) : "memory", "s2", "s3", "scc");
+            }
+        }
+    }
+}
+
+template <int MT, int ACT>
+__device__ __forceinline__ void epilogue128_wide(const f32x4 (&acc)[4][MT], const Epi& e, int M, int m0, int n0, int wm, int wn, int frow, int fq) {
+    bf16* out = reinterpret_cast<bf16*>(e.out);
+    f32x4 bias[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bias[nt] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + n0 + wn * 64 + nt * 16 + fq * 4) : f32x4{0, 0, 0, 0};
+    auto pack2 = [&](float a, float b) -> unsigned {
+        const bf16x2 p = {(bf16)a, (bf16)b};
+        return __builtin_bit_cast(unsigned, p);
+    };
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * (16 * MT) + mt * 16 + frow;
+#pragma unroll
+        for (int run = 0; run < 2; ++run) {
+            const f32x4 va = acc[2 * run][mt] + bias[2 * run], vb = acc[2 * run + 1][mt] + bias[2 * run + 1];
+            unsigned x0 = pack2(act_apply_t<ACT>(va[0]), act_apply_t<ACT>(va[1])), x1 = pack2(act_apply_t<ACT>(va[2]), act_apply_t<ACT>(va[3]));
+            unsigned y0 = pack2(act_apply_t<ACT>(vb[0]), act_apply_t<ACT>(vb[1])), y1 = pack2(act_apply_t<ACT>(vb[2]), act_apply_t<ACT>(vb[3]));
+            auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            auto t0 = __builtin_amdgcn_permlane16_swap((unsigned)s0[0], (unsigned)s0[1], false, false);
+            auto t1 = __builtin_amdgcn_permlane16_swap((unsigned)s1[0], (unsigned)s1[1], false, false);
+            if (m < M) {
+                const i32x4 o = {(int)t0[0], (int)t1[0], (int)t0[1], (int)t1[1]};       // columns 8 fq .. 8 fq + 7 of the 32-column run
+                *reinterpret_cast<i32x4*>(out + (size_t)m * e.ldc + n0 + wn * 64 + run * 32 + fq * 8) = o;
+            }
+        }
+    }
+}
+
 // FP8: operands are OCP e4m3 bytes (K-tile = 128 elements = the same 128-byte LDS rows), one
 // v_mfma_f32_16x16x128_f8f6f4 per fragment pair (2x the bf16 MFMA rate), per-row scales applied to the accumulators.
 template <bool OUT_F32, bool SWIGLU, int MT, bool FP8>
@@ -208,6 +285,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const void* __restrict__ A
         }
     }
     // ---- epilogue (activation resolved once so the body stays unrolled)
+    if constexpr (!SWIGLU) {
+        if (e.resid != nullptr && e.act == ACT_NONE) {
+            epilogue128_resid<OUT_F32, MT>(acc, e, M, m0, n0, wm, wn, frow, fq);
+            return;
+        }
+        if constexpr (!OUT_F32) {
+            if (e.resid == nullptr && e.ldc % 8 == 0 && ((uintptr_t)e.out & 15) == 0) {
+                UFV_ACT_SWITCH(e.act, (epilogue128_wide<MT, ACT_>(acc, e, M, m0, n0, wm, wn, frow, fq)))
+                return;
+            }
+        }
+    }
     UFV_ACT_SWITCH(e.act, (epilogue128<OUT_F32, SWIGLU, MT, ACT_>(acc, e, M, m0, n0, wm, wn, frow, fq)))
 }
 
