@@ -256,14 +256,14 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
             ach = ks["flops"] / (ks["mean_ms"] * 1e-3) / 1e12
             traffic = None
             peak = 2 * MFMA_PEAK_TFLOPS if args.fp8 else MFMA_PEAK_TFLOPS
-            pmc = os.path.join(ROOT, "profiles", "r02", "pmc_bench.json")
+            pmc = os.path.join(ROOT, "profiles", "r03", "pmc_bench.json")
             busy = None
             if os.path.exists(pmc) and not args.fp8:
                 gu = json.load(open(pmc)).get("gate_up", {})
                 traffic, busy = gu.get("hbm_bytes_per_launch"), gu.get("mfma_busy_fraction")
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256<%s,swiglu> gate/up M=%d N=%d K=%d" % ("fp8" if args.fp8 else "bf16", ks["M"], ks["N"], ks["K"]),
                                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": traffic, "traffic_source": "profiles/r02/pmc_bench.json (tools/pmc_bench.sh: rocprofv3 --pmc passes of this command, not re-measured per run)",
+                               "traffic": traffic, "traffic_source": "profiles/r03/pmc_bench.json (tools/pmc_bench.sh: rocprofv3 --pmc passes of this command, not re-measured per run)",
                                "mfma_busy_pmc": busy,
                                "launch_ms": round(ks["mean_ms"], 4), "launches": ks["launches"]}
         step_tf = sum(FLOPS.values()) * args.frames / 32 / (dt / args.steps) / 1e12

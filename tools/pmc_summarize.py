@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""gpurun_out/<tag>/pmc/*/**/counter_collection.csv (tools/pmc_bench.sh) -> profiles/<tag>/pmc_bench.json.
+Per kernel: means of FETCH_SIZE / WRITE_SIZE (KB) / SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE and the launch duration, plus
+the three summary entries bench.py and DESIGN.md quote (gate/up GEMM, ViT attention, LLM attention).  Corrections as MI355X_MICROARCH.md
+prescribes: FETCH_SIZE reports half of the bytes of wide coalesced reads on gfx950 (doubled here), WRITE_SIZE is exact, both sit on the L2's
+memory side (Infinity-Cache hits included); GRBM_GUI_ACTIVE sums the 8 XCDs (/ 8 = elapsed shader cycles), SQ_VALU_MFMA_BUSY_CYCLES sums the
+1024 SIMDs (/ 1024 = busy cycles of one matrix pipe)."""
+import collections, csv, glob, json, os, re, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag, "pmc")
+
+
+def short(name):
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    n = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)          # argument list
+    return n.strip()
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "BUSY"):
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            n = row["Kernel_Name"]
+            if "gemm_nt" in n or "attn_fwd" in n or "layernorm_k" in n or "rmsnorm_k" in n:
+                k = short(n)
+                acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if row["Counter_Name"] in ("GRBM_GUI_ACTIVE",):
+                    acc[k]["duration_ns"].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+means = {}
+for k, d in sorted(acc.items()):
+    means[k] = {c + "_mean": sum(v) / len(v) for c, v in d.items()}
+    means[k]["launches"] = len(d.get("GRBM_GUI_ACTIVE", d.get("SQ_VALU_MFMA_BUSY_CYCLES", [])))
+    if "GRBM_GUI_ACTIVE_mean" in means[k] and "SQ_VALU_MFMA_BUSY_CYCLES_mean" in means[k]:
+        means[k]["elapsed_cycles"] = means[k]["GRBM_GUI_ACTIVE_mean"] / 8.0
+        means[k]["mfma_busy_fraction"] = (means[k]["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / 1024.0) / means[k]["elapsed_cycles"]
+
+
+def summary(match, label, alg_bytes=None):
+    ks = [k for k in means if match(k)]
+    if not ks:
+        return None
+    k = max(ks, key=lambda x: means[x].get("launches", 0))
+    m = means[k]
+    out = {"kernel": label, "kernel_symbol": k, "launches": m.get("launches"), "elapsed_cycles": round(m.get("elapsed_cycles", 0)),
+           "mfma_busy_fraction": round(m.get("mfma_busy_fraction", 0), 4), "duration_us_profiled": round(m.get("duration_ns_mean", 0) / 1e3, 1)}
+    if "FETCH_SIZE_mean" in m and "WRITE_SIZE_mean" in m:
+        out["fetch_bytes"] = int(m["FETCH_SIZE_mean"] * 1024 * 2)
+        out["write_bytes"] = int(m["WRITE_SIZE_mean"] * 1024)
+        out["hbm_bytes_per_launch"] = out["fetch_bytes"] + out["write_bytes"]
+    if alg_bytes:
+        out["algorithmic_bytes_per_launch"] = alg_bytes
+    return out
+
+
+res = {"source": f"tools/pmc_bench.sh {tag}: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, one pass each, no trace "
+                 "domains, on `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`; summarised by tools/pmc_summarize.py",
+       "correction": "gfx950: FETCH_SIZE (KB) reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE (KB) exact; counters sit on the "
+                     "L2's memory side: Infinity-Cache hits included.  GRBM_GUI_ACTIVE sums the 8 XCDs -> / 8 = elapsed shader cycles (reads high on launches shorter than "
+                     "~0.3 ms); SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs",
+       "per_kernel_means": means}
+M, N, K = 2399, 37888, 3584
+res["gate_up"] = summary(lambda k: k.startswith("gemm_nt_256<false, true"), f"gemm_nt_256<bf16, swiglu, 256x256, two-phase> M={M} N={N} K={K}",
+                         alg_bytes=(M * K + N * K + M * (N // 2)) * 2)
+res["vit_attention"] = summary(lambda k: "attn_fwd_vit72" in k, "ViT attention B=32 H=16 S=576 hd=72", alg_bytes=32 * 576 * 1152 * 2 * 4)
+res["llm_attention"] = summary(lambda k: "attn_fwd_mfma<128" in k, "attn_fwd_mfma<128,4,causal,NG2> S=2399 28/4 heads")
+out = os.path.join(root, "profiles", tag)
+os.makedirs(out, exist_ok=True)
+json.dump(res, open(os.path.join(out, "pmc_bench.json"), "w"), indent=1, sort_keys=True)
+for k in ("gate_up", "vit_attention", "llm_attention"):
+    print(k, json.dumps(res[k]))
