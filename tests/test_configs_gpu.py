@@ -258,7 +258,9 @@ def test_config4_training_step_16_frames_7b_dims():
         assert bool(torch.isfinite(b.g).all()) and torch.equal(b.w, b.master.to(torch.bfloat16))
     # the model sees the trained weights: the forward loss through the model's own API equals the next step's pre-update loss
     with torch.no_grad():
-        out = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], images=batch["images"], inference=False)
+        out = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], labels=batch["labels"], images=batch["images"],
+                    images_sam=torch.zeros(1, 1, 3, 8, 8, device="cuda"), offset=[0, 1], masks_list=[torch.zeros(0, 8, 8)], label_list=[torch.zeros(8, 8)],
+                    inference=False)          # (the reference dereferences images_sam unconditionally; no [SEG] in the labels -> the mask terms are 0)
     lm = float(out["loss"] if isinstance(out, dict) else out.loss)
     r4 = tr.train_step(**batch)
     assert abs(lm - float(r4["loss"])) < 2e-3 * abs(lm)
