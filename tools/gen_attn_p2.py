@@ -396,16 +396,20 @@ def build(simple=False):
     ]
     for i in ins2:
         e(i)
-    e("s_waitcnt vmcnt(19) lgkmcnt(0)")      # tile 0 and this wave's staged Q rows are in; unit 2's rows, tile 1 and half of tile 2 (19 ops) may still fly
+    # the first QK^T needs tile 0 and unit 0's Q rows (staging pieces 0..4): 14 of the 37 operations; the memory system serves a wave's requests
+    # in order, so the rest (Q pieces 5..8, unit 2's rows, tile 1, half of tile 2 = 23 operations) stays in flight behind the first MFMAs
+    e("s_waitcnt vmcnt(23) lgkmcnt(0)")
     e("s_barrier")
-    for u in range(2):                       # unit 2's fragments are loaded in period (0, 0), as in every pass
-        for i in q_load(u, (TA, TB)):
-            e(i)
+    for i in q_load(0, (TA, TB)):
+        e(i)
     for i in k_reads(0):
         e(i)
     e("s_waitcnt lgkmcnt(0)")
     for m in mfma_qk(0):
         e(m)
+    e("s_waitcnt vmcnt(19)")                  # unit 1's rows (pieces 5..8); unit 2's fragments are loaded in period (0, 0), as in every pass
+    for i in q_load(1, (TA, TB)):
+        e(i)
     # O descriptor of pass 0's (non-existent) predecessor: num_records = 0 -> every store is dropped
     e(f"s_mov_b32 {sr(S_ODESC)}, {sr(ORS)}"); e(f"s_mov_b32 {sr(S_ODESC + 1)}, {sr(ORS + 1)}"); e(f"s_mov_b32 {sr(S_ODESC + 2)}, 0"); e(f"s_mov_b32 {sr(S_ODESC + 3)}, {sr(ORS + 3)}")
     e("s_nop 7"); e("s_nop 7")
@@ -535,9 +539,10 @@ def build(simple=False):
     for m in mfma_pv(2):
         e(m)
     e("s_nop 7"); e("s_nop 7")
-    for u in range(3):
-        da, db = drain(u, S(1, 0) if u != 1 else S(0, 0))
-        for i in da + db:
+    parts = [drain(u, S(u, 0), S(u, 16)) for u in range(3)]       # every bank is free now: unit u's drain works in S[u]
+    # unit 2's rows leave through staging region 0, which unit 0's rows must have left first
+    for seq in (parts[0][0], parts[1][0], parts[0][1], parts[2][0], parts[1][1], parts[2][1]):
+        for i in seq:
             G.emit_ins(i)
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e("s_branch END%=")
