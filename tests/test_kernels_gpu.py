@@ -202,6 +202,34 @@ def test_vit72_kernel_spikes_force_rescales_and_first_tile_can_be_all_negative()
     assert rel(o, old.float()) <= 2 * ATTN_TOL             # and it agrees with the first-generation kernel
 
 
+def test_vit72_third_generation_bit_identical_and_rescale_paths():
+    """third-generation ViT kernel (csrc/attn_vit_p2.inc, generated asm pass loop; kernel id 14 = what AUTO takes at S = 576): the same numerics as
+    the second generation (kernel 11), so the outputs must be BIT-IDENTICAL -- on ordinary data, with spikes that drive the out-of-line deferred-rescale
+    path in several tiles of several passes (units 0 / 1 / 2, first and later passes), with rows whose first tile is all negative, and for a head count /
+    batch that leaves CUs without a block.  Shapes outside its envelope (S != 576, odd head count) are refused by id 14 and go to kernel 11 under AUTO."""
+    hd = 72
+    for B, H, seed in ((2, 4, 50), (1, 16, 51), (3, 2, 52)):
+        S = 576
+        q, k, v = g(B, S, H, hd, seed=seed), g(B, S, H, hd, seed=seed + 100), g(B, S, H, hd, seed=seed + 200)
+        # growing spikes: tile 1 (key 70), tile 4 (key 300), tile 8 (key 560), seen by rows of every unit and pass (0..95, 96..191, 192..287, and the second half)
+        for row, key, amp in ((5, 70, 3.0), (5, 300, 6.0), (40, 560, 5.0), (70, 130, 4.0), (100, 300, 5.0), (200, 450, 6.0), (250, 70, 4.0), (300, 520, 7.0), (500, 200, 5.0), (575, 575, 6.0)):
+            k[:, key] = q[:, row] * amp
+        k[:, :64] = -q[:, 150:214].abs().mean(dim=(1, 2), keepdim=True) * torch.sign(q[:, 150:151]) * 2.0      # tile 0 strongly negative for row 150
+        q, k, v = bf(q), bf(k), bf(v)
+        st = ((S * H * hd, H * hd),) * 3
+        new = ops.attention(q, k, v, B, H, H, S, S, hd, *st, kernel=14)
+        old = ops.attention(q, k, v, B, H, H, S, S, hd, *st, kernel=11)
+        auto = ops.attention(q, k, v, B, H, H, S, S, hd, *st)
+        assert torch.equal(new, old) and torch.equal(auto, old), (B, H, int((new != old).sum()))
+        assert torch.isfinite(new.float()).all() and rel(new, attn_ref(q, k, v, False)) <= 2 * ATTN_TOL
+    q, k, v = bf(g(1, 288, 2, hd, seed=60)), bf(g(1, 288, 2, hd, seed=61)), bf(g(1, 288, 2, hd, seed=62))
+    with pytest.raises(_lib.UfvError):
+        ops.attention(q, k, v, 1, 2, 2, 288, 288, hd, (288 * 2 * hd, 2 * hd), (288 * 2 * hd, 2 * hd), (288 * 2 * hd, 2 * hd), kernel=14)
+    q3 = bf(g(1, 576, 3, hd, seed=63))
+    o3 = ops.attention(q3, q3, q3, 1, 3, 3, 576, 576, hd, *(((576 * 3 * hd, 3 * hd),) * 3))                    # odd head count: AUTO falls back
+    assert torch.equal(o3, ops.attention(q3, q3, q3, 1, 3, 3, 576, 576, hd, *(((576 * 3 * hd, 3 * hd),) * 3), kernel=11))
+
+
 def test_attention_spike_forces_rescale():
     # one key dominates late in the sequence -> running max jumps (online-softmax rescale path)
     B, H, S, hd = 1, 2, 256, 72
