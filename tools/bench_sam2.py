@@ -15,6 +15,10 @@ def timed(fn, n=3, warm=2):
 
 sam = SAM2(device="cuda")
 base = sam.sam2_model
+if "--fp8" in sys.argv:                       # config #5: W8A8 e4m3 GEMMs in the Hiera-L trunk and the FPN laterals
+    from ufvideo_amd.model._params import set_gemm_dtype
+    set_gemm_dtype(sam, "fp8")
+    print("fp8 trunk")
 for F in (1, 4, 8):
     x = torch.randn(F, 3, 1024, 1024, device="cuda", dtype=torch.bfloat16)
     dt, feats = timed(lambda: base.forward_image_tokens(x))

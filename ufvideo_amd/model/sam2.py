@@ -142,12 +142,13 @@ class Hiera(PackedModule):
             wqkv = torch.cat([_pad2(wq[j * do:(j + 1) * do], dop, dp) for j in range(3)], 0)
             bqkv = torch.cat([_pad1(bq[j * do:(j + 1) * do], dop) for j in range(3)], 0)
             blk = dict(n1=(f32(L.norm1.weight), f32(L.norm1.bias)), n2=(f32(L.norm2.weight), f32(L.norm2.bias)),
-                       wqkv=bf(wqkv), bqkv=f32(bqkv), wo=bf(_pad2(L.attn.proj.weight, dop, dop)), bo=f32(_pad1(L.attn.proj.bias, dop)),
-                       w1=bf(_pad2(L.mlp.layers.get("0").weight, hp, dop)), b1=f32(_pad1(L.mlp.layers.get("0").bias, hp)),
-                       w2=bf(_pad2(L.mlp.layers.get("1").weight, dop, hp)), b2=f32(_pad1(L.mlp.layers.get("1").bias, dop)),
+                       # (self.gw: bf16, or e4m3 + per-channel scale under set_gemm_dtype("fp8") -- config #5: every padded dim is a multiple of 128)
+                       wqkv=self.gw(wqkv), bqkv=f32(bqkv), wo=self.gw(_pad2(L.attn.proj.weight, dop, dop)), bo=f32(_pad1(L.attn.proj.bias, dop)),
+                       w1=self.gw(_pad2(L.mlp.layers.get("0").weight, hp, dop)), b1=f32(_pad1(L.mlp.layers.get("0").bias, hp)),
+                       w2=self.gw(_pad2(L.mlp.layers.get("1").weight, dop, hp)), b2=f32(_pad1(L.mlp.layers.get("1").bias, dop)),
                        dp=dp, dop=dop, hp=hp, proj=None)
             if d != do:
-                blk["proj"] = (bf(_pad2(L.proj.weight, dop, dp)), f32(_pad1(L.proj.bias, dop)))
+                blk["proj"] = (self.gw(_pad2(L.proj.weight, dop, dp)), f32(_pad1(L.proj.bias, dop)))
             blocks.append(blk)
         pk["blocks"] = blocks
         pk["pos"] = {}
@@ -291,7 +292,7 @@ class FpnNeck(PackedModule):
         out = []
         for i, c in enumerate(self.backbone_channel_list):
             cv = self.convs.get(str(i)).conv
-            out.append((bf(_pad2(cv.weight.reshape(self.d_model, c), self.d_model, _pad_dim(c))), f32(cv.bias)))
+            out.append((self.gw(_pad2(cv.weight.reshape(self.d_model, c), self.d_model, _pad_dim(c))), f32(cv.bias)))
         return out
 
     def forward_tokens(self, feats, B):
