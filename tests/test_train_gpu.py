@@ -525,6 +525,71 @@ def test_projector_grad_vs_oracle_autograd(cin, hid, t, hw, depth):
     assert rel_err(dx.float().cpu(), xr.grad) < 6e-2
 
 
+@pytest.mark.parametrize("depth,cin,hid,t,hw", [(2, 64, 128, 4, 6), (1, 128, 256, 3, 8), (3, 64, 64, 2, 5)])
+def test_mlp_projector_grad_vs_autograd(depth, cin, hid, t, hw):
+    """`mlpNx_gelu` / `linear` projectors in training (ref projector.py:95-108 + the mean over frames of temporal_aggregator, videorefer_arch.py:199-201):
+    every parameter gradient and the input gradient against torch autograd of the same graph"""
+    from ufvideo_amd.model.projector import MlpProjector
+    from ufvideo_amd.train_projector import ProjectorGrad, MlpProjectorGrad
+    g_ = torch.Generator().manual_seed(70 + depth)
+    sd = {}
+    for i in range(depth):
+        sd[f"{2 * i}.weight"] = bfr(torch.randn(hid, cin if i == 0 else hid, generator=g_) * 0.1)
+        sd[f"{2 * i}.bias"] = bfr(torch.randn(hid, generator=g_) * 0.1)
+    pj = MlpProjector(cin, hid, depth)
+    pj.load_state_dict(sd)
+    pj = pj.to(DEV)
+    x = bfr(torch.randn(t * hw * hw, cin, generator=g_))
+    dout = torch.randn(hw * hw, hid, generator=g_)
+    with torch.enable_grad():
+        p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        xr = x.clone().requires_grad_(True)
+        h = bfr(xr.view(t, hw * hw, cin).mean(0))
+        for i in range(depth):
+            h = F.linear(h, p[f"{2 * i}.weight"], p[f"{2 * i}.bias"])
+            if i < depth - 1:
+                h = F.gelu(h)
+        h.backward(dout)
+    pg = ProjectorGrad(pj)
+    assert isinstance(pg, MlpProjectorGrad)
+    out, st = pg.forward(x.to(DEV), t, hw)
+    assert out.shape == (hw * hw, hid) and rel_err(out.cpu(), h.detach()) < 2e-2
+    assert rel_err(pj(x.view(1, t, hw * hw, cin).to(DEV).float().mean(1)).cpu()[0], h.detach()) < 2e-2        # == the inference path
+    grads, dx = pg.backward(dout.to(DEV), st)
+    assert set(grads) == set(sd)
+    worst = max((rel_err(grads[k].cpu().reshape(p[k].shape), p[k].grad), k) for k in sd)
+    assert worst[0] < 4e-2, worst
+    assert rel_err(dx.float().cpu(), xr.grad) < 4e-2
+
+
+def test_train_step_with_an_mlp2x_gelu_projector():
+    """the drop-in step with the reference's `mlp2x_gelu` projector trained (adapter stage: tower + decoder frozen): the visual tokens are
+    the MLP of the frame-mean features (16 tokens for the tiny tower), gradients land under the reference's names, the loss falls"""
+    from test_model_gpu import TINY_LLM, TINY_VIT, Tok
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
+    from ufvideo_amd.model.projector import MlpProjector
+    a, w = load_golden("model_tiny")
+    cfg = VideoReferQwen2Config(**TINY_LLM, mm_vision_tower="siglip", mm_vision_select_layer=-2, mm_vision_select_feature="patch",
+                                mm_projector_type="mlp2x_gelu", mm_hidden_size=64, mm_region_encoder_type="pooling", image_aspect_ratio="square",
+                                train_mask_decoder=False, sam_pretrained=None, sam_out_dim=256, num_frames=4, seg_token_id=299, vision_config=TINY_VIT, sam2_trunk=None)
+    m = VideoReferQwen2ForCausalLM(cfg)
+    m.get_vision_tower().load_model()
+    m.load_state_dict({k: v for k, v in w.items() if not k.startswith("model.mm_projector.")}, strict=False)
+    m = m.to(DEV)
+    for mod in m.modules():
+        mod.tokenizer = Tok()
+    assert isinstance(m.get_model().mm_projector, MlpProjector)
+    tr = DecoderTrainer(m, lr=3e-3, weight_decay=0.0, max_grad_norm=1.0, train_projector=True, train_decoder=False)
+    ids = torch.tensor([[5, 6, -201, 7, 8, 9, 10, 11]], device=DEV)
+    labels = ids.clone(); labels[labels < 0] = -100; labels[:, :3] = -100
+    video = t(a["video"]).to(DEV)
+    before = tr.proj_bucket.master.clone()
+    losses = [float(tr.train_step(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids), images=[(video, "video")])["loss"]) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert float((tr.proj_bucket.master - before).abs().max()) > 0
+    assert set(k for k in tr.proj_params) == {"mm_projector.0.weight", "mm_projector.0.bias", "mm_projector.2.weight", "mm_projector.2.bias"}
+
+
 @pytest.mark.parametrize("kind,cin,hid,t,hw,depth", [("stc_connector", 64, 64, 4, 4, 2), ("stc_connector", 128, 256, 3, 5, 1), ("spatial_conv", 64, 64, 3, 6, 0),
                                                      ("stp_connector", 64, 64, 4, 6, 2), ("stp_connector", 64, 128, 5, 5, 1), ("spatial_pool", 64, 64, 3, 5, 0)])
 def test_projector_grad_other_connectors_vs_oracle_autograd(kind, cin, hid, t, hw, depth):
