@@ -9,7 +9,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-function 
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_epi.h $(CSRC)/gemm256_kernel.h $(CSRC)/gemm_state.h $(CSRC)/attn_vit.inc $(CSRC)/attn_vit_p2.inc $(CSRC)/attn_vit_p2_asm.inc include/ufv.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/gemm_epi.h $(CSRC)/gemm256_kernel.h $(CSRC)/gemm_state.h $(CSRC)/attn_vit.inc $(CSRC)/attn_vit_p2.inc $(CSRC)/attn_vit_p2_asm.inc $(CSRC)/attn_c128.inc $(CSRC)/attn_c128_asm.inc include/ufv.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

@@ -13,6 +13,7 @@
 // (Sq = 1) and tiny test shapes.
 #include "common.h"
 #include "../../include/ufv.h"
+#include "gemm_state.h"
 
 #ifndef UFV_STAMP
 #define UFV_STAMP(i)            // tools/attn_lab.hip defines it to record s_memtime at point i (block-level timeline)
@@ -603,6 +604,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 8 ? 3 : 2)) void attn_fwd_mfma_dma(A
 
 #include "attn_vit.inc"
 #include "attn_vit_p2.inc"
+#include "attn_c128.inc"
 
 // ---------------------------------------------------------------------------------------------------------
 // Head-pair variant of the LDS-DMA kernel (diagnostic, kernel ids 7 / 8).  With 168 VGPRs a CU holds 3 waves per SIMD, i.e. ONE
@@ -1166,7 +1168,7 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
     }
-    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || kernel == 10 || kernel == 11 || kernel == 14 || ((kernel == 12 || kernel == 13) && mfma_ok) ||
+    if (kernel == 1 || kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 9 || kernel == 10 || kernel == 11 || kernel == 14 || kernel == 15 || ((kernel == 12 || kernel == 13) && mfma_ok) ||
         (kernel == 0 && mfma_ok && Sq >= 16)) {
         const bool six = (Sq % 192 == 0) && (Sq % 128 != 0);     // e.g. 576 ViT tokens: 3 blocks of 6 waves, no idle wave
         switch (hd) {
@@ -1190,6 +1192,10 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
             case 80: return launch_mfma<80, 4>(a, causal, st);
             case 96: return launch_mfma<96, 4>(a, causal, st);
             case 128:
+                if (kernel == 15) {
+                    if (!(causal && mfma_ok && c128_ok(a))) { ufv_set_error("ufv_attention: kernel 15 is built for causal hd 128 prefill of one sequence (Sq = Sk >= 64, GQA with >= 2 kv heads)"); return UFV_EUNSUPPORTED; }
+                    return launch_c128(a, st);
+                }
                 // kernel 12: key split over two wave groups per block; kernel 13: never.  Default when the launch has few blocks for the chip
                 // (<= ~2.3 per CU: the causal S = 2399 prefill has 532 for 512 slots and ends with its heaviest blocks alone; measured 88 -> 82 us
                 // there, 41 -> 31 us at S = 1200; with many blocks -- S = 4703: 1036 -- the plain kernel's two blocks per CU retire more tiles: 232 vs 254 us)
