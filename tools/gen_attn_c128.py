@@ -29,6 +29,12 @@ NSTAGE = 4
 SCRATCH = NSTAGE * STG                 # 3 KiB: destination of the 3 padding pieces that make 40 = 4 x 10 per tile
 LDS_BYTES = SCRATCH + 3 * 1024 + 64
 THR = 0x40C00000                       # 6.0f
+OPT = os.environ.get("UFV_C128_OPT", "").split(",")
+NOVPRE = "novpre" in OPT
+PRE_A = int(os.environ.get("UFV_C128_PRE", "28"))
+DROP = os.environ.get("UFV_C128_DROP", "").split(",")
+STAMPS = "--stamps" in sys.argv       # lab build: s_memtime deltas of the compute waves summed per segment kind -> [block][wave][8] dwords at %[stp]
+S_NOW, S_PREV, S_DLT = 84, 86, 87      # the K descriptor's SGPRs (loader-only); sums in a120..a127      # lab only: timing experiments with parts of the work removed (results are wrong)
 
 
 def vr(n, c=1): return f"v{n}" if c == 1 else f"v[{n}:{n + c - 1}]"
@@ -47,8 +53,10 @@ INV = PSUM
 LANE, L31, HH, QOFF, OOFF, TG, TF = range(40, 47)
 A_K0, A_V0, A_L31, A_QOFF, A_OOFF = range(112, 117)
 def O(dt, r=0): return 16 * dt + r                   # a0..63
-def KFR(i, half, j=0): return 64 + 8 * (i % 3) + 4 * half + j      # a64..87: ring of 3 k-steps
-def VFR(i, j=0): return 88 + 4 * (i % 6) + j                       # a88..111: ring of 6 V^T fragments
+NSLOT = 12                                                          # a64..111: ONE ring of 12 four-register fragment slots shared by the K and the V^T stream
+def RING(i, j=0): return 64 + 4 * (i % NSLOT) + j
+LEAD = int(os.environ.get("UFV_C128_LEAD", "10"))                  # fragments requested ahead of the one being multiplied (<= NSLOT - 2: a slot is rewritten two MFMAs after its reader)
+MAXFLY = 15                                                         # LDS instructions in flight per wave (lgkmcnt has 4 bits)
 
 # ---- loader-wave registers: v0..9 source offsets of its 10 pieces, v10.. temps
 # ---- fixed SGPRs (s40..s99)
@@ -101,70 +109,76 @@ def emit(G, ins):
 
 
 # ---- phase A: QK^T of the next tile (K fragments streamed from LDS) --------------------------------------------------------
-def phase_a_mfma(slot):
-    """returns the list of 'MFMA groups': each entry = instructions that must be adjacent (waits + the MFMA)"""
-    out = []
-    reads = []
-    for ks in range(8):
-        for half in range(2):
-            reads.append(f"ds_read_b128 {ar(KFR(ks, half), 4)}, {vr(KADDR)} offset:{ks * 32 + half * 32 * PK}")
-    # issue order: reads of k-steps 0,1 up front, then after the MFMAs of k-step ks the reads of ks + 2
-    seq = []
-    seq.append(reads[0:4])
-    for ks in range(8):
-        # outstanding reads allowed when k-step ks is consumed: those of ks+1 (2) [and none beyond, since ks+2's are issued AFTER these MFMAs]
-        allowed = 2 if ks < 7 else 0
-        d0, d1 = vr(S(slot, 0), 16), vr(S(slot, 16), 16)
-        c0 = "0" if ks == 0 else d0
-        c1 = "0" if ks == 0 else d1
-        grp = [f"s_waitcnt lgkmcnt({allowed})",
-               f"v_mfma_f32_32x32x16_bf16 {d0}, {ar(KFR(ks, 0), 4)}, {vr(Q(ks), 4)}, {c0}",
-               f"v_mfma_f32_32x32x16_bf16 {d1}, {ar(KFR(ks, 1), 4)}, {vr(Q(ks), 4)}, {c1}"]
-        if ks + 2 < 8:
-            grp += reads[2 * (ks + 2): 2 * (ks + 2) + 2]
-        seq.append(grp)
-    return seq
+def frag_stream(slot, want_qk, want_pv, i0=0):
+    """the fragment stream of one iteration: 16 K fragments (k-step ks, key half) each feeding one QK^T MFMA into S[slot], then 16 V^T fragments
+    (c outer, dt inner: per accumulator the chunks in the order c = 0..3 of attn_fwd_mfma, consecutive MFMAs independent) each feeding one PV MFMA.
+    Returns (head, groups): head = the reads issued before anything is multiplied, groups[i] = [wait, MFMA, reads issued after it]."""
+    fr = []                                            # (read instructions, mfma)
+    n = i0
+    if want_qk:
+        for ks in range(8):
+            for half in range(2):
+                d = vr(S(slot, 16 * half), 16)
+                fr.append(([f"ds_read_b128 {ar(RING(n), 4)}, {vr(KADDR)} offset:{ks * 32 + half * 32 * PK}"],
+                           f"v_mfma_f32_32x32x16_bf16 {d}, {ar(RING(n), 4)}, {vr(Q(ks), 4)}, {'0' if ks == 0 else d}"))
+                n += 1
+    if want_pv:
+        for c in range(4):
+            for dt in range(4):
+                off = dt * 64 + c * 16 * PV
+                fr.append(([f"ds_read_b64_tr_b16 {ar(RING(n, 0), 2)}, {vr(VADDR)} offset:{off}", f"ds_read_b64_tr_b16 {ar(RING(n, 2), 2)}, {vr(VADDR)} offset:{off + 8 * PV}"],
+                           f"v_mfma_f32_32x32x16_bf16 {ar(O(dt), 16)}, {ar(RING(n), 4)}, {vr(P(4 * c), 4)}, {ar(O(dt), 16)}"))
+                n += 1
+    nf = len(fr)
+    issued = 0
+    fly = []                                           # instruction counts of the fragments in flight, oldest first
+    def pump(i):
+        nonlocal issued
+        out = []
+        while issued < nf and issued - i < LEAD and sum(fly) + len(fr[issued][0]) <= MAXFLY:
+            out += fr[issued][0]; fly.append(len(fr[issued][0])); issued += 1
+        return out
+    head = pump(0)
+    groups = []
+    for i in range(nf):
+        if issued <= i:                                # (cannot happen with LEAD >= 1)
+            raise RuntimeError("fragment not requested")
+        later = sum(fly[1:])
+        g = [f"s_waitcnt lgkmcnt({later})", fr[i][1]]
+        fly.pop(0)
+        g += pump(i + 1)
+        groups.append(g)
+    if "lds" in DROP:
+        head = []
+        groups = [[x for x in g if not x.startswith("ds_read")] for g in groups]
+    return head, groups
 
 
 def finish_softmax(slot):
-    """P = exp2(fma(s, c, -msub)), psum in the order of attn_fwd_mfma (psum += s0[r] + s1[r], r = 0..15), l_run += psum, bf16 pack"""
+    """P = exp2(fma(s, c, -msub)), psum in the order of attn_fwd_mfma (psum += s0[r] + s1[r], r = 0..15), l_run += psum, bf16 pack -- one sequence
+    (the wave's last tile and --simple)"""
+    a, b1, b2, b3 = finish_parts(slot)
+    return a + b1 + b2 + b3
+
+
+def finish_parts(slot):
+    """the same work in four parts: A (beside the QK^T of the next tile) = all the FMAs, the exps and packs of the first key half (P chunks 0, 1);
+    B1 / B2 (beside the first PV MFMAs, which use chunks 0, 1) = exps and packs of chunk 2 / chunk 3; B3 = the row sums, in the order of the reference kernel"""
     s = lambda r: vr(S(slot, r))
-    o = [f"v_cmp_lg_f32 vcc, 0xff800000, {vr(MRUN)}", "s_nop 1", f"v_cndmask_b32 {vr(MSUB)}, 0, {vr(MRUN)}, vcc", f"v_mov_b32 {vr(PSUM)}, 0"]
+    a = [f"v_cmp_lg_f32 vcc, 0xff800000, {vr(MRUN)}", "s_nop 1", f"v_cndmask_b32 {vr(MSUB)}, 0, {vr(MRUN)}, vcc"]
     for r in range(16):
-        o += [f"v_fma_f32 {s(r)}, {s(r)}, {sr(S_SL2)}, -{vr(MSUB)}", f"v_fma_f32 {s(16 + r)}, {s(16 + r)}, {sr(S_SL2)}, -{vr(MSUB)}"]
-    ex = []
+        a.append(f"v_fma_f32 {s(r)}, {s(r)}, {sr(S_SL2)}, -{vr(MSUB)}")
     for r in range(16):
-        ex += [f"v_exp_f32 {s(r)}, {s(r)}", f"v_exp_f32 {s(16 + r)}, {s(16 + r)}"]
-    o += ex[:6]
-    k = 6
-    for r in range(16):
-        o += [f"v_add_f32 {vr(TA)}, {s(r)}, {s(16 + r)}", f"v_add_f32 {vr(PSUM)}, {vr(PSUM)}, {vr(TA)}"]
-        o += ex[k:k + 2]; k += 2
-    assert k >= 32
-    o.append(f"v_add_f32 {vr(LRUN)}, {vr(LRUN)}, {vr(PSUM)}")
-    o += [f"v_cvt_pk_bf16_f32 {vr(P(j))}, {vr(S(slot, 2 * j))}, {vr(S(slot, 2 * j + 1))}" for j in range(16)]
-    return o
-
-
-# ---- phase B: PV of the current tile (V^T fragments streamed) --------------------------------------------------------------
-def phase_b_mfma():
-    frags = []
-    for dt in range(4):
-        for c in range(4):
-            i = dt * 4 + c
-            off = dt * 64 + c * 16 * PV
-            frags.append([f"ds_read_b64_tr_b16 {ar(VFR(i, 0), 2)}, {vr(VADDR)} offset:{off}",
-                          f"ds_read_b64_tr_b16 {ar(VFR(i, 2), 2)}, {vr(VADDR)} offset:{off + 8 * PV}"])
-    seq = [frags[0] + frags[1] + frags[2] + frags[3]]                     # four fragments ahead (ring of 6: a slot is rewritten two MFMAs after its reader)
-    for i in range(16):
-        dt, c = divmod(i, 4)
-        later = min(3, 15 - i)                        # fragments issued after fragment i that may still be in flight
-        grp = [f"s_waitcnt lgkmcnt({2 * later})",
-               f"v_mfma_f32_32x32x16_bf16 {ar(O(dt), 16)}, {ar(VFR(i), 4)}, {vr(P(4 * c), 4)}, {ar(O(dt), 16)}"]
-        if i + 4 < 16:
-            grp += frags[i + 4]
-        seq.append(grp)
-    return seq
+        a.append(f"v_exp_f32 {s(r)}, {s(r)}")
+        a.append(f"v_fma_f32 {s(16 + r)}, {s(16 + r)}, {sr(S_SL2)}, -{vr(MSUB)}")
+    a += [f"v_cvt_pk_bf16_f32 {vr(P(j))}, {vr(S(slot, 2 * j))}, {vr(S(slot, 2 * j + 1))}" for j in range(8)]
+    b1 = [f"v_exp_f32 {s(16 + r)}, {s(16 + r)}" for r in range(8)] + [f"v_cvt_pk_bf16_f32 {vr(P(8 + j))}, {vr(S(slot, 16 + 2 * j))}, {vr(S(slot, 17 + 2 * j))}" for j in range(4)]
+    b2 = [f"v_exp_f32 {s(24 + r)}, {s(24 + r)}" for r in range(8)] + [f"v_cvt_pk_bf16_f32 {vr(P(12 + j))}, {vr(S(slot, 24 + 2 * j))}, {vr(S(slot, 25 + 2 * j))}" for j in range(4)]
+    b3 = [f"v_add_f32 {vr(PSUM)}, {s(0)}, {s(16)}"]                      # psum = 0 + (s0[0] + s1[0]): the sum itself (x + 0 = x for x >= 0)
+    for r in range(1, 16):
+        b3 += [f"v_add_f32 {vr(TA)}, {s(r)}, {s(16 + r)}", f"v_add_f32 {vr(PSUM)}, {vr(PSUM)}, {vr(TA)}"]
+    b3.append(f"v_add_f32 {vr(LRUN)}, {vr(LRUN)}, {vr(PSUM)}")
+    return a, b1, b2, b3
 
 
 def mask_tile(slot):
@@ -172,9 +186,9 @@ def mask_tile(slot):
     o = []
     for r in range(16):
         kk = (r & 3) + 8 * (r >> 2)
-        o += [f"v_add_u32 {vr(TA)}, {kk}, {vr(KJ)}", f"v_cmp_le_i32 vcc, {vr(TA)}, {vr(QI)}", "s_nop 1",
+        o += [f"v_add_u32 {vr(TC)}, {kk}, {vr(KJ)}", f"v_cmp_le_i32 vcc, {vr(TC)}, {vr(QI)}", "s_nop 1",
               f"v_cndmask_b32 {vr(S(slot, r))}, {vr(TE)}, {vr(S(slot, r))}, vcc",
-              f"v_add_u32 {vr(TA)}, {kk + 32}, {vr(KJ)}", f"v_cmp_le_i32 vcc, {vr(TA)}, {vr(QI)}", "s_nop 1",
+              f"v_add_u32 {vr(TC)}, {kk + 32}, {vr(KJ)}", f"v_cmp_le_i32 vcc, {vr(TC)}, {vr(QI)}", "s_nop 1",
               f"v_cndmask_b32 {vr(S(slot, 16 + r))}, {vr(TE)}, {vr(S(slot, 16 + r))}, vcc"]
     return o          # TE holds -inf
 
@@ -203,6 +217,13 @@ def rescale_stub():
     return o
 
 
+def stamp(k):
+    if not STAMPS:
+        return []
+    return [f"s_memtime {sr(S_NOW, 2)}", "s_waitcnt lgkmcnt(0)", f"s_sub_u32 {sr(S_DLT)}, {sr(S_NOW)}, {sr(S_PREV)}", f"v_accvgpr_read_b32 {vr(TD)}, {ar(120 + k)}", "s_nop 0",
+            f"v_add_u32 {vr(TD)}, {sr(S_DLT)}, {vr(TD)}", "s_nop 0", f"v_accvgpr_write_b32 {ar(120 + k)}, {vr(TD)}", f"s_mov_b32 {sr(S_PREV)}, {sr(S_NOW)}"]
+
+
 def build(simple=False):
     G = Gen()
     e = G.e
@@ -212,7 +233,7 @@ def build(simple=False):
         (S_VSS, "vss"), (S_OSS, "oss"), (S_S, "seq"), (S_R, "rr"), (S_HKV, "hkv"), (S_NS, "ns"), (S_NI, "ni"), (S_MR, "mr"), (S_MHKV, "mhkv"), (S_LDS, "lds"),
         (S_WAVE, "wave"), (S_BID, "bid"), (S_G, "grid"))]
     ins += [f"v_mov_b32 {vr(TA)}, %[scale]", f"v_mul_f32 {vr(TA)}, 0x3fb8aa3b, {vr(TA)}", "s_nop 0", f"v_readfirstlane_b32 {sr(S_SL2)}, {vr(TA)}",
-            f"s_mov_b32 {sr(S_ROUND)}, 0", f"s_mov_b32 {sr(S_STG)}, {STG}",
+            f"s_mov_b32 {sr(S_ROUND)}, 0", f"s_mov_b32 {sr(S_STG)}, {STG}", f"s_mov_b32 {sr(S_VALID)}, 0",
             f"v_mbcnt_lo_u32_b32 {vr(LANE)}, -1, 0", f"v_mbcnt_hi_u32_b32 {vr(LANE)}, -1, {vr(LANE)}"]
     for i in ins:
         e(i)
@@ -234,6 +255,10 @@ def build(simple=False):
               f"v_accvgpr_write_b32 {ar(A_QOFF)}, {vr(QOFF)}", f"v_accvgpr_write_b32 {ar(A_OOFF)}, {vr(OOFF)}"]:
         e(i)
     # KADDR / VADDR are rebuilt from the parked stage-0 addresses at every item start
+    if STAMPS:
+        for k in range(8):
+            e(f"v_accvgpr_write_b32 {ar(120 + k)}, 0")
+        e(f"s_memtime {sr(S_NOW, 2)}"); e("s_waitcnt lgkmcnt(0)"); e(f"s_mov_b32 {sr(S_PREV)}, {sr(S_NOW)}")
     e("C_ITEM%=:")
     item_decode(G, loader=False)
     e("s_cbranch_scc1 C_DONE%=")                      # no item left
@@ -248,7 +273,6 @@ def build(simple=False):
               f"s_cmp_lt_i32 {sr(S_SLICE)}, 0", f"s_cselect_b32 {sr(S_TW)}, 0, {sr(S_TW)}",                               # T_w = 0: this wave only joins the barriers
               ]:
         e(i)
-    e("s_barrier")                                     # B_start: every wave has left the previous item's LDS image
     e(f"s_cmp_eq_u32 {sr(S_TW)}, 0")
     e("s_cbranch_scc1 C_IDLE%=")
     # descriptors of this unit: Q / O rows of (head), base + head * 256 bytes; range = whole tensor rows (S - 1) * stride + 256
@@ -265,7 +289,9 @@ def build(simple=False):
     for r in range(64):
         e(f"v_accvgpr_write_b32 {ar(r)}, 0")
     for i in [f"v_mov_b32 {vr(MRUN)}, 0xff800000", f"v_mov_b32 {vr(LRUN)}, 0", f"v_accvgpr_read_b32 {vr(KADDR)}, {ar(A_K0)}", f"v_accvgpr_read_b32 {vr(VADDR)}, {ar(A_V0)}",
-              f"s_mov_b32 {sr(S_STAGE)}, 0", f"s_mov_b32 {sr(S_T)}, 0",
+              # the ring runs on across items: the item's first tile is global tile S_NBASE -> stage S_NBASE % 4
+              f"s_and_b32 {sr(S_STAGE)}, {sr(S_NBASE)}, 3", f"s_mul_i32 {sr(S_TMP)}, {sr(S_STAGE)}, {STG}", f"s_mov_b32 {sr(S_T)}, 0",
+              f"v_add_u32 {vr(KADDR)}, {sr(S_TMP)}, {vr(KADDR)}", f"v_add_u32 {vr(VADDR)}, {sr(S_TMP)}, {vr(VADDR)}",
               # QI = (q0 + l31) - key0 of the diagonal tile = rows relative to the last tile's first key
               f"s_sub_u32 {sr(S_TMP)}, {sr(S_TW)}, 1", f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 6", f"s_sub_u32 {sr(S_TMP)}, {sr(S_Q0ROW)}, {sr(S_TMP)}",
               f"v_add_u32 {vr(QI)}, {sr(S_TMP)}, {vr(L31)}",
@@ -273,8 +299,9 @@ def build(simple=False):
         e(i)
     # ---- tile 0: B_0, K reads + QK^T, (mask if T_w == 1), first max: m_run = tmax
     e("s_barrier")
-    seq = phase_a_mfma(0)
-    for grp in seq:
+    head, groups = frag_stream(0, True, False)
+    emit(G, head)
+    for grp in groups:
         emit(G, grp)
     e("s_nop 7"); e("s_nop 7")
     lbl = G.label("NOMASK0")
@@ -294,33 +321,33 @@ def build(simple=False):
     def full_iter(slot, masked):
         """tile t in S[slot] (max / decision done): A = barrier, K(t+1) -> S[1-slot] with finish(t) in the gaps; B = PV(t) with [mask +] start(t+1)"""
         nxt = 1 - slot
+        emit(G, stamp(0))
         e("s_barrier")                                              # B_{t+1}: tile t + 1 has landed
+        emit(G, stamp(1))
         for i in advance_stage():
             e(i)
         e(f"v_add_u32 {vr(KADDR)}, {sr(S_DELTA)}, {vr(KADDR)}")     # K of tile t + 1; V of tile t is still at VADDR
-        seqa = phase_a_mfma(nxt)
-        fin = finish_softmax(slot)
-        emit(G, seqa[0])
-        groups = seqa[1:]
-        placed = spread(fin, 0, len(groups) - 1)
-        for gi, grp in enumerate(groups):
-            emit(G, grp)
-            for g, ins in placed:
-                if (len(groups) - 1 if simple else g) == gi:
-                    e(ins)
-        e("s_nop 1")
-        seqb = phase_b_mfma()
+        head, groups = frag_stream(nxt, True, True)
+        fa, fb1, fb2, fb3 = finish_parts(slot)
         st = (mask_tile(nxt) if masked else []) + start_softmax(nxt)
-        emit(G, seqb[0])
-        groups = seqb[1:]
-        # the scores of tile t + 1 were written by the last QK^T MFMAs: first use >= 3 MFMAs later
-        placed = spread(st, 3, len(groups) - 1)
+        if "sm" in DROP:
+            fa, fb1, fb2, fb3, st = [], [], [], [], [f"s_mov_b64 {sr(S_ANY, 2)}, 0"]
+        emit(G, head)
+        npre = 0 if simple else min(PRE_A, len(fa))
+        for ins in fa[:npre]:                                       # VALU work while the first K fragments are on their way
+            e(ins)
+        # groups 0..15 = QK^T of tile t + 1, 16..31 = PV of tile t.  P chunks 0, 1 (fa) are first used by group 16, chunk 2 (fb1) by 24, chunk 3 (fb2) by 28;
+        # the scores of tile t + 1 are complete a few MFMAs after group 15
+        placed = spread(fa[npre:], 0, 13) + spread(fb1, 14, 19) + spread(fb2, 18, 23) + spread(fb3, 24, 31) + spread(st, 19, 31)
         for gi, grp in enumerate(groups):
+            if gi == 16:
+                emit(G, stamp(2))
             emit(G, grp)
             for g, ins in placed:
-                if (len(groups) - 1 if simple else g) == gi:
+                if (31 if simple else g) == gi:
                     e(ins)
         e(f"v_add_u32 {vr(VADDR)}, {sr(S_DELTA)}, {vr(VADDR)}")     # V of tile t + 1
+        emit(G, stamp(3))
         lb, back = G.label("RS"), G.label("BK")
         e(f"s_cmp_lg_u64 {sr(S_ANY, 2)}, 0"); e(f"s_cbranch_scc1 {lb}"); e(f"{back}:")
         G.stubs.append((lb, back))
@@ -337,11 +364,14 @@ def build(simple=False):
         for i in fin:
             e(i)
         e("s_nop 1")
-        for grp in phase_b_mfma():
+        head, groups = frag_stream(slot, False, True)
+        emit(G, head)
+        for grp in groups:
             emit(G, grp)
 
     G.stubs = []
     # ---- loop: full iterations while t + 2 < T_w (unmasked), then the masked one (t + 2 == T_w), then the last tile
+    emit(G, stamp(4))
     e("C_LOOP_E%=:")
     e(f"s_add_u32 {sr(S_TMP)}, {sr(S_T)}, 2"); e(f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_TW)}"); e("s_cbranch_scc0 C_TAIL_E%=")
     full_iter(0, False)
@@ -360,6 +390,7 @@ def build(simple=False):
         e("s_branch C_STORE%=")
     # ---- normalise and store: d = 32 dt + (r & 3) + 8 (r >> 2) + 4 h
     e("C_STORE%=:")
+    emit(G, stamp(5))
     e("s_nop 7"); e("s_nop 7"); e("s_nop 7")
     d = [TA, TB, TC, TD, T0]
     for i in [f"v_mov_b32 {vr(T1)}, {vr(LRUN)}", "s_nop 1", f"v_permlane32_swap_b32 {vr(LRUN)}, {vr(T1)}", f"v_add_f32 {vr(LRUN)}, {vr(LRUN)}, {vr(T1)}",
@@ -395,6 +426,8 @@ def build(simple=False):
     e(f"s_cmp_lt_u32 {sr(S_CNT)}, {sr(S_TQ)}"); e("s_cbranch_scc0 C_NEXT%=")
     e("s_barrier"); e(f"s_add_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"); e("s_branch C_IDLE_LOOP%=")
     e("C_NEXT%=:")
+    emit(G, stamp(6))
+    e(f"s_add_u32 {sr(S_NBASE)}, {sr(S_NBASE)}, {sr(S_TQ)}")
     e(f"s_add_u32 {sr(S_ROUND)}, {sr(S_ROUND)}, 1")
     e("s_branch C_ITEM%=")
     for lb, back in G.stubs:
@@ -404,89 +437,99 @@ def build(simple=False):
         e(f"s_branch {back}")
     e("C_DONE%=:")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if STAMPS:
+        for k in range(8):
+            e(f"v_accvgpr_read_b32 {vr(k)}, {ar(120 + k)}")
+        for ins in [f"s_lshl_b32 {sr(S_TMP)}, {sr(S_BID)}, 2", f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_WAVE)}", f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 5",
+                    "s_mov_b32 s84, %[stp0]", "s_mov_b32 s85, %[stp1]", f"s_add_u32 s84, s84, {sr(S_TMP)}", "s_addc_u32 s85, s85, 0",
+                    "v_mov_b32 v8, s84", "v_mov_b32 v9, s85", "s_mov_b64 exec, 1", "s_nop 1",
+                    "global_store_dwordx4 v[8:9], v[0:3], off", "global_store_dwordx4 v[8:9], v[4:7], off offset:16", "s_waitcnt vmcnt(0)", "s_mov_b64 exec, -1"]:
+            e(ins)
     e("s_branch END%=")
 
     # ============ loader waves ========================================================================================================
+    # One code path per loader wave (the piece list of a wave is static: slot j of loader i = global slot 4 j + i; piece p = slot (< 37: K pieces 0..16,
+    # V pieces 17..36) else a padding piece -> scratch).  The tile stream of a block runs on across its items: global tile n -> ring stage n % 4,
+    # issued two barriers ahead of its use, so the first tiles of an item are in flight while the compute waves finish the item before.
     e("LOADER%=:")
-    # slot j of loader i = global slot 4 j + i (i = wave - 4): piece p = slot (< 37) else padding piece slot - 37 (-> scratch)
-    # per-lane source offset of a piece: padded chunk n = 64 p + lane; K (p < 17): row n / 17, c n % 17; V: n' = n - 1088, row n' / 20, c n' % 20; pad chunks fetch c = 0
-    e(f"s_sub_u32 {sr(S_TMP3)}, {sr(S_WAVE)}, 4")
-    for j in range(10):
-        # p = 4 j + i (scalar, per wave); branchless: compute K-form and V-form, select by p < 17 (p >= 37 -> p - 37 < 17: K form)
-        for i in [f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP3)}, {4 * j}", f"s_sub_u32 {sr(S_TMP2)}, {sr(S_TMP)}, 37", f"s_cmp_ge_u32 {sr(S_TMP)}, 37",
-                  f"s_cselect_b32 {sr(S_TMP)}, {sr(S_TMP2)}, {sr(S_TMP)}",                                 # piece index (padding pieces re-fetch K pieces 0..2)
-                  f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_TMP)}, 6", f"v_add_u32 {vr(10)}, {sr(S_TMP2)}, {vr(LANE)}",     # n = 64 p + lane
-                  # K form
-                  f"s_mov_b32 {sr(S_TMP2)}, 0xf0f0f10", f"v_mul_hi_u32 {vr(11)}, {vr(10)}, {sr(S_TMP2)}", f"v_mul_u32_u24 {vr(12)}, 17, {vr(11)}", f"v_sub_u32 {vr(12)}, {vr(10)}, {vr(12)}",     # row, c
-                  f"v_cmp_gt_u32 vcc, 16, {vr(12)}", "s_nop 1", f"v_cndmask_b32 {vr(12)}, 0, {vr(12)}, vcc", f"v_lshlrev_b32 {vr(12)}, 4, {vr(12)}",
-                  f"v_mul_lo_u32 {vr(13)}, {vr(11)}, {sr(S_KSS)}", f"v_add_u32 {vr(13)}, {vr(13)}, {vr(12)}",                                          # K offset
-                  # V form
-                  f"v_subrev_u32 {vr(14)}, 1088, {vr(10)}", f"s_mov_b32 {sr(S_TMP2)}, 0xccccccd", f"v_mul_hi_u32 {vr(11)}, {vr(14)}, {sr(S_TMP2)}", f"v_mul_u32_u24 {vr(12)}, 20, {vr(11)}",
-                  f"v_sub_u32 {vr(12)}, {vr(14)}, {vr(12)}", f"v_cmp_gt_u32 vcc, 16, {vr(12)}", "s_nop 1", f"v_cndmask_b32 {vr(12)}, 0, {vr(12)}, vcc",
-                  f"v_lshlrev_b32 {vr(12)}, 4, {vr(12)}", f"v_mul_lo_u32 {vr(14)}, {vr(11)}, {sr(S_VSS)}", f"v_add_u32 {vr(14)}, {vr(14)}, {vr(12)}",  # V offset
-                  f"s_cmp_lt_u32 {sr(S_TMP)}, 17", f"s_cselect_b64 vcc, -1, 0", "s_nop 1", f"v_cndmask_b32 {vr(j)}, {vr(14)}, {vr(13)}, vcc"]:
-            e(i)
-    e("L_ITEM%=:")
-    item_decode(G, loader=True)
-    e("s_cbranch_scc1 L_DONE%=")
-    # K / V descriptors of the item's kv head
-    for (lo, hi, ss, dst) in ((S_K0, S_K1, S_KSS, S_KR), (S_V0, S_V1, S_VSS, S_VR)):
-        for i in [f"s_lshl_b32 {sr(S_TMP)}, {sr(S_GRP)}, 8", f"s_add_u32 {sr(dst)}, {sr(lo)}, {sr(S_TMP)}", f"s_addc_u32 {sr(dst + 1)}, {sr(hi)}, 0",
-                  f"s_and_b32 {sr(dst + 1)}, {sr(dst + 1)}, 0xffff", f"s_sub_u32 {sr(S_TMP)}, {sr(S_S)}, 1", f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(ss)}",
-                  f"s_add_u32 {sr(dst + 2)}, {sr(S_TMP)}, 256", f"s_mov_b32 {sr(dst + 3)}, 0x20000"]:
-            e(i)
-    e("s_barrier")                                     # B_start
-
-    # generic "issue tile number S_TMP2 into ring stage (S_TMP2 % 4)": the piece's LDS destination = stage base + 1024 p (K, V) or scratch
-    def issue():
-        o = [f"s_and_b32 {sr(S_STAGE)}, {sr(S_TMP2)}, 3", f"s_mul_i32 {sr(S_STAGE)}, {sr(S_STAGE)}, {STG}", f"s_add_u32 {sr(S_STAGE)}, {sr(S_STAGE)}, {sr(S_LDS)}",
-             f"s_lshl_b32 {sr(S_SOFF)}, {sr(S_TMP2)}, 6", f"s_mul_i32 {sr(S_DELTA)}, {sr(S_SOFF)}, {sr(S_KSS)}", f"s_mul_i32 {sr(S_SOFF)}, {sr(S_SOFF)}, {sr(S_VSS)}",
-             f"s_sub_u32 {sr(S_U)}, {sr(S_WAVE)}, 4"]
-        for j in range(10):
-            # p = 4 j + i: K piece (p < 17), V piece (17 <= p < 37), padding (p >= 37)
-            lk, lv, lp, ld = G.label("PK"), G.label("PV"), G.label("PP"), G.label("PD")
-            o += [f"s_add_u32 {sr(S_TMP)}, {sr(S_U)}, {4 * j}", f"s_cmp_lt_u32 {sr(S_TMP)}, 17", f"s_cbranch_scc1 {lk}",
-                  f"s_cmp_lt_u32 {sr(S_TMP)}, 37", f"s_cbranch_scc1 {lv}",
-                  # padding piece -> scratch
-                  f"s_sub_u32 {sr(S_TMP)}, {sr(S_TMP)}, 37", f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 10", f"s_add_u32 m0, {sr(S_TMP)}, {sr(S_LDS)}", f"s_add_u32 m0, m0, {SCRATCH}",
-                  "s_nop 0", f"buffer_load_dwordx4 {vr(j)}, {sr(S_KR, 4)}, {sr(S_DELTA)} offen lds", f"s_branch {ld}",
-                  f"{lk}:", f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 10", f"s_add_u32 m0, {sr(S_TMP)}, {sr(S_STAGE)}", "s_nop 0",
-                  f"buffer_load_dwordx4 {vr(j)}, {sr(S_KR, 4)}, {sr(S_DELTA)} offen lds", f"s_branch {ld}",
-                  f"{lv}:", f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 10", f"s_add_u32 m0, {sr(S_TMP)}, {sr(S_STAGE)}", "s_nop 0",
-                  f"buffer_load_dwordx4 {vr(j)}, {sr(S_VR, 4)}, {sr(S_SOFF)} offen lds",
-                  f"{ld}:"]
-        return o
-    # tiles 0, 1 up front
-    for t0 in range(2):
-        lb = G.label("LSKIP")
-        e(f"s_cmp_le_u32 {sr(S_TQ)}, {t0}"); e(f"s_cbranch_scc1 {lb}")
-        e(f"s_mov_b32 {sr(S_TMP2)}, {t0}")
-        for i in issue():
-            e(i)
-        e(f"{lb}:")
-    e(f"s_mov_b32 {sr(S_T)}, 0")
-    e("L_LOOP%=:")
-    # wait for tile t: tile t + 1 (if it exists) stays in flight
-    l2, l3 = G.label("LW2"), G.label("LWD")
-    e(f"s_add_u32 {sr(S_TMP)}, {sr(S_T)}, 1"); e(f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_TQ)}"); e(f"s_cbranch_scc0 {l2}")
-    e("s_waitcnt vmcnt(10)"); e(f"s_branch {l3}")
-    e(f"{l2}:")
-    e("s_waitcnt vmcnt(0)")
-    e(f"{l3}:")
-    e("s_barrier")                                     # B_t: tile t is in; the compute waves are done with tile t - 2 (its stage = that of tile t + 2)
-    lb = G.label("LNO")
-    e(f"s_add_u32 {sr(S_TMP2)}, {sr(S_T)}, 2"); e(f"s_cmp_lt_u32 {sr(S_TMP2)}, {sr(S_TQ)}"); e(f"s_cbranch_scc0 {lb}")
-    for i in issue():
-        e(i)
-    e(f"{lb}:")
-    e(f"s_add_u32 {sr(S_T)}, {sr(S_T)}, 1")
-    e(f"s_cmp_lt_u32 {sr(S_T)}, {sr(S_TQ)}"); e("s_cbranch_scc1 L_LOOP%=")
-    e(f"s_add_u32 {sr(S_ROUND)}, {sr(S_ROUND)}, 1")
-    e("s_branch L_ITEM%=")
+    for i in range(1, 4):
+        e(f"s_cmp_eq_u32 {sr(S_WAVE)}, {4 + i}"); e(f"s_cbranch_scc1 LOADER{i}%=")
+    for i in range(4):
+        loader_body(G, i)
     e("L_DONE%=:")
     e("s_waitcnt vmcnt(0)")
     e("END%=:")
     return G.lines
+
+S_NISS, S_NWAIT, S_IV = S_HEAD, S_Q0ROW, S_VALID
+S_NBASE = S_VALID                                         # compute-only name: global index of the item's first tile          # loader-only names: tiles issued, barriers passed, issue cursor valid
+
+
+def loader_body(G, i):
+    e = G.e
+    e(f"LOADER{i}%=:")
+    pieces = []                                           # (kind, piece index) per slot
+    for j in range(10):
+        p = 4 * j + i
+        pieces.append(("K", p) if p < 17 else ("V", p) if p < 37 else ("P", p - 37))
+    # per-lane source offsets: padded chunk n = 64 p + lane; K: row n / 17, c n % 17 (c = 16 is padding: fetch c = 0); V: n' = n - 1088, row n' / 20, c n' % 20
+    for j, (kind, p) in enumerate(pieces):
+        pp = p if kind != "V" else p - 17
+        div, magic, ss = (17, 0xf0f0f10, S_KSS) if kind != "V" else (20, 0xccccccd, S_VSS)
+        for ins in [f"v_add_u32 {vr(10)}, {64 * pp}, {vr(LANE)}" if 64 * pp <= 64 else f"v_add_u32 {vr(10)}, {64 * pp}, {vr(LANE)}",
+                    f"s_mov_b32 {sr(S_TMP2)}, 0x{magic:x}", f"v_mul_hi_u32 {vr(11)}, {vr(10)}, {sr(S_TMP2)}", f"v_mul_u32_u24 {vr(12)}, {div}, {vr(11)}",
+                    f"v_sub_u32 {vr(12)}, {vr(10)}, {vr(12)}", f"v_cmp_gt_u32 vcc, 16, {vr(12)}", "s_nop 1", f"v_cndmask_b32 {vr(12)}, 0, {vr(12)}, vcc",
+                    f"v_lshlrev_b32 {vr(12)}, 4, {vr(12)}", f"v_mul_lo_u32 {vr(13)}, {vr(11)}, {sr(ss)}", f"v_add_u32 {vr(j)}, {vr(13)}, {vr(12)}"]:
+            e(ins)
+
+    def cursor_item():
+        """decode the item of round S_ROUND into the issue cursor: S_IV (0: none left), S_TQ, descriptors, S_T = 0"""
+        item_decode(G, loader=True)
+        e(f"s_cselect_b32 {sr(S_IV)}, 0, 1")
+        for (lo, hi, ss, dst) in ((S_K0, S_K1, S_KSS, S_KR), (S_V0, S_V1, S_VSS, S_VR)):
+            for ins in [f"s_lshl_b32 {sr(S_TMP)}, {sr(S_GRP)}, 8", f"s_add_u32 {sr(dst)}, {sr(lo)}, {sr(S_TMP)}", f"s_addc_u32 {sr(dst + 1)}, {sr(hi)}, 0",
+                        f"s_and_b32 {sr(dst + 1)}, {sr(dst + 1)}, 0xffff", f"s_sub_u32 {sr(S_TMP)}, {sr(S_S)}, 1", f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(ss)}",
+                        f"s_add_u32 {sr(dst + 2)}, {sr(S_TMP)}, 256", f"s_mov_b32 {sr(dst + 3)}, 0x20000"]:
+                e(ins)
+        e(f"s_mov_b32 {sr(S_T)}, 0")
+
+    def issue_next():
+        skip, same = G.label("LSK"), G.label("LSAME")
+        e(f"s_cmp_eq_u32 {sr(S_IV)}, 0"); e(f"s_cbranch_scc1 {skip}")
+        for ins in [f"s_and_b32 {sr(S_STAGE)}, {sr(S_NISS)}, 3", f"s_mul_i32 {sr(S_STAGE)}, {sr(S_STAGE)}, {STG}", f"s_add_u32 {sr(S_STAGE)}, {sr(S_STAGE)}, {sr(S_LDS)}",
+                    f"s_lshl_b32 {sr(S_SOFF)}, {sr(S_T)}, 6", f"s_mul_i32 {sr(S_DELTA)}, {sr(S_SOFF)}, {sr(S_KSS)}", f"s_mul_i32 {sr(S_SOFF)}, {sr(S_SOFF)}, {sr(S_VSS)}"]:
+            e(ins)
+        for j, (kind, p) in enumerate(pieces):
+            if kind == "P":
+                e(f"s_add_u32 m0, {sr(S_LDS)}, {SCRATCH + 1024 * p}")
+            else:
+                e(f"s_add_u32 m0, {sr(S_STAGE)}, {1024 * p}")
+            if "dma" not in DROP:
+                e("s_nop 0")
+                e(f"buffer_load_dwordx4 {vr(j)}, {sr(S_VR if kind == 'V' else S_KR, 4)}, {sr(S_SOFF if kind == 'V' else S_DELTA)} offen lds")
+        e(f"s_add_u32 {sr(S_NISS)}, {sr(S_NISS)}, 1"); e(f"s_add_u32 {sr(S_T)}, {sr(S_T)}, 1")
+        e(f"s_cmp_lt_u32 {sr(S_T)}, {sr(S_TQ)}"); e(f"s_cbranch_scc1 {same}")
+        e(f"s_add_u32 {sr(S_ROUND)}, {sr(S_ROUND)}, 1")
+        cursor_item()
+        e(f"{same}:")
+        e(f"{skip}:")
+
+    e(f"s_mov_b32 {sr(S_NISS)}, 0"); e(f"s_mov_b32 {sr(S_NWAIT)}, 0")
+    cursor_item()
+    issue_next()
+    issue_next()
+    loop, l2, l3 = G.label("LLOOP"), G.label("LW2"), G.label("LWD")
+    e(f"{loop}:")
+    e(f"s_cmp_eq_u32 {sr(S_NWAIT)}, {sr(S_NISS)}"); e("s_cbranch_scc1 L_DONE%=")
+    e(f"s_add_u32 {sr(S_TMP)}, {sr(S_NWAIT)}, 1"); e(f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_NISS)}"); e(f"s_cbranch_scc0 {l2}")
+    e("s_waitcnt vmcnt(10)"); e(f"s_branch {l3}")
+    e(f"{l2}:")
+    e("s_waitcnt vmcnt(0)")
+    e(f"{l3}:")
+    e("s_barrier")                                     # tile n is in; the compute waves are done with tile n - 2, whose stage tile n + 2 takes
+    e(f"s_add_u32 {sr(S_NWAIT)}, {sr(S_NWAIT)}, 1")
+    issue_next()
+    e(f"s_branch {loop}")
 
 
 def item_decode(G, loader):
@@ -511,7 +554,7 @@ def main():
     lines = build(simple)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "ufvideo_amd", "csrc", "attn_c128_asm.inc")
-    clob = [f"v{i}" for i in range(128)] + [f"a{i}" for i in range(120)] + [f"s{i}" for i in range(38, 100)] + ["vcc", "scc", "memory"]
+    clob = [f"v{i}" for i in range(128)] + [f"a{i}" for i in range(128 if STAMPS else 120)] + [f"s{i}" for i in range(38, 100)] + ["vcc", "scc", "memory"]
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_c128.py%s -- do not edit.  %d instructions.\n" % (" --simple" if simple else "", len(lines)))
         f.write("#define UFV_ATTN_C128_ASM \\\n")
@@ -520,6 +563,8 @@ def main():
         f.write('    ""\n')
         f.write("#define UFV_ATTN_C128_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + "\n")
         f.write("#define UFV_ATTN_C128_LDS %d\n" % LDS_BYTES)
+        if STAMPS:
+            f.write("#define UFV_ATTN_C128_STAMPS 1\n")
     print(out, len(lines), "lines")
 
 

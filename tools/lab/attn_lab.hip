@@ -102,6 +102,24 @@ int main(int argc, char** argv) {
         for (int p_ = 0; p_ < 3; ++p_) { printf("\n pass %d:", p_); for (int j = 0; j < 9; ++j) { printf("  t%d", j); for (int u = 0; u < 3; ++u) printf(" %4.0f", d[2 + p_ * 27 + j * 3 + u + 1 > NS - 1 ? NS - 1 : 2 + p_ * 27 + j * 3 + u + 1] / nw); } }
         printf("\n epilogue %.0f ; total %.0f cycles\n", d[NS - 1] / nw, tot);
     }
+#ifdef UFV_ATTN_C128_STAMPS
+    if (kernel == 15) {       // per-segment cycle sums of the compute waves (built with gen_attn_c128.py --stamps)
+        unsigned* sb; hipMalloc(&sb, 256 * 4 * 32); hipMemset(sb, 0, 256 * 4 * 32);
+        AttnArgs a;
+        a.q = (const bf16*)qkv; a.k = (const bf16*)(qkv + H * hd); a.v = (const bf16*)(qkv + (H + Hkv) * hd); a.o = (bf16*)o;
+        a.q_bs = a.k_bs = a.v_bs = (int64_t)S * W; a.q_ss = a.k_ss = a.v_ss = W; a.o_bs = (int64_t)S * D; a.o_ss = D;
+        a.B = B; a.Hq = H; a.Hkv = Hkv; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = 1.0f / sqrtf((float)hd); a.q_pos0 = 0; a.lse = (float*)sb;
+        for (int i = 0; i < 20; ++i) launch_c128(a, nullptr);
+        hipDeviceSynchronize();
+        std::vector<unsigned> hsb(256 * 4 * 8);
+        hipMemcpy(hsb.data(), sb, hsb.size() * 4, hipMemcpyDeviceToHost);
+        const char* nm[8] = {"iter tail (rescale, loop)", "barrier wait", "phase A (QK + finish)", "phase B (PV + start)", "item prologue (Q, tile 0)", "last tile", "epilogue + idle barriers", "-"};
+        double sum[8] = {0}; int nw = 0; double tot = 0, mx = 0;
+        for (int w = 0; w < 1024; ++w) { double t = 0; for (int k = 0; k < 8; ++k) { sum[k] += hsb[w * 8 + k]; t += hsb[w * 8 + k]; } if (t > 0) { ++nw; tot += t; mx = std::max(mx, t); } }
+        printf("c128 stamps: %d compute waves, mean total %.0f cycles, max %.0f\n", nw, tot / nw, mx);
+        for (int k = 0; k < 7; ++k) printf("   %-28s %8.0f cycles / wave  (%.1f %%)\n", nm[k], sum[k] / nw, 100.0 * sum[k] / tot);
+    }
+#endif
     // timeline
     hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &st, sizeof(st));
     run(); hipDeviceSynchronize();
