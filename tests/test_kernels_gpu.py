@@ -230,6 +230,36 @@ def test_vit72_third_generation_bit_identical_and_rescale_paths():
     assert torch.equal(o3, ops.attention(q3, q3, q3, 1, 3, 3, 576, 576, hd, *(((576 * 3 * hd, 3 * hd),) * 3), kernel=11))
 
 
+def test_causal_hd128_prefill_kernel_bit_identical_to_the_plain_kernel():
+    """the prefill kernel of csrc/attn_c128.inc (4 compute + 4 loader waves, generated instruction stream; kernel id 15 = what AUTO takes from S = 128 on):
+    the arithmetic of the plain hd-128 kernel (id 13) operation for operation, so the outputs must be BIT-IDENTICAL -- for sequence lengths with every tail
+    (one tile, 32-row slices that end inside a tile, a last slice with 1 valid row), group sizes 2..7, 2..8 kv heads, more items than CUs and fewer, a fused
+    qkv layout (strided rows), and with spikes that drive the deferred-rescale path in middle, last (masked) and first tiles."""
+    hd = 128
+    for (Hq, Hkv, S, seed) in ((4, 2, 64, 70), (4, 2, 65, 71), (8, 2, 200, 72), (6, 2, 129, 73), (28, 4, 777, 74), (32, 8, 1000, 75), (14, 2, 1217, 76), (12, 4, 2399, 77), (10, 2, 96, 78)):
+        W = (Hq + 2 * Hkv) * hd
+        qkv = g(S, W, seed=seed)
+        q, k = qkv[:, :Hq * hd].view(S, Hq, hd), qkv[:, Hq * hd:(Hq + Hkv) * hd].view(S, Hkv, hd)
+        for row, key, amp in ((S - 1, S - 1, 3.0), (S - 1, S // 2, 5.0), (S // 2, S // 2 - 3, 4.0), (min(70, S - 1), 2, 6.0), (min(33, S - 1), min(31, S - 1), 5.0)):
+            k[key, (row % Hkv)] = q[row, (row % Hkv) * (Hq // Hkv)] * amp / 4
+        qkv = bf(qkv)
+        qd, kd, vd = qkv[:, :Hq * hd], qkv[:, Hq * hd:], qkv[:, (Hq + Hkv) * hd:]
+        st = ((0, W),) * 3
+        new = ops.attention(qd, kd, vd, 1, Hq, Hkv, S, S, hd, *st, causal=True, kernel=15)
+        old = ops.attention(qd, kd, vd, 1, Hq, Hkv, S, S, hd, *st, causal=True, kernel=13)
+        assert torch.equal(new, old), (Hq, Hkv, S, int((new != old).sum()))
+        if S >= 128:
+            assert torch.equal(ops.attention(qd, kd, vd, 1, Hq, Hkv, S, S, hd, *st, causal=True), old)           # AUTO takes it
+        ref = attn_ref(qkv[:, :Hq * hd].view(1, S, Hq, hd), qkv[:, Hq * hd:(Hq + Hkv) * hd].view(1, S, Hkv, hd), qkv[:, (Hq + Hkv) * hd:].view(1, S, Hkv, hd), True)
+        assert torch.isfinite(new.float()).all() and rel(new, ref) <= 2 * ATTN_TOL
+    # outside its envelope: refused by id 15, served by the other kernels under AUTO (MHA, one kv head, batch > 1, a query offset)
+    x = bf(g(2, 130, 4, hd, seed=79))
+    with pytest.raises(_lib.UfvError):
+        ops.attention(x, x, x, 2, 4, 4, 130, 130, hd, *(((130 * 4 * hd, 4 * hd),) * 3), causal=True, kernel=15)
+    o = ops.attention(x, x, x, 2, 4, 4, 130, 130, hd, *(((130 * 4 * hd, 4 * hd),) * 3), causal=True)
+    assert rel(o, attn_ref(x, x, x, True)) <= ATTN_TOL
+
+
 def test_attention_spike_forces_rescale():
     # one key dominates late in the sequence -> running max jumps (online-softmax rescale path)
     B, H, S, hd = 1, 2, 256, 72

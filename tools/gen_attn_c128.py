@@ -34,7 +34,7 @@ NOVPRE = "novpre" in OPT
 PRE_A = int(os.environ.get("UFV_C128_PRE", "28"))
 DROP = os.environ.get("UFV_C128_DROP", "").split(",")
 STAMPS = "--stamps" in sys.argv       # lab build: s_memtime deltas of the compute waves summed per segment kind -> [block][wave][8] dwords at %[stp]
-S_NOW, S_PREV, S_DLT = 84, 86, 87      # the K descriptor's SGPRs (loader-only); sums in a120..a127      # lab only: timing experiments with parts of the work removed (results are wrong)
+S_NOW, S_PREV, S_DLT = 88, 90, 91      # the V descriptor's SGPRs (loader-only); sums in a120..a127      # lab only: timing experiments with parts of the work removed (results are wrong)
 
 
 def vr(n, c=1): return f"v{n}" if c == 1 else f"v[{n}:{n + c - 1}]"
@@ -65,6 +65,7 @@ MAXFLY = 15                                                         # LDS instru
  S_TMP3, S_SOFF) = range(40, 82)
 S_KR, S_VR, S_QR, S_OR = 84, 88, 92, 96
 S_CNT = 38
+S_REM, S_OSOFF, S_PAR, S_QV = 84, 85, 86, 87       # compute-only (the K descriptor's registers of the loader waves)
 S_STG = 39                                      # holds STG        # buffer descriptors (4 SGPRs each)
 S_ANY = 82                                      # s[82:83]: rescale decision mask
 
@@ -174,9 +175,14 @@ def finish_parts(slot):
     a += [f"v_cvt_pk_bf16_f32 {vr(P(j))}, {vr(S(slot, 2 * j))}, {vr(S(slot, 2 * j + 1))}" for j in range(8)]
     b1 = [f"v_exp_f32 {s(16 + r)}, {s(16 + r)}" for r in range(8)] + [f"v_cvt_pk_bf16_f32 {vr(P(8 + j))}, {vr(S(slot, 16 + 2 * j))}, {vr(S(slot, 17 + 2 * j))}" for j in range(4)]
     b2 = [f"v_exp_f32 {s(24 + r)}, {s(24 + r)}" for r in range(8)] + [f"v_cvt_pk_bf16_f32 {vr(P(12 + j))}, {vr(S(slot, 24 + 2 * j))}, {vr(S(slot, 25 + 2 * j))}" for j in range(4)]
-    b3 = [f"v_add_f32 {vr(PSUM)}, {s(0)}, {s(16)}"]                      # psum = 0 + (s0[0] + s1[0]): the sum itself (x + 0 = x for x >= 0)
+    # psum = ((s0[0] + s1[0]) + (s0[1] + s1[1])) + ... : the pair sums run one ahead of the chain, in two temporaries, so that no instruction reads
+    # the result of the one right before it
+    tmp = [TA, TD]
+    b3 = [f"v_add_f32 {vr(PSUM)}, {s(0)}, {s(16)}", f"v_add_f32 {vr(tmp[1])}, {s(1)}, {s(17)}"]
     for r in range(1, 16):
-        b3 += [f"v_add_f32 {vr(TA)}, {s(r)}, {s(16 + r)}", f"v_add_f32 {vr(PSUM)}, {vr(PSUM)}, {vr(TA)}"]
+        if r + 1 < 16:
+            b3.append(f"v_add_f32 {vr(tmp[(r + 1) % 2])}, {s(r + 1)}, {s(17 + r)}")
+        b3.append(f"v_add_f32 {vr(PSUM)}, {vr(PSUM)}, {vr(tmp[r % 2])}")
     b3.append(f"v_add_f32 {vr(LRUN)}, {vr(LRUN)}, {vr(PSUM)}")
     return a, b1, b2, b3
 
@@ -249,7 +255,7 @@ def build(simple=False):
               f"v_and_b32 {vr(TC)}, 3, {vr(LANE)}", f"v_lshl_add_u32 {vr(TB)}, {vr(TC)}, 3, {vr(TB)}", f"v_add3_u32 {vr(TF)}, {vr(TA)}, {vr(TB)}, {sr(S_LDS)}",
               f"v_add_u32 {vr(TF)}, {KT}, {vr(TF)}",                                                                                                  # TF = V address in stage 0
               f"v_mul_lo_u32 {vr(TA)}, {vr(L31)}, {sr(S_QSS)}", f"v_lshl_add_u32 {vr(QOFF)}, {vr(HH)}, 4, {vr(TA)}",
-              f"v_mul_lo_u32 {vr(TA)}, {vr(L31)}, {sr(S_OSS)}", f"v_lshl_add_u32 {vr(OOFF)}, {vr(HH)}, 3, {vr(TA)}",
+              f"v_mul_lo_u32 {vr(TA)}, {vr(L31)}, {sr(S_OSS)}", f"v_lshl_add_u32 {vr(OOFF)}, {vr(HH)}, 4, {vr(TA)}",
               f"v_lshlrev_b32 {vr(KJ)}, 2, {vr(HH)}", f"v_mov_b32 {vr(TE)}, 0xff800000",
               f"v_accvgpr_write_b32 {ar(A_K0)}, {vr(TG)}", f"v_accvgpr_write_b32 {ar(A_V0)}, {vr(TF)}", f"v_accvgpr_write_b32 {ar(A_L31)}, {vr(L31)}",
               f"v_accvgpr_write_b32 {ar(A_QOFF)}, {vr(QOFF)}", f"v_accvgpr_write_b32 {ar(A_OOFF)}, {vr(OOFF)}"]:
@@ -259,42 +265,52 @@ def build(simple=False):
         for k in range(8):
             e(f"v_accvgpr_write_b32 {ar(120 + k)}, 0")
         e(f"s_memtime {sr(S_NOW, 2)}"); e("s_waitcnt lgkmcnt(0)"); e(f"s_mov_b32 {sr(S_PREV)}, {sr(S_NOW)}")
-    e("C_ITEM%=:")
-    item_decode(G, loader=False)
-    e("s_cbranch_scc1 C_DONE%=")                      # no item left
-    # unit of this wave: u = 4 q + wave; slice = NS - 1 - u / R; head = g R + u % R; T_w = tiles of the slice
-    for i in [f"s_lshl_b32 {sr(S_U)}, {sr(S_QD)}, 2", f"s_add_u32 {sr(S_U)}, {sr(S_U)}, {sr(S_WAVE)}",
-              f"s_mul_hi_u32 {sr(S_TMP)}, {sr(S_U)}, {sr(S_MR)}",                    # u / R
-              f"s_mul_i32 {sr(S_TMP2)}, {sr(S_TMP)}, {sr(S_R)}", f"s_sub_u32 {sr(S_TMP2)}, {sr(S_U)}, {sr(S_TMP2)}",       # u % R
-              f"s_mul_i32 {sr(S_HEAD)}, {sr(S_GRP)}, {sr(S_R)}", f"s_add_u32 {sr(S_HEAD)}, {sr(S_HEAD)}, {sr(S_TMP2)}",
-              f"s_sub_u32 {sr(S_SLICE)}, {sr(S_NS)}, 1", f"s_sub_i32 {sr(S_SLICE)}, {sr(S_SLICE)}, {sr(S_TMP)}",            # may go negative: no unit
-              f"s_lshl_b32 {sr(S_Q0ROW)}, {sr(S_SLICE)}, 5",
-              f"s_add_u32 {sr(S_TW)}, {sr(S_Q0ROW)}, 31", f"s_lshr_b32 {sr(S_TW)}, {sr(S_TW)}, 6", f"s_add_u32 {sr(S_TW)}, {sr(S_TW)}, 1",
-              f"s_cmp_lt_i32 {sr(S_SLICE)}, 0", f"s_cselect_b32 {sr(S_TW)}, 0, {sr(S_TW)}",                               # T_w = 0: this wave only joins the barriers
-              ]:
-        e(i)
-    e(f"s_cmp_eq_u32 {sr(S_TW)}, 0")
-    e("s_cbranch_scc1 C_IDLE%=")
-    # descriptors of this unit: Q / O rows of (head), base + head * 256 bytes; range = whole tensor rows (S - 1) * stride + 256
-    for (lo, hi, ss, dst) in ((S_Q0, S_Q1, S_QSS, S_QR), (S_O0, S_O1, S_OSS, S_OR)):
+    def unit_decode():
+        """unit of this wave in the decoded item: u = 4 q + wave; slice = NS - 1 - u / R; head = g R + u % R; T_w = tiles of the slice (0: no unit)"""
+        for i in [f"s_lshl_b32 {sr(S_U)}, {sr(S_QD)}, 2", f"s_add_u32 {sr(S_U)}, {sr(S_U)}, {sr(S_WAVE)}",
+                  f"s_mul_hi_u32 {sr(S_TMP)}, {sr(S_U)}, {sr(S_MR)}",                    # u / R
+                  f"s_mul_i32 {sr(S_TMP2)}, {sr(S_TMP)}, {sr(S_R)}", f"s_sub_u32 {sr(S_TMP2)}, {sr(S_U)}, {sr(S_TMP2)}",       # u % R
+                  f"s_mul_i32 {sr(S_HEAD)}, {sr(S_GRP)}, {sr(S_R)}", f"s_add_u32 {sr(S_HEAD)}, {sr(S_HEAD)}, {sr(S_TMP2)}",
+                  f"s_sub_u32 {sr(S_SLICE)}, {sr(S_NS)}, 1", f"s_sub_i32 {sr(S_SLICE)}, {sr(S_SLICE)}, {sr(S_TMP)}",            # may go negative: no unit
+                  f"s_lshl_b32 {sr(S_Q0ROW)}, {sr(S_SLICE)}, 5",
+                  f"s_add_u32 {sr(S_TW)}, {sr(S_Q0ROW)}, 31", f"s_lshr_b32 {sr(S_TW)}, {sr(S_TW)}, 6", f"s_add_u32 {sr(S_TW)}, {sr(S_TW)}, 1",
+                  f"s_cmp_lt_i32 {sr(S_SLICE)}, 0", f"s_cselect_b32 {sr(S_TW)}, 0, {sr(S_TW)}"]:
+            e(i)
+
+    def desc(lo, hi, ss, dst):
+        """rows of head S_HEAD: base + head * 256 bytes; range = whole tensor rows (S - 1) * stride + 256"""
         for i in [f"s_lshl_b32 {sr(S_TMP)}, {sr(S_HEAD)}, 8", f"s_add_u32 {sr(dst)}, {sr(lo)}, {sr(S_TMP)}", f"s_addc_u32 {sr(dst + 1)}, {sr(hi)}, 0",
                   f"s_and_b32 {sr(dst + 1)}, {sr(dst + 1)}, 0xffff", f"s_sub_u32 {sr(S_TMP)}, {sr(S_S)}, 1", f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(ss)}",
                   f"s_add_u32 {sr(dst + 2)}, {sr(S_TMP)}, 256", f"s_mov_b32 {sr(dst + 3)}, 0x20000"]:
             e(i)
-    # Q^T fragments: lane (q = l31, h) <- 16 bytes of row q0 + l31 at column 16 ks + 8 h (rows past the end read as zeros: range-checked)
-    e(f"s_mul_i32 {sr(S_SOFF)}, {sr(S_Q0ROW)}, {sr(S_QSS)}")
-    e(f"v_accvgpr_read_b32 {vr(QOFF)}, {ar(A_QOFF)}"); e(f"v_accvgpr_read_b32 {vr(L31)}, {ar(A_L31)}"); e("s_nop 1")
-    for ks in range(8):
-        e(f"buffer_load_dwordx4 {vr(Q(ks), 4)}, {vr(QOFF)}, {sr(S_QR, 4)}, {sr(S_SOFF)} offen offset:{ks * 32}")
+
+    def q_load():
+        """Q^T fragments of the decoded unit: lane (q = l31, h) <- 16 bytes of row q0 + l31 at column 16 ks + 8 h (rows past the end read as zeros: range-checked)"""
+        desc(S_Q0, S_Q1, S_QSS, S_QR)
+        e(f"s_mul_i32 {sr(S_SOFF)}, {sr(S_Q0ROW)}, {sr(S_QSS)}")
+        e(f"v_accvgpr_read_b32 {vr(TD)}, {ar(A_QOFF)}"); e("s_nop 1")
+        for ks in range(8):
+            e(f"buffer_load_dwordx4 {vr(Q(ks), 4)}, {vr(TD)}, {sr(S_QR, 4)}, {sr(S_SOFF)} offen offset:{ks * 32}")
+
     for r in range(64):
-        e(f"v_accvgpr_write_b32 {ar(r)}, 0")
+        e(f"v_accvgpr_write_b32 {ar(r)}, 0")                # (later items: zeroed again by the epilogue as it reads them)
+    e("C_ITEM%=:")
+    item_decode(G, loader=False)
+    e("s_cbranch_scc1 C_DONE%=")                      # no item left
+    unit_decode()
+    e(f"s_cmp_eq_u32 {sr(S_TW)}, 0")
+    e("s_cbranch_scc1 C_IDLE%=")
+    q_load()
+    e("C_ITEM_GO%=:")                                  # the item is decoded and the unit's Q rows are on their way (asked for during the previous unit's last tile)
+    desc(S_O0, S_O1, S_OSS, S_OR)
     for i in [f"v_mov_b32 {vr(MRUN)}, 0xff800000", f"v_mov_b32 {vr(LRUN)}, 0", f"v_accvgpr_read_b32 {vr(KADDR)}, {ar(A_K0)}", f"v_accvgpr_read_b32 {vr(VADDR)}, {ar(A_V0)}",
+              f"v_accvgpr_read_b32 {vr(TC)}, {ar(A_L31)}",
               # the ring runs on across items: the item's first tile is global tile S_NBASE -> stage S_NBASE % 4
               f"s_and_b32 {sr(S_STAGE)}, {sr(S_NBASE)}, 3", f"s_mul_i32 {sr(S_TMP)}, {sr(S_STAGE)}, {STG}", f"s_mov_b32 {sr(S_T)}, 0",
               f"v_add_u32 {vr(KADDR)}, {sr(S_TMP)}, {vr(KADDR)}", f"v_add_u32 {vr(VADDR)}, {sr(S_TMP)}, {vr(VADDR)}",
               # QI = (q0 + l31) - key0 of the diagonal tile = rows relative to the last tile's first key
               f"s_sub_u32 {sr(S_TMP)}, {sr(S_TW)}, 1", f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 6", f"s_sub_u32 {sr(S_TMP)}, {sr(S_Q0ROW)}, {sr(S_TMP)}",
-              f"v_add_u32 {vr(QI)}, {sr(S_TMP)}, {vr(L31)}",
+              f"v_add_u32 {vr(QI)}, {sr(S_TMP)}, {vr(TC)}",
               "s_waitcnt vmcnt(0)"]:
         e(i)
     # ---- tile 0: B_0, K reads + QK^T, (mask if T_w == 1), first max: m_run = tmax
@@ -355,11 +371,6 @@ def build(simple=False):
 
     def last_iter(slot):
         """the wave's last tile (scores in S[slot], masked, max / decision done): finish + PV, no next tile"""
-        lb = G.label("NOB")
-        e(f"s_mov_b32 {sr(S_CNT)}, {sr(S_TW)}")
-        e(f"s_cmp_lt_u32 {sr(S_TW)}, {sr(S_TQ)}"); e(f"s_cbranch_scc0 {lb}")
-        e("s_barrier"); e(f"s_add_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1")      # B_{T_w} (a longer unit of the quad goes on): frees tile T_w - 2's stage only
-        e(f"{lb}:")
         fin = finish_softmax(slot)
         for i in fin:
             e(i)
@@ -380,10 +391,35 @@ def build(simple=False):
     e("s_branch C_LOOP_E%=")
     for par, slot in (("E", 0), ("O", 1)):
         e(f"C_TAIL_{par}%=:")
-        lab_last = f"C_LAST_{par}%="
-        e(f"s_add_u32 {sr(S_TMP)}, {sr(S_T)}, 1"); e(f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_TW)}"); e(f"s_cbranch_scc0 {lab_last}")
+        lab_last = G.label("TOLAST")
+        e(f"s_mov_b32 {sr(S_PAR)}, {slot}")
+        e(f"s_add_u32 {sr(S_TMP)}, {sr(S_T)}, 1"); e(f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_TW)}"); e(f"s_cbranch_scc0 C_PRELAST%=")
         full_iter(slot, True)                       # t + 2 == T_w: the next tile is the diagonal one
-        e(f"s_branch C_LAST_{'O' if par == 'E' else 'E'}%=")
+        e(f"s_mov_b32 {sr(S_PAR)}, {1 - slot}")
+        e("s_branch C_PRELAST%=")
+    # ---- before the last tile: the barrier a longer unit of the quad still needs, the book-keeping of this item, and the NEXT item's decode + Q rows
+    # (the Q registers are free from here on: the last QK^T has been issued)
+    e("C_PRELAST%=:")
+    nob = G.label("NOB")
+    e(f"s_mov_b32 {sr(S_CNT)}, {sr(S_TW)}")
+    e(f"s_cmp_lt_u32 {sr(S_TW)}, {sr(S_TQ)}"); e(f"s_cbranch_scc0 {nob}")
+    e("s_barrier"); e(f"s_add_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1")      # B_{T_w}: frees tile T_w - 2's stage only
+    e(f"{nob}:")
+    e(f"s_sub_u32 {sr(S_REM)}, {sr(S_TQ)}, {sr(S_CNT)}")             # barriers this wave still owes the item after its last tile
+    e(f"s_add_u32 {sr(S_NBASE)}, {sr(S_NBASE)}, {sr(S_TQ)}")
+    e(f"s_mul_i32 {sr(S_OSOFF)}, {sr(S_Q0ROW)}, {sr(S_OSS)}")
+    e(f"s_add_u32 {sr(S_ROUND)}, {sr(S_ROUND)}, 1")
+    item_decode(G, loader=False)
+    nonext, pdone = G.label("NONEXT"), G.label("PDONE")
+    e(f"s_mov_b32 {sr(S_QV)}, 0")
+    e(f"s_cbranch_scc1 {pdone}")
+    unit_decode()
+    e(f"s_mov_b32 {sr(S_QV)}, 2")
+    e(f"s_cmp_eq_u32 {sr(S_TW)}, 0"); e(f"s_cbranch_scc1 {pdone}")
+    e(f"s_mov_b32 {sr(S_QV)}, 1")
+    q_load()
+    e(f"{pdone}:")
+    e(f"s_cmp_eq_u32 {sr(S_PAR)}, 0"); e("s_cbranch_scc0 C_LAST_O%=")
     for par, slot in (("E", 0), ("O", 1)):
         e(f"C_LAST_{par}%=:")
         last_iter(slot)
@@ -402,31 +438,46 @@ def build(simple=False):
               f"v_fma_f32 {vr(d[0])}, -{vr(d[0])}, {vr(d[3])}, {vr(d[2])}", "s_nop 1",
               f"v_div_fmas_f32 {vr(d[0])}, {vr(d[0])}, {vr(d[1])}, {vr(d[3])}", f"v_div_fixup_f32 {vr(INV)}, {vr(d[0])}, {vr(LRUN)}, 1.0",
               f"v_cmp_lt_f32 vcc, 0, {vr(LRUN)}", "s_nop 1", f"v_cndmask_b32 {vr(INV)}, 0, {vr(INV)}, vcc",
-              f"s_mul_i32 {sr(S_SOFF)}, {sr(S_Q0ROW)}, {sr(S_OSS)}", f"v_accvgpr_read_b32 {vr(S(0, 6))}, {ar(A_OOFF)}"]:
+              f"v_accvgpr_read_b32 {vr(S(0, 6))}, {ar(A_OOFF)}"]:
         e(i)
+    # 16-byte stores: the two key halves of a query (lanes l and l + 32) hold interleaved groups of 4 head-dim values; one permlane32 swap per register pair
+    # gives the low lane d = 8 j' .. 8 j' + 7 of the even group and the high lane those of the odd group (two banks of temporaries, alternating)
     for dt in range(4):
-        for g4 in range(4):
-            x = [S(0, i) for i in range(4)]
-            for i in range(4):
-                e(f"v_accvgpr_read_b32 {vr(x[i])}, {ar(O(dt, 4 * g4 + i))}")
-            e("s_nop 0")
-            for i in range(4):
+        for j in range(2):
+            bank = 8 + 16 * ((2 * dt + j) % 2)
+            x = [S(0, bank + i) for i in range(8)]
+            y = [S(0, bank + 8 + i) for i in range(4)]          # A (even group) -> y[0:2], B (odd group) -> y[2:4]
+            for i in range(8):
+                e(f"v_accvgpr_read_b32 {vr(x[i])}, {ar(O(dt, 8 * j + i))}")
+            for i in range(8):
+                e(f"v_accvgpr_write_b32 {ar(O(dt, 8 * j + i))}, 0")           # the next unit's sums start from 0
+            for i in range(8):
                 e(f"v_mul_f32 {vr(x[i])}, {vr(x[i])}, {vr(INV)}")
-            e(f"v_cvt_pk_bf16_f32 {vr(S(0, 4))}, {vr(x[0])}, {vr(x[1])}")
-            e(f"v_cvt_pk_bf16_f32 {vr(S(0, 5))}, {vr(x[2])}, {vr(x[3])}")
-            e("s_nop 0")
-            e(f"buffer_store_dwordx2 {vr(S(0, 4), 2)}, {vr(S(0, 6))}, {sr(S_OR, 4)}, {sr(S_SOFF)} offen offset:{dt * 64 + g4 * 16}")
+            for i in range(4):
+                e(f"v_cvt_pk_bf16_f32 {vr(y[i])}, {vr(x[2 * i])}, {vr(x[2 * i + 1])}")
             e("s_nop 1")
-    # ---- the barriers of the tiles this wave does not have (T_w .. T_q - 1), then the next item
-    e("s_branch C_IDLE_LOOP%=")
+            e(f"v_permlane32_swap_b32 {vr(y[0])}, {vr(y[2])}")
+            e(f"v_permlane32_swap_b32 {vr(y[1])}, {vr(y[3])}")
+            # after the swaps: low lanes y[0:2] = own even group, y[2:4] = partner's even group -> registers must be ordered (y0, y1, y2, y3) = (A_lo, A_lo', A_hi, A_hi')
+            e("s_nop 0")
+            e(f"buffer_store_dwordx4 {vr(y[0], 4)}, {vr(S(0, 6))}, {sr(S_OR, 4)}, {sr(S_OSOFF)} offen offset:{dt * 64 + j * 32}")
+    # ---- the barriers of the tiles this wave does not have, then the next item (decoded before the last tile)
+    rl, rd = G.label("REM"), G.label("REMD")
+    e(f"{rl}:")
+    e(f"s_cmp_eq_u32 {sr(S_REM)}, 0"); e(f"s_cbranch_scc1 {rd}")
+    e("s_barrier"); e(f"s_sub_u32 {sr(S_REM)}, {sr(S_REM)}, 1"); e(f"s_branch {rl}")
+    e(f"{rd}:")
+    emit(G, stamp(6))
+    e(f"s_cmp_eq_u32 {sr(S_QV)}, 1"); e("s_cbranch_scc1 C_ITEM_GO%=")
+    e(f"s_cmp_eq_u32 {sr(S_QV)}, 0"); e("s_cbranch_scc1 C_DONE%=")
+    # a wave without a unit in the (decoded) item: its T_q barriers, then a fresh decode
     e("C_IDLE%=:")
     e(f"s_mov_b32 {sr(S_CNT)}, 0")
-    e("C_IDLE_LOOP%=:")
-    # barriers executed so far inside the item (after B_start): B_0 .. B_{T_w - 1} (T_w of them; 0 when idle) -> T_q - T_w more
-    e(f"s_cmp_lt_u32 {sr(S_CNT)}, {sr(S_TQ)}"); e("s_cbranch_scc0 C_NEXT%=")
-    e("s_barrier"); e(f"s_add_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"); e("s_branch C_IDLE_LOOP%=")
-    e("C_NEXT%=:")
-    emit(G, stamp(6))
+    il, idn = G.label("IDL"), G.label("IDD")
+    e(f"{il}:")
+    e(f"s_cmp_lt_u32 {sr(S_CNT)}, {sr(S_TQ)}"); e(f"s_cbranch_scc0 {idn}")
+    e("s_barrier"); e(f"s_add_u32 {sr(S_CNT)}, {sr(S_CNT)}, 1"); e(f"s_branch {il}")
+    e(f"{idn}:")
     e(f"s_add_u32 {sr(S_NBASE)}, {sr(S_NBASE)}, {sr(S_TQ)}")
     e(f"s_add_u32 {sr(S_ROUND)}, {sr(S_ROUND)}, 1")
     e("s_branch C_ITEM%=")
@@ -441,8 +492,8 @@ def build(simple=False):
         for k in range(8):
             e(f"v_accvgpr_read_b32 {vr(k)}, {ar(120 + k)}")
         for ins in [f"s_lshl_b32 {sr(S_TMP)}, {sr(S_BID)}, 2", f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_WAVE)}", f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 5",
-                    "s_mov_b32 s84, %[stp0]", "s_mov_b32 s85, %[stp1]", f"s_add_u32 s84, s84, {sr(S_TMP)}", "s_addc_u32 s85, s85, 0",
-                    "v_mov_b32 v8, s84", "v_mov_b32 v9, s85", "s_mov_b64 exec, 1", "s_nop 1",
+                    "s_mov_b32 s88, %[stp0]", "s_mov_b32 s89, %[stp1]", f"s_add_u32 s88, s88, {sr(S_TMP)}", "s_addc_u32 s89, s89, 0",
+                    "v_mov_b32 v8, s88", "v_mov_b32 v9, s89", "s_mov_b64 exec, 1", "s_nop 1",
                     "global_store_dwordx4 v[8:9], v[0:3], off", "global_store_dwordx4 v[8:9], v[4:7], off offset:16", "s_waitcnt vmcnt(0)", "s_mov_b64 exec, -1"]:
             e(ins)
     e("s_branch END%=")

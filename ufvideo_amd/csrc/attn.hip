@@ -1199,6 +1199,8 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
                 // kernel 12: key split over two wave groups per block; kernel 13: never.  Default when the launch has few blocks for the chip
                 // (<= ~2.3 per CU: the causal S = 2399 prefill has 532 for 512 slots and ends with its heaviest blocks alone; measured 88 -> 82 us
                 // there, 41 -> 31 us at S = 1200; with many blocks -- S = 4703: 1036 -- the plain kernel's two blocks per CU retire more tiles: 232 vs 254 us)
+                // default for the prefill of one sequence: the 4 + 4-wave kernel of attn_c128.inc (bit-identical to the plain kernel below)
+                if (causal && kernel == 0 && c128_ok(a) && Sq >= C128_MIN_S) return launch_c128(a, st);
                 if (causal && kernel != 13 && (kernel == 12 || (kernel == 0 && split2_pays(Sq, Hq, B, q_pos0)))) return launch_mfma_split2<4>(a, st);
                 return launch_mfma<128, 4>(a, causal, st);
         }
@@ -1234,7 +1236,9 @@ extern "C" int ufv_attention_causal_lse(const void* q, int64_t q_ss, const void*
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
     a.q_bs = 0; a.q_ss = q_ss; a.k_bs = 0; a.k_ss = k_ss; a.v_bs = 0; a.v_ss = v_ss; a.o_bs = 0; a.o_ss = o_ss;
     a.B = 1; a.Hq = Hq; a.Hkv = Hkv; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = scale; a.q_pos0 = 0; a.lse = lse;
-    // the same kernel choice as ufv_attention's causal hd-128 path: the training forward and the inference path return the same bits
+    // the same bits as ufv_attention's causal hd-128 path: where that takes the kernel of attn_c128.inc (which writes no log-sum-exp) this one takes the
+    // plain kernel, whose arithmetic attn_c128.inc repeats operation for operation; elsewhere the same kernel choice
+    if (c128_shape_ok(a) && S >= C128_MIN_S) return launch_mfma<128, 4>(a, 1, reinterpret_cast<hipStream_t>(stream));
     if (split2_pays(S, Hq, 1, 0)) return launch_mfma_split2<4>(a, reinterpret_cast<hipStream_t>(stream));
     return launch_mfma<128, 4>(a, 1, reinterpret_cast<hipStream_t>(stream));
 }
