@@ -314,6 +314,81 @@ def test_hd128_step_vs_reference_golden(attn, monkeypatch):
     assert worst[0] < 5e-2, worst
 
 
+def test_lora_q_v_adapters_gradients_step_and_merge():
+    """lora=dict(r, alpha): the reference's --lora_enable stage (train.py:829-845; targets = q_proj / v_proj, videorefer_trainer.py:75-90).  Checker: the full
+    decoder backward of this repo (pinned on the reference's own gradients by the tests above) on the MERGED weights W + s B A: loss and d(inputs) must agree,
+    and by the chain rule dB = s dW A^T, dA = s B^T dW for the adapted projections.  Then: rank padding stays zero, AdamW moves only the adapters, the loss
+    falls, the adapters export under peft's names, and detach() merges them into the model's weights."""
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
+    a, llm, w, _ = hd128_golden()
+    D, L, H, KV, hd = llm["hidden_size"], llm["num_hidden_layers"], llm["num_attention_heads"], llm["num_key_value_heads"], 128
+    r, alpha = 8, 16
+    s = alpha / r
+    g = torch.Generator().manual_seed(5)
+    init = {}
+    for i in range(L):
+        for nm, out in (("q_proj", H * hd), ("v_proj", KV * hd)):
+            init[f"model.layers.{i}.self_attn.{nm}.lora_A.weight"] = bfr(torch.randn(r, D, generator=g) * 0.05)
+            init[f"model.layers.{i}.self_attn.{nm}.lora_B.weight"] = bfr(torch.randn(out, r, generator=g) * 0.05)
+
+    def build(weights):
+        m = VideoReferQwen2ForCausalLM(VideoReferQwen2Config(**llm, sam2_trunk=None))
+        m.load_state_dict(weights, strict=False)
+        return m.to(DEV)
+    emb, labels = t(a["inputs_embeds"])[0].to(DEV), _shift(t(a["labels"])[0])
+    tr = DecoderTrainer(build(w), lr=2e-3, lora=dict(r=r, alpha=alpha, init=init), max_grad_norm=1.0)
+    assert not tr.train_decoder and tr.buckets() == [tr.lora_bucket]
+    tr.zero_grad()
+    loss, dx = tr.forward_backward(emb, labels)
+    # the same model with the adapters merged, full backward
+    w2 = dict(w)
+    for i in range(L):
+        for nm in ("q_proj", "v_proj"):
+            k = f"model.layers.{i}.self_attn.{nm}."
+            w2[k + "weight"] = w[k + "weight"] + s * init[k + "lora_B.weight"] @ init[k + "lora_A.weight"]
+    tr2 = DecoderTrainer(build(w2), train_embed=False)
+    tr2.zero_grad()
+    loss2, dx2 = tr2.forward_backward(emb, labels)
+    assert abs(float(loss) - float(loss2)) < 2e-2 * float(loss2)
+    assert rel_err(dx.cpu(), dx2.cpu()) < 4e-2
+    lb, Rp = tr.lora_bucket, tr.Rp
+    for i in range(L):
+        gq = tr2.layers[i].view(tr2.layers[i].g, "wqkv").cpu()
+        acat = lb.view(lb.g, f"Acat.{i}").cpu()
+        for j, (nm, lo, hi) in enumerate((("q_proj", 0, H * hd), ("v_proj", (H + KV) * hd, (H + 2 * KV) * hd))):
+            k = f"model.layers.{i}.self_attn.{nm}."
+            A, B, dWe = init[k + "lora_A.weight"], init[k + "lora_B.weight"], gq[lo:hi]
+            gb = lb.view(lb.g, f"B{nm[0]}.{i}").cpu()
+            assert rel_err(gb[:, :r], s * dWe @ A.t()) < 5e-2, (i, nm)
+            assert rel_err(acat[j * Rp:j * Rp + r], s * B.t() @ dWe) < 5e-2, (i, nm)
+            assert (gb[:, r:] == 0).all() and (acat[j * Rp + r:(j + 1) * Rp] == 0).all()          # rank padding: exact zeros
+    base_before = [b.w.clone() for b in tr.layers]
+    losses = [float(loss)]
+    for _ in range(4):
+        tr.step()
+        tr.zero_grad()
+        losses.append(float(tr.forward_backward(emb, labels)[0]))
+    assert losses[-1] < losses[0], losses
+    assert all(torch.equal(b.w, w0) for b, w0 in zip(tr.layers, base_before))                     # the base weights are frozen
+    sd = tr.export_lora_state_dict()
+    assert len(sd) == 4 * L and sd["base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight"].shape == (r, D) and \
+        sd["base_model.model.model.layers.1.self_attn.v_proj.lora_B.weight"].shape == (KV * hd, r)
+    assert (lb.view(lb.w, "Bq.0")[:, r:] == 0).all() and (lb.view(lb.w, "Acat.0")[r:Rp] == 0).all()
+    m = tr.model
+    tr.detach()
+    own = dict(m.named_parameters())
+    for i in range(L):
+        for nm in ("q_proj", "v_proj"):
+            p = f"base_model.model.model.layers.{i}.self_attn.{nm}."
+            k = f"model.layers.{i}.self_attn.{nm}.weight"
+            want = w[k] + s * sd[p + "lora_B.weight"].cpu() @ sd[p + "lora_A.weight"].cpu()
+            assert rel_err(own[k].float().cpu(), want) < 1e-2, k
+    # inference on the merged model sees the trained adapters: the loss of a plain forward pass equals the trainer's last one
+    tr3 = DecoderTrainer(m, train_embed=False)
+    l3, _ = tr3.forward_backward(emb, labels)
+    assert abs(float(l3) - losses[-1]) < 3e-2 * losses[-1]
+
+
 def test_export_state_dict_roundtrip_before_any_step():
     m, _, w = tiny_model()
     tr = DecoderTrainer(m, train_embed=False)

@@ -105,8 +105,14 @@ class DecoderTrainer:
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
                  train_embed=True, train_projector=False, train_region_encoder=False, train_decoder=True, mm_projector_lr=None,
-                 train_seg_head=False):
-        """train_decoder=False freezes the language model (the reference's tune_mm_mlp_adapter / tune_region_encoder stages,
+                 train_seg_head=False, lora=None):
+        """lora = dict(r=8, alpha=16[, seed=0 | init={name: tensor}]): the reference's --lora_enable stage (train.py:829-845: peft LoraConfig over
+        find_all_linear_names = the q_proj and v_proj Linears outside the multimodal modules, videorefer_trainer.py:75-90): the language model is frozen
+        and y = W x + (alpha / r) B (A x) trains A [r, in] (kaiming-uniform) and B [out, r] (zeros) of every layer's q_proj and v_proj; peft is absent from
+        this image, its published LoRA forward is restated (dropout 0: lora_dropout is a training-time random mask that no restatement can reproduce).
+        Implies train_decoder=False.  detach() / sync_to_model() merge the adapters into the decoder weights; export_lora_state_dict() returns them
+        under peft's names.
+        train_decoder=False freezes the language model (the reference's tune_mm_mlp_adapter / tune_region_encoder stages,
         train.py:882-890: model.requires_grad_(False), then only the adapter's parameters are re-enabled): backward still carries
         dL/dx through every layer, but no weight gradient, no fp32 states and no update exist for the decoder."""
         self.model = model
@@ -120,10 +126,11 @@ class DecoderTrainer:
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.t = 0
-        self.train_decoder = bool(train_decoder)
+        self.lora = dict(lora) if lora else None
+        self.train_decoder = bool(train_decoder) and not self.lora
         self.train_embed = train_embed = bool(train_embed) and self.train_decoder
-        if not self.train_decoder and not (train_projector or train_region_encoder or train_seg_head):
-            raise ValueError("nothing to train: train_decoder=False needs train_projector, train_region_encoder and / or train_seg_head")
+        if not self.train_decoder and not (train_projector or train_region_encoder or train_seg_head or self.lora):
+            raise ValueError("nothing to train: train_decoder=False needs train_projector, train_region_encoder, train_seg_head and / or lora")
         dev = model.device
         self.dev = dev
         D, I = cfg.hidden_size, cfg.intermediate_size
@@ -164,6 +171,33 @@ class DecoderTrainer:
             for k in ("ln1", "ln2", "bqkv"):
                 self.small.view(self.small.w, f"{k}.{i}").copy_(L[k])
                 L[k] = self.small.view(self.small.w, f"{k}.{i}")
+        # ---- optional: LoRA adapters on q_proj / v_proj.  Ranks are padded to 128 (rows of A / columns of B beyond r are zero and stay zero: their
+        # gradients are products with those zeros) so that every adapter product runs on the MFMA GEMM kernels; replicated fp32 bucket like `small`.
+        self.lora_bucket = None
+        if self.lora:
+            r, alpha = int(self.lora.get("r", 8)), float(self.lora.get("alpha", 16))
+            self.lora_r, self.lora_scale, self.Rp = r, alpha / r, _ru(r, 128)
+            Rp = self.Rp
+            names = []
+            for i in range(len(self.layers)):
+                names += [(f"Acat.{i}", (2 * Rp, D)), (f"Bq.{i}", (H * hd, Rp)), (f"Bv.{i}", (KV * hd, Rp))]
+            self.lora_bucket = lb = _Bucket(names, dev, 1, 0, torch.float32, True)
+            init = self.lora.get("init")
+            gen = torch.Generator().manual_seed(int(self.lora.get("seed", 0)))
+            for i in range(len(self.layers)):
+                a = lb.view(lb.w, f"Acat.{i}")
+                for j, nm in enumerate(("q_proj", "v_proj")):
+                    key = f"model.layers.{i}.self_attn.{nm}.lora_A.weight"
+                    if init is not None and key in init:
+                        a[j * Rp:j * Rp + r].copy_(init[key])
+                    else:                                           # peft: kaiming_uniform_(a = sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in))
+                        a[j * Rp:j * Rp + r].copy_((torch.rand(r, D, generator=gen) * 2 - 1) / math.sqrt(D))
+                    keyb = f"model.layers.{i}.self_attn.{nm}.lora_B.weight"
+                    if init is not None and keyb in init:
+                        lb.view(lb.w, f"B{nm[0]}.{i}")[:, :r].copy_(init[keyb])
+            self.lora_wb = torch.zeros((lb.n,), device=dev, dtype=torch.bfloat16)           # bf16 working copies + the transposes the backward reads
+            self.lora_T = [dict(AcatT=torch.empty((D, 2 * Rp), device=dev, dtype=torch.bfloat16), BqT=torch.empty((Rp, H * hd), device=dev, dtype=torch.bfloat16),
+                                BvT=torch.empty((Rp, KV * hd), device=dev, dtype=torch.bfloat16)) for _ in self.layers]
         # ---- optional: the multimodal projector (reference: mm_projector is in the trainable set, train.py:873-912).  Its
         # parameters keep the reference layout (the connector re-packs them after every step); replicated update like `small`.
         self.pgrad = None
@@ -212,6 +246,8 @@ class DecoderTrainer:
                     v.data = self.proj_flat[off:off + n].view(shape)
         for b in self.buckets():
             b.init_states()
+        if self.lora_bucket is not None:
+            self._refresh_lora()
         # ---- transposed weight copies for dX = dY W (the NT GEMM wants W^T rows)
         self.wT = [dict(wqkv=torch.empty((D, self.QW), device=dev, dtype=torch.bfloat16),
                         wo=torch.empty((H * hd, D), device=dev, dtype=torch.bfloat16),
@@ -240,7 +276,18 @@ class DecoderTrainer:
     def buckets(self):
         """the buckets that are exchanged and updated"""
         dec = self.layers + [self.head, self.small] if self.train_decoder else []
-        return dec + ([self.proj_bucket] if self.proj_bucket is not None else [])
+        return dec + ([self.lora_bucket] if self.lora_bucket is not None else []) + ([self.proj_bucket] if self.proj_bucket is not None else [])
+
+    def _lora_w(self, i):
+        lb = self.lora_bucket
+        return lb.view(self.lora_wb, f"Acat.{i}"), lb.view(self.lora_wb, f"Bq.{i}"), lb.view(self.lora_wb, f"Bv.{i}")
+
+    def _refresh_lora(self):
+        """bf16 working copies of the adapters from the fp32 values, and the transposes the backward's NT GEMMs read"""
+        self.lora_wb.copy_(self.lora_bucket.w)
+        for i, t in enumerate(self.lora_T):
+            a, bq, bv = self._lora_w(i)
+            ops.transpose(a, rpad=a.shape[0], out=t["AcatT"]); ops.transpose(bq, rpad=bq.shape[0], out=t["BqT"]); ops.transpose(bv, rpad=bv.shape[0], out=t["BvT"])
 
     def _refresh_transposes(self):
         for b, t in zip(self.layers, self.wT):
@@ -263,6 +310,9 @@ class DecoderTrainer:
                         o=torch.empty((S, H * hd), device=dev, dtype=bf), x_mid=torch.empty((S, D), device=dev, dtype=f32),
                         h2=torch.empty((S, D), device=dev, dtype=bf), gu=torch.empty((S, 2 * I), device=dev, dtype=bf),
                         act=torch.empty((S, I), device=dev, dtype=bf), lse=torch.empty((H, S), device=dev, dtype=f32)) for _ in self.layers]
+        if self.lora_bucket is not None:
+            for st in self.st:
+                st["u"] = torch.empty((S, 2 * self.Rp), device=dev, dtype=bf)              # A x of both adapters, kept for dB
         # scratch shared by all layers
         W = max(2 * I, self.QW, D, H * hd)
         self.sc = dict(dxb=torch.empty((S, D), device=dev, dtype=bf), dxbT=torch.empty((D, Sp), device=dev, dtype=bf),
@@ -270,6 +320,8 @@ class DecoderTrainer:
                        dact=torch.empty((S, I), device=dev, dtype=bf), dgu=torch.empty((S, 2 * I), device=dev, dtype=bf),
                        dh=torch.empty((S, D), device=dev, dtype=f32), do=torch.empty((S, H * hd), device=dev, dtype=bf),
                        dqkv=torch.empty((S, self.QW), device=dev, dtype=bf))
+        if self.lora_bucket is not None:
+            self.sc["du"] = torch.empty((S, 2 * self.Rp), device=dev, dtype=bf)
         self._stash_S = S
 
     def zero_grad(self):
@@ -305,11 +357,17 @@ class DecoderTrainer:
         x = inputs_embeds.to(torch.float32).contiguous().clone()
         rope_tab = ops.rope_table(self.inv_freq, 0, S, hd) if hd % 16 == 0 else None
         # ---------------- forward (same kernels as inference; gate/up kept un-fused so the pre-activations are stashed)
-        for L, st in zip(pk["layers"], self.st):
+        for lf, (L, st) in enumerate(zip(pk["layers"], self.st)):
             st["x_in"][:S].copy_(x)
             h1, qkv, kv, o, h2, gu, act = st["h1"][:S], st["qkv"][:S], st["kv"], st["o"][:S], st["h2"][:S], st["gu"][:S], st["act"][:S]
             ops.rmsnorm(x, L["ln1"], eps, out=h1)
             ops.gemm(h1, L["wqkv"], bias=L["bqkv"], out=qkv)
+            if self.lora_bucket is not None:                                          # q += s B_q (A_q h), v += s B_v (A_v h); every product rounded to bf16
+                a_cat, b_q, b_v = self._lora_w(lf)
+                u, Rp = st["u"][:S], self.Rp
+                ops.gemm(h1, a_cat, out=u)
+                qkv[:, :H * hd].add_(ops.gemm(u[:, :Rp], b_q), alpha=self.lora_scale)
+                qkv[:, (H + KV) * hd:].add_(ops.gemm(u[:, Rp:], b_v), alpha=self.lora_scale)
             ops.rope_kv(qkv, S, H, KV, hd, self.inv_freq, 0, kv, table=rope_tab)
             if self.fused_attn_bwd:                                                  # same kernel + the log-sum-exp the backward needs
                 ops.attention_causal_lse(qkv, kv, kv[:, KV * hd:], o, st["lse"], S, H, KV, hd)
@@ -392,6 +450,19 @@ class DecoderTrainer:
                 ops.attention_bwd(qkv, kv, kv[:, KV * hd:], sc["do"][:S], dqkv, dqkv[:, H * hd:], dqkv[:, (H + KV) * hd:], S, H, KV, hd)
             ops.rope_rows(dqkv, 0, H + KV, hd, self.inv_freq, 0, backward=True)
             ops.gemm(dqkv, wT["wqkv"], out=dh)                                       # d h1, fp32
+            if self.lora_bucket is not None:
+                lb, lt, Rp, u, du = self.lora_bucket, self.lora_T[li], self.Rp, st["u"][:S], sc["du"][:S]
+                a_cat, b_q, b_v = self._lora_w(li)
+                ddq = dqkv[:, :H * hd] * self.lora_scale                             # d(s B u) / d(B u), bf16
+                ddv = dqkv[:, (H + KV) * hd:] * self.lora_scale
+                ops.gemm(ddq, lt["BqT"], out=du[:, :Rp])                             # d u = dd B
+                ops.gemm(ddv, lt["BvT"], out=du[:, Rp:])
+                uT = ops.transpose(u, rpad=Sp, out=inT)                              # [2 Rp, Sp]
+                dW(lb, f"Bq.{li}", ops.transpose(ddq, rpad=Sp, out=dyT), uT[:Rp], H * hd, Rp)
+                dW(lb, f"Bv.{li}", ops.transpose(ddv, rpad=Sp, out=dyT), uT[Rp:2 * Rp], KV * hd, Rp)
+                duT = ops.transpose(du, rpad=Sp, out=dyT)
+                dW(lb, f"Acat.{li}", duT, ops.transpose(h1, rpad=Sp, out=inT), 2 * Rp, D)
+                ops.gemm(du, lt["AcatT"], resid=dh, out=dh)                          # d h1 += d u A
             if td:
                 ops.transpose(dqkv, rpad=Sp, out=dyT)
                 ops.transpose(h1, rpad=Sp, out=inT)
@@ -546,7 +617,8 @@ class DecoderTrainer:
         """(sharded buckets in the order backward produced them, replicated buckets): every rank issues its collectives in this
         order -- the property the gloo test pins, since mismatched orders deadlock or mix buffers on any backend"""
         sharded = (list(reversed(self.layers)) + [self.head]) if self.train_decoder else []
-        replicated = ([self.small] if self.train_decoder else []) + ([self.proj_bucket] if self.proj_bucket is not None else [])
+        replicated = ([self.small] if self.train_decoder else []) + ([self.lora_bucket] if self.lora_bucket is not None else []) + \
+                     ([self.proj_bucket] if self.proj_bucket is not None else [])
         return sharded, replicated
 
     def _exchange(self):
@@ -615,9 +687,11 @@ class DecoderTrainer:
                         v.data.copy_(b.view(b.w, k))
                 for mod in self.aux_modules.values():
                     mod.invalidate()
-            elif b is self.small:
+            elif b is self.small or b is self.lora_bucket:
                 ops.adamw(b.master, g, b.m, b.v, None, self.lr, b1, b2, self.eps, wd, self.t, gscale)
                 b.w.copy_(b.master)
+                if b is self.lora_bucket:
+                    self._refresh_lora()
             else:
                 lo = b.rank * b.shard
                 ops.adamw(b.master, g, b.m, b.v, b.w[lo:lo + b.shard], self.lr, b1, b2, self.eps, wd, self.t, gscale)
@@ -632,12 +706,47 @@ class DecoderTrainer:
         """Writes the trained decoder weights (bf16 working copies of the fp32 masters) into the model's nn.Parameters under the
         reference's names, so that model.state_dict() / save paths export what was trained.  The projector / region-encoder parameters
         are views of the trainer's buffer already.  Every rank holds the full bf16 weights after step(), so no communication."""
+        if self.lora_bucket is not None:
+            self._merge_lora()
         if not self.train_decoder:
             return
         own = dict(self.model.named_parameters())
         with torch.no_grad():
             for k, v in self.export_state_dict().items():
                 own[k].data.copy_(v.to(own[k].dtype))
+
+    def export_lora_state_dict(self):
+        """the adapters under peft's names (what the reference saves with get_peft_state_maybe_zero_3, train.py:962): lora_A [r, in], lora_B [out, r], fp32"""
+        sd, r, Rp, lb = {}, self.lora_r, self.Rp, self.lora_bucket
+        for i in range(len(self.layers)):
+            a = lb.view(lb.w, f"Acat.{i}")
+            for j, nm in enumerate(("q_proj", "v_proj")):
+                p = f"base_model.model.model.layers.{i}.self_attn.{nm}."
+                sd[p + "lora_A.weight"] = a[j * Rp:j * Rp + r].clone()
+                sd[p + "lora_B.weight"] = lb.view(lb.w, f"B{nm[0]}.{i}")[:, :r].clone()
+        return sd
+
+    def _merge_lora(self):
+        """W <- W + (alpha / r) B A for every adapted projection (peft merge_and_unload), into the packed weights AND the model's parameters; the adapters'
+        B are zeroed afterwards so that a second call adds nothing"""
+        cfg = self.cfg
+        H, KV, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        lb, r, Rp = self.lora_bucket, self.lora_r, self.Rp
+        own = dict(self.model.named_parameters())
+        with torch.no_grad():
+            for i, b in enumerate(self.layers):
+                wqkv = b.view(b.w, "wqkv")
+                a = lb.view(lb.w, f"Acat.{i}")
+                for j, (nm, lo, hi) in enumerate((("q_proj", 0, H * hd), ("v_proj", (H + KV) * hd, (H + 2 * KV) * hd))):
+                    bm = lb.view(lb.w, f"B{nm[0]}.{i}")
+                    delta = (bm[:, :r] @ a[j * Rp:j * Rp + r]) * self.lora_scale
+                    wqkv[lo:hi].copy_((wqkv[lo:hi].float() + delta).to(wqkv.dtype))
+                    key = f"model.layers.{i}.self_attn.{nm}.weight"
+                    own[key].data.copy_(wqkv[lo:hi].to(own[key].dtype))
+                    bm.zero_()
+            lb.master.copy_(lb.w)
+        self._refresh_lora()
+        self._refresh_transposes()
 
     def detach(self):
         """sync_to_model(), then release the model: its packed buffers are rebuilt from the (now current) parameters on next use"""
