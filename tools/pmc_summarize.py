@@ -64,7 +64,7 @@ M, N, K = 2399, 37888, 3584
 res["gate_up"] = summary(lambda k: k.startswith("gemm_nt_256<false, true"), f"gemm_nt_256<bf16, swiglu, 256x256, two-phase> M={M} N={N} K={K}",
                          alg_bytes=(M * K + N * K + M * (N // 2)) * 2)
 res["vit_attention"] = summary(lambda k: "attn_fwd_vit72" in k, "ViT attention B=32 H=16 S=576 hd=72", alg_bytes=32 * 576 * 1152 * 2 * 4)
-res["llm_attention"] = summary(lambda k: "attn_fwd_mfma<128" in k, "attn_fwd_mfma<128,4,causal,NG2> S=2399 28/4 heads")
+res["llm_attention"] = summary(lambda k: "attn_fwd_c128" in k or "attn_fwd_mfma<128" in k, "causal attention S=2399 28/4 heads hd=128 (attn_fwd_c128)")
 out = os.path.join(root, "profiles", tag)
 os.makedirs(out, exist_ok=True)
 json.dump(res, open(os.path.join(out, "pmc_bench.json"), "w"), indent=1, sort_keys=True)
