@@ -519,10 +519,12 @@ S_NBASE = S_VALID                                         # compute-only name: g
 def loader_body(G, i):
     e = G.e
     e(f"LOADER{i}%=:")
-    pieces = []                                           # (kind, piece index) per slot
+    pieces = []                                           # (kind, piece index) per slot: loader 0 has 10 pieces per tile, the others 9
     for j in range(10):
         p = 4 * j + i
-        pieces.append(("K", p) if p < 17 else ("V", p) if p < 37 else ("P", p - 37))
+        if p < 37 or "padpieces" in OPT:
+            pieces.append(("K", p) if p < 17 else ("V", p) if p < 37 else ("P", p - 37))
+    npc = len(pieces)
     # per-lane source offsets: padded chunk n = 64 p + lane; K: row n / 17, c n % 17 (c = 16 is padding: fetch c = 0); V: n' = n - 1088, row n' / 20, c n' % 20
     for j, (kind, p) in enumerate(pieces):
         pp = p if kind != "V" else p - 17
@@ -573,7 +575,7 @@ def loader_body(G, i):
     e(f"{loop}:")
     e(f"s_cmp_eq_u32 {sr(S_NWAIT)}, {sr(S_NISS)}"); e("s_cbranch_scc1 L_DONE%=")
     e(f"s_add_u32 {sr(S_TMP)}, {sr(S_NWAIT)}, 1"); e(f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_NISS)}"); e(f"s_cbranch_scc0 {l2}")
-    e("s_waitcnt vmcnt(10)"); e(f"s_branch {l3}")
+    e(f"s_waitcnt vmcnt({npc})"); e(f"s_branch {l3}")
     e(f"{l2}:")
     e("s_waitcnt vmcnt(0)")
     e(f"{l3}:")
