@@ -378,3 +378,21 @@ def test_gemm_kernel_choice_at_the_config2_shapes():
     assert pick(1200, 3584, 18944, 1, 0, 0) < 10000                       # ... never split under an activation
     assert pick(1200, 3584, 18944, 0, 0, 1) < 10000                       # ... or into a bf16 output
     assert pick(100, 3584, 3584, 1, 0, 1) == 0 and pick(2399, 3500, 3584, 1, 0, 1) == 0      # small / unaligned shapes: not the ping-pong kernel
+
+
+def test_generated_kernel_bodies_are_what_their_generators_emit(tmp_path):
+    """csrc/attn_vit_p2_asm.inc and csrc/attn_c128_asm.inc are GENERATED files that travel with the source (the GPU box only compiles): the committed text must
+    be exactly what tools/gen_attn_p2.py / tools/gen_attn_c128.py write with no options (no lab knobs, no stamps), so that nobody reviews one thing and ships another"""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("UFV_")}
+    for gen, inc in (("gen_attn_p2.py", "attn_vit_p2_asm.inc"), ("gen_attn_c128.py", "attn_c128_asm.inc")):
+        work = tmp_path / gen
+        (work / "tools").mkdir(parents=True)
+        (work / "ufvideo_amd" / "csrc").mkdir(parents=True)
+        shutil.copy(os.path.join(root, "tools", gen), work / "tools" / gen)
+        subprocess.run([sys.executable, str(work / "tools" / gen)], check=True, env=env, stdout=subprocess.DEVNULL)
+        fresh = (work / "ufvideo_amd" / "csrc" / inc).read_text()
+        assert fresh == open(os.path.join(root, "ufvideo_amd", "csrc", inc)).read(), f"{inc} is stale: run tools/{gen}"
