@@ -103,6 +103,8 @@ class DecoderTrainer:
     flat buffers, so generate()/forward() see every update.  group: torch.distributed process group (None = default group if
     initialised, else single process)."""
 
+    lora_bucket = None                  # (class default: set by __init__ when lora= is given)
+
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
                  train_embed=True, train_projector=False, train_region_encoder=False, train_decoder=True, mm_projector_lr=None,
                  train_seg_head=False, lora=None):
