@@ -88,19 +88,6 @@ def spread(instrs, g0, g1):
     return [(g0 + (k * (g1 - g0 + 1)) // max(n, 1), ins) for k, ins in enumerate(instrs)]
 
 
-def merge(G, mfmas, placed, simple=False):
-    """emit MFMAs with fillers in the gaps (gap g = after MFMA g-1; gap 0 = before the first)"""
-    gaps = [[] for _ in range(len(mfmas) + 1)]
-    for g, ins in placed:
-        gaps[len(mfmas) if simple else min(max(g, 0), len(mfmas))].append(ins)
-    for ins in gaps[0]:
-        emit(G, ins)
-    for i, m in enumerate(mfmas):
-        emit(G, m)
-        for ins in gaps[i + 1]:
-            emit(G, ins)
-
-
 def emit(G, ins):
     if isinstance(ins, (list, tuple)):
         for x in ins:
@@ -354,13 +341,16 @@ def build(simple=False):
             e(ins)
         # groups 0..15 = QK^T of tile t + 1, 16..31 = PV of tile t.  P chunks 0, 1 (fa) are first used by group 16, chunk 2 (fb1) by 24, chunk 3 (fb2) by 28;
         # the scores of tile t + 1 are complete a few MFMAs after group 15
-        placed = spread(fa[npre:], 0, 13) + spread(fb1, 14, 19) + spread(fb2, 18, 23) + spread(fb3, 24, 31) + spread(st, 19, 31)
+        if simple:             # --simple (bring-up form): the whole softmax of tile t between the two MFMA phases, the next tile's max after the PV
+            placed = [(15, ins) for ins in fa + fb1 + fb2 + fb3] + [(31, ins) for ins in st]
+        else:
+            placed = spread(fa[npre:], 0, 13) + spread(fb1, 14, 19) + spread(fb2, 18, 23) + spread(fb3, 24, 31) + spread(st, 19, 31)
         for gi, grp in enumerate(groups):
             if gi == 16:
                 emit(G, stamp(2))
             emit(G, grp)
             for g, ins in placed:
-                if (31 if simple else g) == gi:
+                if g == gi:
                     e(ins)
         e(f"v_add_u32 {vr(VADDR)}, {sr(S_DELTA)}, {vr(VADDR)}")     # V of tile t + 1
         emit(G, stamp(3))
