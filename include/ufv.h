@@ -98,7 +98,10 @@ int ufv_rmsnorm(const float* x, int ldx, void* y, int y_f32, int ldy, const floa
  * modeling_qwen2.py:150-172).  q/k/v/o bf16; element (b, s, h, d) of X lives at
  * X + b*x_bs + s*x_ss + h*hd + d.  Hq % Hkv == 0 (GQA).  causal: key j visible to query i iff
  * j <= q_pos0 + i.  kernel: 0 auto, 1 MFMA kernel (hd in {64,72,80,96,128}), 2 generic,
- * 5 few-keys kernel (Sk <= 64, hd 16|32, non-causal: SAM2 image->token cross attention). */
+ * 5 few-keys kernel (Sk <= 64, hd 16|32, non-causal: SAM2 image->token cross attention); diagnostic ids that name ONE kernel and fail
+ * with UFV_EUNSUPPORTED outside its envelope: 11 / 14 the second / third generation hd-72 kernels (SigLIP), 12 / 13 the hd-128 kernel
+ * with / without the key split over two wave groups, 15 the causal hd-128 prefill kernel of csrc/attn_c128.inc (B = 1, Sq = Sk >= 64,
+ * q_pos0 = 0, >= 2 kv heads, >= 2 q heads per kv head; what auto takes from Sq = 128 on, bit-identical to 13). */
 int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const void* k, int64_t k_bs, int64_t k_ss, const void* v,
                   int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int64_t o_ss, int B, int Hq, int Hkv, int Sq,
                   int Sk, int hd, float scale, int causal, int q_pos0, int kernel, void* stream);
@@ -447,7 +450,7 @@ int ufv_gemm_splitk(const void* A, int lda, const void* W, int ldw, void* C, int
 int ufv_attention_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, const void* dO, int64_t lddo, void* dq,
                       int64_t lddq, void* dk, void* dv, int64_t lddkv, int S, int Hq, int Hkv, int hd, float scale, void* ws, void* stream);
 /* Fused (flash-style) form of the same backward for hd == 128: nothing of size S x S is written.  ufv_attention_causal_lse is the
- * training forward (same kernel as ufv_attention with causal = 1, batch 1, q_pos0 = 0; *_ss = token strides in elements) that also
+ * training forward (same bits as ufv_attention with causal = 1, batch 1, q_pos0 = 0; *_ss = token strides in elements) that also
  * stores lse fp32 [Hq, S] = log2-domain log-sum-exp of the scaled scores; ufv_attention_bwd_fused takes it with the forward output
  * o bf16 [S, ldo].  k / v need only S rows here.  ws = ufv_attention_bwd_fused_ws_bytes(S, Hq). */
 int ufv_attention_causal_lse(const void* q, int64_t q_ss, const void* k, int64_t k_ss, const void* v, int64_t v_ss, void* o, int64_t o_ss,
