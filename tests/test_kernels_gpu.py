@@ -124,6 +124,22 @@ def test_layernorm(D, dt):
     assert rel(ops.layernorm(x, w, b, 1e-6, act="silu", out_dtype=torch.float32), refs) < 1e-5
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,D", [(4096, 1152), (18432, 1152), (5003, 144), (9216, 1280)])
+def test_layernorm_pipelined_form_bit_identical(M, D, dt):
+    """long inputs (M >= 4096, D <= 1280, bf16 out, no activation) run the persistent pipelined kernel (csrc/ops.hip layernorm_pipe_k: a wave walks several rows and
+    requests the next one before reducing the current one); the same per-lane summation order as the plain kernel, so every row must carry the bits the plain kernel
+    gives it when it is computed in a short call -- including the last rows of a ragged row count and a row-strided input"""
+    x = (g(M, D + 8, seed=M + D) * 3 + 0.5).to(dt)[:, 4:4 + D]
+    w, b = 1 + 0.1 * g(D, seed=17), 0.1 * g(D, seed=18)
+    long = ops.layernorm(x, w, b, 1e-6)
+    for lo in (0, 1234, M - 77):
+        assert torch.equal(long[lo:lo + 77], ops.layernorm(x[lo:lo + 77], w, b, 1e-6)), lo
+    assert rel(long, torch.nn.functional.layer_norm(x.float(), (D,), w, b, 1e-6)) <= ONE_ULP
+    nob = ops.layernorm(x, w, None, 1e-6)
+    assert torch.equal(nob[:50], ops.layernorm(x[:50], w, None, 1e-6))
+
+
 def test_ln_add_silu():
     M, D = 50, 3584
     a, b = bf(g(M, D, seed=19)), bf(g(M, D, seed=20))

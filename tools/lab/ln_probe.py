@@ -13,11 +13,12 @@ def t(fn, n=50):
     return a.elapsed_time(b) * 1000 / n
 
 M, D = 18432, 1152
-x = torch.randn(M, D, device="cuda").to(torch.bfloat16)
-y = torch.empty_like(x)
+DT = torch.float32 if "--f32" in sys.argv else torch.bfloat16
+x = torch.randn(M, D, device="cuda").to(DT)
+y = torch.empty(M, D, device='cuda', dtype=torch.bfloat16)
 w = torch.randn(D, device="cuda"); b = torch.randn(D, device="cuda")
 # rotate over several buffers so that the stream comes from HBM, not from the 256 MB Infinity Cache
-xs = [x.clone() for _ in range(8)]; ys = [torch.empty_like(x) for _ in range(8)]
+xs = [x.clone() for _ in range(8)]; ys = [torch.empty(M, D, device='cuda', dtype=torch.bfloat16) for _ in range(8)]
 i = [0]
 def ln():
     i[0] = (i[0] + 1) % 8
@@ -29,7 +30,7 @@ def ln_hot():
     ops.layernorm(x, w, b, 1e-6, out=y)
 def cp_hot():
     y.copy_(x)
-gb = 2 * M * D * 2 / 1e3
+gb = M * D * (2 + x.element_size()) / 1e3
 for name, fn in (("layernorm (8 rotating buffers)", ln), ("torch copy (8 rotating buffers)", cp), ("layernorm (one buffer)", ln_hot), ("torch copy (one buffer)", cp_hot)):
     us = t(fn)
     print(f"{name:36s} {us:7.1f} us   {gb / us / 1e3:5.2f} TB/s")
