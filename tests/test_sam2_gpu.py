@@ -89,6 +89,15 @@ def test_hiera_l_one_frame_vs_oracle():
     assert [tuple(f.shape) for f in feats] == [tuple(r.shape) for r in ref] == [(1, 144, 128, 128), (1, 288, 64, 64), (1, 576, 32, 32), (1, 1152, 16, 16)]
     for f, r in zip(feats, ref):
         assert rel_err(f.cpu(), r) < 4e-2
+    # runs of blocks with one window size keep the token stream in window order (no per-block partition / un-partition): every token goes through the same
+    # arithmetic, so the features must be BIT-identical to the per-block form, here with 2 frames and a grid (48 x 40 at stage 1) whose windows still divide it
+    x2 = torch.randn(2, 3, 384, 320, generator=torch.Generator().manual_seed(4)).to(DEV)
+    kept = trunk(x2)
+    trunk.keep_window_order = False
+    per_block = trunk(x2)
+    trunk.keep_window_order = True
+    for a_, b_ in zip(kept, per_block):
+        assert torch.equal(a_, b_)
 
 
 # ---- SAM heads with the language token -----------------------------------------------------------------------------------

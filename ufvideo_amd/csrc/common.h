@@ -41,18 +41,6 @@ void ufv_set_error(const char* fmt, ...);
 // ---- activations ----------------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_QUICK_GELU = 5, ACT_SIGMOID = 6 };
 
-// exact (erf) GELU without libm's erff (two polynomial branches + exp, ~35 instructions: the epilogue of a short-K GEMM such as Hiera's fc1, K = 576, was
-// paced by it): erfc(a) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-a^2), t = 1 / (1 + p a), a = |x| / sqrt 2 (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7
-// on erf), with gelu = x erfc(a) / 2 for x < 0 and x (2 - erfc(a)) / 2 for x >= 0, so the negative tail is a product, not a difference of numbers near 1:
-// |gelu error| <= 0.8e-7 |x| everywhere (measured against torch's fp64 gelu in tests/test_kernels_gpu.py), far below one bf16 ulp of the output.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float a = fabsf(x) * 0.7071067811865476f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * a);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float ec = poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * a * a);
-    return 0.5f * x * (x < 0.f ? ec : 2.0f - ec);
-}
-
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
         case ACT_GELU_TANH: {
@@ -60,7 +48,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
             float u = k0 * (x + k1 * x * x * x);
             return 0.5f * x * (1.0f + tanhf(u));
         }
-        case ACT_GELU_ERF: return gelu_erf(x);
+        case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
         case ACT_SILU: return x / (1.0f + __expf(-x));
         case ACT_RELU: return x > 0.f ? x : 0.f;
         case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
@@ -75,7 +63,7 @@ __device__ __forceinline__ float act_apply_t(float x) {
         const float k0 = 0.7978845608028654f, k1 = 0.044715f;
         return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
     }
-    if (ACT == ACT_GELU_ERF) return gelu_erf(x);
+    if (ACT == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
     if (ACT == ACT_SILU) return x / (1.0f + __expf(-x));
     if (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
     if (ACT == ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));

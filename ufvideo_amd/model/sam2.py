@@ -175,12 +175,40 @@ class Hiera(PackedModule):
             self._idx_cache[key] = window_index(B, H, W, ws, device)
         return self._idx_cache[key]
 
+    keep_window_order = True      # consecutive blocks of one window size leave the token stream in window order (see _block)
+
+    def _reorder(self, x, B, H, W, cur, want):
+        """the fp32 stream from token order `cur` to `want` (0 = row-major, ws > 0 = the window-partitioned order of that window size; only sizes that
+        divide the grid are kept as orders, so the index is a permutation)"""
+        if cur == want:
+            return x
+        if cur:
+            idx, _ = self._windows(B, H, W, cur, x.device)
+            x = ops.gather_rows(x, None, torch.empty_like(x), idx)
+        if want:
+            idx, _ = self._windows(B, H, W, want, x.device)
+            x = ops.gather_rows(x, idx, torch.empty_like(x), None)
+        return x
+
     # ---- one MultiScaleBlock (sam2.py:1099-1131) on the fp32 stream x [B*H*W, dp] ----------------------------------------
-    def _block(self, x, blk, w, B, H, W):
+    # `order`: the token order x arrives in.  LayerNorm, the MLP and the residual adds work row by row, and global attention sees all tokens of a frame
+    # whatever their order inside the frame, so a run of blocks with the same window size keeps the stream in that window order: the per-block window
+    # partition (a row gather) and un-partition (a permuted row add) become the identity (2 of ~13 passes over the stream per block); blocks that pool
+    # or change the width, and the stage outputs, get row-major order back.  Every row goes through the same arithmetic: bit-identical outputs.
+    def _block(self, x, blk, w, B, H, W, order=0):
         d, do, heads, ws, qs = blk["dim"], blk["dim_out"], blk["heads"], blk["window"], blk["q_stride"]
         dp, dop = w["dp"], w["dop"]
         dev = x.device
         N = B * H * W
+        plain = w["proj"] is None and not qs
+        if not (self.keep_window_order and plain):
+            want = 0
+        elif ws > 0:
+            want = ws if (H % ws == 0 and W % ws == 0) else 0
+        else:
+            want = order
+        x = self._reorder(x, B, H, W, order, want)
+        order = want
         xn = self._zbuf("xn", (N, dp), dev) if dp != d else torch.empty((N, dp), device=dev, dtype=torch.bfloat16)
         ops.layernorm(x[:, :d] if dp != d else x, w["n1"][0], w["n1"][1], 1e-6, out=xn[:, :d] if dp != d else xn)
         Ho, Wo = (H // 2, W // 2) if qs else (H, W)
@@ -188,7 +216,9 @@ class Hiera(PackedModule):
             sc = ops.gemm(xn, w["proj"][0], bias=w["proj"][1], out_dtype=torch.float32)
             x = ops.maxpool2x2(sc, B, H, W, dop) if qs else sc
         # window partition
-        if ws > 0:
+        if ws > 0 and order == ws:
+            Bw, wh, xw = N // (ws * ws), ws, xn
+        elif ws > 0:
             idx, (Hp, Wp) = self._windows(B, H, W, ws, dev)
             Bw, wh = idx.numel() // (ws * ws), ws
             xw = torch.empty((idx.numel(), dp), device=dev, dtype=torch.bfloat16)
@@ -208,7 +238,7 @@ class Hiera(PackedModule):
                           (Sk * 3 * dop, 3 * dop), out=o)
         y = ops.gemm(o, w["wo"], bias=w["bo"])            # [Bw*Sq, dop] in window order
         # window un-partition + residual
-        if ws > 0:
+        if ws > 0 and order != ws:
             ws2 = ws // 2 if qs else ws
             idx2, _ = self._windows(B, Ho, Wo, ws2, dev)
             ops.add_rows(y, x, idx2)
@@ -219,7 +249,7 @@ class Hiera(PackedModule):
         ops.layernorm(x[:, :do] if dop != do else x, w["n2"][0], w["n2"][1], 1e-6, out=h2[:, :do] if dop != do else h2)
         f = ops.gemm(h2, w["w1"], bias=w["b1"], act="gelu")
         ops.gemm(f, w["w2"], bias=w["b2"], resid=x, out=x)
-        return x, Ho, Wo
+        return x, Ho, Wo, order
 
     def forward_tokens(self, img):
         """img [B,3,H,W] -> list of (fp32 tokens [B*h*w, C_pad], h, w, C) at the stage ends, highest resolution first."""
@@ -228,9 +258,11 @@ class Hiera(PackedModule):
         cols, (H, W) = ops.im2col(img.contiguous(), 7, 4, 3, pk["Kp"])
         x = ops.gemm(cols, pk["patch_w"], bias=pk["patch_b"], resid=self._get_pos_embed((H, W)), resid_rows=H * W, out_dtype=torch.float32)
         outs = []
+        order = 0
         for i, (blk, w) in enumerate(zip(self.schedule, pk["blocks"])):
-            x, H, W = self._block(x, blk, w, B, H, W)
+            x, H, W, order = self._block(x, blk, w, B, H, W, order)
             if (i == self.stage_ends[-1]) or (i in self.stage_ends and self.return_interm_layers):
+                x, order = self._reorder(x, B, H, W, order, 0), 0
                 outs.append((x.clone() if i != self.stage_ends[-1] else x, H, W, blk["dim_out"]))
         return outs
 
