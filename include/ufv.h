@@ -101,7 +101,8 @@ int ufv_rmsnorm(const float* x, int ldx, void* y, int y_f32, int ldy, const floa
  * 5 few-keys kernel (Sk <= 64, hd 16|32, non-causal: SAM2 image->token cross attention); diagnostic ids that name ONE kernel and fail
  * with UFV_EUNSUPPORTED outside its envelope: 11 / 14 the second / third generation hd-72 kernels (SigLIP), 12 / 13 the hd-128 kernel
  * with / without the key split over two wave groups, 15 the causal hd-128 prefill kernel of csrc/attn_c128.inc (B = 1, Sq = Sk >= 64,
- * q_pos0 = 0, >= 2 kv heads, >= 2 q heads per kv head; what auto takes from Sq = 128 on, bit-identical to 13). */
+ * q_pos0 = 0, >= 2 kv heads, >= 2 q heads per kv head; what auto takes from Sq = 128 on, bit-identical to 13), 16 the small-window
+ * kernel (non-causal head_dim 72, Sq, Sk <= 16: Hiera's 4 x 4 windows; auto from 256 (window, head) pairs on). */
 int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const void* k, int64_t k_bs, int64_t k_ss, const void* v,
                   int64_t v_bs, int64_t v_ss, void* o, int64_t o_bs, int64_t o_ss, int B, int Hq, int Hkv, int Sq,
                   int Sk, int hd, float scale, int causal, int q_pos0, int kernel, void* stream);

@@ -276,6 +276,28 @@ def test_causal_hd128_prefill_kernel_bit_identical_to_the_plain_kernel():
     assert rel(o, attn_ref(x, x, x, True)) <= ATTN_TOL
 
 
+@pytest.mark.parametrize("B,H,Hkv,Sq,Sk", [(300, 4, 4, 16, 16), (300, 8, 8, 4, 16), (70, 2, 2, 16, 9), (65, 4, 2, 7, 16), (1, 2, 2, 1, 1)])
+def test_attention_small_windows(B, H, Hkv, Sq, Sk):
+    """csrc/attn.hip attn_win16_k (kernel id 16; what AUTO takes for head_dim 72, Sq, Sk <= 16, >= 256 (window, head) pairs): Hiera's 4 x 4 windows and their
+    q-pooled form, one wave per pair, strided q / k / v views of a fused qkv buffer"""
+    hd = 72
+    W = (H + 2 * Hkv) * hd
+    S = max(Sq, Sk)
+    qkv = bf(g(B, S, W, seed=B + Sq + Sk))
+    q, k, v = qkv[:, :Sq, :H * hd], qkv[:, :Sk, H * hd:(H + Hkv) * hd], qkv[:, :Sk, (H + Hkv) * hd:]
+    st = (S * W, W)
+    o = ops.attention(q, k, v, B, H, Hkv, Sq, Sk, hd, st, st, st, kernel=16)
+    ref = attn_ref(q.reshape(B, Sq, H, hd), k.reshape(B, Sk, Hkv, hd), v.reshape(B, Sk, Hkv, hd), False)
+    assert torch.isfinite(o.float()).all() and rel(o, ref) <= ATTN_TOL
+    auto = ops.attention(q, k, v, B, H, Hkv, Sq, Sk, hd, st, st, st)
+    if B * H >= 256:
+        assert torch.equal(auto, o)
+    else:
+        assert rel(auto, ref) <= ATTN_TOL
+    with pytest.raises(_lib.UfvError):
+        ops.attention(q, k, v, B, H, Hkv, Sq, Sk, hd, st, st, st, causal=True, kernel=16)
+
+
 def test_attention_spike_forces_rescale():
     # one key dominates late in the sequence -> running max jumps (online-softmax rescale path)
     B, H, S, hd = 1, 2, 256, 72

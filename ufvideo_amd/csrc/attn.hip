@@ -1074,6 +1074,105 @@ __global__ __launch_bounds__(256) void attn_fewkeys(AttnArgs a) {
         *reinterpret_cast<bf16x4*>(op + d) = (bf16x4){(bf16)(acc[d] * inv), (bf16)(acc[d + 1] * inv), (bf16)(acc[d + 2] * inv), (bf16)(acc[d + 3] * inv)};
 }
 
+// ---- small windows (Sq <= 16, Sk <= 16, head_dim 72, non-causal): Hiera's 4 x 4 windows and their q-pooled form.  One WAVE per (window, head): the 64-key tiles of
+// the flash kernels spend 16 x 64 MFMA slots on 16 x 16 (or 4 x 16) problems and the launch becomes thousands of nearly empty blocks (350 us per call at 8192 windows x 4
+// heads; 1 ms in the generic kernel for the pooled form).  Here Q, K and V^T of the pair sit in 7 KB of LDS; lane (q = l & 15, g = l >> 4) computes the scores of keys
+// g, g + 4, g + 8, g + 12 with v_dot2c_f32_bf16, the softmax runs over the 4 lanes of a query, P (bf16, as in the flash kernels) goes back through LDS, and the lane
+// produces head dims 18 g .. 18 g + 17 of its query.
+__global__ __launch_bounds__(256) void attn_win16_k(AttnArgs a) {
+    constexpr int HD = 72, CH = HD / 8;                              // 9 chunks of 8 per row
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    __shared__ __attribute__((aligned(16))) bf16 lq[4][16 * HD], lk[4][16 * HD], lvt[4][HD * 16], lp[4][16 * 16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.B * a.Hq) return;                                  // (no block-wide barrier below: a wave only touches its own LDS slices)
+    const int b = pair / a.Hq, hq = pair % a.Hq, hkv = hq / (a.Hq / a.Hkv);
+    const bf16* qp = a.q + b * a.q_bs + hq * HD;
+    const bf16* kp = a.k + b * a.k_bs + hkv * HD;
+    const bf16* vp = a.v + b * a.v_bs + hkv * HD;
+    bf16 *q_ = lq[wave], *k_ = lk[wave], *vt = lvt[wave], *p_ = lp[wave];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = lane + 64 * i;
+        if (c < 16 * CH) {
+            const int r = c / CH, cc = c % CH;
+            *reinterpret_cast<bf16x8*>(q_ + r * HD + cc * 8) = *reinterpret_cast<const bf16x8*>(qp + (int64_t)min(r, a.Sq - 1) * a.q_ss + cc * 8);
+            *reinterpret_cast<bf16x8*>(k_ + r * HD + cc * 8) = *reinterpret_cast<const bf16x8*>(kp + (int64_t)min(r, a.Sk - 1) * a.k_ss + cc * 8);
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vp + (int64_t)min(r, a.Sk - 1) * a.v_ss + cc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vt[(cc * 8 + j) * 16 + r] = r < a.Sk ? vv[j] : (bf16)0.f;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int q = lane & 15, g = lane >> 4;
+    float sc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+        const bf16x8 qv = *reinterpret_cast<const bf16x8*>(q_ + q * HD + cc * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(k_ + (g + 4 * j) * HD + cc * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                sc[j] = __builtin_amdgcn_fdot2_f32_bf16(bf2{qv[2 * e], qv[2 * e + 1]}, bf2{kv[2 * e], kv[2 * e + 1]}, sc[j], false);
+        }
+    }
+    const float sl2 = a.scale * 1.4426950408889634f;
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = (g + 4 * j < a.Sk) ? sc[j] * sl2 : -INFINITY;
+        m = fmaxf(m, sc[j]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float p = __builtin_amdgcn_exp2f(sc[j] - m);
+        l += p;
+        p_[q * 16 + g + 4 * j] = (bf16)p;
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(p_ + q * 16), p1 = *reinterpret_cast<const bf16x8*>(p_ + q * 16 + 8);
+    const float inv = 1.0f / l;
+    if (q < a.Sq) {
+        bf16* op = a.o + b * a.o_bs + (int64_t)q * a.o_ss + hq * HD + 18 * g;
+#pragma unroll
+        for (int dd = 0; dd < 18; dd += 2) {
+            float o2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16* vr = vt + (18 * g + dd + t) * 16;
+                const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vr), v1 = *reinterpret_cast<const bf16x8*>(vr + 8);
+                float acc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2_f32_bf16(bf2{p0[2 * e], p0[2 * e + 1]}, bf2{v0[2 * e], v0[2 * e + 1]}, acc, false);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2_f32_bf16(bf2{p1[2 * e], p1[2 * e + 1]}, bf2{v1[2 * e], v1[2 * e + 1]}, acc, false);
+                o2[t] = acc * inv;
+            }
+            *reinterpret_cast<bf2*>(op + dd) = bf2{(bf16)o2[0], (bf16)o2[1]};
+        }
+    }
+}
+
+static bool win16_ok(const AttnArgs& a, bool aligned) {
+    return aligned && a.hd == 72 && a.Sq <= 16 && a.Sk <= 16 && a.Sq >= 1 && a.Sk >= 1 && a.Hq % a.Hkv == 0;
+}
+
+static int launch_win16(const AttnArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(attn_win16_k, dim3(cdiv(a.B * a.Hq, 4)), dim3(256), 0, st, a);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
 // causal head_dim 128 with a key split over two wave groups per block (see attn_fwd_mfma NG)
 template <int NW>
 int launch_mfma_split2(const AttnArgs& a, hipStream_t st) {
@@ -1164,6 +1263,10 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
                          (q_bs % 8 == 0) && (k_bs % 8 == 0) && (v_bs % 8 == 0) && (o_bs % 4 == 0);
     const bool hd_ok = (hd == 64 || hd == 72 || hd == 80 || hd == 96 || hd == 128);
     const bool mfma_ok = aligned && hd_ok;
+    if (kernel == 16 || (kernel == 0 && !causal && win16_ok(a, aligned) && (int64_t)B * Hq >= 256)) {
+        if (causal || !win16_ok(a, aligned)) { ufv_set_error("ufv_attention: kernel 16 is built for non-causal head_dim 72 with Sq, Sk <= 16 and aligned rows"); return UFV_EUNSUPPORTED; }
+        return launch_win16(a, st);
+    }
     if ((kernel == 1 || kernel == 3) && !mfma_ok) {
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
