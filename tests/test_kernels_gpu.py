@@ -266,6 +266,16 @@ def test_causal_hd128_prefill_kernel_bit_identical_to_the_plain_kernel():
         assert torch.equal(new, old), (Hq, Hkv, S, int((new != old).sum()))
         if S >= 128:
             assert torch.equal(ops.attention(qd, kd, vd, 1, Hq, Hkv, S, S, hd, *st, causal=True), old)           # AUTO takes it
+            # the training forward (same kernel + the log2-domain log-sum-exp per (head, query) written from its epilogue): same output bits, lse against fp32
+            o2 = torch.empty(S, Hq * hd, device=DEV, dtype=torch.bfloat16)
+            lse = torch.full((Hq, S), float("nan"), device=DEV)
+            ops.attention_causal_lse(qd, kd, vd, o2, lse, S, Hq, Hkv, hd)
+            assert torch.equal(o2, old)
+            qf = qkv[:, :Hq * hd].float().view(S, Hq, hd)
+            kf = qkv[:, Hq * hd:(Hq + Hkv) * hd].float().view(S, Hkv, hd).repeat_interleave(Hq // Hkv, 1)
+            sc = torch.einsum("shd,thd->hst", qf, kf) * hd ** -0.5
+            sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool, device=DEV), 1), float("-inf"))
+            assert (lse - torch.logsumexp(sc, -1) / math.log(2.0)).abs().max() < 2e-3
         ref = attn_ref(qkv[:, :Hq * hd].view(1, S, Hq, hd), qkv[:, Hq * hd:(Hq + Hkv) * hd].view(1, S, Hkv, hd), qkv[:, (Hq + Hkv) * hd:].view(1, S, Hkv, hd), True)
         assert torch.isfinite(new.float()).all() and rel(new, ref) <= 2 * ATTN_TOL
     # outside its envelope: refused by id 15, served by the other kernels under AUTO (MHA, one kv head, batch > 1, a query offset)

@@ -66,6 +66,8 @@ MAXFLY = 15                                                         # LDS instru
 S_KR, S_VR, S_QR, S_OR = 84, 88, 92, 96
 S_CNT = 38
 S_REM, S_OSOFF, S_PAR, S_QV = 84, 85, 86, 87       # compute-only (the K descriptor's registers of the loader waves)
+S_LSE = 88                                         # s[88:89], compute-only (the V descriptor's registers of the loader waves): lse pointer
+S_LSEOFF, S_ROWS = 80, 77                          # (= S_TMP3, S_DELTA: free between the last tile's set-up and the next item)
 S_STG = 39                                      # holds STG        # buffer descriptors (4 SGPRs each)
 S_ANY = 82                                      # s[82:83]: rescale decision mask
 
@@ -227,6 +229,8 @@ def build(simple=False):
         (S_WAVE, "wave"), (S_BID, "bid"), (S_G, "grid"))]
     ins += [f"v_mov_b32 {vr(TA)}, %[scale]", f"v_mul_f32 {vr(TA)}, 0x3fb8aa3b, {vr(TA)}", "s_nop 0", f"v_readfirstlane_b32 {sr(S_SL2)}, {vr(TA)}",
             f"s_mov_b32 {sr(S_ROUND)}, 0", f"s_mov_b32 {sr(S_STG)}, {STG}", f"s_mov_b32 {sr(S_VALID)}, 0",
+            # optional fp32 [Hq, S] output: log2-domain log-sum-exp per (head, query) for the fused backward (0 = none; the stamps build uses the operand for its buffer)
+            f"s_mov_b32 {sr(S_LSE)}, {'0' if STAMPS else '%[stp0]'}", f"s_mov_b32 {sr(S_LSE + 1)}, {'0' if STAMPS else '%[stp1]'}",
             f"v_mbcnt_lo_u32_b32 {vr(LANE)}, -1, 0", f"v_mbcnt_hi_u32_b32 {vr(LANE)}, -1, {vr(LANE)}"]
     for i in ins:
         e(i)
@@ -398,6 +402,8 @@ def build(simple=False):
     e(f"s_sub_u32 {sr(S_REM)}, {sr(S_TQ)}, {sr(S_CNT)}")             # barriers this wave still owes the item after its last tile
     e(f"s_add_u32 {sr(S_NBASE)}, {sr(S_NBASE)}, {sr(S_TQ)}")
     e(f"s_mul_i32 {sr(S_OSOFF)}, {sr(S_Q0ROW)}, {sr(S_OSS)}")
+    e(f"s_mul_i32 {sr(S_LSEOFF)}, {sr(S_HEAD)}, {sr(S_S)}"); e(f"s_add_u32 {sr(S_LSEOFF)}, {sr(S_LSEOFF)}, {sr(S_Q0ROW)}"); e(f"s_lshl_b32 {sr(S_LSEOFF)}, {sr(S_LSEOFF)}, 2")
+    e(f"s_sub_u32 {sr(S_ROWS)}, {sr(S_S)}, {sr(S_Q0ROW)}")                # valid rows of this unit (>= 32 except in the last slice)
     e(f"s_add_u32 {sr(S_ROUND)}, {sr(S_ROUND)}, 1")
     item_decode(G, loader=False)
     nonext, pdone = G.label("NONEXT"), G.label("PDONE")
@@ -421,6 +427,7 @@ def build(simple=False):
     d = [TA, TB, TC, TD, T0]
     for i in [f"v_mov_b32 {vr(T1)}, {vr(LRUN)}", "s_nop 1", f"v_permlane32_swap_b32 {vr(LRUN)}, {vr(T1)}", f"v_add_f32 {vr(LRUN)}, {vr(LRUN)}, {vr(T1)}",
               # (lanes 0-31 now hold lo + hi in LRUN?  swap: LRUN = [lo, lo'], T1 = [hi, hi'] where primed = the other half's value -> lo + hi in both)
+              "LSE_HERE",
               f"v_div_scale_f32 {vr(d[0])}, {sr(S_ANY, 2)}, {vr(LRUN)}, {vr(LRUN)}, 1.0", f"v_rcp_f32 {vr(d[1])}, {vr(d[0])}", "s_nop 0",
               f"v_fma_f32 {vr(d[2])}, -{vr(d[0])}, {vr(d[1])}, 1.0", f"v_fmac_f32 {vr(d[1])}, {vr(d[2])}, {vr(d[1])}",
               f"v_div_scale_f32 {vr(d[2])}, vcc, 1.0, {vr(LRUN)}, 1.0", f"v_mul_f32 {vr(d[3])}, {vr(d[2])}, {vr(d[1])}",
@@ -429,6 +436,18 @@ def build(simple=False):
               f"v_div_fmas_f32 {vr(d[0])}, {vr(d[0])}, {vr(d[1])}, {vr(d[3])}", f"v_div_fixup_f32 {vr(INV)}, {vr(d[0])}, {vr(LRUN)}, 1.0",
               f"v_cmp_lt_f32 vcc, 0, {vr(LRUN)}", "s_nop 1", f"v_cndmask_b32 {vr(INV)}, 0, {vr(INV)}, vcc",
               f"v_accvgpr_read_b32 {vr(S(0, 6))}, {ar(A_OOFF)}"]:
+        if i == "LSE_HERE":
+            nolse = G.label("NOLSE")
+            for j in [f"s_cmp_eq_u64 {sr(S_LSE, 2)}, 0", f"s_cbranch_scc1 {nolse}",
+                      # lse[head][q0 + l31] = m + log2(l) from the lanes of the first key half, rows < S
+                      f"s_mov_b32 {sr(S_QR)}, {sr(S_LSE)}", f"s_and_b32 {sr(S_QR + 1)}, {sr(S_LSE + 1)}, 0xffff", f"s_mul_i32 {sr(S_TMP)}, {sr(S_R)}, {sr(S_HKV)}",
+                      f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_S)}", f"s_lshl_b32 {sr(S_QR + 2)}, {sr(S_TMP)}, 2", f"s_mov_b32 {sr(S_QR + 3)}, 0x20000",
+                      f"v_log_f32 {vr(T0)}, {vr(LRUN)}", f"v_accvgpr_read_b32 {vr(TB)}, {ar(A_L31)}", "s_nop 0", f"v_add_f32 {vr(T0)}, {vr(MRUN)}, {vr(T0)}",
+                      f"v_cmp_gt_u32 {sr(S_ANY, 2)}, {sr(S_ROWS)}, {vr(TB)}", f"v_lshlrev_b32 {vr(TB)}, 2, {vr(TB)}", "s_nop 3", f"s_mov_b32 {sr(S_ANY + 1)}, 0",
+                      f"s_mov_b64 {sr(S_TMP, 2)}, exec", f"s_mov_b64 exec, {sr(S_ANY, 2)}", "s_nop 1",
+                      f"buffer_store_dword {vr(T0)}, {vr(TB)}, {sr(S_QR, 4)}, {sr(S_LSEOFF)} offen", f"s_mov_b64 exec, {sr(S_TMP, 2)}", "s_nop 1", f"{nolse}:"]:
+                e(j)
+            continue
         e(i)
     # 16-byte stores: the two key halves of a query (lanes l and l + 32) hold interleaved groups of 4 head-dim values; one permlane32 swap per register pair
     # gives the low lane d = 8 j' .. 8 j' + 7 of the even group and the high lane those of the odd group (two banks of temporaries, alternating)

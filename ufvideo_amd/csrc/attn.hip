@@ -1339,9 +1339,8 @@ extern "C" int ufv_attention_causal_lse(const void* q, int64_t q_ss, const void*
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.o = (bf16*)o;
     a.q_bs = 0; a.q_ss = q_ss; a.k_bs = 0; a.k_ss = k_ss; a.v_bs = 0; a.v_ss = v_ss; a.o_bs = 0; a.o_ss = o_ss;
     a.B = 1; a.Hq = Hq; a.Hkv = Hkv; a.Sq = S; a.Sk = S; a.hd = hd; a.scale = scale; a.q_pos0 = 0; a.lse = lse;
-    // the same bits as ufv_attention's causal hd-128 path: where that takes the kernel of attn_c128.inc (which writes no log-sum-exp) this one takes the
-    // plain kernel, whose arithmetic attn_c128.inc repeats operation for operation; elsewhere the same kernel choice
-    if (c128_shape_ok(a) && S >= C128_MIN_S) return launch_mfma<128, 4>(a, 1, reinterpret_cast<hipStream_t>(stream));
+    // the same kernel choice (and bits) as ufv_attention's causal hd-128 path; attn_c128.inc writes the log-sum-exp from its epilogue
+    if (c128_shape_ok(a) && S >= C128_MIN_S) return launch_c128(a, reinterpret_cast<hipStream_t>(stream));
     if (split2_pays(S, Hq, 1, 0)) return launch_mfma_split2<4>(a, reinterpret_cast<hipStream_t>(stream));
     return launch_mfma<128, 4>(a, 1, reinterpret_cast<hipStream_t>(stream));
 }
