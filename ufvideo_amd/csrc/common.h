@@ -41,13 +41,17 @@ void ufv_set_error(const char* fmt, ...);
 // ---- activations ----------------------------------------------------------------------
 enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_RELU = 4, ACT_QUICK_GELU = 5, ACT_SIGMOID = 6 };
 
+// GELU (tanh form), 0.5 x (1 + tanh u) with u = sqrt(2/pi) (x + 0.044715 x^3), written as x / (1 + exp(-2u)): the same function (0.5 (1 + tanh u) is the
+// logistic of 2u) in one v_exp_f32 + one v_rcp_f32 and no branch.  libm's tanhf takes a polynomial or an exp path by magnitude, so a wave with both kinds of
+// lanes ran both: the epilogue of the ViT's fc1 GEMM (80 M activations per call) cost 35-70 us by DATA on a 155 us GEMM (tools/lab/gelu_data_probe.py).
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
-        case ACT_GELU_TANH: {
-            const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-            float u = k0 * (x + k1 * x * x * x);
-            return 0.5f * x * (1.0f + tanhf(u));
-        }
+        case ACT_GELU_TANH: return gelu_tanh(x);
         case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
         case ACT_SILU: return x / (1.0f + __expf(-x));
         case ACT_RELU: return x > 0.f ? x : 0.f;
@@ -59,10 +63,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
 
 template <int ACT>
 __device__ __forceinline__ float act_apply_t(float x) {
-    if (ACT == ACT_GELU_TANH) {
-        const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-        return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));
-    }
+    if (ACT == ACT_GELU_TANH) return gelu_tanh(x);
     if (ACT == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
     if (ACT == ACT_SILU) return x / (1.0f + __expf(-x));
     if (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
