@@ -46,6 +46,14 @@ def test_fused_norm_quant_equals_norm_then_quant():
         qa = ops.rmsnorm(x, w, 1e-6, quant=True)
         q, s = ops.quantize_fp8(ops.rmsnorm(x, w, 1e-6))
         assert torch.equal(qa.q, q) and torch.equal(qa.scale, s)
+    # long inputs take the pipelined persistent form of the fused LayerNorm + quantiser (csrc/quant.hip layernorm_fp8_pipe_k): same codes and scales
+    for M, D in ((18432, 1152), (5003, 144)):
+        x = (torch.randn(M, D + 8, generator=g) * 2).to(DEV)[:, 4:4 + D]
+        w = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV); b = (0.1 * torch.randn(D, generator=g)).to(DEV)
+        for xx in (x, x.to(torch.bfloat16)):
+            qa = ops.layernorm(xx, w, b, 1e-6, quant=True)
+            q, s = ops.quantize_fp8(ops.layernorm(xx, w, b, 1e-6))
+            assert torch.equal(qa.q, q) and torch.equal(qa.scale, s)
     # single-pass (K <= 8192) and two-pass (large K / f32) row quantisers agree with the restatement
     for K in (8192, 18944):
         xb = (torch.randn(9, K, generator=g) * 3).to(torch.bfloat16)

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void norm_fp8_k(const void* __restrict__ x, in
         if (lane + 64 * i < nv) {
             v[i] = ld4<XDT>(x, (int64_t)row * ldx + 4 * (lane + 64 * i));
             if (RMS) sum += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-            else sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            else sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];            // layernorm_k's order: the fused form rounds exactly as norm + quantise
         }
     float mean = 0.f, rstd;
     if (RMS) {
@@ -153,6 +153,81 @@ __global__ __launch_bounds__(256) void norm_fp8_k(const void* __restrict__ x, in
         }
 }
 
+// Pipelined form of norm_fp8_k<XDT, false> for long inputs (the ViT's 18 432 x 1152 stream under set_gemm_dtype("fp8")): persistent blocks, a wave walks rows
+// g, g + G, ... and requests the next row before it reduces, normalises and quantises the current one (csrc/ops.hip layernorm_pipe_k); weight / bias staged once
+// per block in LDS.  The same arithmetic in the same order per row: bit-identical.
+template <int XDT, int NV>
+__global__ __launch_bounds__(256) void layernorm_fp8_pipe_k(const void* __restrict__ x, int ldx, uint8_t* __restrict__ q, int64_t ldq, float* __restrict__ scale,
+                                                            const float* __restrict__ w, const float* __restrict__ b, int M, int D, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float lnq_wb[];
+    const int lane = threadIdx.x & 63, nv = D >> 2;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        reinterpret_cast<f32x4*>(lnq_wb)[i] = reinterpret_cast<const f32x4*>(w)[i];
+        reinterpret_cast<f32x4*>(lnq_wb + D)[i] = b ? reinterpret_cast<const f32x4*>(b)[i] : f32x4{0, 0, 0, 0};
+    }
+    __syncthreads();
+    const int G = gridDim.x * 4;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    f32x4 v[NV], nx[NV];
+    if (row < M) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < nv) v[i] = ld4<XDT>(x, (int64_t)row * ldx + 4 * (lane + 64 * i));
+    }
+    while (row < M) {
+        const int nrow = row + G;
+        if (nrow < M) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (lane + 64 * i < nv) nx[i] = ld4<XDT>(x, (int64_t)nrow * ldx + 4 * (lane + 64 * i));
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < nv) sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];            // layernorm_k's order: the fused form rounds exactly as norm + quantise
+        const float mean = wave_sum(sum) / D;
+        float qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < nv)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[i][j] - mean;
+                    qq += d * d;
+                }
+        const float rstd = rsqrtf(wave_sum(qq) / D + eps);
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < nv) {
+                const int c = 4 * (lane + 64 * i);
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(lnq_wb + c);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(lnq_wb + D + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float y = (v[i][j] - mean) * rstd * ww[j] + bb[j];
+                    v[i][j] = (float)(bf16)y;
+                    amax = fmaxf(amax, fabsf(v[i][j]));
+                }
+            }
+        amax = wave_max(amax);
+        const float s = amax > 0.f ? amax / E4M3_MAX : 1.0f;
+        const float inv = 1.0f / s;
+        if (lane == 0) scale[row] = s;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (lane + 64 * i < nv) {
+                int w0 = 0;
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w0, true);
+                *reinterpret_cast<int*>(q + (int64_t)row * ldq + 4 * (lane + 64 * i)) = w0;
+            }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = nx[i];
+        row = nrow;
+    }
+}
+
 __global__ void dequantize_fp8_k(const uint8_t* __restrict__ q, int64_t ldq, const float* __restrict__ scale, float* __restrict__ out,
                                  int64_t ldo, int M, int K) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -193,6 +268,15 @@ extern "C" int ufv_layernorm_fp8(const void* x, int x_dtype, int ldx, void* q, i
     UFV_REQUIRE(x && q && scale && w && M > 0 && D > 0, "ufv_layernorm_fp8: bad arguments");
     UFV_REQUIRE(D % 4 == 0 && D <= 4096 && ldx % 4 == 0 && ldq % 4 == 0, "ufv_layernorm_fp8: D=%d must be a multiple of 4 and <= 4096", D);
     dim3 g((M + 3) / 4), blk(256);
+    if (D <= 1280 && M >= 4096 && (x_dtype == UFV_DT_F32 || x_dtype == UFV_DT_BF16)) {          // long inputs: the pipelined persistent form (as ufv_layernorm)
+        const int blocks = M / 16 < 1024 ? M / 16 : 1024;
+        if (x_dtype == UFV_DT_F32)
+            hipLaunchKernelGGL((layernorm_fp8_pipe_k<UFV_DT_F32, 5>), dim3(blocks), blk, 2 * D * sizeof(float), ST(stream), x, ldx, (uint8_t*)q, ldq, scale, w, b, M, D, eps);
+        else
+            hipLaunchKernelGGL((layernorm_fp8_pipe_k<UFV_DT_BF16, 5>), dim3(blocks), blk, 2 * D * sizeof(float), ST(stream), x, ldx, (uint8_t*)q, ldq, scale, w, b, M, D, eps);
+        UFV_CHECK_LAUNCH();
+        return UFV_OK;
+    }
     if (x_dtype == UFV_DT_F32) hipLaunchKernelGGL((norm_fp8_k<UFV_DT_F32, false>), g, blk, 0, ST(stream), x, ldx, (uint8_t*)q, ldq, scale, w, b, M, D, eps);
     else if (x_dtype == UFV_DT_BF16) hipLaunchKernelGGL((norm_fp8_k<UFV_DT_BF16, false>), g, blk, 0, ST(stream), x, ldx, (uint8_t*)q, ldq, scale, w, b, M, D, eps);
     else { ufv_set_error("ufv_layernorm_fp8: unsupported input dtype %d", x_dtype); return UFV_EINVAL; }
