@@ -357,23 +357,35 @@ def build(simple=False):
     for k in range(NPIECE):
         for i in dma_piece(KVR, VOFFR(k), "0", [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k}"]):
             e(i)
-    for k in range(QPIECES):
+    # Only what the first QK^T needs goes out first (tile 0 + unit 0's rows: 14 operations, 14 MB chip-wide); the other 23 (unit 1 / 2 rows, tile 1, half of
+    # tile 2) are issued behind the first MFMAs.  With all 37 up front every block's first bytes queue behind 41 MB of everybody's later ones: the kernel
+    # started ~5 k cycles later (lab, same box: 83 -> 79 us).  UFV_P2_OPT=early23 restores the old order.
+    LATE = "early23" not in OPT
+    for k in range(5 if LATE else QPIECES):
         for i in dma_piece(QR, VOFFR(k), sr(S_QSOFF), [f"s_add_u32 m0, {sr(S_QST)}, {1024 * k}"]):
             e(i)
     e(f"s_add_u32 {sr(S_Q2OFF)}, {sr(S_QSOFF)}, {sr(S_T64)}")
-    for i in q2_fetch():
-        if i[0] == "VMEM":
-            e(i[1])
-    for k in range(NPIECE):
-        for i in dma_piece(KVR, VOFFR(k), sr(S_T64), [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k + STG}"]):
-            e(i)
-    e(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_T64)}, 1")
-    for k in range(5):
-        for i in dma_piece(KVR, VOFFR(k), sr(S_TMP), [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k + 2 * STG}"]):
-            e(i)
+
+    def rest23():
+        for k in range(5 if LATE else QPIECES, QPIECES):
+            for i in dma_piece(QR, VOFFR(k), sr(S_QSOFF), [f"s_add_u32 m0, {sr(S_QST)}, {1024 * k}"]):
+                e(i)
+        for i in q2_fetch():
+            if i[0] == "VMEM":
+                e(i[1])
+        for k in range(NPIECE):
+            for i in dma_piece(KVR, VOFFR(k), sr(S_T64), [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k + STG}"]):
+                e(i)
+        e(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_T64)}, 1")
+        for k in range(5):
+            for i in dma_piece(KVR, VOFFR(k), sr(S_TMP), [f"s_add_u32 m0, {sr(S_DST)}, {1024 * k + 2 * STG}"]):
+                e(i)
+    if not LATE:
+        rest23()
     e(f"s_mul_i32 {sr(S_T4)}, {sr(S_SS)}, 96")
-    e(f"s_add_u32 {sr(S_QSOFF)}, {sr(S_QSOFF)}, {sr(S_T4)}")            # -> rows of pass 1
-    e(f"s_add_u32 {sr(S_Q2OFF)}, {sr(S_Q2OFF)}, {sr(S_T4)}")
+    if not LATE:
+        e(f"s_add_u32 {sr(S_QSOFF)}, {sr(S_QSOFF)}, {sr(S_T4)}")            # -> rows of pass 1
+        e(f"s_add_u32 {sr(S_Q2OFF)}, {sr(S_Q2OFF)}, {sr(S_T4)}")
     # the rest of the per-lane addresses is computed while the first tiles are in flight.  Nothing is zeroed: every accumulator chain of a
     # pass starts from the constant 0, and what the dummy PV / drain of pass 0 computes from uninitialised registers is never stored
     ins2 = [
@@ -398,7 +410,7 @@ def build(simple=False):
         e(i)
     # the first QK^T needs tile 0 and unit 0's Q rows (staging pieces 0..4): 14 of the 37 operations; the memory system serves a wave's requests
     # in order, so the rest (Q pieces 5..8, unit 2's rows, tile 1, half of tile 2 = 23 operations) stays in flight behind the first MFMAs
-    e("s_waitcnt vmcnt(23) lgkmcnt(0)")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)" if LATE else "s_waitcnt vmcnt(23) lgkmcnt(0)")
     e("s_barrier")
     for i in q_load(0, (TA, TB)):
         e(i)
@@ -407,6 +419,10 @@ def build(simple=False):
     e("s_waitcnt lgkmcnt(0)")
     for m in mfma_qk(0):
         e(m)
+    if LATE:
+        rest23()
+        e(f"s_add_u32 {sr(S_QSOFF)}, {sr(S_QSOFF)}, {sr(S_T4)}")            # -> rows of pass 1
+        e(f"s_add_u32 {sr(S_Q2OFF)}, {sr(S_Q2OFF)}, {sr(S_T4)}")
     e("s_waitcnt vmcnt(19)")                  # unit 1's rows (pieces 5..8); unit 2's fragments are loaded in period (0, 0), as in every pass
     for i in q_load(1, (TA, TB)):
         e(i)
