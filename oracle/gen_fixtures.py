@@ -341,6 +341,9 @@ def build_ref_model(workdir, projector="spatial_conv"):
     return model, cfg, tok
 
 
+GEN_SCALE = 3.75        # fx_model: decoder-matrix scale of the second pair of greedy sequences (searched on the oracle: 8 + 6 distinct ids, widest top-1 margins)
+
+
 def fx_model(workdir):
     """End-to-end on a tiny model through the REFERENCE's own classes: splice, forward, generate."""
     print("[model: splice / forward / generate]")
@@ -448,6 +451,29 @@ def fx_model(workdir):
         toks2_o, _ = O.greedy_generate(sd, TINY_LLM, out["sp_vid_only_nolab_emb"], out["sp_vid_only_nolab_am"], 6, (298,))
         assert gen2["output"].tolist() == toks2_o.tolist(), (gen2["output"].tolist(), toks2_o.tolist())
         out["gen2_tokens"] = gen2["output"]
+        # ---- generate again with the decoder's matrices x GEN_SCALE.  With the weights above both greedy sequences are ONE repeated id
+        # ([235] x 8, [1] x 6), which a broken KV cache or a stuck position counter would also emit.  Scaled, the reference walks through
+        # 8 and 6 DIFFERENT ids (top-1 margins >= 3 % of the largest logit at every step, so the sequence does not hinge on a rounding).
+        scaled = [p_ for n_, p_ in model.named_parameters() if n_.startswith("model.layers.") and p_.ndim == 2]
+        saved = [p_.detach().clone() for p_ in scaled]
+        for p_ in scaled:
+            p_.mul_(GEN_SCALE)
+        gs = model.generate(ids, attention_mask=am, images=c["images"], masks=c["masks"], frame=c["frame"],
+                            ann_indices=c["ann"], frame_nums=c["fn"], images_sam=sam, offset=[0, 1], masks_list=None,
+                            label_list=torch.zeros(56, 56), do_sample=False, max_new_tokens=8, use_cache=True,
+                            pad_token_id=0, eos_token_id=298)["output"]
+        gs2 = model.generate(ids2, attention_mask=torch.ones_like(ids2), images=c2["images"], images_sam=sam, offset=[0, 1],
+                             label_list=torch.zeros(56, 56), do_sample=False, max_new_tokens=6, use_cache=True,
+                             pad_token_id=0, eos_token_id=298)["output"]
+        for p_, s_ in zip(scaled, saved):
+            p_.copy_(s_)                   # (x 3.75 then / 3.75 is not the identity in fp32)
+        sds = {k: (v * GEN_SCALE if (k.startswith("model.layers.") and v.ndim == 2) else v) for k, v in sd.items()}      # (sd aliases the parameters: built after they are restored)
+        gs_o, _ = O.greedy_generate(sds, TINY_LLM, emb, am2, 8, eos_token_ids=(298,))
+        gs2_o, _ = O.greedy_generate(sds, TINY_LLM, out["sp_vid_only_nolab_emb"], out["sp_vid_only_nolab_am"], 6, (298,))
+        print("   generate (decoder matrices x %g) ref" % GEN_SCALE, gs.tolist(), gs2.tolist())
+        assert gs.tolist() == gs_o.tolist() and gs2.tolist() == gs2_o.tolist(), (gs_o.tolist(), gs2_o.tolist())
+        assert len(set(gs[0].tolist())) == 8 and len(set(gs2[0].tolist())) == 6, "the scaled sequences must not repeat an id"
+        out["gens_scale"] = np.float64(GEN_SCALE); out["gens_tokens"] = gs; out["gens2_tokens"] = gs2
         # text_hidden_fcs (a10)
         hfc = model.get_model().text_hidden_fcs[0](fo.hidden_states[-1])
         close(O.text_hidden_fcs(sd, fo.hidden_states[-1]), hfc, what="text_hidden_fcs")

@@ -27,6 +27,11 @@ def load_golden(name):
     return arrs, w
 
 
+def scaled_decoder(w, scale):
+    """The state dict of oracle/gen_fixtures.py's second generate() pair: every 2-D `model.layers.*` matrix x scale."""
+    return {k: (v * float(scale) if (k.startswith("model.layers.") and v.ndim == 2) else v) for k, v in w.items()}
+
+
 def t(a):
     return torch.from_numpy(np.asarray(a))
 

@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from conftest import load_golden, t, rel_err  # noqa: E402
+from conftest import load_golden, t, rel_err, scaled_decoder  # noqa: E402
 from oracle import ref_cpu as O  # noqa: E402
 from ufvideo_amd import ops  # noqa: E402
 from ufvideo_amd.model import (VideoReferQwen2Config, VideoReferQwen2ForCausalLM, UFVideoForCausalLM, SiglipVisionTower,  # noqa: E402
@@ -39,8 +39,10 @@ SAM_TINY = dict(embed_dim=16, num_heads=1, stages=(1, 2, 3, 1), global_att_block
                 window_pos_embed_bkg_spatial_size=(7, 7))
 
 
-def tiny_model(sam2_trunk=None, sam_seeds=None):
+def tiny_model(sam2_trunk=None, sam_seeds=None, decoder_scale=None):
     a, w = load_golden("model_tiny")
+    if decoder_scale is not None:
+        w = scaled_decoder(w, decoder_scale)
     cfg = VideoReferQwen2Config(**TINY_LLM, mm_vision_tower="siglip", mm_vision_select_layer=-2, mm_vision_select_feature="patch",
                                 mm_projector_type="spatial_conv", mm_hidden_size=64, mm_region_encoder_type="pooling",
                                 image_aspect_ratio="square", train_mask_decoder=False, sam_pretrained=None, sam_out_dim=256,
@@ -62,6 +64,36 @@ def tiny_model(sam2_trunk=None, sam_seeds=None):
     for mod in m.modules():
         mod.tokenizer = Tok()
     return m, a, w
+
+
+def test_generate_distinct_greedy_tokens_vs_reference_golden():
+    """generate() through the HIP path (prefill kernel, KV cache, one decode step per token) against the sequences the REFERENCE emits
+    with the decoder matrices x 3.75 (oracle/gen_fixtures.py GEN_SCALE): 8 and 6 ids, all different, which a stuck position counter, a
+    KV cache that drops or repeats a row, or a decode step that ignores the cache cannot reproduce (the unscaled goldens are one id
+    repeated).  Also with the HIP-graph decode path off / on, and cut short by max_new_tokens."""
+    a0, _ = load_golden("model_tiny")
+    m, a, w = tiny_model(decoder_scale=a0["gens_scale"])
+    video, frame, mask = t(a["video"]).to(DEV), t(a["frame"]).to(DEV), t(a["mask"]).to(DEV)
+    sam = torch.zeros(1, 4, 3, 8, 8, device=DEV)
+    ids = t(a["sp_vid_region_ids"]).to(DEV); am = torch.ones_like(ids)
+    kw = dict(images=[(video, "video")], masks=[mask], frame=[frame], ann_indices=[[[0], [1]]], frame_nums=[2], images_sam=sam, offset=[0, 1],
+              masks_list=None, label_list=torch.zeros(56, 56), do_sample=False, use_cache=True, pad_token_id=0, eos_token_id=298)
+    gold = a["gens_tokens"].tolist()
+    assert len(set(gold[0])) == 8
+    gen = m.generate(ids, attention_mask=am, max_new_tokens=8, **kw)
+    assert gen["output"].cpu().tolist() == gold and gen["pred_masks"] == []
+    assert m.generate(ids, attention_mask=am, max_new_tokens=5, **kw)["output"].cpu().tolist() == [gold[0][:5]]
+    assert m.generate(ids, attention_mask=am, max_new_tokens=8, decode_graph=False, **kw)["output"].cpu().tolist() == gold     # one C call per token
+    ids2 = t(a["sp_vid_only_ids"]).to(DEV)
+    gold2 = a["gens2_tokens"].tolist()
+    assert len(set(gold2[0])) == 6
+    gen2 = m.generate(ids2, attention_mask=torch.ones_like(ids2), images=[(video, "video")], images_sam=sam, offset=[0, 1],
+                      label_list=torch.zeros(56, 56), do_sample=False, max_new_tokens=6, pad_token_id=0, eos_token_id=298)
+    assert gen2["output"].cpu().tolist() == gold2
+    # the second sequence again right after the first (the cache object is reused: stale rows must not leak into the new prompt)
+    gen3 = m.generate(ids2, attention_mask=torch.ones_like(ids2), images=[(video, "video")], images_sam=sam, offset=[0, 1],
+                      label_list=torch.zeros(56, 56), do_sample=False, max_new_tokens=6, pad_token_id=0, eos_token_id=298)
+    assert gen3["output"].cpu().tolist() == gold2
 
 
 def test_alias_and_loud_failure():

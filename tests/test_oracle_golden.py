@@ -4,7 +4,7 @@ oracle as the checker for the HIP path."""
 import numpy as np
 import torch
 
-from conftest import load_golden, t, rel_err
+from conftest import load_golden, t, rel_err, scaled_decoder
 from oracle import ref_cpu as O
 
 TINY_VIT = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4, image_size=56,
@@ -159,6 +159,27 @@ def test_qwen2_forward_kv_and_generate():
     toks2, _ = O.greedy_generate(w, TINY_LLM, t(a["sp_vid_only_nolab_emb"]), t(a["sp_vid_only_nolab_am"]), 6, (298,))
     assert toks2.tolist() == a["gen2_tokens"].tolist()
     assert rel_err(O.text_hidden_fcs(w, t(a["fw_hidden_last"])), t(a["fcs_out"])) < TOL
+
+
+def test_generate_distinct_tokens_golden():
+    """The reference's greedy sequences with the decoder matrices x 3.75 (oracle/gen_fixtures.py GEN_SCALE): 8 and 6 DIFFERENT ids, so
+    a stuck position counter or a broken KV cache cannot reproduce them (the unscaled goldens are one id repeated).  fp32 oracle and
+    its bf16 mirror both walk the reference's sequence; the top-1 margins are >= 2.5 % of the largest logit at every step."""
+    a, w = load_golden("model_tiny")
+    ws = scaled_decoder(w, a["gens_scale"])
+    g1, g2 = a["gens_tokens"].tolist(), a["gens2_tokens"].tolist()
+    assert len(set(g1[0])) == 8 and len(set(g2[0])) == 6
+    for emb, am, n, gold in ((t(a["sp_vid_region_nolab_emb"]), t(a["sp_vid_region_nolab_am"]), 8, g1),
+                             (t(a["sp_vid_only_nolab_emb"]), t(a["sp_vid_only_nolab_am"]), 6, g2)):
+        toks, _ = O.greedy_generate(ws, TINY_LLM, emb, am, n, eos_token_ids=(298,))
+        assert toks.tolist() == gold
+        with O.bf16_mirror():
+            toks_m, _ = O.greedy_generate(ws, TINY_LLM, emb, am, n, eos_token_ids=(298,))
+        assert toks_m.tolist() == gold
+        full = torch.cat([emb, ws["model.embed_tokens.weight"].float()[toks[0]][None]], 1)
+        lg = O.qwen2_forward(ws, TINY_LLM, full, torch.ones(1, full.shape[1], dtype=torch.long))["logits"][0, emb.shape[1] - 1:-1]
+        top2 = lg.topk(2, -1).values
+        assert ((top2[:, 0] - top2[:, 1]).min() / lg.abs().max()).item() > 0.025
 
 
 def test_kv_cache_decode_equals_full_forward():
