@@ -25,8 +25,11 @@
  *    part waits for its predecessor's flag -- BOUNDED: if a predecessor is not scheduled within ~2^21
  *    polls (seconds; only possible when the launch's <= 256 blocks cannot all become resident beside
  *    another long-running kernel) the waiter sets the device's error word and goes on; that launch's
- *    tile is wrong, nothing hangs, and the next ufv_gemm on the device returns UFV_EHIP
- *    (ufv_gemm_error_state / ufv_gemm_clear_error).
+ *    tile is wrong, nothing hangs, and the next SPLIT-K launch on the device returns UFV_EHIP (the
+ *    word is read where the flag ring is handed out; unsplit GEMMs never wait on a turn and are not
+ *    gated).  ufv_gemm_error_state reads the word at any time -- a caller that needs the guarantee
+ *    per step checks it there (ufvideo_amd.train.DecoderTrainer.step does) -- and
+ *    ufv_gemm_clear_error resets it.
  */
 #ifndef UFV_H_
 #define UFV_H_

@@ -370,6 +370,24 @@ def test_lora_q_v_adapters_gradients_step_and_merge():
         losses.append(float(tr.forward_backward(emb, labels)[0]))
     assert losses[-1] < losses[0], losses
     assert all(torch.equal(b.w, w0) for b, w0 in zip(tr.layers, base_before))                     # the base weights are frozen
+    # a sync_to_model() BETWEEN steps (a periodic checkpoint) writes the merged view into the parameters and changes nothing of the run:
+    # next loss, gradients, masters and moments bit-identical to the same step without it, adapters still exported un-merged
+    snap = (lb.w.clone(), lb.master.clone(), lb.m.clone(), lb.v.clone())
+    tr.zero_grad(); l_a, _ = tr.forward_backward(emb, labels); g_a = lb.g.clone() if hasattr(lb, "g") else None
+    tr.sync_to_model()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(snap, (lb.w, lb.master, lb.m, lb.v)))
+    assert all(torch.equal(b.w, w0) for b, w0 in zip(tr.layers, base_before))
+    tr.zero_grad(); l_b, _ = tr.forward_backward(emb, labels)
+    assert float(l_a) == float(l_b)
+    if g_a is not None:
+        assert torch.equal(g_a, lb.g)
+    own_mid = dict(tr.model.named_parameters())
+    sd_mid = tr.export_lora_state_dict()
+    assert float(sd_mid["base_model.model.model.layers.0.self_attn.q_proj.lora_B.weight"].abs().max()) > 0          # not merged away
+    k0 = "model.layers.0.self_attn.q_proj.weight"
+    want0 = w[k0] + s * sd_mid["base_model.model.model.layers.0.self_attn.q_proj.lora_B.weight"].cpu() @ sd_mid["base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight"].cpu()
+    assert rel_err(own_mid[k0].float().cpu(), want0) < 1e-2
+    tr.zero_grad()
     sd = tr.export_lora_state_dict()
     assert len(sd) == 4 * L and sd["base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight"].shape == (r, D) and \
         sd["base_model.model.model.layers.1.self_attn.v_proj.lora_B.weight"].shape == (KV * hd, r)

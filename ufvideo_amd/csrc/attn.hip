@@ -1178,11 +1178,9 @@ template <int NW>
 int launch_mfma_split2(const AttnArgs& a, hipStream_t st) {
     constexpr int smem = 4 * Cfg<128>::STAGE;
     static_assert((size_t)NW * 64 * (Cfg<128>::DT * 16 + 2) * 4 <= (size_t)smem, "merge buffer must fit in the staging area");
-    static bool attr_set = false;
-    if (!attr_set) {
+    UFV_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<128, NW, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    );
     dim3 grid(cdiv(a.Sq, 32 * NW), a.Hq, a.B);
     hipLaunchKernelGGL((attn_fwd_mfma<128, NW, true, 2>), grid, dim3(NW * 128), smem, st, a);
     UFV_CHECK_LAUNCH();
@@ -1196,14 +1194,12 @@ static inline bool split2_pays(int Sq, int Hq, int B, int q_pos0) {
 template <int HD, int NW>
 int launch_mfma(const AttnArgs& a, int causal, hipStream_t st) {
     constexpr int smem = 2 * Cfg<HD>::STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    UFV_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<HD, NW, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma<HD, NW, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    );
     dim3 grid(cdiv(a.Sq, 32 * NW), a.Hq, a.B);
     if (causal)
         hipLaunchKernelGGL((attn_fwd_mfma<HD, NW, true>), grid, dim3(NW * 64), smem, st, a);
@@ -1216,14 +1212,12 @@ int launch_mfma(const AttnArgs& a, int causal, hipStream_t st) {
 template <int HD, int NW, bool PP>
 int launch_mfma_dma(const AttnArgs& a, int causal, hipStream_t st) {
     constexpr int smem = (PP ? 4 : 3) * (2 * 64 * HD * 2 + 256) + NW * 32 * (HD * 2 + 16);      // K/V ring + per-wave Q / O staging
-    static bool attr_set = false;
-    if (!attr_set) {
+    UFV_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_dma<HD, NW, true, PP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_dma<HD, NW, false, PP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    );
     const int nqt = cdiv(a.Sq, 32 * NW), groups = a.Hq * a.B, gper = (groups + 7) / 8;
     dim3 grid(8 * gper * nqt);
     if (causal) hipLaunchKernelGGL((attn_fwd_mfma_dma<HD, NW, true, PP>), grid, dim3(NW * 64), smem, st, a);
@@ -1235,11 +1229,9 @@ int launch_mfma_dma(const AttnArgs& a, int causal, hipStream_t st) {
 template <int HD, int NW, bool PP>
 int launch_pair(const AttnArgs& a, hipStream_t st) {
     constexpr int smem = 2 * (PP ? 4 : 3) * (2 * 64 * HD * 2 + 256);
-    static bool attr_set = false;
-    if (!attr_set) {
+    UFV_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pair<HD, NW, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
+    );
     const int groups = (a.Hq / 2) * a.B, gper = (groups + 7) / 8;
     hipLaunchKernelGGL((attn_fwd_pair<HD, NW, PP>), dim3(8 * gper), dim3(2 * NW * 64), smem, st, a);
     UFV_CHECK_LAUNCH();
@@ -1266,6 +1258,10 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
     if (kernel == 16 || (kernel == 0 && !causal && win16_ok(a, aligned) && (int64_t)B * Hq >= 256)) {
         if (causal || !win16_ok(a, aligned)) { ufv_set_error("ufv_attention: kernel 16 is built for non-causal head_dim 72 with Sq, Sk <= 16 and aligned rows"); return UFV_EUNSUPPORTED; }
         return launch_win16(a, st);
+    }
+    if ((kernel == 14 && hd != 72) || (kernel == 15 && hd != 128)) {      // the diagnostic ids of the two generated kernels name ONE head_dim each
+        ufv_set_error("ufv_attention: kernel %d is built for head_dim %d (hd=%d)", kernel, kernel == 14 ? 72 : 128, hd);
+        return UFV_EUNSUPPORTED;
     }
     if ((kernel == 1 || kernel == 3) && !mfma_ok) {
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);

@@ -360,13 +360,11 @@ extern "C" int ufv_attention_bwd_fused(const void* q, int64_t ldq, const void* k
     BwdArgs a;
     a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v; a.dO = (const bf16*)dO;
     a.ldq = ldq; a.ldkv = ldkv; a.lddo = lddo; a.lse = lse; a.delta = delta; a.S = S; a.Hq = Hq; a.Hkv = Hkv; a.scale = scale;
-    static bool attr_set = false;
     constexpr int SM_DQ = 2 * STAGE_DQ, SM_DKV = 2 * STAGE_DKV;
-    if (!attr_set) {
+    UFV_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_k), hipFuncAttributeMaxDynamicSharedMemorySize, SM_DQ);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_k), hipFuncAttributeMaxDynamicSharedMemorySize, SM_DKV);
-        attr_set = true;
-    }
+    );
     const int64_t nw = (int64_t)S * Hq;
     hipLaunchKernelGGL(attn_bwd_delta_k, dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, (const bf16*)dO, lddo, (const bf16*)o, ldo, S, Hq, delta);
     UFV_CHECK_LAUNCH();

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -36,6 +37,21 @@ void ufv_set_error(const char* fmt, ...);
             ufv_set_error(__VA_ARGS__); \
             return UFV_EINVAL;          \
         }                               \
+    } while (0)
+
+// Runs BODY once per DEVICE and call site (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: a process-wide `static bool` left the
+// kernels of a second device in the same process without it).  One bit per device ordinal in a 64-bit mask; two threads racing on a device's first launch
+// both run BODY, which is idempotent.
+#define UFV_ONCE_PER_DEVICE(...)                                          \
+    do {                                                                  \
+        static std::atomic<uint64_t> done_{0};                            \
+        int dev_ = 0;                                                     \
+        (void)hipGetDevice(&dev_);                                        \
+        const uint64_t bit_ = 1ull << (dev_ & 63);                        \
+        if (!(done_.load(std::memory_order_acquire) & bit_)) {            \
+            __VA_ARGS__                                                   \
+            done_.fetch_or(bit_, std::memory_order_release);              \
+        }                                                                 \
     } while (0)
 
 // ---- activations ----------------------------------------------------------------------

@@ -602,12 +602,10 @@ __global__ __launch_bounds__(256) void gemv1_nt(const bf16* __restrict__ a, cons
 
 template <bool F, bool S, int MT, bool Q>
 int launch_fast_mt(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    UFV_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<F, S, MT, Q>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Tile<MT>::SMEM_BYTES);
-        attr_set = true;
-    }
+    );
     const int tiles = cdiv(M, Tile<MT>::BM) * (N / BN);
     hipLaunchKernelGGL((gemm_nt_128<F, S, MT, Q>), dim3(tiles), dim3(256), Tile<MT>::SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
     UFV_CHECK_LAUNCH();
@@ -888,12 +886,10 @@ extern "C" int ufv_gemm_splitk(const void* A, int lda, const void* W, int ldw, v
         const int nk = K / BK, per = cdiv(nk, nsplit);
         splits = cdiv(nk, per);                                    // no empty slice
         e.ksplit = splits > 1 ? splits : 0;
-        static bool attr_set = false;
-        if (!attr_set) {
+        UFV_ONCE_PER_DEVICE(
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_128<true, false, 6, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, Tile<6>::SMEM_BYTES);
-            attr_set = true;
-        }
+        );
         const int tiles = cdiv(M, Tile<6>::BM) * (N / BN);
         hipLaunchKernelGGL((gemm_nt_128<true, false, 6, false>), dim3(tiles, splits), dim3(256), Tile<6>::SMEM_BYTES, st, A, W, e, M, N, K, lda, ldw);
         UFV_CHECK_LAUNCH();

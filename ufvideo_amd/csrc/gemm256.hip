@@ -29,11 +29,9 @@ static int launch256_t(const void* A, const void* W, const Epi& e, int M, int N,
         ufv_set_error("ufv_gemm: the stream-K split is not built for the SwiGLU epilogue (its tile counts are large anyway)");
         return UFV_EUNSUPPORTED;
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
+        UFV_ONCE_PER_DEVICE(
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM256);
-            attr_set = true;
-        }
+        );
         const int n_cu = pp_n_cu();
         const int tiles = cdiv(M, 256) * cdiv(N, 256);
         const int nk = K / (Q ? 128 : 64);

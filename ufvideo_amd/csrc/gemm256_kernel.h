@@ -689,12 +689,10 @@ static inline int pp_group(int tiles_m) { return tiles_m <= 16 ? tiles_m : cdiv(
 
 template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false>
 static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st, int ksplit = 1) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    UFV_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM256);
-        attr_set = true;
-    }
+    );
     using T = PP<MA0, MA1, NB1>;
     const int rem = N % T::BN;
     if (rem != 0 && rem != 128) {

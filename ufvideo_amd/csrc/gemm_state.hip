@@ -7,7 +7,8 @@
 //     (thousands), and since ticket bases only grow a stale value can never satisfy a `>=` wait;
 //   * a pinned host word the kernels set when a bounded turn wait expires (a part's predecessor was never scheduled: more blocks than
 //     the device could keep resident beside some other kernel).  The launch then finishes with a wrong tile instead of hanging, and the
-//     next ufv_gemm call on that device returns UFV_EHIP with the reason.
+//     next SPLIT-K launch on that device returns UFV_EHIP with the reason (ufv_splitk_acquire reads the word; unsplit GEMMs are not gated);
+//     ufv_gemm_error_state() reads it at any time.
 #include "common.h"
 #include "gemm_state.h"
 #include <mutex>

@@ -22,7 +22,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import ops, _lib
 
 
 def _ru(x, m):
@@ -316,7 +316,7 @@ class DecoderTrainer:
             for st in self.st:
                 st["u"] = torch.empty((S, 2 * self.Rp), device=dev, dtype=bf)              # A x of both adapters, kept for dB
         # scratch shared by all layers
-        W = max(2 * I, self.QW, D, H * hd)
+        W = max(2 * I, self.QW, D, H * hd, 2 * self.Rp if self.lora_bucket is not None else 0)      # (the LoRA backward transposes [S, 2 Rp] into inT / dyT)
         self.sc = dict(dxb=torch.empty((S, D), device=dev, dtype=bf), dxbT=torch.empty((D, Sp), device=dev, dtype=bf),
                        inT=torch.empty((W, Sp), device=dev, dtype=bf), dyT=torch.empty((W, Sp), device=dev, dtype=bf),
                        dact=torch.empty((S, I), device=dev, dtype=bf), dgu=torch.empty((S, 2 * I), device=dev, dtype=bf),
@@ -652,7 +652,12 @@ class DecoderTrainer:
         return out
 
     def step(self):
-        """Gradient exchange, global-norm clipping (HF Trainer max_grad_norm), AdamW on this rank's shard, all-gather."""
+        """Gradient exchange, global-norm clipping (HF Trainer max_grad_norm), AdamW on this rank's shard, all-gather.  Raises when a split-K GEMM of the
+        forward / backward pass left the device's error word set (a timed-out turn wait: that launch's tile is wrong, include/ufv.h Conventions)."""
+        err = _lib.load().ufv_gemm_error_state()
+        if err != 0:
+            raise _lib.UfvError(f"a split-K GEMM of this step timed out waiting for its turn (error word {err}): the gradients are not trustworthy; "
+                                f"ufv_gemm_clear_error() resets the word")
         self.t += 1
         self._exchange()
         shards = self._grad_shards()
@@ -707,15 +712,38 @@ class DecoderTrainer:
     def sync_to_model(self):
         """Writes the trained decoder weights (bf16 working copies of the fp32 masters) into the model's nn.Parameters under the
         reference's names, so that model.state_dict() / save paths export what was trained.  The projector / region-encoder parameters
-        are views of the trainer's buffer already.  Every rank holds the full bf16 weights after step(), so no communication."""
+        are views of the trainer's buffer already.  Every rank holds the full bf16 weights after step(), so no communication.
+        With LoRA adapters the parameters receive the MERGED view W + (alpha / r) B A (what peft's merge_and_unload would export) and
+        NOTHING of the trainer changes: the packed base weights stay frozen, B, its fp32 master and the Adam moments are untouched, so a
+        sync between two steps (a periodic checkpoint) does not alter the optimisation, and export_lora_state_dict() keeps returning the
+        adapters (the reference saves them un-merged: train.py:962 get_peft_state_maybe_zero_3)."""
         if self.lora_bucket is not None:
-            self._merge_lora()
+            self._write_lora_merged_params()
         if not self.train_decoder:
             return
         own = dict(self.model.named_parameters())
         with torch.no_grad():
             for k, v in self.export_state_dict().items():
                 own[k].data.copy_(v.to(own[k].dtype))
+
+    def _lora_targets(self):
+        cfg = self.cfg
+        H, KV, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        return (("q_proj", 0, H * hd), ("v_proj", (H + KV) * hd, (H + 2 * KV) * hd))
+
+    def _write_lora_merged_params(self):
+        """nn.Parameters of the adapted projections <- bf16(W + (alpha / r) B A); reads the trainer's buffers, writes none of them"""
+        lb, r, Rp = self.lora_bucket, self.lora_r, self.Rp
+        own = dict(self.model.named_parameters())
+        with torch.no_grad():
+            for i, b in enumerate(self.layers):
+                wqkv = b.view(b.w, "wqkv")
+                a = lb.view(lb.master, f"Acat.{i}")
+                for j, (nm, lo, hi) in enumerate(self._lora_targets()):
+                    bm = lb.view(lb.master, f"B{nm[0]}.{i}")
+                    delta = (bm[:, :r].float() @ a[j * Rp:j * Rp + r].float()) * self.lora_scale
+                    key = f"model.layers.{i}.self_attn.{nm}.weight"
+                    own[key].data.copy_((wqkv[lo:hi].float() + delta).to(own[key].dtype))
 
     def export_lora_state_dict(self):
         """the adapters under peft's names (what the reference saves with get_peft_state_maybe_zero_3, train.py:962): lora_A [r, in], lora_B [out, r], fp32"""
@@ -728,18 +756,17 @@ class DecoderTrainer:
                 sd[p + "lora_B.weight"] = lb.view(lb.w, f"B{nm[0]}.{i}")[:, :r].clone()
         return sd
 
-    def _merge_lora(self):
-        """W <- W + (alpha / r) B A for every adapted projection (peft merge_and_unload), into the packed weights AND the model's parameters; the adapters'
-        B are zeroed afterwards so that a second call adds nothing"""
-        cfg = self.cfg
-        H, KV, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    def merge_lora(self):
+        """peft merge_and_unload, explicitly: W <- W + (alpha / r) B A into the PACKED base weights and the model's parameters, B (working copy and fp32
+        master) zeroed afterwards so that a second call adds nothing.  This ends the adapters' training run (their Adam moments no longer describe B);
+        sync_to_model() / detach() never call it."""
         lb, r, Rp = self.lora_bucket, self.lora_r, self.Rp
         own = dict(self.model.named_parameters())
         with torch.no_grad():
             for i, b in enumerate(self.layers):
                 wqkv = b.view(b.w, "wqkv")
                 a = lb.view(lb.w, f"Acat.{i}")
-                for j, (nm, lo, hi) in enumerate((("q_proj", 0, H * hd), ("v_proj", (H + KV) * hd, (H + 2 * KV) * hd))):
+                for j, (nm, lo, hi) in enumerate(self._lora_targets()):
                     bm = lb.view(lb.w, f"B{nm[0]}.{i}")
                     delta = (bm[:, :r] @ a[j * Rp:j * Rp + r]) * self.lora_scale
                     wqkv[lo:hi].copy_((wqkv[lo:hi].float() + delta).to(wqkv.dtype))
@@ -751,7 +778,8 @@ class DecoderTrainer:
         self._refresh_transposes()
 
     def detach(self):
-        """sync_to_model(), then release the model: its packed buffers are rebuilt from the (now current) parameters on next use"""
+        """sync_to_model() (with adapters: the merged view W + (alpha / r) B A in the parameters), then release the model: its packed buffers are rebuilt
+        from the (now current) parameters on next use"""
         self.sync_to_model()
         if getattr(self, "_splitk_before", None) is not None:
             from . import _lib as _L
