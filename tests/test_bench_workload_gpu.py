@@ -164,16 +164,17 @@ def test_bench_workload_stage_by_stage_vs_oracle(bench_model):
         print(f"PARITY next token: arg-max equal {bool(g.argmax() == lg_32.argmax())}, fp32 margin {margin:.3e}, max logit error {err:.3e}, top-5 overlap {t5}")
     if MEASURE:
         return
-    # bounds: 2 x what MI355X measured (profiles/r04/parity_table.json) and never further from fp32 than the mirror (x 1.5 + 1e-3)
-    assert r_t["rel_l2_vs_mirror"] <= 9e-3 and r_t["rel_l2_vs_fp32"] <= 1.4e-2, r_t
-    assert r_t["vs_fp32"] <= 1.5 * r_t["mirror_vs_fp32"] + 1e-3, r_t
-    assert r_p["rel_l2_vs_mirror"] <= 2.5e-2 and r_p["rel_l2_vs_fp32"] <= 3e-2, r_p
-    assert r_ptf["vs_bf16_mirror"] <= 2e-2, r_ptf
-    assert r_n["rel_l2_vs_fp32"] <= 4e-2 and r_l["rel_l2_vs_fp32"] <= 4e-2, (r_n, r_l)
-    assert r_l["vs_fp32"] <= 1.5 * r_l["mirror_vs_fp32"] + 1e-3, r_l
-    if margin > 3.0 * err:
+    # bounds: 2 x what MI355X measured (profiles/r04/parity_table_bench.json) and never further from fp32 than the mirror (x 1.5 + 1e-3)
+    assert r_t["rel_l2_vs_mirror"] <= 9e-3 and r_t["rel_l2_vs_fp32"] <= 7.6e-3, r_t                 # measured 4.4e-3 / 3.8e-3 (mirror vs fp32 3.8e-3)
+    assert r_t["vs_fp32"] <= 1.5 * r_t["mirror_vs_fp32"] + 1e-3, r_t                                   # max norm 4.1e-3 vs 4.0e-3
+    assert r_p["rel_l2_vs_mirror"] <= 2.5e-2 and r_p["rel_l2_vs_fp32"] <= 2e-2, r_p                 # 1.3e-2 / 1.0e-2 (1.0e-2)
+    assert r_p["vs_fp32"] <= 1.5 * r_p["mirror_vs_fp32"] + 1e-3, r_p
+    assert r_ptf["vs_bf16_mirror"] <= 2.2e-2, r_ptf                                                    # 1.1e-2 (48 storage points, the connector's noise floor)
+    assert r_n["rel_l2_vs_fp32"] <= 2.8e-2 and r_l["rel_l2_vs_fp32"] <= 1.2e-2, (r_n, r_l)          # 1.4e-2 (1.35e-2) / 6.0e-3 (5.8e-3)
+    assert r_n["vs_fp32"] <= 1.5 * r_n["mirror_vs_fp32"] + 1e-3 and r_l["vs_fp32"] <= 1.5 * r_l["mirror_vs_fp32"] + 1e-3, (r_n, r_l)
+    if margin > 3.0 * err:                                                                             # measured: margin 0.150, error 0.031 -> decided, equal
         assert bool(g.argmax() == lg_32.argmax())
-    assert t5 >= 3
+    assert t5 >= 4                                                                                     # 5 of 5
 
 
 def test_teacher_forced_every_tower_layer(bench_model):
@@ -216,7 +217,14 @@ def test_teacher_forced_every_decoder_layer(bench_model):
     xe = (torch.randn(1, S, 3584, generator=torch.Generator().manual_seed(64)) * 0.5).to(DEV)
     cos, sin = O.rope_cos_sin(torch.arange(S), 128, 1e6)
     bias = torch.zeros(S, S).masked_fill(torch.arange(S)[None, :] > torch.arange(S)[:, None], torch.finfo(torch.float32).min)[None, None]
-    worst = 0.0
+    worst = worst_half = 0.0
+    H, KV, hd = 28, 4, 128
+    pk = model.model.packed()
+    h = torch.empty((S, 3584), device=DEV, dtype=torch.bfloat16)
+    qkv = torch.empty((S, (H + 2 * KV) * hd), device=DEV, dtype=torch.bfloat16)
+    o = torch.empty((S, H * hd), device=DEV, dtype=torch.bfloat16)
+    act = torch.empty((S, 18944), device=DEV, dtype=torch.bfloat16)
+    tab = ops.rope_table(pk["inv_freq"], 0, S, hd)
     with torch.no_grad():
         logits, cache, hs, normed = model._decode_batch(xe, None, None, True, 1)
         hs = [h[0] if h.dim() == 3 else h for h in hs]
@@ -235,15 +243,39 @@ def test_teacher_forced_every_decoder_layer(bench_model):
             dm = float(((g - xin[0]) - (ym[0] - xin[0])).abs().max() / (ym[0] - xin[0]).abs().max())
             r = record(f"decoder layer {i} teacher-forced (d 3584, S 383)", streams[i + 1], ym[0], y32[0], vs_mirror_rel_to_layer_delta=dm)
             worst = max(worst, r["vs_bf16_mirror"])
+            # the two halves of the layer, each on the HIP path's own input: attention block (RMSNorm -> QKV -> RoPE -> causal GQA flash attention -> o_proj +
+            # residual) and MLP block (RMSNorm -> gate/up + SwiGLU -> down + residual), the op sequence of csrc/stages.hip issued from here; the oracle's
+            # half = its layer with the other half's output projection zeroed
+            L = pk["layers"][i]
+            x = streams[i].float().clone().contiguous()
+            kvb = torch.zeros((512, 2 * KV * hd), device=DEV, dtype=torch.bfloat16)
+            ops.gemm(ops.rmsnorm(x, L["ln1"], 1e-6, out=h), L["wqkv"], bias=L["bqkv"], out=qkv)
+            ops.rope_kv(qkv, S, H, KV, hd, pk["inv_freq"], 0, kvb, table=tab)
+            ops.attention(qkv, kvb, kvb[:, KV * hd:], 1, H, KV, S, S, hd, (0, qkv.stride(0)), (0, kvb.stride(0)), (0, kvb.stride(0)), causal=True, q_pos0=0, out=o)
+            ops.gemm(o, L["wo"], resid=x, out=x)
+            x_mid = x.clone()
+            ops.gemm(ops.rmsnorm(x, L["ln2"], 1e-6, out=h), L["wgu"], swiglu=True, out=act)
+            ops.gemm(act, L["wd"], resid=x, out=x)
+            assert torch.equal(x, streams[i + 1].float()), f"layer {i}: the op-level sequence and the stage call differ"
+            sd_att = dict(lsd); sd_att[p + "mlp.down_proj.weight"] = torch.zeros_like(lsd[p + "mlp.down_proj.weight"])
+            sd_mlp = dict(lsd); sd_mlp[p + "self_attn.o_proj.weight"] = torch.zeros_like(lsd[p + "self_attn.o_proj.weight"])
+            xm_in = x_mid.cpu()[None]
+            with O.bf16_mirror():
+                am_, _ = O.qwen2_layer(sd_att, p, xin, lcfg, cos, sin, None, bias)
+                mm_, _ = O.qwen2_layer(sd_mlp, p, xm_in, lcfg, cos, sin, None, bias)
+            ra = record(f"decoder layer {i}: attention block teacher-forced", x_mid, am_[0], None)
+            rm = record(f"decoder layer {i}: MLP block teacher-forced", x, mm_[0], None)
+            worst_half = max(worst_half, ra["vs_bf16_mirror"], rm["vs_bf16_mirror"])
             if not MEASURE:
-                assert r["vs_bf16_mirror"] <= 2e-3, r
+                assert r["vs_bf16_mirror"] <= (4e-3 if i == 0 else 2e-3), r          # layer 0 (a 0.5-sigma random stream, the layer adds as much again): 3.05e-3 = the
+                assert ra["vs_bf16_mirror"] <= 2e-3 and rm["vs_bf16_mirror"] <= 2e-3, (ra, rm)   # chain noise floor of one layer (PARITY.md); its halves hold 2e-3
                 assert r["vs_fp32"] <= 1.5 * r["mirror_vs_fp32"] + 1e-3, r
         with O.bf16_mirror():
             nm = O.rmsnorm(x_last.float().cpu(), O._rb(nw), 1e-6)
         r = record("decoder final norm teacher-forced", normed, nm, O.rmsnorm(x_last.float().cpu(), nw, 1e-6))
         if not MEASURE:
             assert r["vs_bf16_mirror"] <= 1e-3, r
-    REPORT.append({"stage": "decoder layers 0..27 teacher-forced: worst vs mirror", "vs_bf16_mirror": worst})
+    REPORT.append({"stage": "decoder layers 0..27 teacher-forced: worst vs mirror", "vs_bf16_mirror": worst, "worst_half_layer_vs_mirror": worst_half})
 
 
 def test_zz_write_report():
