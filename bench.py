@@ -114,7 +114,7 @@ def one_step(model, video, ids, am, cache, frameshard=False):
         mmf = encode_frame_sharded(model, video)[None]
     _, am2, _, emb, _, _ = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, [(video, "video")], None, None, None, None,
                                                                       mm_features=mmf)
-    logits, *_ = model._decode_batch(emb, am2, cache, False, 1)
+    logits, *_ = model._decode_batch(emb, am2, cache, False, 1, consume=True)          # as generate() hands its splice result on: no 34 MB copy of it
     return logits, emb.shape[1]
 
 

@@ -65,3 +65,71 @@ def test_bench_gpus2_on_a_one_gpu_box_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "visible" in r.stderr and "{" not in r.stdout
+
+
+FRAMESHARD_CHILD = r'''
+import os, sys
+sys.path.insert(0, os.environ["UFV_ROOT"])
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)          # two ranks on ONE device: RCCL refuses duplicate GPUs, the exchange runs over gloo
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+import bench
+from ufvideo_amd import parallel as P
+from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM
+# the bench model's tower (SigLIP-so400m dims at 336 px, 26 layers run) and connector (STC-v35 1152 -> 3584) with the bench's seeds; a one-layer
+# decoder stands in for the 7B one (the decoder does not frame-shard and is not part of this check)
+llm = dict(vocab_size=512, hidden_size=3584, intermediate_size=1024, num_hidden_layers=1, num_attention_heads=28, num_key_value_heads=4,
+           rope_theta=1e6, rms_norm_eps=1e-6)
+cfg = VideoReferQwen2Config(**llm, mm_vision_tower="siglip-so400m-patch14-384", mm_vision_select_layer=-2, mm_vision_select_feature="patch",
+                            mm_projector_type="stc_connector_v35", mm_hidden_size=1152, mm_region_encoder_type="pooling", image_aspect_ratio="square",
+                            train_mask_decoder=False, sam_pretrained=None, sam_out_dim=256, num_frames=32, seg_token_id=511, sam2_trunk=None,
+                            vision_config=bench.VISION)
+model = VideoReferQwen2ForCausalLM(cfg, device=dev, seed=0)
+model.get_vision_tower().load_model(device=dev, seed=7)
+video, _, _ = bench.synthetic_inputs(dev)                               # the bench clip: 32 frames 336 x 336 from default_rng(1234)
+chunks = P.frame_chunks(32, world)
+assert chunks == [(0, 16), (16, 32)]
+calls = []
+def encode_fn(frames):                                                  # the product's tower + projector on THIS rank's 16 frames; tokens leave over gloo from the host
+    calls.append(tuple(frames.shape))
+    feats = model.get_vision_tower().encode(frames)
+    return model.temporal_aggregator(feats[None])[0].cpu()
+toks = P.encode_frame_sharded(model, video, encode_fn=encode_fn)
+assert calls == [(16, 3, 336, 336)] and tuple(toks.shape) == (2304, 3584)
+with torch.no_grad():
+    whole = model.encode_images_or_videos([(video, "video")])[0].cpu()  # all 32 frames in this process
+# rank order = temporal order: tokens [1152 r, 1152 r + 1152) are frames [16 r, 16 r + 16); every rank holds the whole clip's tokens, bit for bit
+assert torch.equal(toks, whole), float((toks - whole).abs().max())
+mine = toks[1152 * rank: 1152 * (rank + 1)]
+other = toks[1152 * (1 - rank): 1152 * (2 - rank)]
+assert not torch.equal(mine, other)
+dist.barrier()
+dist.destroy_process_group()
+print(f"FRAMESHARD_OK rank {rank}")
+'''
+
+
+def test_frame_sharded_encode_world_size_two_on_one_gpu_equals_single_process():
+    """SURVEY 8(e) on the REAL encoder: two processes share cuda:0, rank r runs the HIP tower (26 layers, d 1152) and STC-v35 connector on frames
+    [16 r, 16 r + 16) of the bench clip, `encode_frame_sharded` / `all_gather_tokens` exchange the visual tokens (gloo: RCCL refuses two ranks on one
+    device), and every rank ends with exactly the 2304 x 3584 tokens one process computes from all 32 frames -- torch.equal: contiguous even-length
+    chunks need no halo (Conv3d padding 0, temporal stride 2) and rank order is temporal order (inference_PixRQA.py:38-45,186).  The most multi-GPU
+    evidence a 1-GPU box can give; a scaling CURVE stays unmeasured on hardware until a SCALE record exists."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, UFV_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", FRAMESHARD_CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=900))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"FRAMESHARD_OK rank {r}" in so, (so[-1500:], se[-3000:])

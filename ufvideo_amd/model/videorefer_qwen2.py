@@ -341,7 +341,7 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
                 raise NotImplementedError("only right-padded attention masks are supported")
         return tot
 
-    def _decode_batch(self, inputs_embeds, attention_mask, past_key_values, output_hidden_states, logits_to_keep):
+    def _decode_batch(self, inputs_embeds, attention_mask, past_key_values, output_hidden_states, logits_to_keep, consume=False):
         """inputs_embeds [B,S,D] fp32 (device).  Right padding is trimmed per sample via attention_mask; a batch > 1 (the training
         collator's, ref train.py:678-732 / videorefer_arch.py:333-368) runs as ONE packed token stream with per-sample RoPE
         positions, KV caches and attention (no padding FLOPs) and comes back padded to [B, S, ...] as HF returns it.
@@ -355,7 +355,14 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
             pos0 = 0 if past_key_values is None else past_key_values.get_seq_length()
             valid = self._valid_lengths(attention_mask, 1, S)[0] - pos0 if attention_mask is not None else S
             cache = past_key_values or KVCache(cfg.num_hidden_layers, max(valid + 64, 256), width, inputs_embeds.device)
-            x = ops.convert(inputs_embeds[0, :valid], torch.float32) if inputs_embeds.dtype != torch.float32 else inputs_embeds[0, :valid].clone()
+            # the layer loop updates the stream in place: a caller's inputs_embeds is copied first; `consume` (the embeddings this model's own splice
+            # just built, handed straight on by generate() / bench.py) skips the 34 MB copy
+            if inputs_embeds.dtype != torch.float32:
+                x = ops.convert(inputs_embeds[0, :valid], torch.float32)
+            elif consume and not output_hidden_states and inputs_embeds[0, :valid].is_contiguous():
+                x = inputs_embeds[0, :valid]
+            else:
+                x = inputs_embeds[0, :valid].clone()
             hs = [x.clone()] if output_hidden_states else None
             x = self.model.run_layers(x, cache, pos0, collect_hidden=hs)
             normed = self.model.final_norm(x)                                    # fp32 [valid, D]
@@ -526,7 +533,7 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
             output = ModelOutput(loss=None, logits=logits, past_key_values=cache, attentions=None,
                                  hidden_states=tuple(h.unsqueeze(0) for h in hs))
             return {"output": output, "pred_masks": pred_masks, "gt_masks": masks_list}
-        out = self._greedy(inputs_embeds, attention_mask, **kwargs)
+        out = self._greedy(inputs_embeds, attention_mask, consume_embeds=True, **kwargs)         # (inputs_embeds is this call's own splice result)
         toks = out["sequences"]
         self.last_generate = out
         pred_masks = []
@@ -576,7 +583,7 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         cfg = self.config
         width = 2 * cfg.num_key_value_heads * cfg.head_dim
         cache = KVCache(cfg.num_hidden_layers, S + max_new_tokens + 8, width, dev)
-        logits, cache, _, normed = self._decode_batch(inputs_embeds, attention_mask, cache, False, 1)
+        logits, cache, _, normed = self._decode_batch(inputs_embeds, attention_mask, cache, False, 1, consume=bool(unused.get("consume_embeds", False)))
         hidden_steps = [normed]
         tokens = []
         tok = torch.empty((1,), device=dev, dtype=torch.int64)
