@@ -907,3 +907,55 @@ def test_dwconv_se_gather_kernels_vs_torch(Fr, H, W, C):
     assert torch.equal(back, ref)
     s2 = ops.add_bf16(h, h)
     assert torch.equal(s2.float(), (h.float() * 2).to(torch.bfloat16).float())
+
+
+def test_forward_training_is_an_autograd_node_loss_backward_fills_grad_like_the_reference():
+    """`ufvideo/train.py` under the HF Trainer calls `loss = model(**batch)["loss"]; loss.backward(); optimizer.step()`
+    (videorefer_trainer.py:244-413 -> Trainer.training_step).  Here forward(inference=False) under autograd returns the loss attached to ONE
+    autograd node; backward() leaves d(loss)/d(parameter) in `.grad` under the reference's parameter names -- checked against the REFERENCE's own
+    loss.backward() (golden train_grad_tiny: every decoder gradient), accumulation over two backward calls, a torch optimizer stepping the
+    nn.Parameters (the engine re-reads them: the next loss is lower), and no-grad forward still returning plain values."""
+    a, _ = load_golden("train_grad_tiny")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_grad_tiny.npz"))
+    m, arrs, _ = tiny_model()
+    ids, labels = t(a["ids"]).to(DEV), t(a["labels_in"]).to(DEV)
+    video = t(arrs["video"]).to(DEV)
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids), images=[(video, "video")],
+                 images_sam=torch.zeros(1, 4, 3, 8, 8, device=DEV), offset=[0, 1], masks_list=None, label_list=None)
+    with torch.no_grad():
+        plain = m(**batch)                                            # values only, no graph
+    assert not plain["loss"].requires_grad
+    names = [n for n, _ in m.named_parameters() if n.startswith(("model.layers.", "model.norm.", "lm_head.", "model.embed_tokens."))]
+    own = dict(m.named_parameters())
+    for n in names:
+        own[n].requires_grad_(True)
+    out = m(**batch)
+    loss = out["loss"]
+    assert loss.requires_grad and loss.grad_fn is not None and set(out) >= {"loss", "ce_loss", "mask_loss"}
+    assert abs(float(loss) - float(a["ce_loss"])) < 2e-2 * float(a["ce_loss"]) and abs(float(loss) - float(plain["loss"])) < 2e-2 * float(loss)
+    loss.backward()
+    ref = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g::")}
+    assert set(ref) == set(names)
+    worst = max((rel_err(own[k].grad.float().cpu(), ref[k]), k) for k in ref)
+    assert worst[0] < 8e-2, worst                                      # bf16 .grad of a bf16 parameter; the fp32 buffers hold 5e-2 (test_tiny_model_step_vs_reference_golden)
+    assert all(p.grad is None for n, p in m.named_parameters() if n not in names)          # tower / projector stay frozen
+    # accumulation: a second backward of a scaled loss adds 0.5 x the same gradient
+    g1 = {k: own[k].grad.clone() for k in names}
+    (m(**batch)["loss"] * 0.5).backward()
+    k = "model.layers.1.mlp.down_proj.weight"
+    assert rel_err(own[k].grad.float(), 1.5 * g1[k].float()) < 1e-2
+    # a torch optimizer on the nn.Parameters: the engine picks the new values up
+    for p in own.values():
+        p.grad = None
+    opt = torch.optim.SGD([own[n] for n in names], lr=0.05)
+    l0 = m(**batch)["loss"]; l0.backward(); opt.step(); opt.zero_grad()
+    l1 = m(**batch)["loss"]; l1.backward(); opt.step(); opt.zero_grad()
+    l2 = m(**batch)["loss"]
+    assert float(l2) < float(l1) < float(l0), (float(l0), float(l1), float(l2))
+    # giving the packed weights back: inference sees the trained parameters
+    m.release_grad_engine()
+    for p in own.values():
+        p.requires_grad_(False)
+    with torch.no_grad():
+        after = m(**batch)
+    assert abs(float(after["loss"]) - float(l2)) < 2e-2 * float(l2)

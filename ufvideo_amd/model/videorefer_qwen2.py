@@ -114,6 +114,26 @@ def pack_swiglu(gate, up):
     return torch.stack([gate.view(I // 16, 16, K), up.view(I // 16, 16, K)], dim=1).reshape(2 * I, K).contiguous()
 
 
+class _TrainingLoss(torch.autograd.Function):
+    """loss = model(**batch)["loss"] as an autograd node over the trainable nn.Parameters.  forward runs the whole hand-written forward + backward
+    (DecoderTrainer.loss_and_grads: the HIP kernels of csrc/train*.hip, attn_bwd.hip, seg_train.hip) and keeps d(loss)/d(parameter) under the
+    reference's names; backward scales them by the incoming gradient and returns them, so torch accumulates `.grad` exactly as it does for the
+    reference's module tree (gradient accumulation, `loss / n` scaling and DDP's hooks on the parameters all work unchanged)."""
+
+    @staticmethod
+    def forward(ctx, engine, batch, names, terms, *params):
+        with torch.no_grad():
+            out = engine.loss_and_grads(**batch)
+            grads = engine.export_grad_dict(only=set(names))
+        ctx.grads = [grads[n].to(p.dtype) if n in grads else None for n, p in zip(names, params)]
+        terms.update(out)
+        return out["loss"].detach().clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None, None, None) + tuple(None if gr is None else gr * g.to(gr.dtype) for gr in ctx.grads)
+
+
 class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
     """Decoder body: embed_tokens, layers.N.*, norm (HF Qwen2Model names) + the multimodal modules."""
 
@@ -414,6 +434,12 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         # the reference dereferences images_sam unconditionally (videorefer_qwen2.py:155)
         batch_size, num_frames_sam = images_sam.shape[:2]
         if not inference:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                # the reference's training call (videorefer_trainer.py -> HF Trainer.training_step: loss = model(**inputs)["loss"]; loss.backward()):
+                # the loss comes back attached to an autograd node whose backward hands every trainable parameter its gradient
+                return self._training_losses_autograd(dict(input_ids=input_ids, labels=labels, attention_mask=attention_mask, images=images, masks=masks,
+                                                           frame=frame, ann_indices=ann_indices, frame_nums=frame_nums, video_file=video_file,
+                                                           images_sam=images_sam, offset=offset, masks_list=masks_list, label_list=label_list))
             return self._training_losses(input_ids, attention_mask, past_key_values, labels, images, masks, frame, ann_indices, frame_nums,
                                          video_file, images_sam, offset, masks_list, label_list)
         if inputs_embeds is None:
@@ -430,6 +456,52 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
                            hidden_states=tuple(h if h.dim() == 3 else h.unsqueeze(0) for h in hs) if hs is not None else None, attentions=None)
 
     __call__ = forward
+
+    # ---- forward(inference=False) under autograd: `model(**batch)["loss"].backward()` ---------------------------------------------------
+    def _grad_engine(self):
+        """The forward + backward engine behind the autograd path: a ufvideo_amd.train.DecoderTrainer without optimizer states, covering the parameter
+        groups that currently require grad (decoder [+ embed_tokens], mm_projector, region_encoder, text_hidden_fcs + SAM2 mask decoder).  Built on first
+        use and re-built when the set of trainable groups changes; while it exists it owns the decoder's packed weights (as any DecoderTrainer does) and
+        re-reads the nn.Parameters whenever an optimizer has changed them."""
+        from ..train import DecoderTrainer
+        inner = self.get_model()
+        req = lambda mod: mod is not None and any(p.requires_grad for p in mod.parameters())
+        dec = any(p.requires_grad for n, p in self.named_parameters() if n.startswith(("model.layers.", "model.norm.", "lm_head.")))
+        emb = bool(inner.embed_tokens.weight.requires_grad)
+        key = (dec or emb, emb, req(getattr(inner, "mm_projector", None)), req(getattr(inner, "region_encoder", None)),
+               req(getattr(inner, "text_hidden_fcs", None)) and getattr(inner, "mask_encoder", None) is not None)
+        eng = getattr(self, "_engine", None)
+        if eng is not None and eng[0] != key:
+            eng[1].detach()
+            eng = None
+        if eng is None:
+            if not any(key):
+                raise RuntimeError("forward(inference=False): no supported parameter group requires grad (the vision tower is frozen, as in the reference)")
+            tr = DecoderTrainer(self, train_decoder=key[0], train_embed=key[1], train_projector=key[2], train_region_encoder=key[3], train_seg_head=key[4],
+                                optimizer_states=False)
+            eng = self._engine = [key, tr, None]
+        return eng
+
+    def release_grad_engine(self):
+        """drops the autograd path's engine and gives the decoder's packed weights back to the model (they are re-packed from the nn.Parameters)"""
+        eng = getattr(self, "_engine", None)
+        if eng is not None:
+            eng[1].detach()
+            self._engine = None
+
+    def _training_losses_autograd(self, batch):
+        eng = self._grad_engine()
+        tr = eng[1]
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        stamp = tuple(p._version for _, p in self.named_parameters())
+        if eng[2] != stamp:                         # an optimizer (or a load) has written the parameters since the engine last read them
+            tr.refresh_from_model()
+            eng[2] = tuple(p._version for _, p in self.named_parameters())
+        terms = {}
+        loss = _TrainingLoss.apply(tr, batch, [n for n, _ in named], terms, *[p for _, p in named])
+        out = {k: v.detach() for k, v in terms.items()}
+        out["loss"] = loss
+        return out
 
     @torch.no_grad()
     def _training_losses(self, input_ids, attention_mask, past_key_values, labels, images, masks, frame, ann_indices, frame_nums,

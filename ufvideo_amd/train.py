@@ -107,8 +107,11 @@ class DecoderTrainer:
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
                  train_embed=True, train_projector=False, train_region_encoder=False, train_decoder=True, mm_projector_lr=None,
-                 train_seg_head=False, lora=None):
-        """lora = dict(r=8, alpha=16[, seed=0 | init={name: tensor}]): the reference's --lora_enable stage (train.py:829-845: peft LoraConfig over
+                 train_seg_head=False, lora=None, optimizer_states=True):
+        """optimizer_states=False: the forward + backward engine only -- no fp32 masters / Adam moments are allocated and step() raises; the gradients are
+        read with export_grad_dict() (this is what `forward(inference=False)` under autograd builds, model/videorefer_qwen2.py: the optimizer is then the
+        caller's, e.g. the HF Trainer's, on the model's own nn.Parameters).
+        lora = dict(r=8, alpha=16[, seed=0 | init={name: tensor}]): the reference's --lora_enable stage (train.py:829-845: peft LoraConfig over
         find_all_linear_names = the q_proj and v_proj Linears outside the multimodal modules, videorefer_trainer.py:75-90): the language model is frozen
         and y = W x + (alpha / r) B (A x) trains A [r, in] (kaiming-uniform) and B [out, r] (zeros) of every layer's q_proj and v_proj; peft is absent from
         this image, its published LoRA forward is restated (dropout 0: lora_dropout is a training-time random mask that no restatement can reproduce).
@@ -246,8 +249,10 @@ class DecoderTrainer:
                 if same:
                     self.proj_flat[off:off + n].view(shape).copy_(v)
                     v.data = self.proj_flat[off:off + n].view(shape)
-        for b in self.buckets():
-            b.init_states()
+        self.optimizer_states = bool(optimizer_states)
+        if self.optimizer_states:
+            for b in self.buckets():
+                b.init_states()
         if self.lora_bucket is not None:
             self._refresh_lora()
         # ---- transposed weight copies for dX = dY W (the NT GEMM wants W^T rows)
@@ -478,14 +483,14 @@ class DecoderTrainer:
             ops.scatter_add_rows(dx, embed_ids.to(self.dev).contiguous(), self.head.view(self.head.g, "embed"))
         return loss, dx
 
-    def train_step(self, input_ids=None, labels=None, attention_mask=None, images=None, masks=None, frame=None, ann_indices=None,
-                   frame_nums=None, video_file=None, **_unused):
-        """One optimizer step on a collated batch with the keys the reference's collator produces (train.py:706-732; SURVEY
-        §3.5): splice (the tower is frozen; projector / region encoder are trained when the trainer was built with
+    def loss_and_grads(self, input_ids=None, labels=None, attention_mask=None, images=None, masks=None, frame=None, ann_indices=None,
+                       frame_nums=None, video_file=None, **_unused):
+        """Forward + backward of one collated batch (the keys the reference's collator produces, train.py:706-732; SURVEY
+        §3.5) into the gradient buffers, no update: splice (the tower is frozen; projector / region encoder are trained when the trainer was built with
         train_projector / train_region_encoder, else they run forward-only),
         causal-LM loss averaged over the batch's supervised tokens (HF Qwen2ForCausalLM), backward, exchange, AdamW.
         The remaining collator keys (images_sam, offset, masks_list, label_list) are accepted; a batch whose labels contain [SEG] or
-        whose masks_list holds ground-truth masks raises NotImplementedError (see below).  Returns {"loss", "ce_loss", "grad_norm"}: for
+        whose masks_list holds ground-truth masks raises NotImplementedError (see below).  Returns {"loss", "ce_loss", ...}: for
         the batches that are accepted the mask terms of the reference's loss are zero, so "loss" is the reference's loss."""
         m = self.model
         # The reference's objective adds bce_loss_weight * BCE + dice_loss_weight * DICE of the SAM2 masks for every [SEG] in the labels
@@ -593,11 +598,17 @@ class DecoderTrainer:
             for k, leaf in seg_leaves.items():
                 if leaf.grad is not None:
                     self.proj_bucket.view(self.proj_bucket.g, k).add_(leaf.grad)
-        self.step()
         ce = loss                                          # ce_loss_weight is part of the per-token weight (and so of the gradient)
         mask_loss = mask_bce + mask_dice
-        return {"loss": ce + mask_loss, "ce_loss": ce, "mask_bce_loss": mask_bce, "mask_dice_loss": mask_dice, "mask_loss": mask_loss,
-                "grad_norm": getattr(self, "last_grad_norm", None)}
+        return {"loss": ce + mask_loss, "ce_loss": ce, "mask_bce_loss": mask_bce, "mask_dice_loss": mask_dice, "mask_loss": mask_loss}
+
+    def train_step(self, **batch):
+        """One optimizer step on a collated batch with the keys the reference's collator produces (train.py:706-732):
+        loss_and_grads(**batch), then exchange + clip + AdamW (step()).  Returns the loss terms + "grad_norm"."""
+        out = self.loss_and_grads(**batch)
+        self.step()
+        out["grad_norm"] = getattr(self, "last_grad_norm", None)
+        return out
 
     # ---- data-parallel exchange + update (ZeRO-2) -----------------------------------------------------------------------
     def _reduce_async(self, b):
@@ -654,6 +665,8 @@ class DecoderTrainer:
     def step(self):
         """Gradient exchange, global-norm clipping (HF Trainer max_grad_norm), AdamW on this rank's shard, all-gather.  Raises when a split-K GEMM of the
         forward / backward pass left the device's error word set (a timed-out turn wait: that launch's tile is wrong, include/ufv.h Conventions)."""
+        if not self.optimizer_states:
+            raise RuntimeError("this DecoderTrainer was built with optimizer_states=False (gradient engine of the autograd path): the optimizer is the caller's")
         err = _lib.load().ufv_gemm_error_state()
         if err != 0:
             raise _lib.UfvError(f"a split-K GEMM of this step timed out waiting for its turn (error word {err}): the gradients are not trustworthy; "
@@ -831,6 +844,71 @@ class DecoderTrainer:
             self.mm_projector_lr = self.base_mm_projector_lr * ratio
 
     # ---- export in the reference's parameter names --------------------------------------------------------------------
+    def _decoder_names(self):
+        """[(reference parameter name, bucket, entry, row slice | 'gate' | 'up' | None)] of the decoder's parameters (HF Qwen2 names)"""
+        cfg = self.cfg
+        H, KV, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        out = []
+        for i, b in enumerate(self.layers):
+            p = f"model.layers.{i}."
+            for nm, lo, hi in (("q_proj", 0, H * hd), ("k_proj", H * hd, (H + KV) * hd), ("v_proj", (H + KV) * hd, (H + 2 * KV) * hd)):
+                out.append((p + f"self_attn.{nm}.weight", b, "wqkv", (lo, hi)))
+                out.append((p + f"self_attn.{nm}.bias", self.small, f"bqkv.{i}", (lo, hi)))
+            out += [(p + "self_attn.o_proj.weight", b, "wo", None), (p + "mlp.gate_proj.weight", b, "wgu", "gate"), (p + "mlp.up_proj.weight", b, "wgu", "up"),
+                    (p + "mlp.down_proj.weight", b, "wd", None), (p + "input_layernorm.weight", self.small, f"ln1.{i}", None),
+                    (p + "post_attention_layernorm.weight", self.small, f"ln2.{i}", None)]
+        out += [("model.norm.weight", self.small, "norm", None), ("lm_head.weight", self.head, "lm_head", (0, self.V))]
+        if self.train_embed:
+            out.append(("model.embed_tokens.weight", self.head, "embed", None))
+        return out
+
+    def _slice(self, buf_view, sel):
+        I = self.cfg.intermediate_size
+        if sel is None:
+            return buf_view
+        if sel == "gate" or sel == "up":                       # gate / up rows are interleaved in blocks of 16 (pack_swiglu)
+            return buf_view.view(I // 16, 2, 16, -1)[:, 0 if sel == "gate" else 1]
+        return buf_view[sel[0]:sel[1]]
+
+    def export_grad_dict(self, dtype=torch.float32, only=None):
+        """d(loss)/d(parameter) of the last accumulation window under the reference's parameter names, un-packed (q / k / v split, gate / up
+        de-interleaved), as copies in `dtype`: decoder (when trained), mm_projector / region_encoder / text_hidden_fcs / mask decoder (when trained).
+        `only`: a set of names to export.  This rank's gradients BEFORE any exchange (world 1: the gradients)."""
+        out = {}
+        if self.train_decoder:
+            I = self.cfg.intermediate_size
+            for name, b, entry, sel in self._decoder_names():
+                if only is not None and name not in only:
+                    continue
+                g = self._slice(b.view(b.g, entry), sel)
+                g = g.reshape(I, -1) if sel in ("gate", "up") else g
+                out[name] = g.to(dtype, copy=True)
+        if self.proj_bucket is not None:
+            pb = self.proj_bucket
+            for k in self.proj_params:
+                if only is None or ("model." + k) in only:
+                    out["model." + k] = pb.view(pb.g, k).to(dtype, copy=True)
+        return out
+
+    def refresh_from_model(self):
+        """The other direction of sync_to_model(): the model's nn.Parameters (just updated by an optimizer of the caller's) -> this engine's packed
+        buffers, transposes and the auxiliary modules' packed copies.  Used by the autograd path before every forward whose parameters changed."""
+        own = dict(self.model.named_parameters())
+        with torch.no_grad():
+            for name, b, entry, sel in self._decoder_names():
+                dst = self._slice(b.view(b.w, entry), sel)
+                src = own[name].data
+                dst.copy_(src.view(dst.shape[0], 16, -1) if sel in ("gate", "up") else src)
+                if self.optimizer_states and b.master is not None and b.world == 1:
+                    self._slice(b.view(b.master, entry), sel).copy_(src.view(dst.shape[0], 16, -1) if sel in ("gate", "up") else src)
+            if self.proj_bucket is not None:
+                pb = self.proj_bucket
+                for k, v in self.proj_params.items():
+                    pb.view(pb.w, k).copy_(v.data)
+                for mod in self.aux_modules.values():
+                    mod.invalidate()
+        self._refresh_transposes()
+
     def export_state_dict(self):
         """Updated decoder weights under the reference's (HF Qwen2) key names, un-packed (q/k/v split, gate/up de-interleaved)."""
         cfg = self.cfg
