@@ -42,6 +42,22 @@ MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICRO
 FLOPS = dict(vit=15.89e12, proj=4.69e12, llm=32.48e12)
 
 
+PMC_FILE = "profiles/r04/pmc_bench.json"
+GEMM_SOURCES = ("ufvideo_amd/csrc/gemm256_kernel.h", "ufvideo_amd/csrc/gemm256.hip", "ufvideo_amd/csrc/gemm_epi.h", "ufvideo_amd/csrc/gemm.hip",
+                "ufvideo_amd/csrc/common.h")
+
+
+def gemm_sources_sha256():
+    """fingerprint of the dominant kernel's sources: the committed PMC summary (roofline.traffic, mfma_busy_pmc) carries the fingerprint of the tree it
+    was measured on (tools/pmc_summarize.py) and is only quoted while it matches this tree's"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in GEMM_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 class _Tok:
     def convert_tokens_to_ids(self, toks):
         return [151645 for _ in toks]
@@ -90,7 +106,9 @@ class KernelTimer:
     def on(self, v):
         from ufvideo_amd import _lib
         self._on = bool(v)
-        _lib.call("ufv_gemm_timing", int(self._on))
+        # every 7th gate/up launch (4 of the 28 per step, a different layer each): an event pair costs the stream ~11 us of idle, so bracketing all
+        # 28 took 0.3 ms out of every timed step (rocprofv3 kernel trace, profiles/r04); the mean over steps x 4 launches is what `roofline` reports
+        _lib.call("ufv_gemm_timing", 7 if self._on else 0)
 
     def summary(self):
         import ctypes
@@ -256,14 +274,22 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
             ach = ks["flops"] / (ks["mean_ms"] * 1e-3) / 1e12
             traffic = None
             peak = 2 * MFMA_PEAK_TFLOPS if args.fp8 else MFMA_PEAK_TFLOPS
-            pmc = os.path.join(ROOT, "profiles", "r03", "pmc_bench.json")
-            busy = None
+            pmc = os.path.join(ROOT, PMC_FILE)
+            busy, pmc_note = None, f"{PMC_FILE} (tools/pmc_bench.sh: rocprofv3 --pmc passes of this command, not re-measured per run)"
             if os.path.exists(pmc) and not args.fp8:
-                gu = json.load(open(pmc)).get("gate_up", {})
-                traffic, busy = gu.get("hbm_bytes_per_launch"), gu.get("mfma_busy_fraction")
+                rec = json.load(open(pmc))
+                have, want = rec.get("gemm_sources_sha256"), gemm_sources_sha256()
+                if have == want:
+                    gu = rec.get("gate_up", {})
+                    traffic, busy = gu.get("hbm_bytes_per_launch"), gu.get("mfma_busy_fraction")
+                else:
+                    # counters of a DIFFERENT build of the kernel are not quoted: null, and say so where the driver's log shows it
+                    pmc_note = (f"STALE, not quoted: {PMC_FILE} was measured on GEMM sources {str(have)[:12]}, this tree has {want[:12]}; "
+                                f"re-run tools/pmc_bench.sh")
+                    print("bench.py: " + pmc_note, file=sys.stderr, flush=True)
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256<%s,swiglu> gate/up M=%d N=%d K=%d" % ("fp8" if args.fp8 else "bf16", ks["M"], ks["N"], ks["K"]),
                                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                               "traffic": traffic, "traffic_source": "profiles/r03/pmc_bench.json (tools/pmc_bench.sh: rocprofv3 --pmc passes of this command, not re-measured per run)",
+                               "traffic": traffic, "traffic_source": pmc_note,
                                "mfma_busy_pmc": busy,
                                "launch_ms": round(ks["mean_ms"], 4), "launches": ks["launches"]}
         step_tf = sum(FLOPS.values()) * args.frames / 32 / (dt / args.steps) / 1e12

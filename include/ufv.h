@@ -428,9 +428,9 @@ int ufv_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_
  * (head h at column h*hd, RoPE applied), k / v bf16 [>= round_up(S,128) rows, ldkv] (kv-head g at column g*hd), dO bf16 [S, lddo]
  * -> dq [S, lddq], dk / dv [S, lddkv] bf16.  ws = ufv_attention_bwd_ws_bytes(S, Hq, Hkv, hd). */
 int64_t ufv_attention_bwd_ws_bytes(int S, int Hq, int Hkv, int hd);
-/* Measurement aid (bench.py's roofline entry): while enabled, every ufv_gemm / ufv_gemm_fp8 launch with the SwiGLU epilogue and M > 64 -- the
+/* Measurement aid (bench.py's roofline entry): enable = n > 0: every n-th ufv_gemm / ufv_gemm_fp8 launch with the SwiGLU epilogue and M > 64 -- the
  * decoder's gate/up projection, the dominant kernel -- is bracketed by a HIP event pair on its own stream, whether it is issued op by op or
- * inside a stage call.  ufv_gemm_timing_read waits for the recorded launches, returns their count, copies up to `cap` durations (ms) and
+ * inside a stage call (a bracket idles the stream for ~11 us: bench.py samples every 7th launch, 4 of a step's 28); 0 = off.  ufv_gemm_timing_read waits for the recorded launches, returns their count, copies up to `cap` durations (ms) and
  * shapes (M, N, K per launch) and forgets them.  Not thread-safe; off by default. */
 int ufv_gemm_timing(int enable);
 /* which kernel UFV_GEMM_AUTO takes for a bf16 GEMM of this shape (host arithmetic, no launch): 0 = the 128-wide / small-shape kernels, else the

@@ -10,4 +10,6 @@ for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/$C.err
 done
 rocprofv3 --pmc SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/BUSY -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/BUSY.err
+# wave lifetimes in shader cycles (quad-cycles x 4): the denominator that does not depend on GRBM_GUI_ACTIVE, which reads high on launches well under 0.3 ms
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d $OUT/WAVE -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/WAVE.err
 python3 $R/tools/pmc_summarize.py $TAG

@@ -19,7 +19,7 @@ def short(name):
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for sub in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "BUSY"):
+for sub in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "BUSY", "WAVE"):
     for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             n = row["Kernel_Name"]
@@ -35,6 +35,14 @@ for k, d in sorted(acc.items()):
     if "GRBM_GUI_ACTIVE_mean" in means[k] and "SQ_VALU_MFMA_BUSY_CYCLES_mean" in means[k]:
         means[k]["elapsed_cycles"] = means[k]["GRBM_GUI_ACTIVE_mean"] / 8.0
         means[k]["mfma_busy_fraction"] = (means[k]["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / 1024.0) / means[k]["elapsed_cycles"]
+    if "SQ_WAVE_CYCLES_mean" in means[k] and "SQ_WAVES_mean" in means[k] and "SQ_VALU_MFMA_BUSY_CYCLES_mean" in means[k] and means[k]["SQ_WAVES_mean"] > 0:
+        # mean lifetime of a wave in shader cycles (SQ_WAVE_CYCLES counts quad-cycles), and the matrix pipe's busy cycles per SIMD over the time its
+        # waves were resident: waves / 1024 SIMDs waves share a pipe one after (or beside) the other, so resident time per SIMD = lifetime x waves / 1024
+        # when they run one at a time (attn_fwd_vit72_p2: 1024 waves, one per SIMD) -- an upper bound on residency otherwise
+        life = 4.0 * means[k]["SQ_WAVE_CYCLES_mean"] / means[k]["SQ_WAVES_mean"]
+        means[k]["wave_lifetime_cycles"] = life
+        means[k]["mfma_busy_per_simd_cycles"] = means[k]["SQ_VALU_MFMA_BUSY_CYCLES_mean"] / 1024.0
+        means[k]["mfma_busy_fraction_of_wave_lifetime"] = means[k]["mfma_busy_per_simd_cycles"] / life if means[k]["SQ_WAVES_mean"] <= 1024.5 else None
 
 
 def summary(match, label, alg_bytes=None):
@@ -45,6 +53,9 @@ def summary(match, label, alg_bytes=None):
     m = means[k]
     out = {"kernel": label, "kernel_symbol": k, "launches": m.get("launches"), "elapsed_cycles": round(m.get("elapsed_cycles", 0)),
            "mfma_busy_fraction": round(m.get("mfma_busy_fraction", 0), 4), "duration_us_profiled": round(m.get("duration_ns_mean", 0) / 1e3, 1)}
+    if m.get("mfma_busy_fraction_of_wave_lifetime") is not None:
+        out["mfma_busy_fraction_of_wave_lifetime"] = round(m["mfma_busy_fraction_of_wave_lifetime"], 4)
+        out["wave_lifetime_cycles"] = round(m["wave_lifetime_cycles"])
     if "FETCH_SIZE_mean" in m and "WRITE_SIZE_mean" in m:
         out["fetch_bytes"] = int(m["FETCH_SIZE_mean"] * 1024 * 2)
         out["write_bytes"] = int(m["WRITE_SIZE_mean"] * 1024)
@@ -54,7 +65,10 @@ def summary(match, label, alg_bytes=None):
     return out
 
 
-res = {"source": f"tools/pmc_bench.sh {tag}: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, one pass each, no trace "
+sys.path.insert(0, root)
+import bench as _bench          # noqa: E402  (only for the source fingerprint; nothing of it runs)
+res = {"gemm_sources_sha256": _bench.gemm_sources_sha256(),
+       "source": f"tools/pmc_bench.sh {tag}: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, one pass each, no trace "
                  "domains, on `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`; summarised by tools/pmc_summarize.py",
        "correction": "gfx950: FETCH_SIZE (KB) reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE (KB) exact; counters sit on the "
                      "L2's memory side: Infinity-Cache hits included.  GRBM_GUI_ACTIVE sums the 8 XCDs -> / 8 = elapsed shader cycles (reads high on launches shorter than "

@@ -771,7 +771,8 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
 // Launch timing of the dominant kernel for bench.py's roofline entry (ufv_gemm_timing): while enabled, every tile-kernel GEMM with the SwiGLU
 // epilogue (the decoder's gate/up projection) is bracketed by a HIP event pair on ITS stream, wherever the call comes from (op-level or a stage call).
 struct TimedLaunch { hipEvent_t s, e; int M, N, K; };
-static bool g_timing = false;
+static int g_timing = 0;                 // 0 = off; n > 0: every n-th eligible launch is bracketed (each bracket costs the stream ~11 us of idle: two event packets)
+static unsigned g_timing_seen = 0;
 static std::vector<TimedLaunch>& timed_launches() { static std::vector<TimedLaunch> v; return v; }
 
 template <bool Q>
@@ -783,7 +784,8 @@ int gemm_entry(const void* A, int lda, const float* a_scale, const void* W, int 
     e.scale_m = a_scale; e.scale_n = w_scale; e.dump_f32 = 0; e.ksplit = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     TimedLaunch tl{};
-    const bool timed = g_timing && swiglu && M > 64 && hipEventCreate(&tl.s) == hipSuccess && hipEventCreate(&tl.e) == hipSuccess;
+    const bool timed = g_timing > 0 && swiglu && M > 64 && (g_timing_seen++ % (unsigned)g_timing) == 0 && hipEventCreate(&tl.s) == hipSuccess &&
+                       hipEventCreate(&tl.e) == hipSuccess;
     if (timed) (void)hipEventRecord(tl.s, st);
     int rc;
     if (out_f32)
@@ -812,7 +814,8 @@ extern "C" int ufv_gemm_choice(int M, int N, int K, int out_f32, int swiglu, int
 extern "C" int ufv_gemm_set_splitk(int enable) { return g_splitk.exchange(enable != 0 ? 1 : 0); }
 
 extern "C" int ufv_gemm_timing(int enable) {
-    g_timing = enable != 0;
+    g_timing = enable < 0 ? 0 : enable;
+    g_timing_seen = 0;
     return UFV_OK;
 }
 

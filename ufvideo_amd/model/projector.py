@@ -222,7 +222,7 @@ class STCConnector(PackedModule):
         else:
             hw = x.shape[2]
         outs = [self.forward_one(x[i].reshape(t * hw * hw, x.shape[-1]), t, hw) for i in range(b)]
-        return torch.stack(outs, 0)
+        return outs[0].unsqueeze(0) if b == 1 else torch.stack(outs, 0)          # (one video: a view, not a 33 MB device copy)
 
 
 class STCConnectorV35(STCConnector):
