@@ -921,7 +921,8 @@ def test_forward_training_is_an_autograd_node_loss_backward_fills_grad_like_the_
     ids, labels = t(a["ids"]).to(DEV), t(a["labels_in"]).to(DEV)
     video = t(arrs["video"]).to(DEV)
     batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids), images=[(video, "video")],
-                 images_sam=torch.zeros(1, 4, 3, 8, 8, device=DEV), offset=[0, 1], masks_list=None, label_list=None)
+                 images_sam=torch.zeros(1, 4, 3, 8, 8, device=DEV), offset=[0, 1], masks_list=[torch.zeros(0, 56, 56)],
+                 label_list=[torch.zeros(56, 56)])
     with torch.no_grad():
         plain = m(**batch)                                            # values only, no graph
     assert not plain["loss"].requires_grad

@@ -255,11 +255,12 @@ def drain(u, bank, bank_b=None):
         b.append(f"ds_read_b128 {vr(rows[i], 4)}, {vr(ORADDR)} offset:{reg + 1024 * i}")
     b.append("s_waitcnt lgkmcnt(0)")
     for i in range(4):
-        b.append(("VMEM", f"buffer_store_dwordx4 {vr(rows[i], 4)}, {vr(VOFFO(i))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen"))
+        if "ostore" not in DROP:
+            b.append(("VMEM", f"buffer_store_dwordx4 {vr(rows[i], 4)}, {vr(VOFFO(i))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen"))
     b += ["s_nop 1", f"ds_read_b128 {vr(rows[0], 4)}, {vr(ORADDR)} offset:{reg + 4096}", "s_waitcnt lgkmcnt(0)",
-          ("GROUP", [f"s_mov_b64 exec, {sr(S_EXLO, 2)}",
-                     ("VMEM", f"buffer_store_dwordx4 {vr(rows[0], 4)}, {vr(VOFFO(4))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen"),
-                     "s_mov_b64 exec, -1"]), "s_nop 1"]
+          ("GROUP", [f"s_mov_b64 exec, {sr(S_EXLO, 2)}"] +
+                    ([] if "ostore" in DROP else [("VMEM", f"buffer_store_dwordx4 {vr(rows[0], 4)}, {vr(VOFFO(4))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen")]) +
+                    ["s_mov_b64 exec, -1"]), "s_nop 1"]
     return a, b
 
 
@@ -361,13 +362,14 @@ def build(simple=False):
     # tile 2) are issued behind the first MFMAs.  With all 37 up front every block's first bytes queue behind 41 MB of everybody's later ones: the kernel
     # started ~5 k cycles later (lab, same box: 83 -> 79 us).  UFV_P2_OPT=early23 restores the old order.
     LATE = "early23" not in OPT
-    for k in range(5 if LATE else QPIECES):
+    NFIRST = QPIECES if ("p18" in OPT or not LATE) else 5      # p18: unit 1's rows too go out up front (18 operations), so that nothing is waited for twice
+    for k in range(NFIRST):
         for i in dma_piece(QR, VOFFR(k), sr(S_QSOFF), [f"s_add_u32 m0, {sr(S_QST)}, {1024 * k}"]):
             e(i)
     e(f"s_add_u32 {sr(S_Q2OFF)}, {sr(S_QSOFF)}, {sr(S_T64)}")
 
     def rest23():
-        for k in range(5 if LATE else QPIECES, QPIECES):
+        for k in range(NFIRST, QPIECES):
             for i in dma_piece(QR, VOFFR(k), sr(S_QSOFF), [f"s_add_u32 m0, {sr(S_QST)}, {1024 * k}"]):
                 e(i)
         for i in q2_fetch():
@@ -517,6 +519,8 @@ def build(simple=False):
                     # the staging regions are out by then (region 0 is read last, in period (1, 0))
                     qd = []
                     for k in [k for k in (2 * (j - 1), 2 * (j - 1) + 1) if k < QPIECES]:
+                        if "qdma" in DROP:
+                            continue
                         qd.append(("GROUP", [f"s_add_u32 m0, {sr(S_QST)}, {1024 * k}", "s_nop 0",
                                              ("VMEM", f"buffer_load_dwordx4 {vr(VOFFR(k))}, {sr(QR, 4)}, {sr(S_QSOFF)} offen lds")]))
                     if j == 5:
@@ -579,7 +583,7 @@ def main():
     simple = "--simple" in sys.argv
     lines = build(simple)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = os.path.join(root, "ufvideo_amd", "csrc", "attn_vit_p2_asm.inc")
+    out = os.environ.get("UFV_P2_OUT") or os.path.join(root, "ufvideo_amd", "csrc", "attn_vit_p2_asm.inc")
     clob = [f"v{i}" for i in range(256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(40, 100)] + ["vcc", "memory"]
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_p2.py%s -- do not edit.  %d instructions.\n" % (" --simple" if simple else "", len(lines)))

@@ -16,6 +16,7 @@ __device__ unsigned long long* g_stamps;      // [blocks][8]
     unsigned xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); g_stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc_ << 32) | id_; } } } while (0)
 void ufv_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 extern "C" const char* ufv_last_error(void) { return ""; }
+int ufv_dev_n_cu() { static int n = 0; if (!n) { hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0); n = p.multiProcessorCount; } return n; }      // (gemm_state.hip's, for the lab)
 #include "../../ufvideo_amd/csrc/attn.hip"
 
 static inline float bf2f(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void layernorm_k(const void* x, int ldx, void*
 // chunks before it reduces and stores the current one (layernorm_k's waves all load, then all reduce, then all store: with ~2 rounds of blocks per CU the
 // memory system idles through every reduce phase); weight and bias are staged once per block in LDS.  Same per-lane summation order as layernorm_k:
 // bit-identical results.
-template <int XDT, bool YF32, int NV, int ACT = ACT_NONE>
+template <int XDT, bool YF32, int NV>
 __global__ __launch_bounds__(256) void layernorm_pipe_k(const void* x, int ldx, void* y, int ldy, const float* w, const float* b, int M, int D, float eps) {
     extern __shared__ __attribute__((aligned(16))) float ln_wb[];
     const int lane = threadIdx.x & 63, nv = D >> 2;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void layernorm_pipe_k(const void* x, int ldx, 
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(ln_wb + D + c);
                 f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = act_apply_t<ACT>((v[i][j] - mean) * rstd * ww[j] + bb[j]);
+                for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * ww[j] + bb[j];
                 store4<YF32>(y, (int64_t)row * ldy + c, o);
             }
 #pragma unroll
@@ -229,80 +229,10 @@ __global__ __launch_bounds__(256) void ln_add_silu_k(const bf16* a, const float*
         }
 }
 
-// Pipelined form of ln_add_silu_k for long inputs (the connector's 18 432 x 3584 stage): persistent 8-wave blocks, the four parameter vectors staged ONCE
-// per block in LDS (as plain global loads they are 57 KB per row against the row's own 21 KB of traffic: the kernel ran at the L2's pace, 3.4 TB/s of
-// algorithmic bytes), a wave walks rows r, r + G, ... and requests the next row's chunks before it reduces and stores the current one.  Same per-lane
-// summation order and element arithmetic as ln_add_silu_k: bit-identical results.
-template <bool HAS_B>
-__global__ __launch_bounds__(512) void ln_add_silu_pipe_k(const bf16* __restrict__ a, const float* __restrict__ wa, const float* __restrict__ ba,
-                                                          const bf16* __restrict__ b, const float* __restrict__ wb, const float* __restrict__ bb,
-                                                          bf16* __restrict__ out, int M, int D, float eps) {
-    extern __shared__ __attribute__((aligned(16))) float lw[];          // wa | ba | (wb | bb)
-    const int lane = threadIdx.x & 63, nc = D >> 3;
-    for (int i = threadIdx.x; i < (D >> 2); i += 512) {
-        reinterpret_cast<f32x4*>(lw)[i] = reinterpret_cast<const f32x4*>(wa)[i];
-        reinterpret_cast<f32x4*>(lw + D)[i] = reinterpret_cast<const f32x4*>(ba)[i];
-        if (HAS_B) {
-            reinterpret_cast<f32x4*>(lw + 2 * D)[i] = reinterpret_cast<const f32x4*>(wb)[i];
-            reinterpret_cast<f32x4*>(lw + 3 * D)[i] = reinterpret_cast<const f32x4*>(bb)[i];
-        }
-    }
-    __syncthreads();
-    const int G = gridDim.x * 8;
-    int row = blockIdx.x * 8 + (threadIdx.x >> 6);
-    bf16x8 va[8], vb[8], na[8], nb[8];
-    if (row < M) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (lane + 64 * i < nc) {
-                va[i] = *reinterpret_cast<const bf16x8*>(a + (int64_t)row * D + 8 * (lane + 64 * i));
-                vb[i] = *reinterpret_cast<const bf16x8*>(b + (int64_t)row * D + 8 * (lane + 64 * i));
-            }
-    }
-    while (row < M) {
-        const int nrow = row + G;
-        if (nrow < M) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (lane + 64 * i < nc) {
-                    na[i] = *reinterpret_cast<const bf16x8*>(a + (int64_t)nrow * D + 8 * (lane + 64 * i));
-                    nb[i] = *reinterpret_cast<const bf16x8*>(b + (int64_t)nrow * D + 8 * (lane + 64 * i));
-                }
-        }
-        float ma, ra, mb = 0.f, rb = 1.f;
-        ln_stats8(va, nc, lane, D, eps, ma, ra);
-        if (HAS_B) ln_stats8(vb, nc, lane, D, eps, mb, rb);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (lane + 64 * i < nc) {
-                const int c = 8 * (lane + 64 * i);
-                float w1[8], b1[8], w2[8], b2[8];
-                *reinterpret_cast<f32x4*>(w1) = *reinterpret_cast<const f32x4*>(lw + c); *reinterpret_cast<f32x4*>(w1 + 4) = *reinterpret_cast<const f32x4*>(lw + c + 4);
-                *reinterpret_cast<f32x4*>(b1) = *reinterpret_cast<const f32x4*>(lw + D + c); *reinterpret_cast<f32x4*>(b1 + 4) = *reinterpret_cast<const f32x4*>(lw + D + c + 4);
-                if (HAS_B) {
-                    *reinterpret_cast<f32x4*>(w2) = *reinterpret_cast<const f32x4*>(lw + 2 * D + c); *reinterpret_cast<f32x4*>(w2 + 4) = *reinterpret_cast<const f32x4*>(lw + 2 * D + c + 4);
-                    *reinterpret_cast<f32x4*>(b2) = *reinterpret_cast<const f32x4*>(lw + 3 * D + c); *reinterpret_cast<f32x4*>(b2 + 4) = *reinterpret_cast<const f32x4*>(lw + 3 * D + c + 4);
-                }
-                bf16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float t = ((float)va[i][j] - ma) * ra * w1[j] + b1[j];
-                    float sv = (float)vb[i][j];
-                    if (HAS_B) sv = (sv - mb) * rb * w2[j] + b2[j];
-                    o[j] = (bf16)act_apply_t<ACT_SILU>(t + sv);
-                }
-                *reinterpret_cast<bf16x8*>(out + (int64_t)row * D + c) = o;
-            }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { va[i] = na[i]; vb[i] = nb[i]; }
-        row = nrow;
-    }
-}
-
 template <bool YF32>
 __global__ __launch_bounds__(256) void rmsnorm_k(const float* x, int ldx, void* y, int ldy, const float* w, int M, int D,
                                                  float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // blockDim.x / 64 rows per block
     if (row >= M) return;
     const int nv = D >> 2;
     f32x4 v[MAXV];
@@ -615,129 +545,6 @@ __global__ __launch_bounds__(256) void dwconv_ln_silu_k(const bf16* __restrict__
                 *reinterpret_cast<bf16x8*>(y + ((int64_t)(f * H + py) * W + x0 + p) * C + c) = o;
             }
         }
-}
-
-// Row-walking form of dwconv_ln_silu_k (round 4).  The kernel above loads its 9 x C taps (129 KB at C = 3584) and the LayerNorm parameters once per
-// 4-pixel block: more parameter bytes than activation bytes, all of them L2 traffic (1.45 GB per call on the 32 x 24 x 24 x 3584 stage against 264 MB of
-// algorithmic HBM bytes: 150 us).  Here a block keeps the nine taps of its channels in REGISTERS (144 per lane) and walks `nsb` consecutive 4-pixel
-// segments of one image row: parameters once per 4 nsb pixels, input columns shared between neighbouring segments through L2 as before.  The order of
-// the additions into every output (dy, then dx ascending), the two-pass statistics and the element arithmetic are those of dwconv_ln_silu_k:
-// bit-identical output.
-__global__ __launch_bounds__(256) void dwconv_ln_silu_row_k(const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w9,
-                                                            const float* __restrict__ lnw, const float* __restrict__ lnb, int F, int H, int W,
-                                                            int C, float eps, int nsb) {
-    constexpr int PX = 4, MAXI = 2;
-    __shared__ float red[2][4][PX];
-    const int nseg = (W + PX - 1) / PX, nblk = (nseg + nsb - 1) / nsb;
-    const int sb = blockIdx.x % nblk, py = (blockIdx.x / nblk) % H, f = blockIdx.x / (nblk * H);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nc = C >> 3, cpw = (nc + 3) >> 2;
-    int cidx[MAXI];
-    bool cok[MAXI];
-#pragma unroll
-    for (int i = 0; i < MAXI; ++i) {
-        const int q = lane + 64 * i;
-        cok[i] = q < cpw && wave * cpw + q < nc;
-        cidx[i] = cok[i] ? 8 * (wave * cpw + q) : 0;
-    }
-    float wt[3][3][MAXI][8];                                // [dy][dx][chunk][channel]: resident for the whole block
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int i = 0; i < MAXI; ++i) {
-                const float* wk = w9 + (dy * 3 + dx) * C + cidx[i];
-                const f32x4 a = *reinterpret_cast<const f32x4*>(wk), b = *reinterpret_cast<const f32x4*>(wk + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { wt[dy][dx][i][j] = a[j]; wt[dy][dx][i][4 + j] = b[j]; }
-            }
-    const int seg_end = min(nseg, (sb + 1) * nsb);
-#pragma unroll 1
-    for (int seg = sb * nsb; seg < seg_end; ++seg) {
-        const int x0 = seg * PX;
-        float acc[MAXI][PX][8];
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i)
-#pragma unroll
-            for (int p = 0; p < PX; ++p)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][p][j] = 0.f;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = py + dy;
-            if (yy < 0 || yy >= H) continue;
-            const bf16* row = x + ((int64_t)(f * H + yy) * W) * C;
-#pragma unroll
-            for (int col = -1; col <= PX; ++col) {
-                const int xx = x0 + col;
-                if (xx < 0 || xx >= W) continue;
-#pragma unroll
-                for (int i = 0; i < MAXI; ++i)
-                    if (cok[i]) {
-                        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(row + (int64_t)xx * C + cidx[i]);
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const int p = col - (dx - 1);
-                            if (p >= 0 && p < PX)
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) acc[i][p][j] += (float)xv[j] * wt[dy + 1][dx][i][j];
-                        }
-                    }
-            }
-        }
-        float mean[PX], rstd[PX];
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            float sm = 0.f;
-#pragma unroll
-            for (int i = 0; i < MAXI; ++i)
-                if (cok[i])
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) sm += acc[i][p][j];
-            sm = wave_sum(sm);
-            if (lane == 0) red[0][wave][p] = sm;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < PX; ++p) mean[p] = (red[0][0][p] + red[0][1][p] + red[0][2][p] + red[0][3][p]) / C;
-#pragma unroll
-        for (int p = 0; p < PX; ++p) {
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < MAXI; ++i)
-                if (cok[i])
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float d = acc[i][p][j] - mean[p];
-                        q += d * d;
-                    }
-            q = wave_sum(q);
-            if (lane == 0) red[1][wave][p] = q;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < PX; ++p) rstd[p] = rsqrtf((red[1][0][p] + red[1][1][p] + red[1][2][p] + red[1][3][p]) / C + eps);
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i)
-            if (cok[i]) {
-                const int c = cidx[i];
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnw + c), g1 = *reinterpret_cast<const f32x4*>(lnw + c + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(lnb + c), b1 = *reinterpret_cast<const f32x4*>(lnb + c + 4);
-#pragma unroll
-                for (int p = 0; p < PX; ++p) {
-                    if (x0 + p >= W) continue;
-                    bf16x8 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        o[j] = (bf16)act_apply_t<ACT_SILU>((acc[i][p][j] - mean[p]) * rstd[p] * g0[j] + b0[j]);
-                        o[4 + j] = (bf16)act_apply_t<ACT_SILU>((acc[i][p][4 + j] - mean[p]) * rstd[p] * g1[j] + b1[j]);
-                    }
-                    *reinterpret_cast<bf16x8*>(y + ((int64_t)(f * H + py) * W + x0 + p) * C + c) = o;
-                }
-            }
-        __syncthreads();                                   // `red` is rewritten by the next segment
-    }
 }
 
 // out[f, c] = mean_p x[f*P + p, c].  Block = 8 row groups x 64 lanes, lane owns 8 channels (16-byte loads, 512 channels per
@@ -1056,23 +863,12 @@ extern "C" int ufv_layernorm(const void* x, int x_dtype, int ldx, void* y, int y
     dim3 g(cdiv(M, 4)), blk(256);
     // long inputs without activation (the ViT's 18 432 x 1152 stream): the pipelined persistent form, >= 4 rows per wave, <= 4 blocks per CU
     // (measured on 18 432 x 1152 fp32 -> bf16: 30.3 -> 22.9 us from cache, 38.5 -> 27.4 us from HBM; 2 / 3 / 4 blocks per CU within 2 %)
-    static const bool old_elementwise = getenv("UFV_OLD_ELEMENTWISE") != nullptr;          // lab A/B: the round-3 forms of the connector's elementwise kernels
     if (act == ACT_NONE && D <= 1280 && !y_f32 && M >= 4096 && (x_dtype == UFV_DT_F32 || x_dtype == UFV_DT_BF16)) {
         const int blocks = M / 16 < 1024 ? M / 16 : 1024;
         if (x_dtype == UFV_DT_F32)
             hipLaunchKernelGGL((layernorm_pipe_k<UFV_DT_F32, false, 5>), dim3(blocks), blk, 2 * D * sizeof(float), ST(stream), x, ldx, y, ldy, w, b, M, D, eps);
         else
             hipLaunchKernelGGL((layernorm_pipe_k<UFV_DT_BF16, false, 5>), dim3(blocks), blk, 2 * D * sizeof(float), ST(stream), x, ldx, y, ldy, w, b, M, D, eps);
-        UFV_CHECK_LAUNCH();
-        return UFV_OK;
-    }
-    // round 4: wide bf16 rows with the SiLU fused (the connector's LayerNorm2d + SiLU on 18 432 x 3584: w / b were 28 KB of L2 reads per 14 KB row)
-    if (!old_elementwise && (act == ACT_NONE || act == ACT_SILU) && D > 1280 && !y_f32 && M >= 4096 && x_dtype == UFV_DT_BF16 && b) {
-        const int blocks = M / 16 < 768 ? M / 16 : 768;
-        if (act == ACT_SILU)
-            hipLaunchKernelGGL((layernorm_pipe_k<UFV_DT_BF16, false, MAXV, ACT_SILU>), dim3(blocks), blk, 2 * D * sizeof(float), ST(stream), x, ldx, y, ldy, w, b, M, D, eps);
-        else
-            hipLaunchKernelGGL((layernorm_pipe_k<UFV_DT_BF16, false, MAXV, ACT_NONE>), dim3(blocks), blk, 2 * D * sizeof(float), ST(stream), x, ldx, y, ldy, w, b, M, D, eps);
         UFV_CHECK_LAUNCH();
         return UFV_OK;
     }
@@ -1098,20 +894,6 @@ extern "C" int ufv_ln_add_silu(const void* a, const float* wa, const float* ba, 
                                void* out, int M, int D, float eps, void* stream) {
     UFV_REQUIRE(a && wa && ba && b && out && M > 0, "ufv_ln_add_silu: bad arguments");
     UFV_REQUIRE(D % 8 == 0 && D <= 4096, "ufv_ln_add_silu: D=%d must be a multiple of 8 and <= 4096", D);
-    static const bool old_elementwise = getenv("UFV_OLD_ELEMENTWISE") != nullptr;
-    if (!old_elementwise && M >= 4096 && (wb == nullptr || bb != nullptr)) {
-        const int n_cu = ufv_dev_n_cu();
-        const int blocks = M / 32 < 2 * n_cu ? M / 32 : 2 * n_cu;                      // >= 4 rows per wave, 2 blocks of 8 waves per CU (57 KB of LDS each)
-        const size_t lds = (size_t)(wb ? 4 : 2) * D * sizeof(float);
-        if (wb) {
-            UFV_ONCE_PER_DEVICE((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_add_silu_pipe_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536););
-            hipLaunchKernelGGL((ln_add_silu_pipe_k<true>), dim3(blocks), dim3(512), lds, ST(stream), (const bf16*)a, wa, ba, (const bf16*)b, wb, bb, (bf16*)out, M, D, eps);
-        } else {
-            hipLaunchKernelGGL((ln_add_silu_pipe_k<false>), dim3(blocks), dim3(512), lds, ST(stream), (const bf16*)a, wa, ba, (const bf16*)b, wb, bb, (bf16*)out, M, D, eps);
-        }
-        UFV_CHECK_LAUNCH();
-        return UFV_OK;
-    }
     hipLaunchKernelGGL(ln_add_silu_k, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), (const bf16*)a, wa, ba, (const bf16*)b, wb, bb,
                        (bf16*)out, M, D, eps);
     UFV_CHECK_LAUNCH();
@@ -1122,8 +904,11 @@ extern "C" int ufv_rmsnorm(const float* x, int ldx, void* y, int y_f32, int ldy,
                            void* stream) {
     UFV_REQUIRE(x && y && w && M > 0, "ufv_rmsnorm: bad arguments");
     UFV_REQUIRE(D % 4 == 0 && D <= 4 * 64 * MAXV && ldx % 4 == 0 && ldy % 4 == 0, "ufv_rmsnorm: D=%d unsupported", D);
-    if (y_f32) hipLaunchKernelGGL((rmsnorm_k<true>), dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, ldx, y, ldy, w, M, D, eps);
-    else hipLaunchKernelGGL((rmsnorm_k<false>), dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), x, ldx, y, ldy, w, M, D, eps);
+    // one wave per row.  Few rows (the decoder's S = 2399: 9.4 rows per CU): one-wave blocks, so that the CUs' row counts differ by one row, not by a block
+    // of four (600 four-row blocks gave CUs 8 or 12 rows)
+    const int rpb = M < 8192 ? 1 : 4;
+    if (y_f32) hipLaunchKernelGGL((rmsnorm_k<true>), dim3(cdiv(M, rpb)), dim3(64 * rpb), 0, ST(stream), x, ldx, y, ldy, w, M, D, eps);
+    else hipLaunchKernelGGL((rmsnorm_k<false>), dim3(cdiv(M, rpb)), dim3(64 * rpb), 0, ST(stream), x, ldx, y, ldy, w, M, D, eps);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
@@ -1196,16 +981,8 @@ extern "C" int ufv_dwconv3x3_ln_silu(const void* x, void* y, const float* w9, co
                                      int W, int C, float eps, void* stream) {
     UFV_REQUIRE(x && y && w9 && lnw && lnb && F > 0, "ufv_dwconv3x3_ln_silu: bad arguments");
     UFV_REQUIRE(C % 8 == 0 && C <= 4096, "ufv_dwconv3x3_ln_silu: C=%d must be a multiple of 8 and <= 4096", C);
-    static const bool old_elementwise = getenv("UFV_OLD_ELEMENTWISE") != nullptr;
-    const int nseg = cdiv(W, 4);
-    int nsb = 1;                                            // 4-pixel segments per block: as many as leave >= 1024 blocks (2 resident per CU by registers)
-    for (int cand : {6, 3, 2})
-        if ((int64_t)F * H * cdiv(nseg, cand) >= 1024) { nsb = cand; break; }
-    if (!old_elementwise && nsb > 1)
-        hipLaunchKernelGGL(dwconv_ln_silu_row_k, dim3(F * H * cdiv(nseg, nsb)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F, H, W, C, eps, nsb);
-    else
-        hipLaunchKernelGGL(dwconv_ln_silu_k, dim3(F * H * cdiv(W, 4)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F,
-                           H, W, C, eps);
+    hipLaunchKernelGGL(dwconv_ln_silu_k, dim3(F * H * cdiv(W, 4)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F,
+                       H, W, C, eps);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
