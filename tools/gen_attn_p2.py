@@ -256,10 +256,10 @@ def drain(u, bank, bank_b=None):
     b.append("s_waitcnt lgkmcnt(0)")
     for i in range(4):
         if "ostore" not in DROP:
-            b.append(("VMEM", f"buffer_store_dwordx4 {vr(rows[i], 4)}, {vr(VOFFO(i))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen"))
+            b.append(("VMEM", f"buffer_store_dwordx4 {vr(rows[i], 4)}, {vr(VOFFO(i))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen{STMOD}"))
     b += ["s_nop 1", f"ds_read_b128 {vr(rows[0], 4)}, {vr(ORADDR)} offset:{reg + 4096}", "s_waitcnt lgkmcnt(0)",
           ("GROUP", [f"s_mov_b64 exec, {sr(S_EXLO, 2)}"] +
-                    ([] if "ostore" in DROP else [("VMEM", f"buffer_store_dwordx4 {vr(rows[0], 4)}, {vr(VOFFO(4))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen")]) +
+                    ([] if "ostore" in DROP else [("VMEM", f"buffer_store_dwordx4 {vr(rows[0], 4)}, {vr(VOFFO(4))}, {sr(S_ODESC, 4)}, {sr(S_T3)} offen{STMOD}")]) +
                     ["s_mov_b64 exec, -1"]), "s_nop 1"]
     return a, b
 
@@ -317,6 +317,7 @@ def emit_ins(G, ins):
 Gen.emit_ins = emit_ins
 
 
+STMOD = "".join(" " + m for m in ("nt", "sc0", "sc1") if ("st_" + m) in os.environ.get("UFV_P2_OPT", "").split(","))      # cache-policy bits of the O stores (experiments)
 OPT = set(os.environ.get("UFV_P2_OPT", "").split(","))        # scheduling experiments (results stay correct)
 DROP = set(os.environ.get("UFV_P2_DROP", "").split(","))      # timing experiments only (wrong results): dma, exp, max, seam, barrier, vread, kread
 
@@ -349,7 +350,10 @@ def build(simple=False):
                 f"v_sub_u32 {vr(TC)}, {vr(TA)}, {vr(TC)}", f"v_lshlrev_b32 {vr(TC)}, 4, {vr(TC)}", f"v_mul_lo_u32 {vr(TD)}, {vr(TB)}, {sr(S_SS)}",
                 f"v_add_u32 {vr(VOFFR(k))}, {vr(TD)}, {vr(TC)}"]
         if k < 5:
-            ins += [f"v_mul_lo_u32 {vr(TD)}, {vr(TB)}, {sr(S_OS)}", f"v_add_u32 {vr(VOFFO(k))}, {vr(TD)}, {vr(TC)}"]
+            if "stlin" in OPT:      # timing experiment: every store instruction writes ONE contiguous KB (the output lands in the wrong place)
+                ins += [f"v_lshlrev_b32 {vr(TD)}, 4, {vr(LANE)}", f"v_add_u32 {vr(VOFFO(k))}, {1024 * k}, {vr(TD)}"]
+            else:
+                ins += [f"v_mul_lo_u32 {vr(TD)}, {vr(TB)}, {sr(S_OS)}", f"v_add_u32 {vr(VOFFO(k))}, {vr(TD)}, {vr(TC)}"]
     for i in ins:
         e(i)
     if STAMPS:
