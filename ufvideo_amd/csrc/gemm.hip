@@ -360,11 +360,13 @@ __global__ __launch_bounds__(256) void gemv_nt(const bf16* __restrict__ A, const
 #pragma unroll
         for (int r = 0; r < MR; ++r) {
             if (r < M) {
+                // two products per instruction (v_dot2_f32_bf16, fp32 accumulate): with a cvt + cvt + fma per element the kernel was VALU-bound on the
+                // 32-row SE products of the connector (896 x 3584 and 3584 x 896: 26 us each, 16 per clip)
                 const bf16x8 av = *reinterpret_cast<const bf16x8*>(A + (size_t)r * lda + k);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    s0[r] += (float)av[j] * (float)wv[j];
-                    if (SWIGLU) s1[r] += (float)av[j] * (float)uv[j];
+                for (int j = 0; j < 4; ++j) {
+                    s0[r] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{av[2 * j], av[2 * j + 1]}, bf16x2{wv[2 * j], wv[2 * j + 1]}, s0[r], false);
+                    if (SWIGLU) s1[r] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{av[2 * j], av[2 * j + 1]}, bf16x2{uv[2 * j], uv[2 * j + 1]}, s1[r], false);
                 }
             }
         }
