@@ -29,6 +29,12 @@
 #define UFV_GSTAMP_DECL
 #define UFV_GSTAMP_FLUSH
 #endif
+#ifndef UFV_TSTAMP         /* lab builds (tools/lab/gemm_tile_lab.hip): a per-TILE timeline (K loop start, first K-tiles, K loop end, seam, epilogue end) */
+#define UFV_TSTAMP(slot)
+#define UFV_TSTAMP_K(tt)
+#define UFV_TSTAMP_DECL
+#define UFV_TSTAMP_NEXT
+#endif
 
 namespace {
 
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     constexpr int NSTW = 2 * MT;
     constexpr bool RELAX_OK = PH2 && !SKT && !KSPL && (L_ALL + NST <= 63);
     int relax = 0;                                           // 0: strict waits; 1: NST stores may stay in flight; 2: NSTW
+    UFV_TSTAMP_DECL
     while (have) {
     const int len = k1 - k0;
     f32x4 acc[NT][MT];   // [nt][mt]
@@ -511,6 +518,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     }
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // waves 4-7 run one barrier behind
+    UFV_TSTAMP(0);
 
     UFV_GSTAMP_DECL
     if constexpr (PH2) {
@@ -542,6 +550,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, MA0, MA1, 5, 6, 7)
         UFV_GSTAMP(8);
+        UFV_TSTAMP_K(tt);
     }
     } else {
     for (int tt = 0; tt < len; ++tt) {
@@ -571,6 +580,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();      // balance the stagger barrier
+    UFV_TSTAMP(5);
     UFV_GSTAMP_FLUSH;
 #undef UFV_SYNC_THEN_MMA
 
@@ -609,6 +619,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     const int cm0 = m0, cn0 = n0, cpart = item_part, ctile = item_tile, clen = len;
     have = next_item(m0, n0, k0, k1);
     if (have) { set_src(m0, n0); kbeg = k0; kend = k1; prologue_loads(); }
+    UFV_TSTAMP(6);
     if constexpr (SK) if (part_head) {
         // this block's range ended inside the tile: the following blocks hold the rest, in order
         int covered = len;                          // K-tiles of the tile accounted for so far (this block's k0 was 0)
@@ -674,6 +685,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             relax = RELAX_OK && interior ? 1 : 0;
         }
     }
+    UFV_TSTAMP(7);
+    UFV_TSTAMP_NEXT
     }   // persistent tile loop
 #undef UFV_WAIT_KEEP_A0_B1
 }
