@@ -60,19 +60,29 @@ enum { ACT_NONE = 0, ACT_GELU_TANH = 1, ACT_GELU_ERF = 2, ACT_SILU = 3, ACT_RELU
 // GELU (tanh form), 0.5 x (1 + tanh u) with u = sqrt(2/pi) (x + 0.044715 x^3), written as x / (1 + exp(-2u)): the same function (0.5 (1 + tanh u) is the
 // logistic of 2u) in one v_exp_f32 + one v_rcp_f32 and no branch.  libm's tanhf takes a polynomial or an exp path by magnitude, so a wave with both kinds of
 // lanes ran both: the epilogue of the ViT's fc1 GEMM (80 M activations per call) cost 35-70 us by DATA on a 155 us GEMM (tools/lab/gelu_data_probe.py).
+// Round 4: the exponent -2 log2(e) u = x (C0 + C1 x^2) with the constants folded (C0 = -2 log2(e) sqrt(2/pi), C1 = 0.044715 C0): mul, fma, mul instead of
+// mul, mul, fma, mul, mul in front of the two transcendentals -- the fc1 epilogue (128 activations per lane and tile, two waves per SIMD) is VALU-bound on this
+// function (per-tile timeline: epilogue 11.2 / 16.2 k ticks against 7.4 / 9.2 k for the same tile without it), and the three operations pair up as packed fp32.
 __device__ __forceinline__ float gelu_tanh(float x) {
-    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
+    const float a = x * fmaf(x * x, -0.10294324f, -2.3022082f);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
 }
+
+// logistic(x) = 1 / (1 + e^-x) as one v_exp_f32 + one v_rcp_f32 (<= 1 ulp from the quotient).  Written as `1 / (1 + __expf(-x))` hipcc emits the IEEE division
+// sequence (v_div_scale x 2, v_rcp, 4 fma, v_div_fmas, v_div_fixup): 10 more vector instructions per element, which made the connector's "HBM-bound" LayerNorm + SiLU /
+// depthwise + LN + SiLU / LN + add + SiLU kernels (66 M activations per call) and the SwiGLU epilogue of gate/up (64 pairs per lane and tile) VALU-bound (round 4).
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float silu_fast(float x) { return x * sigmoid_fast(x); }
+__device__ __forceinline__ float swiglu_f(float g, float u) { return g * sigmoid_fast(g) * u; }      // SwiGLU: silu(gate) * up, every kernel's one formula
 
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
         case ACT_GELU_TANH: return gelu_tanh(x);
         case ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
-        case ACT_SILU: return x / (1.0f + __expf(-x));
+        case ACT_SILU: return silu_fast(x);
         case ACT_RELU: return x > 0.f ? x : 0.f;
-        case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));
-        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+        case ACT_QUICK_GELU: return x * sigmoid_fast(1.702f * x);
+        case ACT_SIGMOID: return sigmoid_fast(x);
         default: return x;
     }
 }
@@ -81,10 +91,10 @@ template <int ACT>
 __device__ __forceinline__ float act_apply_t(float x) {
     if (ACT == ACT_GELU_TANH) return gelu_tanh(x);
     if (ACT == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
-    if (ACT == ACT_SILU) return x / (1.0f + __expf(-x));
+    if (ACT == ACT_SILU) return silu_fast(x);
     if (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
-    if (ACT == ACT_QUICK_GELU) return x / (1.0f + __expf(-1.702f * x));
-    if (ACT == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-x));
+    if (ACT == ACT_QUICK_GELU) return x * sigmoid_fast(1.702f * x);
+    if (ACT == ACT_SIGMOID) return sigmoid_fast(x);
     return x;
 }
 

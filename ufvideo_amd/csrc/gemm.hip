@@ -48,7 +48,7 @@ __device__ __forceinline__ void epilogue128(const f32x4 (&acc)[4][MT], const Epi
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float gte = acc[2 * p][mt][j], up = acc[2 * p + 1][mt][j];
-                        v[j] = gte / (1.0f + __expf(-gte)) * up;
+                        v[j] = swiglu_f(gte, up);
                     }
                     epi_store4<OUT_F32, ACT_NONE>(e, m, n, v[0], v[1], v[2], v[3]);
                 }
@@ -320,7 +320,7 @@ __global__ void gemm_nt_generic(const bf16* __restrict__ A, const bf16* __restri
             g += x * (float)wg[k];
             u += x * (float)wu[k];
         }
-        v = g / (1.0f + __expf(-g)) * u;
+        v = swiglu_f(g, u);
     } else {
         const bf16* w = W + (size_t)n * ldw;
         float s = 0.f;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void gemv_nt(const bf16* __restrict__ A, const
         float v = wave_sum(s0[r]);
         if (SWIGLU) {
             const float u = wave_sum(s1[r]);
-            v = v / (1.0f + __expf(-v)) * u;
+            v = swiglu_f(v, u);
         } else {
             if (e.bias) v += e.bias[n];
             v = act_apply(v, e.act);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void gemv_nt_fp8(const uint8_t* __restrict__ A
         float v = wave_sum(s0[r]) * e.scale_m[m] * e.scale_n[row0];
         if (SWIGLU) {
             const float u = wave_sum(s1[r]) * e.scale_m[m] * e.scale_n[row0 + 16];
-            v = v / (1.0f + __expf(-v)) * u;
+            v = swiglu_f(v, u);
         } else {
             if (e.bias) v += e.bias[n];
             v = act_apply(v, e.act);
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void gemv1_nt(const bf16* __restrict__ a, cons
         if (SWIGLU) {
             float u = wave_sum(s1[j]);
             if (W8) u *= a_scale * w_scale[rows[j] + 16];
-            v = v / (1.0f + __expf(-v)) * u;
+            v = swiglu_f(v, u);
         } else {
             if (e.bias) v += e.bias[min(n, n_out - 1)];
             v = act_apply(v, e.act);

@@ -187,7 +187,7 @@ __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2 + NB1][MA0 + MA
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float gte = acc[2 * nh][mt][j], up = acc[2 * nh + 1][mt][j];
-                            v[j] = gte / (1.0f + __expf(-gte)) * up;
+                            v[j] = swiglu_f(gte, up);
                         }
                         epi_store4b<OUT_F32, ACT_NONE>(e, m, n, v[0], v[1], v[2], v[3], f32x4{0, 0, 0, 0});
                     } else {
@@ -614,7 +614,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     if (!part_tail && !SWIGLU && e.bias && (!KSPL || item_part == 0)) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bias[nt] = *reinterpret_cast<const f32x4*>(e.bias + col_of(nt));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The wait names the bias registers as its outputs: to hipcc they are then values an asm statement produced, not results of loads that may still be
+        // in flight.  Without that the compiler, which cannot see this wait, put its own `s_waitcnt vmcnt(0)` in front of the first use of a bias register
+        // in EVERY (row, run) block of the epilogue -- behind the previous block's store, so each of a wave's 16 output stores was drained before the next
+        // one was even computed (round 4: 16 x vmcnt(0) per tile in the ISA of every epilogue256_wide variant; the epilogue took 7.4 - 9.2 k ticks of a
+        // 61 k-tick tile where the chip's write rate allows 4.8 k).
+        if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3])::"memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2])::"memory");
     }
     const int cm0 = m0, cn0 = n0, cpart = item_part, ctile = item_tile, clen = len;
     have = next_item(m0, n0, k0, k1);

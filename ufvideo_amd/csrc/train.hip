@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void swiglu_k(const bf16* __restrict__ gu, int
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float gf = (float)g[j];
-                a[j] = (bf16)(gf / (1.0f + __expf(-gf)) * (float)u[j]);
+                a[j] = (bf16)swiglu_f(gf, (float)u[j]);
             }
             *reinterpret_cast<bf16x8*>(out + (int64_t)m * ldo + ch * 8) = a;
         } else {
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void swiglu_k(const bf16* __restrict__ gu, int
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float gf = (float)g[j], uf = (float)u[j], df = (float)d[j];
-                const float s = 1.0f / (1.0f + __expf(-gf));
+                const float s = sigmoid_fast(gf);
                 dg[j] = (bf16)(df * uf * s * (1.0f + gf * (1.0f - s)));
                 du[j] = (bf16)(df * gf * s);
             }

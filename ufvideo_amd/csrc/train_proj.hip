@@ -16,8 +16,8 @@ inline int grid_for(int64_t n, int per_block = 256) {
 
 __device__ __forceinline__ float act_grad(float x, int act) {
     switch (act) {
-        case ACT_SILU: { const float s = 1.0f / (1.0f + __expf(-x)); return s * (1.0f + x * (1.0f - s)); }
-        case ACT_SIGMOID: { const float s = 1.0f / (1.0f + __expf(-x)); return s * (1.0f - s); }
+        case ACT_SILU: { const float s = sigmoid_fast(x); return s * (1.0f + x * (1.0f - s)); }
+        case ACT_SIGMOID: { const float s = sigmoid_fast(x); return s * (1.0f - s); }
         case ACT_GELU_ERF: return 0.5f * (1.0f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
         case ACT_RELU: return x > 0.f ? 1.f : 0.f;
         default: return 1.f;
