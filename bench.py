@@ -108,7 +108,7 @@ class KernelTimer:
         self._on = bool(v)
         # every 7th gate/up launch (4 of the 28 per step, a different layer each): an event pair costs the stream ~11 us of idle, so bracketing all
         # 28 took 0.3 ms out of every timed step (rocprofv3 kernel trace, profiles/r04); the mean over steps x 4 launches is what `roofline` reports
-        _lib.call("ufv_gemm_timing", 7 if self._on else 0)
+        _lib.call("ufv_gemm_timing", 7 if (self._on and not os.environ.get("UFV_BENCH_NO_TIMER")) else 0)     # (UFV_BENCH_NO_TIMER: lab A/B runs, tools/lab/ab_bench.sh)
 
     def summary(self):
         import ctypes

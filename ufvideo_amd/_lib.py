@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libufv_hip.so")
+# (UFV_LIBRARY overrides the in-tree build: lab A/B runs of two builds on one box, tools/lab/ab_bench.sh; unset in every product / test / bench run)
+LIB_PATH = os.environ.get("UFV_LIBRARY") or os.path.join(_HERE, "libufv_hip.so")
 
 ACT = {None: 0, "none": 0, "gelu_pytorch_tanh": 1, "gelu_tanh": 1, "gelu": 2, "gelu_erf": 2, "silu": 3, "relu": 4,
        "quick_gelu": 5, "sigmoid": 6}
