@@ -116,6 +116,8 @@ __device__ __forceinline__ void epilogue128_wide(const f32x4 (&acc)[4][MT], cons
     f32x4 bias[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) bias[nt] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + n0 + wn * 64 + nt * 16 + fq * 4) : f32x4{0, 0, 0, 0};
+    // (the bias registers leave this wait as asm outputs: otherwise hipcc waits vmcnt(0) for them in front of every (row, run) block, i.e. behind every store)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3])::"memory");
     auto pack2 = [&](float a, float b) -> unsigned {
         const bf16x2 p = {(bf16)a, (bf16)b};
         return __builtin_bit_cast(unsigned, p);

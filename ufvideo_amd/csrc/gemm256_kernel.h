@@ -131,24 +131,30 @@ template <int ACT, int MA0, int MA1, int NB1>
 __device__ __forceinline__ void epilogue256_wide(const f32x4 (&acc)[2 + NB1][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc,
                                                  int frow, int fq, const f32x4 (&bias)[2 + NB1]) {
     constexpr int MT = MA0 + MA1;
-    bf16* out = reinterpret_cast<bf16*>(e.out);
+    // Round 4: the stores go through ONE buffer descriptor over the whole output (num_records = M rows): a row past M is dropped by the hardware, so there is no
+    // exec masking, and an address is a 32-bit per-lane offset + an immediate -- the flat form cost five 64-bit vector operations per store (the epilogue is
+    // VALU-bound: ~35 vector instructions per store, two waves per SIMD, 7 - 9 k ticks of a 61 k-tick K = 1152 tile).  The caller guarantees M * ldc * 2 < 2^31.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, M * e.ldc * 2, 0x20000);
+    const int step = 32 * e.ldc;                                                                   // bytes between accumulator rows mt and mt + 1 (16 matrix rows)
+    const int col0 = n0 + wc * 32 + fq * 8;
+    const int off_h0 = ((m0 + wr * 16 * MA0 + frow) * e.ldc + col0) * 2;                          // this lane's row of accumulator row 0 (A0 half), run 0
+    const int off_h1 = ((m0 + 32 * MA0 + wr * 16 * MA1 + frow) * e.ldc + col0) * 2;               // ... of accumulator row MA0 (A1 half)
     auto pack2 = [&](float a, float b) -> unsigned {
         const bf16x2 p = {(bf16)a, (bf16)b};
         return __builtin_bit_cast(unsigned, p);
     };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow;
+        const int off = mt < MA0 ? off_h0 + mt * step : off_h1 + (mt - MA0) * step;
 #pragma unroll
         for (int run = 0; run < 2; ++run) {
             const int nb = n0 + run * 128;
             if (nb >= N) continue;
-            if (run == 1 && NB1 == 1) {               // a 16-column second half has no partner n-tile: the 8-byte store
-                if (m < M) {
-                    const f32x4 v = acc[2][mt] + bias[2];
-                    const bf16x4 o = {(bf16)act_apply_t<ACT>(v[0]), (bf16)act_apply_t<ACT>(v[1]), (bf16)act_apply_t<ACT>(v[2]), (bf16)act_apply_t<ACT>(v[3])};
-                    *reinterpret_cast<bf16x4*>(out + (size_t)m * e.ldc + nb + wc * 16 + fq * 4) = o;
-                }
+            if (run == 1 && NB1 == 1) {               // a 16-column second half has no partner n-tile: the 8-byte store (columns 128 + 16 wc + 4 fq ..)
+                const f32x4 v = acc[2][mt] + bias[2];
+                const bf16x4 o = {(bf16)act_apply_t<ACT>(v[0]), (bf16)act_apply_t<ACT>(v[1]), (bf16)act_apply_t<ACT>(v[2]), (bf16)act_apply_t<ACT>(v[3])};
+                typedef __attribute__((ext_vector_type(2))) int i32x2;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, o), rs, off + (128 - wc * 16 - fq * 4) * 2, 0, 0);
                 continue;
             }
             const f32x4 va = acc[2 * run][mt] + bias[2 * run], vb = acc[2 * run + 1][mt] + bias[2 * run + 1];
@@ -158,10 +164,47 @@ __device__ __forceinline__ void epilogue256_wide(const f32x4 (&acc)[2 + NB1][MA0
             auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
             auto t0 = __builtin_amdgcn_permlane16_swap((unsigned)s0[0], (unsigned)s0[1], false, false);
             auto t1 = __builtin_amdgcn_permlane16_swap((unsigned)s1[0], (unsigned)s1[1], false, false);
-            if (m < M) {
-                const i32x4 o = {(int)t0[0], (int)t1[0], (int)t0[1], (int)t1[1]};       // columns 8 fq .. 8 fq + 7 of the run
-                *reinterpret_cast<i32x4*>(out + (size_t)m * e.ldc + nb + wc * 32 + fq * 8) = o;
+            const i32x4 o = {(int)t0[0], (int)t1[0], (int)t0[1], (int)t1[1]};       // columns 8 fq .. 8 fq + 7 of the run
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs, off + run * 256, 0, 0);
+        }
+    }
+}
+
+// SwiGLU epilogue with 16-byte stores (round 4).  A lane holds 4 output columns (8 bytes of bf16) per (accumulator row, half): columns 4 fq .. 4 fq + 3 of the
+// 16-column output tile, so the plain form issues 16 eight-byte stores per wave and tile.  One v_permlane16_swap per register over a PAIR of accumulator rows
+// (x = row mt, y = row mt + 1: the swap exchanges x's odd 16-lane rows with y's even ones) leaves lane rows 0 / 2 with columns 0..7 / 8..15 of row mt and lane
+// rows 1 / 3 with the same columns of row mt + 1: 8 sixteen-byte stores, through a buffer descriptor (rows >= M dropped by the hardware, 32-bit offsets).
+// Same values, same rounding: bit-identical output.
+template <int MA0, int MA1>
+__device__ __forceinline__ void epilogue256_swiglu_wide(const f32x4 (&acc)[4][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc, int frow, int fq) {
+    static_assert(MA0 % 2 == 0 && MA1 % 2 == 0, "accumulator rows are stored in pairs inside each A half");
+    constexpr int MT = MA0 + MA1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, M * e.ldc * 2, 0x20000);
+    const int step2 = 64 * e.ldc;                                                                  // bytes between accumulator-row pairs (32 matrix rows)
+    const int col0 = (n0 >> 1) + wc * 16 + 8 * (fq >> 1);
+    const int rsel = 16 * (fq & 1);                                                                // lane rows 1 / 3 carry accumulator row mt + 1
+    const int off_h0 = ((m0 + wr * 16 * MA0 + frow + rsel) * e.ldc + col0) * 2;
+    const int off_h1 = ((m0 + 32 * MA0 + wr * 16 * MA1 + frow + rsel) * e.ldc + col0) * 2;
+    auto pack2 = [&](float a, float b) -> unsigned {
+        const bf16x2 p = {(bf16)a, (bf16)b};
+        return __builtin_bit_cast(unsigned, p);
+    };
+#pragma unroll
+    for (int mp = 0; mp < MT; mp += 2) {
+        const int off = mp < MA0 ? off_h0 + (mp >> 1) * step2 : off_h1 + ((mp - MA0) >> 1) * step2;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            if (n0 + nh * 128 >= N) continue;
+            unsigned x[2], y[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                x[k] = pack2(swiglu_f(acc[2 * nh][mp][2 * k], acc[2 * nh + 1][mp][2 * k]), swiglu_f(acc[2 * nh][mp][2 * k + 1], acc[2 * nh + 1][mp][2 * k + 1]));
+                y[k] = pack2(swiglu_f(acc[2 * nh][mp + 1][2 * k], acc[2 * nh + 1][mp + 1][2 * k]), swiglu_f(acc[2 * nh][mp + 1][2 * k + 1], acc[2 * nh + 1][mp + 1][2 * k + 1]));
             }
+            auto t0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
+            auto t1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
+            const i32x4 o = {(int)t0[0], (int)t1[0], (int)t0[1], (int)t1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs, off + nh * 128, 0, 0);
         }
     }
 }
@@ -450,9 +493,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // operations) outstanding -- the first K-tile's two phases then run while the store burst drains instead of behind it.  Exact only when
     // every store instruction of the epilogue was issued (interior tile); 0 otherwise and for a block's first item.
     constexpr int NST = SWIGLU ? 2 * MT : MT * NT;           // store instructions of the 8-byte / residual epilogues; the 16-byte bf16 epilogue issues 2 * MT
+    constexpr int NSTS = MT;                                 // the 16-byte SwiGLU epilogue: one store per accumulator-row pair and half
     constexpr int NSTW = 2 * MT;
     constexpr bool RELAX_OK = PH2 && !SKT && !KSPL && (L_ALL + NST <= 63);
-    int relax = 0;                                           // 0: strict waits; 1: NST stores may stay in flight; 2: NSTW
+    int relax = 0;                                           // 0: strict waits; 1: NST stores may stay in flight; 2: NSTW; 3: NSTS
     UFV_TSTAMP_DECL
     while (have) {
     const int len = k1 - k0;
@@ -510,6 +554,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         if (len > 1) {                                 // A0 / B0 / B1 of the first K-tile; its A1 and the second tile's three stay in flight
             if (RELAX_OK && relax == 1) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
+            else if (RELAX_OK && relax == 3) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
             else wait_vmcnt<L_ALL>();
         } else wait_vmcnt<T::LA1>();
     } else {
@@ -534,6 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         if (tt + 1 < len) {                            // behind A1[t]: A0/B0/B1[t+1] and A1[t+1] (+ at the item's first K-tile the previous epilogue's stores)
             if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
+            else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
             else wait_vmcnt<L_ALL>();
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, 0, MA0, 1, 2, 3)
@@ -546,6 +592,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         if (tt + 2 < len) {                            // behind them: A1[t+1] and A0/B0/B1[t+2]
             if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
+            else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
             else wait_vmcnt<L_ALL>();
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, MA0, MA1, 5, 6, 7)
@@ -677,15 +724,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     } else {
         bool by_rows = false;
         if constexpr (!SWIGLU && !FP8) by_rows = e.resid != nullptr && e.act == ACT_NONE;
+        bool swide = false;
+        if constexpr (!OUT_F32 && SWIGLU && MA0 % 2 == 0 && MA1 % 2 == 0 && NB1 == 2)
+            swide = e.resid == nullptr && e.ldc % 8 == 0 && ((uintptr_t)e.out & 15) == 0 && (int64_t)M * e.ldc < (1ll << 30);
         bool wide = false;
-        if constexpr (!OUT_F32 && !SWIGLU) wide = e.resid == nullptr && e.ldc % 8 == 0 && ((uintptr_t)e.out & 15) == 0;
+        if constexpr (!OUT_F32 && !SWIGLU) wide = e.resid == nullptr && e.ldc % 8 == 0 && ((uintptr_t)e.out & 15) == 0 && (int64_t)M * e.ldc < (1ll << 30);
         const bool interior = cm0 + BM <= M && cn0 + BN <= N;     // every store instruction of the epilogue is issued
         if (by_rows) {
             if constexpr (!SWIGLU && !FP8) epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
             relax = RELAX_OK ? 1 : 0;                             // this form issues every store instruction, edge tiles included
+        } else if (swide) {
+            if constexpr (!OUT_F32 && SWIGLU && MA0 % 2 == 0 && MA1 % 2 == 0 && NB1 == 2) epilogue256_swiglu_wide<MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq);
+            relax = RELAX_OK && cn0 + BN <= N ? 3 : 0;
         } else if (wide) {
             if constexpr (!OUT_F32 && !SWIGLU) { UFV_ACT_SWITCH(e.act, (epilogue256_wide<ACT_, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias))) }
-            relax = RELAX_OK && interior ? 2 : 0;
+            relax = RELAX_OK && cn0 + BN <= N ? 2 : 0;            // buffer stores: every store instruction is issued on row-edge tiles too (the hardware drops rows >= M)
         } else {
             UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_, false, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias)))
             relax = RELAX_OK && interior ? 1 : 0;
