@@ -11,11 +11,11 @@
 #include <cstdint>
 #include <vector>
 #include <algorithm>
-__device__ unsigned long long* g_ts;      // [blocks][2 groups][8 tiles][8 slots]
+__device__ unsigned long long* g_ts;      // [blocks][2 groups][8 tiles][16 slots]
 #define UFV_TSTAMP_DECL int ts_tile = 0;
 #define UFV_TSTAMP_NEXT ++ts_tile;
 #define UFV_TSTAMP(slot) do { if (g_ts && lane == 0 && (wave & 3) == 0 && ts_tile < 8) \
-    g_ts[((((size_t)blockIdx.x * 2 + (wave >> 2)) * 8 + ts_tile) * 8) + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+    g_ts[((((size_t)blockIdx.x * 2 + (wave >> 2)) * 8 + ts_tile) * 16) + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define UFV_TSTAMP_K(tt) do { if ((tt) < 4) UFV_TSTAMP(1 + (tt)); } while (0)
 void ufv_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 extern "C" const char* ufv_last_error(void) { return ""; }
@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     (void)hipMemset(r, 0, (size_t)M * N * 4);
     Epi e; memset(&e, 0, sizeof(e));
     e.out = f32res ? (void*)r : c; e.ldc = N; e.act = act; e.resid = f32res ? r : nullptr; e.ldr = N; e.bias = bias;
-    const size_t nst = 256 * 2 * 8 * 8;
+    const size_t nst = 256 * 2 * 8 * 16;
     unsigned long long* st; (void)hipMalloc(&st, nst * 8); (void)hipMemset(st, 0, nst * 8);
     unsigned long long* nullp = nullptr;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ts), &nullp, sizeof(nullp));
@@ -71,15 +71,17 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 8; ++i) {
                 std::vector<double> d;
                 for (int b = 0; b < 256; ++b) {
-                    const unsigned long long* p = h.data() + (((size_t)b * 2 + g) * 8 + t) * 8;
-                    const unsigned long long* pn = p + 8;
+                    const unsigned long long* p = h.data() + (((size_t)b * 2 + g) * 8 + t) * 16;
+                    const unsigned long long* pn = p + 16;
                     unsigned long long x0 = i < 7 ? p[i] : p[7], x1 = i < 7 ? p[i + 1] : (t < 7 ? pn[0] : 0);
                     if (x0 && x1 && x1 > x0) d.push_back((double)(x1 - x0));
                 }
                 printf(" %s %.0f |", names[i], med(d));
             }
             std::vector<double> d;
-            for (int b = 0; b < 256; ++b) { const unsigned long long* p = h.data() + (((size_t)b * 2 + g) * 8 + t) * 8; if (p[0] && p[8]) d.push_back((double)(p[8] - p[0])); }
+            for (int b = 0; b < 256; ++b) { const unsigned long long* p = h.data() + (((size_t)b * 2 + g) * 8 + t) * 16; if (p[0] && p[16]) d.push_back((double)(p[16] - p[0])); }
+            { std::vector<double> d1, d2, d3; for (int b = 0; b < 256; ++b) { const unsigned long long* p = h.data() + (((size_t)b * 2 + g) * 8 + t) * 16; if (p[5] && p[8] && p[9] && p[6]) { d1.push_back((double)(p[8] - p[5])); d2.push_back((double)(p[9] - p[8])); d3.push_back((double)(p[6] - p[9])); } }
+              printf(" [bias wait %.0f, next_item + set_src %.0f, DMA issue %.0f]", med(d1), med(d2), med(d3)); }
             tile_total = med(d);
             printf(" tile period %.0f\n", tile_total);
         }

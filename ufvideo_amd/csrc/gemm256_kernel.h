@@ -670,8 +670,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2])::"memory");
     }
     const int cm0 = m0, cn0 = n0, cpart = item_part, ctile = item_tile, clen = len;
+    UFV_TSTAMP(8);
     have = next_item(m0, n0, k0, k1);
-    if (have) { set_src(m0, n0); kbeg = k0; kend = k1; prologue_loads(); }
+    if (have) { set_src(m0, n0); kbeg = k0; kend = k1; UFV_TSTAMP(9); prologue_loads(); }
     UFV_TSTAMP(6);
     if constexpr (SK) if (part_head) {
         // this block's range ended inside the tile: the following blocks hold the rest, in order
