@@ -494,6 +494,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // every store instruction of the epilogue was issued (interior tile); 0 otherwise and for a block's first item.
     constexpr int NST = SWIGLU ? 2 * MT : MT * NT;           // store instructions of the 8-byte / residual epilogues; the 16-byte bf16 epilogue issues 2 * MT
     constexpr int NSTS = MT;                                 // the 16-byte SwiGLU epilogue: one store per accumulator-row pair and half
+    // INVARIANT the relaxed waits rest on: the epilogue that ran last issued EXACTLY this many vector-memory instructions after the next tile's prologue DMA.
+    // epilogue256_resid issues its loads / stores from inline asm (count fixed by construction, every store issued on edge tiles too); epilogue256_wide and
+    // epilogue256_swiglu_wide issue one __builtin_amdgcn_raw_buffer_store per (row, run) / (row pair, half) -- 16-byte buffer stores of different rows, which
+    // hipcc can neither merge nor predicate away (rows >= M are dropped by the descriptor, a tile cut in N takes the strict waits); the plain epilogue256
+    // relaxes only on interior tiles.  A toolchain that changed one of these counts would under-wait the first K-tile: the bit-identity tests against the
+    // 128-wide kernel (tests/test_kernels_gpu.py) are the guard, and tools/lab/gemm_tile_lab.hip the place to re-count (`grep -c buffer_store` in the -S output).
     constexpr int NSTW = 2 * MT;
     constexpr bool RELAX_OK = PH2 && !SKT && !KSPL && (L_ALL + NST <= 63);
     int relax = 0;                                           // 0: strict waits; 1: NST stores may stay in flight; 2: NSTW; 3: NSTS
