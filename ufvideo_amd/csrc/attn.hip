@@ -1362,6 +1362,11 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_decode_fused(const bf16* __restrict__ qkv, int Hq, int Hkv, const float* __restrict__ inv_freq, int pos_host,
                                                           const int* __restrict__ pos_dev, bf16* kv, int ldkv, bf16* o, float scale, float* ws, int nsplit) {
     constexpr int CPR = HD / 8, KPI = 64 / CPR, HALF = HD / 2;
+    // The launch is a chain of memory round trips, not a stream (5 MB of cache per layer): every key / value row a lane will use is REQUESTED before the
+    // first one is consumed -- NIT rows of K and NIT rows of V per lane and chunk of CHUNK keys (one chunk covers 256 keys per split: 4096 positions at
+    // 16 splits) -- and the RoPE trigonometry runs underneath.  (With one load per loop iteration a split of 150 keys was 2 x 10 dependent HBM round trips:
+    // 24 us per launch, 0.68 ms per token.)  The arithmetic and its order are those of the three-kernel sequence.
+    constexpr int NIT = 64 / KPI, CHUNK = NIT * 4 * KPI;
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     float* sc = reinterpret_cast<float*>(smem_d);
     __shared__ float red[16];
@@ -1376,27 +1381,48 @@ __global__ __launch_bounds__(256) void attn_decode_fused(const bf16* __restrict_
     const int k0 = split * per, k1 = min(nk, k0 + per), n = max(k1 - k0, 0);
     float* out = ws + ((size_t)hq * nsplit + split) * (HD + 2);
     int* counter = reinterpret_cast<int*>(ws + (size_t)Hq * nsplit * (HD + 2)) + hq;
-    // rotate-half RoPE of one 8-element chunk of head row `p` (dims 8ch .. 8ch+7; the partner dims are HALF away), rounded to bf16 as the cache holds it
-    auto rope_chunk = [&](const bf16* p) -> bf16x8 {
-        const bool lo = ch * 8 < HALF;
-        const bf16x8 mine = *reinterpret_cast<const bf16x8*>(p + ch * 8);
-        const bf16x8 other = *reinterpret_cast<const bf16x8*>(p + (lo ? ch * 8 + HALF : ch * 8 - HALF));
+    const bf16* kb = kv + hkv * HD + ch * 8;
+    const bf16* vb = kv + (Hkv + hkv) * HD + ch * 8;
+    bf16x8 kreg[NIT], vreg[NIT];
+    // rows past the split's end are clamped to row `pos` (inside the cache; it may be the row another block is appending right now: such a value is never used)
+    auto request = [&](bf16x8 (&r)[NIT], const bf16* base, int c0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = min(k0 + c0 + (it * 4 + wave) * KPI + sub, pos);
+            r[it] = *reinterpret_cast<const bf16x8*>(base + (int64_t)row * ldkv);
+        }
+    };
+    // the small operands first (memory returns in order: they arrive ahead of the cache rows and the trigonometry starts on them): the 8 frequencies of this
+    // lane's chunk as two vector loads (one scalar load + wait per frequency was 8 dependent L2 round trips per rotated row), q's and the new k's halves, v
+    const bool lo = ch * 8 < HALF;
+    const int partner = lo ? ch * 8 + HALF : ch * 8 - HALF;
+    const bool has_new = k1 == nk && n > 0;                    // this split ends with the new token
+    const f32x4 fr0 = *reinterpret_cast<const f32x4*>(inv_freq + (ch * 8) % HALF), fr1 = *reinterpret_cast<const f32x4*>(inv_freq + (ch * 8) % HALF + 4);
+    const bf16* qrow = qkv + hq * HD;
+    const bf16* krow = qkv + (Hq + hkv) * HD;
+    // unconditional (a split without keys, or without the new token, reads valid rows it does not use): a branch here makes the compiler wait for ALL of it at the join
+    const bf16x8 q_mine = *reinterpret_cast<const bf16x8*>(qrow + ch * 8), q_other = *reinterpret_cast<const bf16x8*>(qrow + partner);
+    const bf16x8 k_mine = *reinterpret_cast<const bf16x8*>(krow + ch * 8), k_other = *reinterpret_cast<const bf16x8*>(krow + partner);
+    const bf16x8 vnew = *reinterpret_cast<const bf16x8*>(qkv + (Hq + Hkv + hkv) * HD + ch * 8);
+    bf16x8 knew = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("" ::: "memory");                             // keep this order: the scheduler would otherwise put the 32 row requests first
+    request(kreg, kb, 0);
+    request(vreg, vb, 0);
+    asm volatile("" ::: "memory");
+    // rotate-half RoPE of one 8-element chunk of a head row (dims 8ch .. 8ch+7; the partner dims are HALF away), rounded to bf16 as the cache holds it
+    auto rope_chunk = [&](const bf16x8 mine, const bf16x8 other) -> bf16x8 {
         bf16x8 r;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int i = (ch * 8 + j) % HALF;
-            const float ang = (float)pos * inv_freq[i];
+            const float ang = (float)pos * (j < 4 ? fr0[j & 3] : fr1[j & 3]);
             const float c = cosf(ang), sn = sinf(ang);
             const float x1 = lo ? (float)mine[j] : (float)other[j], x2 = lo ? (float)other[j] : (float)mine[j];
             r[j] = lo ? (bf16)(x1 * c - x2 * sn) : (bf16)(x2 * c + x1 * sn);
         }
         return r;
     };
-    const bool has_new = k1 == nk && n > 0;                    // this split ends with the new token
-    bf16x8 knew = {0, 0, 0, 0, 0, 0, 0, 0}, vnew = knew;
     if (has_new) {
-        knew = rope_chunk(qkv + (Hq + hkv) * HD);
-        vnew = *reinterpret_cast<const bf16x8*>(qkv + (Hq + Hkv + hkv) * HD + ch * 8);
+        knew = rope_chunk(k_mine, k_other);
         if (hq % (Hq / Hkv) == 0 && wave == 0 && sub == 0) {      // one block per kv head appends the row for later tokens
             *reinterpret_cast<bf16x8*>(kv + (int64_t)pos * ldkv + hkv * HD + ch * 8) = knew;
             *reinterpret_cast<bf16x8*>(kv + (int64_t)pos * ldkv + (Hkv + hkv) * HD + ch * 8) = vnew;
@@ -1404,24 +1430,28 @@ __global__ __launch_bounds__(256) void attn_decode_fused(const bf16* __restrict_
     }
     float mx = -INFINITY, sum = 0.f;
     if (n > 0) {
-        const bf16x8 qv = rope_chunk(qkv + hq * HD);
+        const bf16x8 qv = rope_chunk(q_mine, q_other);
         float qf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) qf[j] = (float)qv[j] * scale;
-        const bf16* kb = kv + hkv * HD + ch * 8;
-        const bf16* vb = kv + (Hkv + hkv) * HD + ch * 8;
-        for (int j0 = wave * KPI; j0 < n; j0 += 4 * KPI) {
-            const int j = j0 + sub;
-            float s = 0.f;
-            if (j < n) {
-                const bf16x8 kvv = (k0 + j == pos) ? knew : *reinterpret_cast<const bf16x8*>(kb + (int64_t)(k0 + j) * ldkv);
+        for (int c0 = 0; c0 < n; c0 += CHUNK) {
+            if (c0 > 0) request(kreg, kb, c0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += qf[e] * (float)kvv[e];
+            for (int it = 0; it < NIT; ++it) {
+                const int j = c0 + (it * 4 + wave) * KPI + sub;
+                if (c0 + (it * 4 + wave) * KPI < n) {                // wave-uniform: the iterations the one-load-per-iteration loop ran
+                    float s = 0.f;
+                    if (j < n) {
+                        const bf16x8 kvv = (k0 + j == pos) ? knew : kreg[it];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) s += qf[e] * (float)kvv[e];
+                    }
+#pragma unroll
+                    for (int oo = 1; oo < CPR; oo <<= 1) s += __shfl_xor(s, oo, 64);
+                    if (j < n && ch == 0) sc[j] = s;
+                    if (j < n) mx = fmaxf(mx, s);
+                }
             }
-#pragma unroll
-            for (int oo = 1; oo < CPR; oo <<= 1) s += __shfl_xor(s, oo, 64);
-            if (j < n && ch == 0) sc[j] = s;
-            if (j < n) mx = fmaxf(mx, s);
         }
         mx = wave_max(mx);
         if (lane == 0) red[wave] = mx;
@@ -1435,13 +1465,17 @@ __global__ __launch_bounds__(256) void attn_decode_fused(const bf16* __restrict_
         sum = block_sum(sum, red + 4);
         __syncthreads();
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int j0 = wave * KPI; j0 < n; j0 += 4 * KPI) {
-            const int j = j0 + sub;
-            if (j < n) {
-                const float pj = sc[j];
-                const bf16x8 vv = (k0 + j == pos) ? vnew : *reinterpret_cast<const bf16x8*>(vb + (int64_t)(k0 + j) * ldkv);
+        for (int c0 = 0; c0 < n; c0 += CHUNK) {
+            if (c0 > 0) request(vreg, vb, c0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += pj * (float)vv[e];
+            for (int it = 0; it < NIT; ++it) {
+                const int j = c0 + (it * 4 + wave) * KPI + sub;
+                if (j < n) {
+                    const float pj = sc[j];
+                    const bf16x8 vv = (k0 + j == pos) ? vnew : vreg[it];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += pj * (float)vv[e];
+                }
             }
         }
 #pragma unroll
@@ -1468,44 +1502,52 @@ __global__ __launch_bounds__(256) void attn_decode_fused(const bf16* __restrict_
     __syncthreads();
     if (!last_flag) return;
     if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next token
-    // system-scope loads, issued in batches of 8 with ONE wait per batch (an atomic load per value would pay 3 * nsplit memory round trips in sequence)
+    // The merge: ONE round trip.  System-scope loads; thread d requests its dimension's partial of up to 16 splits and threads request the (m, l) pairs in the
+    // same breath, one wait for all of it (the registers pass through the waiting asm so that nothing reads them early).  More than 16 splits: further batches.
     const float* base = ws + (size_t)hq * nsplit * (HD + 2);
     float* ml = sc;                                            // [nsplit][2] (m, l) shared by the block; the score buffer is free now
-    __syncthreads();
+    const int d = tid < HD ? tid : HD - 1;
+    float v16[16];
+    {
+        const float* q[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q[j] = base + 2 + d + (size_t)min(j, nsplit - 1) * (HD + 2);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=&v"(v16[j]) : "v"(q[j]) : "memory");
+    }
+    __syncthreads();                                           // every thread is done with sc[] as scores
     for (int i = tid; i < 2 * nsplit; i += 256) {
         float vv;
         const float* pp = base + (i >> 1) * (HD + 2) + (i & 1);
         asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(vv) : "v"(pp) : "memory");
         ml[i] = vv;
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v16[0]), "+v"(v16[1]), "+v"(v16[2]), "+v"(v16[3]), "+v"(v16[4]), "+v"(v16[5]), "+v"(v16[6]), "+v"(v16[7]),
+                 "+v"(v16[8]), "+v"(v16[9]), "+v"(v16[10]), "+v"(v16[11]), "+v"(v16[12]), "+v"(v16[13]), "+v"(v16[14]), "+v"(v16[15]) :: "memory");
     __syncthreads();
     float m = -INFINITY;
     for (int s2 = 0; s2 < nsplit; ++s2) m = fmaxf(m, ml[2 * s2]);
-    for (int d = tid; d < HD; d += 256) {
-        float num = 0.f, den = 0.f;
-        for (int s0 = 0; s0 < nsplit; s0 += 8) {
-            float v8[8];
-            const float* p0 = base + 2 + d;
-            const float* q[8];
+    float num = 0.f, den = 0.f;
+    for (int s0 = 0; s0 < nsplit; s0 += 16) {
+        if (s0 > 0) {
+            const float* q[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) q[j] = p0 + (size_t)min(s0 + j, nsplit - 1) * (HD + 2);
-            asm volatile("global_load_dword %0, %8, off sc0 sc1\n\tglobal_load_dword %1, %9, off sc0 sc1\n\t"
-                         "global_load_dword %2, %10, off sc0 sc1\n\tglobal_load_dword %3, %11, off sc0 sc1\n\t"
-                         "global_load_dword %4, %12, off sc0 sc1\n\tglobal_load_dword %5, %13, off sc0 sc1\n\t"
-                         "global_load_dword %6, %14, off sc0 sc1\n\tglobal_load_dword %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(v8[0]), "=&v"(v8[1]), "=&v"(v8[2]), "=&v"(v8[3]), "=&v"(v8[4]), "=&v"(v8[5]), "=&v"(v8[6]), "=&v"(v8[7])
-                         : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]) : "memory");
+            for (int j = 0; j < 16; ++j) q[j] = base + 2 + d + (size_t)min(s0 + j, nsplit - 1) * (HD + 2);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (s0 + j < nsplit) {
-                    const float pm = ml[2 * (s0 + j)];
-                    const float w = (pm == -INFINITY) ? 0.f : __expf(pm - m);
-                    num += w * v8[j];
-                    den += w * ml[2 * (s0 + j) + 1];
-                }
+            for (int j = 0; j < 16; ++j) asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=&v"(v16[j]) : "v"(q[j]) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v16[0]), "+v"(v16[1]), "+v"(v16[2]), "+v"(v16[3]), "+v"(v16[4]), "+v"(v16[5]), "+v"(v16[6]), "+v"(v16[7]),
+                         "+v"(v16[8]), "+v"(v16[9]), "+v"(v16[10]), "+v"(v16[11]), "+v"(v16[12]), "+v"(v16[13]), "+v"(v16[14]), "+v"(v16[15]) :: "memory");
         }
-        o[hq * HD + d] = (bf16)(num / den);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (s0 + j < nsplit) {
+                const float pm = ml[2 * (s0 + j)];
+                const float w = (pm == -INFINITY) ? 0.f : __expf(pm - m);
+                num += w * v16[j];
+                den += w * ml[2 * (s0 + j) + 1];
+            }
     }
+    if (tid < HD) o[hq * HD + tid] = (bf16)(num / den);
 }
 
 extern "C" int64_t ufv_attention_decode_fused_ws_bytes(int Hq, int hd, int nsplit) {
