@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512) void rate_k(const char* src, long cu_stride, i
         for (int i = 0; i < 8; ++i) {
             // piece = 8 rows x 128 B (the GEMM's staging piece): lane -> (row lane >> 3, 16-byte chunk lane & 7); rows 256 B apart as in a K-major panel
             const int piece = (r * 8 + i) * 8 + wave;
-            const long off = ((long)(piece * 8 + (lane >> 3)) * 256 + (lane & 7) * 16) % window;
+            const unsigned off = ((unsigned)(piece * 8 + (lane >> 3)) * 256u + (lane & 7) * 16u) & (unsigned)(window - 1);      // window: a power of two
             if (MODE == 0) __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(smem + wave * 8192 + i * 1024), 16, 0, 0);
             else if (MODE == 2) __builtin_amdgcn_global_load_lds(GLB_PTR(base + off), LDS_PTR(smem + wave * 8192 + i * 1024), 4, 0, 0);
             else {
@@ -68,6 +68,7 @@ int main() {
         const double bytes = (double)rounds * 8 * 8 * per_instr;             // per CU
         printf("%-34s window %4d KB: %8.1f us  %7.0f ticks(100 MHz) per CU -> %6.1f B / ns / CU = %5.2f TB/s chip-wide; %5.1f ns per wave-instruction per CU\n", name,
                window >> 10, best * 1e3, cmean, bytes / (best * 1e6), bytes * blocks / (best * 1e-3) / 1e12, best * 1e6 / (rounds * 64.0));
+        fflush(stdout);
     };
     for (int window : {65536, 1 << 20}) {
         run(0, window, "LDS-DMA dwordx4 (16 B / lane)");
