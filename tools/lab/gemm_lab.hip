@@ -23,6 +23,7 @@ extern "C" const char* ufv_last_error(void) { return ""; }
 #include "../../ufvideo_amd/csrc/gemm256_b.hip"
 #include "../../ufvideo_amd/csrc/gemm256_s.hip"
 int ufv_launch_pp_shape_fp8(const void*, const void*, const Epi&, int, int, int, int, int, bool, int, hipStream_t) { return 1; }
+#include "../../ufvideo_amd/csrc/gemm_state.hip"
 
 static inline uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 
@@ -79,6 +80,19 @@ int main(int argc, char** argv) {
         std::vector<double> d;
         for (int b = 0; b < 256; ++b) { const unsigned long long* p = h.data() + ((size_t)b * 2 + g) * 16; if (p[0] && p[ns - 1]) d.push_back((double)(p[ns - 1] - p[0])); }
         if (!d.empty()) { std::sort(d.begin(), d.end()); printf("  | K-tile %.0f", d[d.size() / 2]); }
+        if (shape >= 1000) {      // the load steps in parts: fragment reads issued | DMA issued | counted wait   (phase A: 0 -> 9 -> 10 -> 1; phase B: 4 -> 11 -> 12 -> 5)
+            const int seq[2][4] = {{0, 9, 10, 1}, {4, 11, 12, 5}};
+            for (int ph = 0; ph < 2; ++ph) {
+                printf("  | load step %c reads/dma/wait", ph ? 'B' : 'A');
+                for (int j = 0; j < 3; ++j) {
+                    std::vector<double> dd;
+                    for (int b = 0; b < 256; ++b) { const unsigned long long* p = h.data() + ((size_t)b * 2 + g) * 16; if (p[seq[ph][j]] && p[seq[ph][j + 1]]) dd.push_back((double)(p[seq[ph][j + 1]] - p[seq[ph][j]])); }
+                    if (dd.empty()) { printf(" -"); continue; }
+                    std::sort(dd.begin(), dd.end());
+                    printf(" %.0f", dd[dd.size() / 2]);
+                }
+            }
+        }
         std::vector<double> lp;
         for (int b = 0; b < 256; ++b) { const unsigned long long* p = h.data() + ((size_t)b * 2 + g) * 16; if (p[13] && p[14]) lp.push_back((double)(p[14] - p[13]) / (double)p[15]); }
         if (!lp.empty()) { std::sort(lp.begin(), lp.end()); printf("  | whole K loop / K-tiles %.0f", lp[lp.size() / 2]); }

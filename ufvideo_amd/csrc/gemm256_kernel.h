@@ -443,6 +443,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
 
     // ---- LDS-DMA sources: half-tile `which` (0=A0 1=A1 2=B0 3=B1), one or two 8-row pieces per wave (T::L*)
     const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+#ifndef UFV_FPF_MODE
+#define UFV_FPF_MODE 1       /* lab: 0 = never */
+#endif
+#ifndef UFV_FPF_SHAPE         /* the shapes measured faster with it inside the clip (LABNOTES round 4); lab: -DUFV_FPF_SHAPE(a,b,c)=... */
+#define UFV_FPF_SHAPE(MA0_, MA1_, NB1_) ((MA0_) + (MA1_) <= 7 && (NB1_) == 1)
+#endif
+    constexpr bool FPF = PH2 && !FP8 && !SKT && UFV_FPF_MODE == 1 && UFV_FPF_SHAPE(MA0, MA1, NB1);      // fragment prefetch: see the K loop
     const char* src[4][2];
     auto set_src = [&](int m0_, int n0_) {
 #pragma unroll
@@ -556,7 +563,58 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     UFV_GSTAMP(S2);                                                                                          \
     __builtin_amdgcn_s_barrier();
 
-    if constexpr (PH2) {
+    // FPF (fragment prefetch): the ds_reads of a phase are issued BETWEEN THE MFMAs OF THE PHASE BEFORE IT, into a second set of fragment registers, instead of in
+    // a burst at the head of the phase's load step.  Timeline of the 192 x 192 shape (tools/lab/gemm_lab.hip, ticks per K-tile and wave): MFMA 2 x 350, fragment reads
+    // 250 + 85 (the four waves of a group read at once: the LDS array serves 48 KB in one burst), DMA issue 80 + 245, counted waits 140, barriers 120 -- a wave's own
+    // instruction stream is 1630 ticks, 920 of them not MFMA, and two groups can only hide each other's halves: 2000 ticks per K-tile for 4 x 350 of MFMA.  Reads issued one
+    // or two at a time behind a group of MFMAs cost a few cycles each (the LDS array is idle then) and the load steps shrink to DMA issue + wait.
+    // WHICH reads may move: the two wave groups run one barrier apart and every wave stages its own pieces of every half-tile.  A read at the head of a load step follows the
+    // covering wait by TWO barriers -- the lagging group's wait is behind it too.  A read inside the MFMA step follows it by ONE: for the leading group (waves 0-3) the
+    // pieces the lagging waves staged are not covered yet (seen as wrong, varying sums once every CU streams from HBM: M 2399, K >= 8192, tools/scratch history in
+    // LABNOTES).  The A halves are group-local (wave w stages rows 16 w .. of a half, group g reads rows 16 MA g ..: its own waves' or the leading group's), so both groups
+    // prefetch A; the B halves are read by everybody, so only the LAGGING group keeps its prefetched B fragments -- the leading group reads B again at the head of its
+    // phase A, where the classic schedule read it (its prefetch is issued all the same: no branch between the MFMAs, the second read overwrites it).
+    // Costs (MA1 + NT) x 8 registers.
+    bf16x8 aF0[FPF ? MA0 : 1][2], aF1[FPF ? MA1 : 1][2], bF[FPF ? 2 : 1][FPF ? NT : 1][2];
+    // read op r of a fragment list: A-half h frag i, k-half c  /  B frag j (0,1 = the 128-column half, 2.. = the other), k-half c
+    auto rd_a0 = [&](const char* stg, int r) { aF0[r >> 1][r & 1] = *reinterpret_cast<const bf16x8*>(stg + a_row_off[0] + (r >> 1) * 2048 + ((r & 1) ? coff1 : coff0)); };
+    auto rd_a1 = [&](const char* stg, int r) { aF1[r >> 1][r & 1] = *reinterpret_cast<const bf16x8*>(stg + 16384 + a_row_off[1] + (r >> 1) * 2048 + ((r & 1) ? coff1 : coff0)); };
+    auto rd_b = [&](auto pc, const char* stg, int r) {
+        constexpr int P = decltype(pc)::value;
+        const int j = r >> 1;
+        const char* half = j < 2 ? stg + 32768 + b_row_off[0] + j * 2048 : stg + 49152 + b_row_off[1] + (j - 2) * 2048;
+        bF[FPF ? P : 0][FPF ? j : 0][r & 1] = *reinterpret_cast<const bf16x8*>(half + ((r & 1) ? coff1 : coff0));
+    };
+#define UFV_MMA_STEP(AF, BF, MTB, MCNT, S0, S1, S2, ISSUE, TAILWAIT)                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    UFV_GSTAMP(S0);                                                                                          \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+    UFV_GSTAMP(S1);                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    __builtin_amdgcn_s_setprio(1);                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
+        _Pragma("unroll") for (int n_ = 0; n_ < NT; ++n_) {                                                  \
+            _Pragma("unroll") for (int m_ = 0; m_ < MCNT; ++m_)                                              \
+                acc[n_][MTB + m_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[n_][kk], AF[m_][kk], acc[n_][MTB + m_], 0, 0, 0); \
+            ISSUE(kk * NT + n_);                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
+        }                                                                                                    \
+    __builtin_amdgcn_s_setprio(0);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                       \
+    UFV_GSTAMP(S2);                                                                                          \
+    TAILWAIT();                                                                                              \
+    __builtin_amdgcn_s_barrier();
+
+#define UFV_WAIT_G(EXTRA) wait_vmcnt<FPF ? L_ALL + (EXTRA) : 0>()
+    if constexpr (FPF) {
+        if (len > 1) {                                 // as below: [A0 B0 B1] of the first K-tile; its A1 and the second tile's three stay in flight
+            if (RELAX_OK && relax == 1) UFV_WAIT_G(RELAX_OK ? NST : 0);
+            else if (RELAX_OK && relax == 2) UFV_WAIT_G(RELAX_OK ? NSTW : 0);
+            else if (RELAX_OK && relax == 3) UFV_WAIT_G(RELAX_OK ? NSTS : 0);
+            else UFV_WAIT_G(0);
+        } else wait_vmcnt<T::LA1>();
+    } else if constexpr (PH2) {
         if (len > 1) {                                 // A0 / B0 / B1 of the first K-tile; its A1 and the second tile's three stay in flight
             if (RELAX_OK && relax == 1) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
@@ -572,7 +630,75 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     UFV_TSTAMP(0);
 
     UFV_GSTAMP_DECL
-    if constexpr (PH2) {
+    if constexpr (FPF) {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    // the first phase's fragments (the pre-loop wait + barrier above guard them)
+#pragma unroll
+    for (int r = 0; r < 2 * MA0; ++r) rd_a0(smem, r);
+#pragma unroll
+    for (int r = 0; r < 2 * NT; ++r) rd_b(P0{}, smem, r);
+    auto ktile = [&](auto pc, int tt) {
+        constexpr int P = decltype(pc)::value;                // = tt & 1: the ring stage and the B fragment set of this K-tile
+        using PN = std::integral_constant<int, P ^ 1>;
+        const int t = k0 + tt, d = P;
+        const char* buf = smem + d * 65536;
+        const char* nbuf = smem + (d ^ 1) * 65536;
+        // phase A: load step = request A1[t+1], retire A1[t] (behind it: [A0 B0 B1][t+1], A1[t+1] and, at an item's first K-tile, the previous epilogue's stores);
+        // MFMAs on (A0, B) with the reads of A1[t] between them
+        UFV_GSTAMP(0);
+        if (wave < 4) {                                // leading group: B fragments at the classic place (two barriers behind every wave's wait for them)
+#pragma unroll
+            for (int r = 0; r < 2 * NT; ++r) rd_b(pc, buf, r);
+        }
+        UFV_GSTAMP(9);
+        stage(d ^ 1, 1, t + 1);
+        UFV_GSTAMP(10);
+        if (tt + 1 < len) {
+            if (RELAX_OK && relax == 1 && tt == 0) UFV_WAIT_G(RELAX_OK ? NST : 0);
+            else if (RELAX_OK && relax == 2 && tt == 0) UFV_WAIT_G(RELAX_OK ? NSTW : 0);
+            else if (RELAX_OK && relax == 3 && tt == 0) UFV_WAIT_G(RELAX_OK ? NSTS : 0);
+            else UFV_WAIT_G(0);
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int GRP = 2 * NT, RA = 2 * MA1, PER_A = (RA + GRP - 1) / GRP;
+        auto issue_a = [&](int g) {
+#pragma unroll
+            for (int r = g * PER_A; r < (g + 1) * PER_A; ++r)
+                if (r < RA) rd_a1(buf, r);
+        };
+        auto no_tail = [&]() {};
+        UFV_MMA_STEP(aF0, bF[P], 0, MA0, 1, 2, 3, issue_a, no_tail)
+        // phase B: load step = request [A0 B0 B1][t+2], retire those of [t+1] (behind them: A1[t+1] and the new three); MFMAs on (A1, B) with the reads of K-tile t+1's
+        // A0 and B between them (past the item's last K-tile they read stale LDS into registers nobody uses)
+        UFV_GSTAMP(4);
+        UFV_GSTAMP(11);
+        stage(d, 0, t + 2);
+        stage(d, 2, t + 2);
+        stage(d, 3, t + 2);
+        UFV_GSTAMP(12);
+        if (tt + 2 < len) {
+            if (RELAX_OK && relax == 1 && tt == 0) UFV_WAIT_G(RELAX_OK ? NST : 0);
+            else if (RELAX_OK && relax == 2 && tt == 0) UFV_WAIT_G(RELAX_OK ? NSTW : 0);
+            else if (RELAX_OK && relax == 3 && tt == 0) UFV_WAIT_G(RELAX_OK ? NSTS : 0);
+            else UFV_WAIT_G(0);
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int RB = 2 * (MA0 + NT), PER_B = (RB + GRP - 1) / GRP;
+        auto issue_b = [&](int g) {
+#pragma unroll
+            for (int r = g * PER_B; r < (g + 1) * PER_B; ++r) {
+                if (r < 2 * MA0) rd_a0(nbuf, r);
+                else if (r < RB) rd_b(PN{}, nbuf, r - 2 * MA0);
+            }
+        };
+        UFV_MMA_STEP(aF1, bF[P], MA0, MA1, 5, 6, 7, issue_b, no_tail)
+        UFV_GSTAMP(8);
+        UFV_TSTAMP_K(tt);
+    };
+    for (int tt = 0; tt < len; tt += 2) {
+        ktile(P0{}, tt);
+        if (tt + 1 < len) ktile(P1{}, tt + 1);
+    }
+    } else if constexpr (PH2) {
     for (int tt = 0; tt < len; ++tt) {
         const int t = k0 + tt, d = tt & 1;
         const char* buf = smem + d * 65536;
@@ -581,7 +707,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         read_b(buf + 32768, H0{});
         read_a(buf, H0{});
         read_b(buf + 49152, H1{});
+        UFV_GSTAMP(9);
         stage(d ^ 1, 1, t + 1);
+        UFV_GSTAMP(10);
         if (tt + 1 < len) {                            // behind A1[t]: A0/B0/B1[t+1] and A1[t+1] (+ at the item's first K-tile the previous epilogue's stores)
             if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
@@ -592,9 +720,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         // phase B: A1 -> bottom half; prefetch A0 / B0 / B1 [t+2]; retire A0 / B0 / B1 [t+1]
         UFV_GSTAMP(4);
         read_a(buf + 16384, H1{});
+        UFV_GSTAMP(11);
         stage(d, 0, t + 2);
         stage(d, 2, t + 2);
         stage(d, 3, t + 2);
+        UFV_GSTAMP(12);
         if (tt + 2 < len) {                            // behind them: A1[t+1] and A0/B0/B1[t+2]
             if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
@@ -636,6 +766,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     UFV_TSTAMP(5);
     UFV_GSTAMP_FLUSH;
 #undef UFV_SYNC_THEN_MMA
+#undef UFV_MMA_STEP
+#undef UFV_WAIT_G
 
 
     // ---- item seam: every wave has finished its LDS reads (final barrier above) -> start the NEXT item's
