@@ -589,7 +589,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     UFV_GSTAMP(S0);                                                                                          \
     __builtin_amdgcn_s_barrier();                                                                            \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
     UFV_GSTAMP(S1);                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
@@ -597,6 +596,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         _Pragma("unroll") for (int n_ = 0; n_ < NT; ++n_) {                                                  \
             _Pragma("unroll") for (int m_ = 0; m_ < MCNT; ++m_)                                              \
                 acc[n_][MTB + m_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[n_][kk], AF[m_][kk], acc[n_][MTB + m_], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
             ISSUE(kk * NT + n_);                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                               \
         }                                                                                                    \
@@ -647,10 +647,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         // phase A: load step = request A1[t+1], retire A1[t] (behind it: [A0 B0 B1][t+1], A1[t+1] and, at an item's first K-tile, the previous epilogue's stores);
         // MFMAs on (A0, B) with the reads of A1[t] between them
         UFV_GSTAMP(0);
-        if (wave < 4) {                                // leading group: B fragments at the classic place (two barriers behind every wave's wait for them)
-#pragma unroll
-            for (int r = 0; r < 2 * NT; ++r) rd_b(pc, buf, r);
-        }
         UFV_GSTAMP(9);
         stage(d ^ 1, 1, t + 1);
         UFV_GSTAMP(10);
@@ -660,6 +656,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             else if (RELAX_OK && relax == 3 && tt == 0) UFV_WAIT_G(RELAX_OK ? NSTS : 0);
             else UFV_WAIT_G(0);
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave < 4) {                                // leading group: B fragments at the classic place (two barriers behind every wave's wait for them); the MFMA
+#pragma unroll                                         // step waits for them one fragment at a time (no lgkmcnt(0) at its head: the compiler counts, LDS returns in order)
+            for (int r = 0; r < 2 * NT; ++r) rd_b(pc, buf, r);
+        }
         constexpr int GRP = 2 * NT, RA = 2 * MA1, PER_A = (RA + GRP - 1) / GRP;
         auto issue_a = [&](int g) {
 #pragma unroll
