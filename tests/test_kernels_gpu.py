@@ -462,6 +462,24 @@ def test_gemm_pingpong_tile_shapes_bitwise_equal_128_kernel(shape):
             ops.gemm(bf(g(256, 64, seed=1)), bf(g(512, 64, seed=2)), swiglu=True, kernel=kern)
 
 
+@pytest.mark.parametrize("shape", [1331, 1431, 1441])
+def test_gemm_tile_shapes_with_every_cu_streaming_long_k(shape):
+    """The fragment-prefetch schedule (gemm256_kernel.h FPF) reads LDS one barrier after the load step's wait; its first form let the leading wave group read
+    pieces the lagging group had not waited for yet -- bit-equal on every short-K case above, wrong and varying sums only with a full grid (247 tiles) streaming a
+    long K from HBM.  This is that case, at the forced shapes and their 4-part split forms: bit-equal to the 128-wide kernel / deterministic, three launches each."""
+    M, N = 2399, 3584
+    for K in (8192, 18944):
+        a, w = bf(g(M, K, seed=M % 97)), bf(g(N, K, seed=N % 89, scale=0.05))
+        resid = g(M, N, seed=5)
+        want = ops.gemm(a, w, resid=resid, out_dtype=torch.float32, kernel=ops.GEMM_FAST)
+        kern = ops.GEMM_FAST256 | (shape << 8)
+        for _ in range(3):
+            assert torch.equal(ops.gemm(a, w, resid=resid, out_dtype=torch.float32, kernel=kern), want), (shape, K)
+        split = ops.GEMM_FAST256 | ((shape + 40000) << 8)
+        outs = [ops.gemm(a, w, resid=resid, out_dtype=torch.float32, kernel=split) for _ in range(3)]
+        assert rel(outs[0], want) < 4e-6 and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (shape, K)
+
+
 @pytest.mark.parametrize("shape,parts", [(1441, 4), (1442, 5), (1442, 2), (1432, 3), (1332, 7), (1322, 8), (1431, 6), (1331, 5)])
 def test_gemm_split_k_turn_ordered_sum(shape, parts):
     """Aligned split-K of the ping-pong kernel (UFV_GEMM_PP(shape + 10000 * parts)): the parts of a tile add into the fp32 output in turn order,
