@@ -446,10 +446,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
 #ifndef UFV_FPF_MODE
 #define UFV_FPF_MODE 1       /* lab: 0 = never */
 #endif
-#ifndef UFV_FPF_SHAPE         /* the shapes measured faster with it inside the clip (LABNOTES round 4); lab: -DUFV_FPF_SHAPE(a,b,c)=... */
-#define UFV_FPF_SHAPE(MA0_, MA1_, NB1_) ((MA0_) + (MA1_) <= 7 && (NB1_) == 1)
+#ifndef UFV_FPF_LEVEL         /* per shape: 2 = A and B fragments prefetched (two B sets), 1 = A only (B read at the classic place by both groups), 0 = classic schedule.
+                                 The shapes measured faster with it inside the clip (LABNOTES round 4); lab: -D'UFV_FPF_LEVEL(a,b,c)=...' */
+#define UFV_FPF_LEVEL(MA0_, MA1_, NB1_) (((MA0_) + (MA1_) <= 7 && (NB1_) == 1) ? 2 : 0)
 #endif
-    constexpr bool FPF = PH2 && !FP8 && !SKT && UFV_FPF_MODE == 1 && UFV_FPF_SHAPE(MA0, MA1, NB1);      // fragment prefetch: see the K loop
+    constexpr int FPL = (PH2 && !FP8 && !SKT && UFV_FPF_MODE == 1) ? UFV_FPF_LEVEL(MA0, MA1, NB1) : 0;
+    constexpr bool FPF = FPL > 0;                              // fragment prefetch: see the K loop
+    // what FPF rests on: the leading group (waves 0-3) reads A rows [0, 16 MA) of each half, and waves 0-3 stage rows [0, 32 LA) of it
+    static_assert(!FPF || (16 * MA0 <= 32 * T::LA0 && 16 * MA1 <= 32 * T::LA1), "fragment prefetch: the leading group's A rows must be staged by its own waves");
     const char* src[4][2];
     auto set_src = [&](int m0_, int n0_) {
 #pragma unroll
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // prefetch A; the B halves are read by everybody, so only the LAGGING group keeps its prefetched B fragments -- the leading group reads B again at the head of its
     // phase A, where the classic schedule read it (its prefetch is issued all the same: no branch between the MFMAs, the second read overwrites it).
     // Costs (MA1 + NT) x 8 registers.
-    bf16x8 aF0[FPF ? MA0 : 1][2], aF1[FPF ? MA1 : 1][2], bF[FPF ? 2 : 1][FPF ? NT : 1][2];
+    bf16x8 aF0[FPF ? MA0 : 1][2], aF1[FPF ? MA1 : 1][2], bF[FPL == 2 ? 2 : 1][FPF ? NT : 1][2];
     // read op r of a fragment list: A-half h frag i, k-half c  /  B frag j (0,1 = the 128-column half, 2.. = the other), k-half c
     auto rd_a0 = [&](const char* stg, int r) { aF0[r >> 1][r & 1] = *reinterpret_cast<const bf16x8*>(stg + a_row_off[0] + (r >> 1) * 2048 + ((r & 1) ? coff1 : coff0)); };
     auto rd_a1 = [&](const char* stg, int r) { aF1[r >> 1][r & 1] = *reinterpret_cast<const bf16x8*>(stg + 16384 + a_row_off[1] + (r >> 1) * 2048 + ((r & 1) ? coff1 : coff0)); };
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         constexpr int P = decltype(pc)::value;
         const int j = r >> 1;
         const char* half = j < 2 ? stg + 32768 + b_row_off[0] + j * 2048 : stg + 49152 + b_row_off[1] + (j - 2) * 2048;
-        bF[FPF ? P : 0][FPF ? j : 0][r & 1] = *reinterpret_cast<const bf16x8*>(half + ((r & 1) ? coff1 : coff0));
+        bF[FPL == 2 ? P : 0][FPF ? j : 0][r & 1] = *reinterpret_cast<const bf16x8*>(half + ((r & 1) ? coff1 : coff0));
     };
 #define UFV_MMA_STEP(AF, BF, MTB, MCNT, S0, S1, S2, ISSUE, TAILWAIT)                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -636,8 +640,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // the first phase's fragments (the pre-loop wait + barrier above guard them)
 #pragma unroll
     for (int r = 0; r < 2 * MA0; ++r) rd_a0(smem, r);
+    if constexpr (FPL == 2) {
 #pragma unroll
-    for (int r = 0; r < 2 * NT; ++r) rd_b(P0{}, smem, r);
+        for (int r = 0; r < 2 * NT; ++r) rd_b(P0{}, smem, r);
+    }
     auto ktile = [&](auto pc, int tt) {
         constexpr int P = decltype(pc)::value;                // = tt & 1: the ring stage and the B fragment set of this K-tile
         using PN = std::integral_constant<int, P ^ 1>;
@@ -656,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             else if (RELAX_OK && relax == 3 && tt == 0) UFV_WAIT_G(RELAX_OK ? NSTS : 0);
             else UFV_WAIT_G(0);
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (wave < 4) {                                // leading group: B fragments at the classic place (two barriers behind every wave's wait for them); the MFMA
+        if (FPL == 1 || wave < 4) {                    // (level 1: every wave) leading group: B fragments at the classic place (two barriers behind every wave's wait for them); the MFMA
 #pragma unroll                                         // step waits for them one fragment at a time (no lgkmcnt(0) at its head: the compiler counts, LDS returns in order)
             for (int r = 0; r < 2 * NT; ++r) rd_b(pc, buf, r);
         }
@@ -667,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
                 if (r < RA) rd_a1(buf, r);
         };
         auto no_tail = [&]() {};
-        UFV_MMA_STEP(aF0, bF[P], 0, MA0, 1, 2, 3, issue_a, no_tail)
+        UFV_MMA_STEP(aF0, bF[FPL == 2 ? P : 0], 0, MA0, 1, 2, 3, issue_a, no_tail)
         // phase B: load step = request [A0 B0 B1][t+2], retire those of [t+1] (behind them: A1[t+1] and the new three); MFMAs on (A1, B) with the reads of K-tile t+1's
         // A0 and B between them (past the item's last K-tile they read stale LDS into registers nobody uses)
         UFV_GSTAMP(4);
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             else if (RELAX_OK && relax == 3 && tt == 0) UFV_WAIT_G(RELAX_OK ? NSTS : 0);
             else UFV_WAIT_G(0);
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        constexpr int RB = 2 * (MA0 + NT), PER_B = (RB + GRP - 1) / GRP;
+        constexpr int RB = FPL == 2 ? 2 * (MA0 + NT) : 2 * MA0, PER_B = (RB + GRP - 1) / GRP;
         auto issue_b = [&](int g) {
 #pragma unroll
             for (int r = g * PER_B; r < (g + 1) * PER_B; ++r) {
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
                 else if (r < RB) rd_b(PN{}, nbuf, r - 2 * MA0);
             }
         };
-        UFV_MMA_STEP(aF1, bF[P], MA0, MA1, 5, 6, 7, issue_b, no_tail)
+        UFV_MMA_STEP(aF1, bF[FPL == 2 ? P : 0], MA0, MA1, 5, 6, 7, issue_b, no_tail)
         UFV_GSTAMP(8);
         UFV_TSTAMP_K(tt);
     };
