@@ -670,9 +670,10 @@ inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool ca
     // Long-K fp32 products whose 192x192 tiling fills the chip (the decoder's `down` at S = 2399: 247 tiles for 256 CUs; 475 at 64 frames): since the
     // row-pipelined residual epilogue (round 3) the unsplit 192x192 kernel beats both the split-K form and the 128-wide kernel there (292 us against
     // 314 / 353, tools/gemm_shapes.py); the tick model above still carries the old epilogue's K-tile floor for small tiles, so this case is decided here.
-    if (out_f32 && !swiglu && K >= 8192 && M >= 256 && (N % 192 == 0 || N % 192 == 128)) {
+    // (round 4: bf16 outputs too -- the connector's Conv3d as a GEMM, 2304 x 3584 x 28672, 228 tiles: 427 us against 580 on the 128-wide kernel the model picked)
+    if (!swiglu && K >= 8192 && M >= 256 && (N % 192 == 0 || N % 192 == 128)) {
         const long t = (long)cdiv(M, 192) * cdiv(N, 192);
-        if ((double)t / (256.0 * ((t + 255) / 256)) >= 0.9) return 1331;
+        if ((out_f32 || t <= 256) && (double)t / (256.0 * ((t + 255) / 256)) >= (out_f32 ? 0.9 : 0.85)) return 1331;
     }
     if (can_split && out_f32 && !swiglu && K % 64 == 0) {
         // regression over 31 measured (shape, parts) runs of tools/gemm_splitk.py (within 5 % of all but the 3-part splits, which it flatters
