@@ -175,6 +175,9 @@ int ufv_upsample2x_add(float* x, const float* prev, int B, int H, int W, int C, 
 
 /* greedy sampling: out[0] = argmax(logits[0..N)) with torch.argmax tie-breaking (lowest index) */
 int ufv_argmax(const float* logits, int N, int64_t* out, void* stream);
+/* the same result from 64 blocks (the decode step's form): `ws` = ufv_argmax_ws_bytes() bytes whose LAST int is zero before the first call (it returns to zero) */
+int64_t ufv_argmax_ws_bytes(void);
+int ufv_argmax_ws(const float* logits, int N, int64_t* out, void* ws, void* stream);
 
 /* frame batching tail of process_video (mm_utils.py:284,291): u8 HWC frames -> (x/255 - mean)/std -> bf16 NCHW */
 int ufv_preprocess_u8(const uint8_t* frames, void* out, int T, int H, int W, const float* mean3, const float* std3,

@@ -398,6 +398,25 @@ def test_gather_rows_and_argmax_and_convert():
         assert ops.argmax(z).item() == n // 2
         z[5] = float("nan")
         assert ops.argmax(z).item() == 5
+    # the 64-block form of the decode step (partials + last-arriving block merges): same answers, workspace reusable without re-zeroing
+    ws = torch.zeros(_lib.load().ufv_argmax_ws_bytes(), device=DEV, dtype=torch.uint8)
+    assert ops.argmax(x, ws=ws).item() == 1234
+    for n in (7, 255, 4097, 16384, 151747, 151748, 262144):
+        y = g(n, seed=145 + n)
+        assert ops.argmax(y, ws=ws).item() == torch.argmax(y).item()
+        z = torch.zeros(n, device=DEV); z[n - 1] = 1.0; z[n // 2] = 1.0
+        assert ops.argmax(z, ws=ws).item() == n // 2
+        z[min(5, n - 1)] = float("nan")
+        assert ops.argmax(z, ws=ws).item() == min(5, n - 1)
+    assert int(ws.view(torch.int32)[-1]) == 0
+    # gather: the vector form (aligned rows, D % 8 == 0), few rows and many, every dtype pair
+    for n_rows in (1, 5, 300):
+        for sd, dd in [(torch.bfloat16, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32), (torch.float16, torch.bfloat16), (torch.float32, torch.bfloat16)]:
+            tab = g(400, 3584, seed=7).to(sd)
+            sidx = torch.randint(0, 400, (n_rows,), device=DEV); sidx[0] = 399
+            out = torch.full((n_rows, 3584), 7.0, device=DEV, dtype=dd)
+            ops.gather_rows(tab, sidx, out, None)
+            assert torch.equal(out, tab[sidx].to(dd)), (n_rows, sd, dd)
     for a, b_ in [(torch.float32, torch.bfloat16), (torch.float16, torch.bfloat16), (torch.bfloat16, torch.float32)]:
         t = g(1000, seed=45).to(a)
         assert torch.equal(ops.convert(t, b_), t.to(b_))

@@ -38,6 +38,7 @@ SIGNATURES = {
     "ufv_gather_rows": [_p, _i, _l, _p, _p, _i, _l, _p, _i, _i, _p],
     "ufv_mask_pool": [_p, _i, _p, _p, _p, _i, _i, _i, _p],
     "ufv_argmax": [_p, _i, _p, _p],
+    "ufv_argmax_ws": [_p, _i, _p, _p, _p],
     "ufv_preprocess_u8": [_p, _p, _i, _i, _i, _p, _p, _p],
     "ufv_convert": [_p, _i, _p, _i, _l, _p],
     "ufv_im2col": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -104,7 +105,7 @@ SIGNATURES = {
     "ufv_attention_bwd_fused": [_p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p],
 }
 # entry points that return a size instead of a status
-SIZE_FUNCS = {"ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l), "ufv_attention_decode_fused_ws_bytes": ([_i, _i, _i], _l), "ufv_gemm_timing_read": ([_p, _p, _i], _i), "ufv_gemm_choice": ([_i, _i, _i, _i, _i, _i], _i), "ufv_gemm_set_splitk": ([_i], _i), "ufv_gemm_error_state": ([], _i),
+SIZE_FUNCS = {"ufv_argmax_ws_bytes": ([], _l), "ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l), "ufv_attention_decode_fused_ws_bytes": ([_i, _i, _i], _l), "ufv_gemm_timing_read": ([_p, _p, _i], _i), "ufv_gemm_choice": ([_i, _i, _i, _i, _i, _i], _i), "ufv_gemm_set_splitk": ([_i], _i), "ufv_gemm_error_state": ([], _i),
               "ufv_qwen2_prefill_ws_bytes": ([_p, _i], _l), "ufv_vit_forward_ws_bytes": ([_p, _i], _l), "ufv_stc_forward_ws_bytes": ([_p, _i, _i], _l),
               "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l), "ufv_attention_bwd_fused_ws_bytes": ([_i, _i], _l),
               "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l), "ufv_mask_dot_bwd_ws_bytes": ([_i, _i], _l)}

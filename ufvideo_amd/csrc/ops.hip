@@ -669,6 +669,47 @@ __global__ __launch_bounds__(256) void gather_rows_k(const void* src, int64_t ld
     }
 }
 
+// the same copy with 8 elements per lane and access (rows 16-byte aligned, D % 8 == 0): RW = waves per row -- 1: four rows per block; 4: one row per block (the decode
+// step's single embedding row was 56 one-element iterations of ONE wave: 25 us for 7 KB)
+template <int SDT, bool DF32, int RW>
+__global__ __launch_bounds__(256) void gather_rows8_k(const void* src, int64_t lds_, const int64_t* sidx, void* dst, int64_t ldd, const int64_t* didx, int n, int D) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = RW == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    if (r >= n) return;
+    const int64_t sr = sidx ? sidx[r] : r, dr = didx ? didx[r] : r;
+    if (dr < 0) return;
+    for (int c = (RW == 1 ? lane : threadIdx.x) * 8; c < D; c += 512 * RW) {
+        float v[8];
+        if (sr < 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        } else if (SDT == UFV_DT_F32) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + sr * lds_ + c), b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + sr * lds_ + c + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+        } else if (SDT == UFV_DT_BF16) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(src) + sr * lds_ + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+        } else {
+            typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+            const f16x8 a = *reinterpret_cast<const f16x8*>(reinterpret_cast<const _Float16*>(src) + sr * lds_ + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+        }
+        if (DF32) {
+            float* o = reinterpret_cast<float*>(dst) + dr * ldd + c;
+            *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(dst) + dr * ldd + c) = o;
+        }
+    }
+}
+
 // masked mean pooling: out[i, c] = sum_p feat[frame_of[i], p, c] * mask[i, p] / (sum_p mask[i,p] + 1e-8)
 template <int DT>
 __global__ __launch_bounds__(256) void mask_pool_k(const void* feat, const float* mask, const int32_t* frame_of, float* out,
@@ -746,6 +787,75 @@ __global__ __launch_bounds__(1024) void argmax_k(const float* x, int N, int64_t*
             if (better(bv[w], bi[w], best, idx)) { best = bv[w]; idx = bi[w]; }
         out[0] = idx;
     }
+}
+
+// The same arg-max over 64 blocks (one pass of 16-byte loads per block, all requested at once) for the decode step: block partials go to `ws` with agent-scope stores and
+// the block that arrives last at the counter merges them (ws: 64 floats, 64 ints, one counter that is ZERO before the first call and returns to zero).  Same order
+// relation as argmax_k (NaN beats everything, ties keep the lowest index): the result does not depend on the partition.  (One 1024-thread block walked the 600 KB of
+// logits in 10 dependent round trips: 27 us per token.)
+constexpr int ARGMAX_NB = 64;
+__global__ __launch_bounds__(256) void argmax_blocks_k(const float* x, int N, int64_t* out, float* ws) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    __shared__ int last_flag;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    auto better = [](float v, int i, float bv_, int bi_) {
+        const bool vn = v != v, bn = bv_ != bv_;
+        if (vn != bn) return vn;
+        if (vn && bn) return i < bi_;
+        return v > bv_ || (v == bv_ && i < bi_);
+    };
+    const int per = ((N + ARGMAX_NB - 1) / ARGMAX_NB + 3) & ~3;           // a multiple of 4: block ranges start on 16-byte boundaries
+    const int lo = blockIdx.x * per, hi = min(N, lo + per);
+    constexpr int MAXV = 4;                                                // 16-byte loads per thread in flight (N <= 64 * 256 * 4 * MAXV = 262144 in one pass)
+    f32x4 v[MAXV];
+    const int n4 = hi > lo ? (hi - lo) >> 2 : 0;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x + lo);
+    for (int c0 = threadIdx.x; c0 < n4; c0 += 256 * MAXV) {
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u) v[u] = x4[min(c0 + u * 256, n4 - 1)];
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u)
+            if (c0 + u * 256 < n4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (better(v[u][j], lo + 4 * (c0 + u * 256) + j, best, idx)) { best = v[u][j]; idx = lo + 4 * (c0 + u * 256) + j; }
+    }
+    for (int i = lo + 4 * n4 + threadIdx.x; i < hi; i += 256)
+        if (better(x[i], i, best, idx)) { best = x[i]; idx = i; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (better(ov, oi, best, idx)) { best = ov; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    int* wi = reinterpret_cast<int*>(ws + ARGMAX_NB);
+    int* counter = wi + ARGMAX_NB;
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(bv[w], bi[w], best, idx)) { best = bv[w]; idx = bi[w]; }
+        __hip_atomic_store(ws + blockIdx.x, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(wi + blockIdx.x, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // write-through stores acknowledged = visible device-wide
+        last_flag = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ARGMAX_NB - 1;
+    }
+    __syncthreads();
+    if (!last_flag || threadIdx.x >= 64) return;
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float pv;
+    int pi;
+    asm volatile("global_load_dword %0, %2, off sc0 sc1\n\tglobal_load_dword %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(pv), "=&v"(pi) : "v"(ws + threadIdx.x), "v"(wi + threadIdx.x) : "memory");
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(pv, o, 64);
+        const int oi = __shfl_xor(pi, o, 64);
+        if (better(ov, oi, pv, pi)) { pv = ov; pi = oi; }
+    }
+    if (threadIdx.x == 0) out[0] = pi;
 }
 
 __global__ __launch_bounds__(256) void preprocess_u8_k(const uint8_t* fr, bf16* out, int T, int H, int W, float m0, float m1,
@@ -1040,7 +1150,12 @@ extern "C" int ufv_gather_rows(const void* src, int src_dtype, int64_t ld_src, c
     if (n == 0) return UFV_OK;
     UFV_REQUIRE(src && dst && n > 0 && D > 0, "ufv_gather_rows: bad arguments");
     dim3 g(cdiv(n, 4)), blk(256);
-#define GR(SD, DF) hipLaunchKernelGGL((gather_rows_k<SD, DF>), g, blk, 0, ST(stream), src, ld_src, src_idx, dst, ld_dst, dst_idx, n, D)
+    const int ses = src_dtype == UFV_DT_F32 ? 4 : 2, des = dst_dtype == UFV_DT_F32 ? 4 : 2;
+    const bool vec = D % 8 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && (ld_src * ses) % 16 == 0 && (ld_dst * des) % 16 == 0;
+    const bool few = n <= 64;                    // few rows: one block per row
+#define GR(SD, DF) do { if (vec && few) hipLaunchKernelGGL((gather_rows8_k<SD, DF, 4>), dim3(n), blk, 0, ST(stream), src, ld_src, src_idx, dst, ld_dst, dst_idx, n, D); \
+                        else if (vec) hipLaunchKernelGGL((gather_rows8_k<SD, DF, 1>), g, blk, 0, ST(stream), src, ld_src, src_idx, dst, ld_dst, dst_idx, n, D); \
+                        else hipLaunchKernelGGL((gather_rows_k<SD, DF>), g, blk, 0, ST(stream), src, ld_src, src_idx, dst, ld_dst, dst_idx, n, D); } while (0)
     const bool df32 = dst_dtype == UFV_DT_F32;
     UFV_REQUIRE(dst_dtype == UFV_DT_F32 || dst_dtype == UFV_DT_BF16, "ufv_gather_rows: dst must be f32 or bf16");
     if (src_dtype == UFV_DT_F32) { if (df32) GR(UFV_DT_F32, true); else GR(UFV_DT_F32, false); }
@@ -1067,6 +1182,16 @@ extern "C" int ufv_mask_pool(const void* feat, int feat_dtype, const float* mask
 extern "C" int ufv_argmax(const float* logits, int N, int64_t* out, void* stream) {
     UFV_REQUIRE(logits && out && N > 0, "ufv_argmax: bad arguments");
     hipLaunchKernelGGL(argmax_k, dim3(1), dim3(1024), 0, ST(stream), logits, N, out);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int64_t ufv_argmax_ws_bytes(void) { return (int64_t)(sizeof(float) * ARGMAX_NB + sizeof(int) * (ARGMAX_NB + 1)); }
+
+// ws: ufv_argmax_ws_bytes() bytes, 16-byte aligned, whose last int is ZERO before the first call (it returns to zero); logits 16-byte aligned
+extern "C" int ufv_argmax_ws(const float* logits, int N, int64_t* out, void* ws, void* stream) {
+    UFV_REQUIRE(logits && out && ws && N > 0 && ((uintptr_t)logits % 16 == 0) && ((uintptr_t)ws % 4 == 0), "ufv_argmax_ws: bad arguments");
+    hipLaunchKernelGGL(argmax_blocks_k, dim3(ARGMAX_NB), dim3(256), 0, ST(stream), logits, N, out, (float*)ws);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }

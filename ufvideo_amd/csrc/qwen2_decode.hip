@@ -28,6 +28,7 @@ extern "C" int64_t ufv_qwen2_decode_ws_bytes(const ufv_qwen2_model* m) {
     const int64_t fused = (m->hd == 64 || m->hd == 128) ? ufv_attention_decode_fused_ws_bytes(m->n_q, m->hd, m->attn_splits) : 0;
     const int64_t plain = ufv_attention_decode_ws_bytes(1, m->n_q, m->hd, m->attn_splits);
     b += align256((size_t)(fused > plain ? fused : plain));
+    b += align256((size_t)ufv_argmax_ws_bytes());    // arg-max partials + arrival counter (zero before the first step, like the attention counters)
     return (int64_t)b;
 }
 
@@ -49,6 +50,12 @@ static int decode_step_impl(const ufv_qwen2_model* m, const int64_t* token_dev, 
     void* o = p; p += align256(2 * (size_t)H * hd);
     void* act = p; p += align256(2 * (size_t)I);
     void* aws = p;
+    {
+        const int64_t fused_b = (hd == 64 || hd == 128) ? ufv_attention_decode_fused_ws_bytes(H, hd, m->attn_splits) : 0;
+        const int64_t plain_b = ufv_attention_decode_ws_bytes(1, H, hd, m->attn_splits);
+        p += align256((size_t)(fused_b > plain_b ? fused_b : plain_b));
+    }
+    void* amws = p;
     const float scale = 1.0f / sqrtf((float)hd);
     // the workspace's arrival counters must be zero before the first step (the caller zero-fills `ws` once); UFV_DECODE_FUSED_ATTN=0: three launches
     static const bool fused_env = getenv("UFV_DECODE_FUSED_ATTN") == nullptr || getenv("UFV_DECODE_FUSED_ATTN")[0] != '0';
@@ -85,7 +92,8 @@ static int decode_step_impl(const ufv_qwen2_model* m, const int64_t* token_dev, 
     if (hidden_out) UFV_TRY(ufv_convert(normed, UFV_DT_F32, hidden_out, UFV_DT_F32, D, stream));
     UFV_TRY(ufv_convert(normed, UFV_DT_F32, h, UFV_DT_BF16, D, stream));
     UFV_TRY(ufv_gemv1(h, nullptr, nullptr, 0.f, m->lm_head, D, nullptr, logits, 1, m->vocab, D, nullptr, UFV_ACT_NONE, nullptr, 0, stream));
-    UFV_TRY(ufv_argmax(logits, m->vocab, next_token_dev, stream));
+    if (((uintptr_t)logits & 15) == 0) UFV_TRY(ufv_argmax_ws(logits, m->vocab, next_token_dev, amws, stream));
+    else UFV_TRY(ufv_argmax(logits, m->vocab, next_token_dev, stream));
     if (pos_dev) UFV_TRY(ufv_add_int(pos_dev, 1, stream));
     return UFV_OK;
 }

@@ -383,11 +383,16 @@ def mask_loss_sums(pred, gt):
     return out
 
 
-def argmax(logits, out=None):
+def argmax(logits, out=None, ws=None):
+    """index of the maximum (ties: the lowest, NaN wins, like torch.argmax).  ws: a zero-initialised uint8 tensor of ufv_argmax_ws_bytes() bytes selects the
+    64-block form the decode step uses (its counter returns to zero: the tensor can be reused)."""
     _chk(logits, torch.float32, "logits")
     if out is None:
         out = torch.empty((1,), device=logits.device, dtype=torch.int64)
-    _lib.call("ufv_argmax", logits.data_ptr(), logits.numel(), out.data_ptr(), _stream())
+    if ws is not None and logits.data_ptr() % 16 == 0:
+        _lib.call("ufv_argmax_ws", logits.data_ptr(), logits.numel(), out.data_ptr(), ws.data_ptr(), _stream())
+    else:
+        _lib.call("ufv_argmax", logits.data_ptr(), logits.numel(), out.data_ptr(), _stream())
     return out
 
 
