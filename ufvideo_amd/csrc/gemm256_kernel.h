@@ -452,10 +452,36 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
 #endif
     constexpr int FPL = (PH2 && !FP8 && !SKT && UFV_FPF_MODE == 1) ? UFV_FPF_LEVEL(MA0, MA1, NB1) : 0;
     constexpr bool FPF = FPL > 0;                              // fragment prefetch: see the K loop
+    // X2 (with FPF): 96-row A halves staged EXACTLY -- 12 pieces of 8 rows instead of 16 (a 96-row half was staged as 128 rows), compact slots.  Per group (A stays
+    // group-local) the 6 pieces of such a half go to 4 waves as 2 + 2 + 1 + 1; where both halves have 96 rows (192 x 192) the second one takes 1 + 1 + 2 + 2, so every wave
+    // issues six DMA instructions per K-tile and the counted waits stay uniform; with one such half (224 x 192) waves 0, 1 of a group issue seven, waves 2, 3 six, and the
+    // waits take the wave's own count.
+#ifndef UFV_X2_MODE
+#define UFV_X2_MODE 1        /* lab: 0 = padded staging */
+#endif
+    constexpr bool X2 = FPF && FPL == 2 && UFV_X2_MODE == 1 && NB1 == 1 && (MA0 == 3 || MA1 == 3) && MA0 >= 3 && MA1 >= 3;
+    constexpr int OA1 = X2 ? (MA0 == 3 ? 12288 : 16384) : 16384, OB0 = X2 ? OA1 + (MA1 == 3 ? 12288 : 16384) : 32768, OB1 = OB0 + 16384, STG = X2 ? OB1 + 8192 : 65536;
+    const int gj = wave & 3, gg = wave >> 2;
+    const bool x_hi = gj < 2;
+    // pieces of this wave in each A half, and its first piece: a 96-row half as 2 2 1 1 (or 1 1 2 2: the second such half), a 128-row half as always
+    const int la0x = MA0 == 3 ? (x_hi ? 2 : 1) : 2, la1x = MA1 == 3 ? ((MA0 == 3) != x_hi ? 2 : 1) : 2;
+    const int pa0x = MA0 == 3 ? 6 * gg + (x_hi ? 2 * gj : 4 + (gj - 2)) : 2 * wave;
+    const int pa1x = MA1 == 3 ? 6 * gg + (MA0 == 3 ? (x_hi ? gj : 2 + 2 * (gj - 2)) : (x_hi ? 2 * gj : 4 + (gj - 2))) : 2 * wave;
+    constexpr bool XCLS = X2 && (MA0 == 3) != (MA1 == 3);          // two classes of waves (7 / 6 instructions per K-tile)
     // what FPF rests on: the leading group (waves 0-3) reads A rows [0, 16 MA) of each half, and waves 0-3 stage rows [0, 32 LA) of it
     static_assert(!FPF || (16 * MA0 <= 32 * T::LA0 && 16 * MA1 <= 32 * T::LA1), "fragment prefetch: the leading group's A rows must be staged by its own waves");
     const char* src[4][2];
     auto set_src = [&](int m0_, int n0_) {
+        if constexpr (X2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                src[0][i] = A + (size_t)min(m0_ + (pa0x + min(i, la0x - 1)) * 8 + lrow, M - 1) * lda * ES + lchunk * 16;
+                src[1][i] = A + (size_t)min(m0_ + 32 * MA0 + (pa1x + min(i, la1x - 1)) * 8 + lrow, M - 1) * lda * ES + lchunk * 16;
+                src[2][i] = W + (size_t)min(n0_ + (wave * 2 + i) * 8 + lrow, N - 1) * ldw * ES + lchunk * 16;
+                src[3][i] = W + (size_t)min(n0_ + 128 + wave * 8 + lrow, N - 1) * ldw * ES + lchunk * 16;
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -468,6 +494,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     };
     int kbeg = 0, kend = 0;                        // K-tile range of the item being loaded
     auto stage = [&](int d, int which, int kt) {
+        if constexpr (X2) {
+            if (kt < kend) {
+                const int l = which == 0 ? la0x : which == 1 ? la1x : which == 2 ? 2 : 1;
+                char* dst = smem + d * STG + (which == 0 ? pa0x * 1024 : which == 1 ? OA1 + pa1x * 1024 : which == 2 ? OB0 + wave * 2048 : OB1 + wave * 1024);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][0] + kt * 128), LDS_PTR(dst), 16, 0, 0);
+                if (l == 2) __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][1] + kt * 128), LDS_PTR(dst + 1024), 16, 0, 0);
+            }
+            return;
+        }
         const int l = which == 0 ? T::LA0 : which == 1 ? T::LA1 : which == 2 ? T::LB0 : T::LB1;
         if (kt < kend) {
             char* dst = smem + d * 65536 + which * 16384 + wave * (1024 * l);
@@ -582,11 +617,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     bf16x8 aF0[FPF ? MA0 : 1][2], aF1[FPF ? MA1 : 1][2], bF[FPL == 2 ? 2 : 1][FPF ? NT : 1][2];
     // read op r of a fragment list: A-half h frag i, k-half c  /  B frag j (0,1 = the 128-column half, 2.. = the other), k-half c
     auto rd_a0 = [&](const char* stg, int r) { aF0[r >> 1][r & 1] = *reinterpret_cast<const bf16x8*>(stg + a_row_off[0] + (r >> 1) * 2048 + ((r & 1) ? coff1 : coff0)); };
-    auto rd_a1 = [&](const char* stg, int r) { aF1[r >> 1][r & 1] = *reinterpret_cast<const bf16x8*>(stg + 16384 + a_row_off[1] + (r >> 1) * 2048 + ((r & 1) ? coff1 : coff0)); };
+    auto rd_a1 = [&](const char* stg, int r) { aF1[r >> 1][r & 1] = *reinterpret_cast<const bf16x8*>(stg + OA1 + a_row_off[1] + (r >> 1) * 2048 + ((r & 1) ? coff1 : coff0)); };
     auto rd_b = [&](auto pc, const char* stg, int r) {
         constexpr int P = decltype(pc)::value;
         const int j = r >> 1;
-        const char* half = j < 2 ? stg + 32768 + b_row_off[0] + j * 2048 : stg + 49152 + b_row_off[1] + (j - 2) * 2048;
+        const char* half = j < 2 ? stg + OB0 + b_row_off[0] + j * 2048 : stg + OB1 + b_row_off[1] + (j - 2) * 2048;
         bF[FPL == 2 ? P : 0][FPF ? j : 0][r & 1] = *reinterpret_cast<const bf16x8*>(half + ((r & 1) ? coff1 : coff0));
     };
 #define UFV_MMA_STEP(AF, BF, MTB, MCNT, S0, S1, S2, ISSUE, TAILWAIT)                                                    \
@@ -610,14 +645,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     TAILWAIT();                                                                                              \
     __builtin_amdgcn_s_barrier();
 
-#define UFV_WAIT_G(EXTRA) wait_vmcnt<FPF ? L_ALL + (EXTRA) : 0>()
+    constexpr int L_F = X2 ? (MA0 == 3 && MA1 == 3 ? 6 : 7) : L_ALL;      // DMA instructions per wave and K-tile in the prefetch forms (XCLS: of waves 0, 1 of a group; 2, 3: one less)
+#define UFV_WAIT_G(EXTRA)                                                                                    \
+    do {                                                                                                     \
+        if (XCLS && !x_hi) wait_vmcnt<FPF ? L_F - (XCLS ? 1 : 0) + (EXTRA) : 0>();                           \
+        else wait_vmcnt<FPF ? L_F + (EXTRA) : 0>();                                                          \
+    } while (0)
     if constexpr (FPF) {
         if (len > 1) {                                 // as below: [A0 B0 B1] of the first K-tile; its A1 and the second tile's three stay in flight
             if (RELAX_OK && relax == 1) UFV_WAIT_G(RELAX_OK ? NST : 0);
             else if (RELAX_OK && relax == 2) UFV_WAIT_G(RELAX_OK ? NSTW : 0);
             else if (RELAX_OK && relax == 3) UFV_WAIT_G(RELAX_OK ? NSTS : 0);
             else UFV_WAIT_G(0);
-        } else wait_vmcnt<T::LA1>();
+        } else if constexpr (X2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the A1 count differs by wave there: wait for all of it
+        else wait_vmcnt<T::LA1>();
     } else if constexpr (PH2) {
         if (len > 1) {                                 // A0 / B0 / B1 of the first K-tile; its A1 and the second tile's three stay in flight
             if (RELAX_OK && relax == 1) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
@@ -648,8 +689,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         constexpr int P = decltype(pc)::value;                // = tt & 1: the ring stage and the B fragment set of this K-tile
         using PN = std::integral_constant<int, P ^ 1>;
         const int t = k0 + tt, d = P;
-        const char* buf = smem + d * 65536;
-        const char* nbuf = smem + (d ^ 1) * 65536;
+        const char* buf = smem + d * STG;
+        const char* nbuf = smem + (d ^ 1) * STG;
         // phase A: load step = request A1[t+1], retire A1[t] (behind it: [A0 B0 B1][t+1], A1[t+1] and, at an item's first K-tile, the previous epilogue's stores);
         // MFMAs on (A0, B) with the reads of A1[t] between them
         UFV_GSTAMP(0);
