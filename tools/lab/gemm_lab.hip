@@ -1,5 +1,5 @@
 // Stand-alone lab for the ping-pong GEMM (not part of the product): builds csrc/gemm256.hip into one executable with an s_memtime
-// timeline of one steady-state K-tile (UFV_GSTAMP: waves 0 and 4 of every block, K-tile 8 of the block's first tile), times a
+// timeline of one steady-state K-tile (UFV_GSTAMP: waves 0 and 4 of every block, K-tile 8 -- or 100 of a long loop -- of the block's first tile), times a
 // shape and prints the median step durations.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/lab/gemm_lab.hip -o tools/lab/gemm_lab && tools/lab/gemm_lab M N K shape [f32res]
 #include <hip/hip_runtime.h>
@@ -14,7 +14,8 @@
 __device__ unsigned long long* g_stamps;      // [blocks][2][16]
 #define UFV_GSTAMP_DECL unsigned long long gs0 = 0, gs1 = 0, gs2 = 0, gs3 = 0, gs4 = 0, gs5 = 0, gs6 = 0, gs7 = 0, gs8 = 0, gs9 = 0, gs10 = 0, gs11 = 0, gs12 = 0, gs13 = 0; \
     const bool gs_on = g_stamps != nullptr && round == 1; if (gs_on) gs13 = __builtin_amdgcn_s_memtime();
-#define UFV_GSTAMP(i) do { if (gs_on && tt == 8) gs##i = __builtin_amdgcn_s_memtime(); } while (0)
+// the sampled K-tile: the 100th of a long K loop (steady state: the first ones of a launch wait for cold HBM pages), else the 9th
+#define UFV_GSTAMP(i) do { if (gs_on && tt == (len > 120 ? 100 : 8)) gs##i = __builtin_amdgcn_s_memtime(); } while (0)
 #define UFV_GSTAMP_FLUSH do { if (gs_on && lane == 0 && (wave & 3) == 0) { unsigned long long* p_ = g_stamps + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 16; \
     p_[0] = gs0; p_[1] = gs1; p_[2] = gs2; p_[3] = gs3; p_[4] = gs4; p_[5] = gs5; p_[6] = gs6; p_[7] = gs7; p_[8] = gs8; p_[9] = gs9; p_[10] = gs10; p_[11] = gs11; \
     p_[12] = gs12; p_[13] = gs13; p_[14] = __builtin_amdgcn_s_memtime(); p_[15] = len; } } while (0)
