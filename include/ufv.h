@@ -27,9 +27,11 @@
  *    another long-running kernel) the waiter sets the device's error word and goes on; that launch's
  *    tile is wrong, nothing hangs, and the next SPLIT-K launch on the device returns UFV_EHIP (the
  *    word is read where the flag ring is handed out; unsplit GEMMs never wait on a turn and are not
- *    gated).  ufv_gemm_error_state reads the word at any time -- a caller that needs the guarantee
- *    per step checks it there (ufvideo_amd.train.DecoderTrainer.step does) -- and
- *    ufv_gemm_clear_error resets it.
+ *    gated).  ufv_gemm_error_state reads the word at any time; the kernels set it WHEN THEY RUN, so a
+ *    caller that needs the guarantee per step synchronises the stream first and then reads it
+ *    (ufvideo_amd.train.DecoderTrainer.step does, before the update touches the fp32 masters, and with
+ *    several ranks it all-reduces the flag so that every rank refuses the step together).  A negative
+ *    return is UFV_EHIP (no current device), not a time-out.  ufv_gemm_clear_error resets the word.
  */
 #ifndef UFV_H_
 #define UFV_H_

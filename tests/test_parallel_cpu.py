@@ -302,6 +302,67 @@ def test_trainer_exchange_order_world2_gloo():
                 assert g.numel() * 2 == n and torch.equal(g, mean[rank * (n // 2):(rank + 1) * (n // 2)]), (rank, i)
 
 
+def _error_gate_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ufvideo_amd import train as TR
+
+        class FakeLib:                                            # rank 0's device reports a timed-out turn wait, rank 1's is clean
+            def ufv_gemm_error_state(self):
+                return 1 if rank == 0 else 0
+
+            def ufv_last_error(self):
+                return b""
+
+        class FakeMod:
+            UfvError = TR._lib.UfvError
+
+            @staticmethod
+            def load():
+                return FakeLib()
+        TR._lib = FakeMod
+        tr = object.__new__(TR.DecoderTrainer)
+        tr.world, tr.rank, tr.group, tr.dev = world, rank, None, torch.device("cpu")
+        try:
+            tr._check_gemm_errors()
+            q.put((rank, "no error raised"))
+        except FakeMod.UfvError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gemm_error_gate_raises_on_every_rank_world2_gloo():
+    """DecoderTrainer.step()'s split-K error gate with world 2: only rank 0's device word is set, BOTH ranks raise (the flag is all-reduced with MAX
+    before anybody raises) -- a rank-local raise in front of the exchange would leave the other rank waiting in reduce-scatter."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_error_gate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert "timed out waiting for its turn" in res[0] and "NOT applied" in res[0], res
+    assert "another rank reported" in res[1], res
+
+
+def test_gemm_error_gate_names_a_missing_device_as_such():
+    """ufv_gemm_error_state returns UFV_EHIP (negative) when there is no current HIP device: that is reported as a runtime failure, not as a split-K
+    timeout (here: the CPU container, the real library, no GPU)."""
+    from ufvideo_amd import train as TR, _lib
+    import pytest
+    tr = object.__new__(TR.DecoderTrainer)
+    tr.world, tr.rank, tr.group, tr.dev = 1, 0, None, torch.device("cpu")
+    if _lib.load().ufv_gemm_error_state() >= 0:
+        pytest.skip("a HIP device is visible: the word reads 0")
+    with pytest.raises(_lib.UfvError, match="NOT a split-K timeout"):
+        tr._check_gemm_errors()
+
+
 def test_bucket_layout_and_shard_bounds():
     """host logic of the ZeRO-2 buckets (no GPU): every parameter view starts on a 128-byte boundary, the flat length divides by
     64 x world (so every rank's shard is whole and aligned), views alias the flat buffers, shards tile the buffer"""

@@ -133,3 +133,69 @@ def test_frame_sharded_encode_world_size_two_on_one_gpu_equals_single_process():
             raise
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"FRAMESHARD_OK rank {r}" in so, (so[-1500:], se[-3000:])
+
+
+AUTOGRAD_DDP_CHILD = r'''
+import os, sys
+sys.path.insert(0, os.environ["UFV_ROOT"]); sys.path.insert(0, os.path.join(os.environ["UFV_ROOT"], "tests"))
+import numpy as np, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)      # an initialised default group, as under torchrun / the HF Trainer (two ranks on ONE device: gloo)
+torch.cuda.set_device(0)
+from ufvideo_amd import _lib
+from test_model_gpu import tiny_model
+from conftest import load_golden, t, rel_err
+DEV = "cuda"
+a, _ = load_golden("train_grad_tiny")
+z = np.load(os.path.join(os.environ["UFV_ROOT"], "tests", "golden", "train_grad_tiny.npz"))
+m, arrs, _ = tiny_model()
+ids, labels = t(a["ids"]).to(DEV), t(a["labels_in"]).to(DEV)
+video = t(arrs["video"]).to(DEV)
+batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids), images=[(video, "video")],
+             images_sam=torch.zeros(1, 4, 3, 8, 8, device=DEV), offset=[0, 1], masks_list=[torch.zeros(0, 56, 56)], label_list=[torch.zeros(56, 56)])
+names = [n for n, _ in m.named_parameters() if n.startswith(("model.layers.", "model.norm.", "lm_head.", "model.embed_tokens."))]
+own = dict(m.named_parameters())
+for n in names:
+    own[n].requires_grad_(True)
+sk_before = _lib.load().ufv_gemm_set_splitk(1); _lib.load().ufv_gemm_set_splitk(sk_before)
+loss = m(**batch)["loss"] * (1.0 + rank)                              # rank-dependent scale: the gradients of the two ranks differ by exactly 2 x
+eng = m._engine[1]
+assert eng.world == 1 and eng.rank == 0 and eng.comm_stream is None, (eng.world, eng.rank)     # rank-local: the averaging is the caller's (DDP's hooks)
+sk_now = _lib.load().ufv_gemm_set_splitk(sk_before)
+assert sk_now == sk_before, "the gradient engine must not switch the split-K GEMM form off in the caller's process"
+loss.backward()                                                       # raised AttributeError (b.gshard) before round 5; would have issued its own reduce-scatters
+ref = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("g::")}
+worst = max((rel_err(own[k].grad.float().cpu() / (1.0 + rank), ref[k]), k) for k in ref)
+assert worst[0] < 8e-2, worst
+# what DDP does with the result: all-reduce(mean) of .grad over the group -- here by hand; both ranks then hold 1.5 x the reference gradient
+k = "model.layers.1.mlp.down_proj.weight"
+g = own[k].grad.float().cpu()
+dist.all_reduce(g); g /= world
+assert rel_err(g, 1.5 * ref[k]) < 8e-2
+m.release_grad_engine()
+dist.barrier(); dist.destroy_process_group()
+print(f"AUTOGRAD_DDP_OK rank {rank}")
+'''
+
+
+def test_autograd_path_is_rank_local_under_an_initialised_process_group_world_two():
+    """The reference trains under torchrun + the HF Trainer (DDP / DeepSpeed own the gradient exchange).  `model(**batch)["loss"].backward()` in a
+    process whose default group has world size 2 must (i) run -- the gradient engine has no ZeRO shards to reduce into, (ii) issue no collective of
+    its own and leave the split-K switch alone, (iii) fill `.grad` with THIS rank's gradient (checked against the reference's backward, golden
+    train_grad_tiny), which the caller's averaging then combines.  Two processes on cuda:0 over gloo."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, UFV_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", AUTOGRAD_DDP_CHILD], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"AUTOGRAD_DDP_OK rank {r}" in so, (so[-1500:], se[-3000:])

@@ -269,3 +269,45 @@ def test_seg_head_at_sam2_l_dimensions():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
         n_grad += int(float(p.grad.abs().max()) > 0)
     assert n_grad >= len(leaves) - 12 - 18 - 8                 # three of the four hyper-networks are not picked; key biases are analytically zero
+
+
+def test_autograd_path_with_seg_targets_fills_grad_of_text_hidden_fcs_and_mask_decoder():
+    """`model(**batch)["loss"].backward()` (the HF Trainer's call, model/videorefer_qwen2.py _TrainingLoss) on a batch WITH [SEG] targets: the gradient
+    engine behind the autograd node has no fp32 masters (optimizer_states=False) and runs inside an autograd.Function.forward (grad mode off), while the
+    mask branch differentiates through torch autograd -- the engine builds its leaves from the working weights and switches grad mode on locally.  Checked
+    against the reference's own loss.backward() (golden seg_grad_tiny `two_obj`): total loss, text_hidden_fcs gradients, mask-decoder gradient norms."""
+    a, m, arrs, w = _seg_model()
+    name = "two_obj"
+    ids, labels, gt = t(a[name + "_ids"]).to(DEV), t(a[name + "_labels"]).to(DEV), t(a[name + "_gt"])
+    video = t(arrs["video"]).to(DEV)
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids), images=[(video, "video")], images_sam=t(a["images_sam"]).to(DEV),
+                 offset=[0, 1], masks_list=[gt], label_list=[torch.zeros(*gt.shape[1:])])
+    own = dict(m.named_parameters())
+    names = [n for n in own if n.startswith(("model.layers.", "model.norm.", "lm_head.", "model.embed_tokens.", "model.text_hidden_fcs.",
+                                             "model.mask_encoder.sam2_model.sam_mask_decoder."))]
+    for n in names:
+        own[n].requires_grad_(True)
+    out = m(**batch)
+    ref = a[name + "_losses"]
+    got = [float(out[k]) for k in ("loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss")]
+    assert np.allclose(got, ref, rtol=2e-2), (got, ref.tolist())
+    assert out["loss"].requires_grad
+    out["loss"].backward()
+    n_fcs = 0
+    for key in a:
+        if key.startswith(name + "_g::model.text_hidden_fcs."):
+            pn = key[len(name) + 4:]
+            assert own[pn].grad is not None, pn
+            assert rel_err(own[pn].grad.float().cpu(), t(a[key])) < GRAD_TOL, pn
+            n_fcs += 1
+    assert n_fcs == 4
+    gsum = {k[len("model."):]: type("G", (), {"grad": p.grad})() for k, p in own.items() if k.startswith("model.mask_encoder.")}
+    for key in a:                       # heads the loss does not reach: the engine exports an all-zero gradient where torch leaves None
+        if key.startswith(name + "_nograd::"):
+            pn = "mask_encoder.sam2_model." + key[len(name) + 9:]
+            assert gsum[pn].grad is None or float(gsum[pn].grad.abs().max()) == 0.0, pn
+            gsum[pn].grad = None
+    _check_sam_grads(a, name, gsum, GRAD_TOL + 0.05, 0.06)                       # (.grad takes the parameter's dtype: one more rounding than the fp32 buckets)
+    k = "model.layers.1.mlp.down_proj.weight"
+    assert rel_err(own[k].grad.float().cpu(), t(a[f"{name}_g::{k}"])) < 8e-2
+    m.release_grad_engine()

@@ -128,7 +128,14 @@ class DecoderTrainer:
         self.base_lr, self.mm_projector_lr = lr, mm_projector_lr
         self.base_mm_projector_lr = mm_projector_lr
         self.group = group
+        self.optimizer_states = bool(optimizer_states)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if not self.optimizer_states:
+            # The gradient engine of the autograd path is RANK-LOCAL whatever process group exists: under HF Trainer / torchrun / DDP (the reference's
+            # deployment) the averaging of `.grad` is DDP's, through its hooks on the nn.Parameters -- an engine that also issued reduce-scatters inside
+            # forward would compete with them (and has no shards to reduce into: init_states() is skipped).  So: world 1, no side stream, no
+            # split-K toggle, no _reduce_async / _exchange.
+            self.world = 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.t = 0
         self.lora = dict(lora) if lora else None
@@ -249,7 +256,6 @@ class DecoderTrainer:
                 if same:
                     self.proj_flat[off:off + n].view(shape).copy_(v)
                     v.data = self.proj_flat[off:off + n].view(shape)
-        self.optimizer_states = bool(optimizer_states)
         if self.optimizer_states:
             for b in self.buckets():
                 b.init_states()
@@ -546,8 +552,10 @@ class DecoderTrainer:
         seg_leaves = None
         if self.seg is not None and (has_gt or has_seg):
             # fp32 leaves over the masters of the mask branch; their .grad is folded into the auxiliary bucket after the last sample
+            # (the gradient engine of the autograd path has no masters: optimizer_states=False -- its leaves are fp32 copies of the working weights)
             pb = self.proj_bucket
-            seg_leaves = {k: pb.view(pb.master, k).detach().requires_grad_(True) for k in self.proj_params
+            src_buf = pb.master if pb.master is not None else pb.w
+            seg_leaves = {k: pb.view(src_buf, k).detach().float().requires_grad_(True) for k in self.proj_params
                           if k.startswith(("text_hidden_fcs.", "mask_encoder."))}
             if torch.is_tensor(offset):
                 offset = offset.tolist()
@@ -562,10 +570,15 @@ class DecoderTrainer:
                 if rows.numel():
                     def hook(hb, b=b, rows=rows):
                         nonlocal mask_bce, mask_dice
-                        hid = hb[rows.to(hb.device)].float().requires_grad_(True)
-                        hw = tuple(label_list[b].shape)
-                        bce_b, dice_b = self.seg.forward_backward(seg_leaves, hid, images_sam[b], masks_list[b], hw, w_bce, w_dice, num_masks_total)
-                        mask_bce, mask_dice = mask_bce + bce_b, mask_dice + dice_b
+                        # the mask branch differentiates through torch autograd (train_seg.py: _Cast / lin nodes over the HIP kernels); this hook also runs
+                        # inside _TrainingLoss.forward, where grad mode is off: switch it on locally or no graph is recorded and hid.grad stays None
+                        with torch.enable_grad():
+                            hid = hb[rows.to(hb.device)].detach().float().requires_grad_(True)
+                            hw = tuple(label_list[b].shape)
+                            bce_b, dice_b = self.seg.forward_backward(seg_leaves, hid, images_sam[b], masks_list[b], hw, w_bce, w_dice, num_masks_total)
+                        if hid.grad is None:
+                            raise RuntimeError("mask-loss branch: no gradient reached the [SEG] hidden states")
+                        mask_bce, mask_dice = mask_bce + bce_b.detach(), mask_dice + dice_b.detach()
                         return rows, hid.grad
                 else:
                     assert masks_list[b].shape[0] == 0, f"gt_mask.shape: {tuple(masks_list[b].shape)}, pred_mask.shape: (0, ...)"
@@ -662,15 +675,34 @@ class DecoderTrainer:
             out.append((b, b.g if (self.world == 1 or b.world == 1) else b.gshard))
         return out
 
+    def _check_gemm_errors(self):
+        """The per-step guarantee of include/ufv.h (Conventions): the kernels of this step's forward / backward set the device's pinned error word when a
+        split-K turn wait expires, so the word means something only AFTER they have run -- the stream is synchronised before it is read (once per optimizer
+        step: the update cannot overlap the backward pass anyway, it consumes its gradients), so a bad step is refused before AdamW touches the fp32
+        masters, not one step later.  With world > 1 the flag is all-reduced (MAX) BEFORE any rank raises: a rank-local raise in front of _exchange()
+        would leave the other ranks waiting in reduce-scatter.  A negative return is the library failing to find the device, reported as that."""
+        if self.dev.type == "cuda":
+            torch.cuda.current_stream(self.dev).synchronize()
+        err = int(_lib.load().ufv_gemm_error_state())
+        if self.world > 1:
+            flag = torch.tensor([err if err > 0 else (1 << 20 if err < 0 else 0)], device=self.dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            worst = int(flag.item())
+            if worst != 0 and err == 0:
+                raise _lib.UfvError(f"another rank reported a GEMM error (code {worst}) in this step: every rank refuses the update together")
+        if err < 0:
+            raise _lib.UfvError(f"ufv_gemm_error_state failed (code {err}: no current HIP device / runtime error) -- this is NOT a split-K timeout: "
+                                f"{_lib.load().ufv_last_error().decode()}")
+        if err != 0:
+            raise _lib.UfvError(f"a split-K GEMM of this step timed out waiting for its turn (error word {err}): the gradients are not trustworthy and "
+                                f"the update was NOT applied; ufv_gemm_clear_error() resets the word")
+
     def step(self):
         """Gradient exchange, global-norm clipping (HF Trainer max_grad_norm), AdamW on this rank's shard, all-gather.  Raises when a split-K GEMM of the
         forward / backward pass left the device's error word set (a timed-out turn wait: that launch's tile is wrong, include/ufv.h Conventions)."""
         if not self.optimizer_states:
             raise RuntimeError("this DecoderTrainer was built with optimizer_states=False (gradient engine of the autograd path): the optimizer is the caller's")
-        err = _lib.load().ufv_gemm_error_state()
-        if err != 0:
-            raise _lib.UfvError(f"a split-K GEMM of this step timed out waiting for its turn (error word {err}): the gradients are not trustworthy; "
-                                f"ufv_gemm_clear_error() resets the word")
+        self._check_gemm_errors()
         self.t += 1
         self._exchange()
         shards = self._grad_shards()
