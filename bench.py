@@ -124,14 +124,18 @@ class KernelTimer:
         return dict(mean_ms=float(np.mean(ms[:n])), launches=n, M=M, N=N, K=K, flops=2.0 * M * N * K)
 
 
-def one_step(model, video, ids, am, cache, frameshard=False):
+def one_step(model, video, ids, am, cache, frameshard=False, host=None):
+    """host = (ids, attention mask) as CPU tensors: what `ufvideo_amd.mm_infer` hands to generate() on every call (it tokenises on the host and keeps
+    that copy), so the splice plan is built without reading the device tensors back.  Nothing is remembered between steps (rounds 3-4 cached the
+    read-back per tensor object, which only a loop over one tensor ever hit)."""
     cache.len = 0
     mmf = None
     if frameshard:
         from ufvideo_amd.parallel import encode_frame_sharded
         mmf = encode_frame_sharded(model, video)[None]
+    ih, ah = host if host is not None else (None, None)
     _, am2, _, emb, _, _ = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, [(video, "video")], None, None, None, None,
-                                                                      mm_features=mmf)
+                                                                      mm_features=mmf, input_ids_host=ih, attention_mask_host=ah)
     logits, *_ = model._decode_batch(emb, am2, cache, False, 1, consume=True)          # as generate() hands its splice result on: no 34 MB copy of it
     return logits, emb.shape[1]
 
@@ -228,6 +232,9 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
     if args.fp8:
         model.set_gemm_dtype("fp8")
     video, ids, am = inputs(device, args.frames)
+    if step is one_step and torch.is_tensor(ids):
+        import functools
+        step = functools.partial(one_step, host=(ids.cpu(), am.cpu()))       # the prompt's host copy, as mm_infer passes it (copied once, outside the timed region)
     if cache_factory is None:
         from ufvideo_amd.model import KVCache
         cfg = model.config
@@ -254,7 +261,8 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
         timer.on = False
     assert torch.isfinite(logits).all()
     if dist is not None:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        # (the rehearsal mode below runs gloo, whose collectives take host tensors; RCCL takes the device scalar)
+        tt = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -266,8 +274,11 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
         "higher_is_better": True, "scaling": "strong" if fs else "weak", "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"UFVideo-7B dims, {args.frames} frames {IMG}x{IMG}, {'W8A8 e4m3 GEMMs (config #5a), bf16 elsewhere' if args.fp8 else 'bf16'}, prompt 96 ids -> S={S}, "
                                f"encode+project+splice+prefill to last-position logits; clip replicas per GPU",
-                   "video_tokens_per_clip": tokens_per_clip, "llm_seq_len": S, "parallelism": (f"frameshard{world}+allgather" if fs else f"clip-dp{world}")},
+                   "video_tokens_per_clip": tokens_per_clip, "llm_seq_len": S,
+                   "prompt": "device tensors + the caller's host copy of the ids / mask, as ufvideo_amd.mm_infer passes them (no per-tensor cache between steps)", "parallelism": (f"frameshard{world}+allgather" if fs else f"clip-dp{world}")},
     }
+    if REHEARSAL():
+        out["rehearsal"] = f"TEST ONLY: {world} ranks share cuda:0 over gloo (UFV_BENCH_REHEARSAL); not a multi-GPU measurement"
     if rank == 0:
         ks = timer.summary()
         if ks:
@@ -324,12 +335,19 @@ def _free_port():
         return so.getsockname()[1]
 
 
+def REHEARSAL():
+    """UFV_BENCH_REHEARSAL=1 (tests/test_parallel_gpu.py only): the N ranks of `--gpus N` all use cuda:0 and talk over gloo (RCCL refuses two ranks on one
+    device), so that the launch path an 8-GPU node hits first -- launch_ranks -> torch.distributed.run -> main -> run() with a real model, barrier + MAX
+    reduction, rank-0 JSON -- can run on a 1-GPU box.  The line it prints carries a `rehearsal` key and is not a scaling number."""
+    return os.environ.get("UFV_BENCH_REHEARSAL") == "1"
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks as ONE child `python -m torch.distributed.run` and return its exit
     code.  Nothing in this process has touched the GPU (torch.cuda.device_count() does not initialise it on this image) and nothing is
     exec'ed over it: the ranks are children."""
     import subprocess
-    if not args.stub:
+    if not args.stub and not REHEARSAL():
         have = torch.cuda.device_count()
         if have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) visible on this host; refusing to report a {args.gpus}-GPU line "
@@ -372,7 +390,12 @@ def main(argv=None):
             dist.init_process_group("gloo")
         out = _stub_run(args, rank, world, dist)
     else:
-        if world > 1:
+        if world > 1 and REHEARSAL():
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        elif world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             torch.cuda.set_device(local_rank)

@@ -473,3 +473,24 @@ def test_decode_graph_replay_equals_per_launch_decode():
     torch.manual_seed(7); s0 = m.generate(ids, do_sample=True, temperature=2.0, top_p=0.9, decode_graph=False, **kw)["output"].cpu()
     torch.manual_seed(7); s1 = m.generate(ids, do_sample=True, temperature=2.0, top_p=0.9, decode_graph=True, **kw)["output"].cpu()
     assert torch.equal(s0, s1)
+
+
+def test_splice_from_the_callers_host_copy_equals_the_device_read_back():
+    """prepare_inputs_labels_for_multimodal(input_ids_host=, attention_mask_host=): the splice plan built from the caller's host copy of the prompt
+    (what mm_infer and bench.py pass) gives the tensors the device read-back gives; a host copy of another shape is refused; nothing is cached between
+    calls (a prompt tensor rewritten in place through `.data`, which does not bump `_version`, is seen)."""
+    m, a, w = tiny_model()
+    video = t(a["video"]).to(DEV)
+    ids = t(a["sp_vid_ids"]).to(DEV) if "sp_vid_ids" in a else torch.tensor([[5, 6, -201, 7, 8, 9]], device=DEV)
+    am = torch.ones_like(ids)
+    args = (None, None, [(video, "video")], None, None, None, None)
+    with torch.no_grad():
+        _, am1, _, e1, _, mk1 = m.prepare_inputs_labels_for_multimodal(ids, am, *args)
+        _, am2, _, e2, _, mk2 = m.prepare_inputs_labels_for_multimodal(ids, am, *args, input_ids_host=ids.cpu(), attention_mask_host=am.cpu().tolist())
+        assert torch.equal(e1, e2) and torch.equal(am1, am2) and mk1 == mk2
+        with pytest.raises(ValueError, match="input_ids_host"):
+            m.prepare_inputs_labels_for_multimodal(ids, am, *args, input_ids_host=ids.cpu()[:, :-1])
+        ids.data[0, 0] = 11                                    # same tensor object, same _version: rounds 3-4 served the stale plan from a cache
+        _, _, _, e3, _, _ = m.prepare_inputs_labels_for_multimodal(ids, am, *args)
+        assert not torch.equal(e3[0, 0], e1[0, 0])
+        assert torch.equal(e3[0, 0], m.get_model().embed_table()[11].float())

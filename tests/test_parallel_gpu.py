@@ -199,3 +199,25 @@ def test_autograd_path_is_rank_local_under_an_initialised_process_group_world_tw
             raise
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"AUTOGRAD_DDP_OK rank {r}" in so, (so[-1500:], se[-3000:])
+
+
+def test_bench_gpus2_real_run_rehearsal_two_ranks_on_one_gpu():
+    """The command the driver issues on a multi-GPU node, `python bench.py --gpus 2 ...`, end to end with the REAL model: bench.main -> launch_ranks ->
+    `python -m torch.distributed.run` child -> two ranks -> main() -> run() with dist != None (barrier + synchronize on both sides of exactly K steps,
+    MAX over ranks, rank 0 prints ONE JSON line).  A 1-GPU box cannot give two devices, so UFV_BENCH_REHEARSAL=1 puts both ranks on cuda:0 over gloo;
+    everything else is the product path.  Checks the line's contract fields; the value is NOT a scaling number (two processes share one GPU) and is
+    only required to be consistent with the ms_per_step it was computed from."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(UFV_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["config"]["parallelism"] == "clip-dp2"
+    assert "rehearsal" in d and "roofline" in d and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 2304 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]      # whole-job tokens of BOTH ranks / the MAX time
+    assert d["config"]["llm_seq_len"] == 2399

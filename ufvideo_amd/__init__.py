@@ -52,8 +52,9 @@ def mm_infer(image_or_video, instruct, model, tokenizer, modal="video", masks=No
         raise ValueError(f"Unsupported choice: {choice}")
 
     prompt = tokenizer.apply_chat_template(message, tokenize=False, add_generation_prompt=True)
-    input_ids = tokenizer_multimodal_token(prompt, tokenizer, modal_token, return_tensors="pt").unsqueeze(0).long().to(dev)
-    attention_masks = input_ids.ne(tokenizer.pad_token_id).long().to(dev)
+    ids_host = tokenizer_multimodal_token(prompt, tokenizer, modal_token, return_tensors="pt").unsqueeze(0).long()
+    am_host = ids_host.ne(tokenizer.pad_token_id).long()
+    input_ids, attention_masks = ids_host.to(dev), am_host.to(dev)      # the host copies go along: the splice plan is built from them, no device read-back
     stopping_criteria = KeywordsStoppingCriteria([tokenizer.eos_token], tokenizer, input_ids)
 
     do_sample = kwargs.get("do_sample", False)
@@ -67,7 +68,8 @@ def mm_infer(image_or_video, instruct, model, tokenizer, modal="video", masks=No
             input_ids, attention_mask=attention_masks, images=tensor, do_sample=do_sample, temperature=temperature,
             max_new_tokens=max_new_tokens, top_p=top_p, use_cache=True, stopping_criteria=[stopping_criteria],
             pad_token_id=tokenizer.eos_token_id, masks=masks, ann_indices=ann_indices, frame_nums=frame_nums, frame=frame,
-            images_sam=images_sam, offset=offset, masks_list=masks_list, label_list=label_list, video_file="")
+            images_sam=images_sam, offset=offset, masks_list=masks_list, label_list=label_list, video_file="",
+            input_ids_host=ids_host, attention_mask_host=am_host)
     if not seg:
         return tokenizer.batch_decode(output_ids["output"], skip_special_tokens=True)[0].strip(), output_ids
     return output_ids

@@ -63,6 +63,12 @@ template <int MA0, int MA1, int NB1> struct PP {
 // memory round trips per wave and tile, ~16 us of a 35 us out_proj tile.  Here the residual rows of accumulator row mt + 1 are requested
 // before row mt is stored, the loads are inline asm (no compiler-inserted waits) and the waits are counted: one round trip is exposed per
 // tile, the rest run under each other.  Same arithmetic, same element order: bit-identical output.
+// ISA markers (tests/test_isa_epilogue_stores.py): every epilogue form brackets its body with two comment lines in the listing.  The relaxed item-seam waits of
+// the K loop (NST / NSTW / NSTS below) are exact only if the epilogue that ran last issued EXACTLY that many vector-memory stores; the CPU test compiles the kernels
+// to gfx950 assembly, walks every path between a BEGIN and its END and counts the vector-memory instructions on it.  ("memory": nothing that touches memory moves
+// across a marker; the markers emit no instruction.)
+#define UFV_EPI_MARK(text) asm volatile("; UFV_EPI_" text ::: "memory")
+
 template <bool OUT_F32, int MA0, int MA1, int NB1>
 __device__ __forceinline__ void epilogue256_resid(const f32x4 (&acc)[2 + NB1][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc,
                                                   int frow, int fq, const f32x4 (&bias)[2 + NB1]) {
@@ -76,6 +82,7 @@ __device__ __forceinline__ void epilogue256_resid(const f32x4 (&acc)[2 + NB1][MA
         ncol[nt] = nok[nt] ? ncol[nt] : 0;            // a half-tile past N: loads a valid address, stores nothing
     }
     auto row_of = [&](int mt) { return m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow; };
+    UFV_EPI_MARK("BEGIN resid");
     f32x4 r[2][NT];
     auto request = [&](int mt, f32x4 (&dst)[NT]) {
         const int m = min(row_of(mt), M - 1);
@@ -120,6 +127,7 @@ __device__ __forceinline__ void epilogue256_resid(const f32x4 (&acc)[2 + NB1][MA
             }
         }
     }
+    UFV_EPI_MARK("END resid");
 }
 
 
@@ -134,27 +142,32 @@ __device__ __forceinline__ void epilogue256_wide(const f32x4 (&acc)[2 + NB1][MA0
     // Round 4: the stores go through ONE buffer descriptor over the whole output (num_records = M rows): a row past M is dropped by the hardware, so there is no
     // exec masking, and an address is a 32-bit per-lane offset + an immediate -- the flat form cost five 64-bit vector operations per store (the epilogue is
     // VALU-bound: ~35 vector instructions per store, two waves per SIMD, 7 - 9 k ticks of a 61 k-tick K = 1152 tile).  The caller guarantees M * ldc * 2 < 2^31.
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, M * e.ldc * 2, 0x20000);
-    const int step = 32 * e.ldc;                                                                   // bytes between accumulator rows mt and mt + 1 (16 matrix rows)
-    const int col0 = n0 + wc * 32 + fq * 8;
-    const int off_h0 = ((m0 + wr * 16 * MA0 + frow) * e.ldc + col0) * 2;                          // this lane's row of accumulator row 0 (A0 half), run 0
-    const int off_h1 = ((m0 + 32 * MA0 + wr * 16 * MA1 + frow) * e.ldc + col0) * 2;               // ... of accumulator row MA0 (A1 half)
+    // (sizes and offsets in UNSIGNED arithmetic: a row past M of an output close to 2^31 bytes lands above 2^31 -- still beyond num_records, dropped)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (int)((unsigned)M * (unsigned)e.ldc * 2u), 0x20000);
+    const unsigned step = 32u * (unsigned)e.ldc;                                                   // bytes between accumulator rows mt and mt + 1 (16 matrix rows)
+    const unsigned col0 = n0 + wc * 32 + fq * 8;
+    const unsigned off_h0 = ((unsigned)(m0 + wr * 16 * MA0 + frow) * (unsigned)e.ldc + col0) * 2u;              // this lane's row of accumulator row 0 (A0 half), run 0
+    const unsigned off_h1 = ((unsigned)(m0 + 32 * MA0 + wr * 16 * MA1 + frow) * (unsigned)e.ldc + col0) * 2u;   // ... of accumulator row MA0 (A1 half)
     auto pack2 = [&](float a, float b) -> unsigned {
         const bf16x2 p = {(bf16)a, (bf16)b};
         return __builtin_bit_cast(unsigned, p);
     };
+    // Round 5: EVERY store instruction is issued on EVERY path -- a run past N (the tile cut at N % BN == 128) is sent to an offset with bit 31 set, beyond any
+    // descriptor this epilogue accepts (M * ldc * 2 < 2^31), where the hardware drops it like a row past M.  No branch between the stores, and the count the relaxed
+    // seam waits rest on (NSTW) holds on edge tiles too; tests/test_isa_epilogue_stores.py walks the listing.
+    const unsigned drop1 = n0 + 128 >= N ? 0x80000000u : 0u;
+    UFV_EPI_MARK("BEGIN wide");
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int off = mt < MA0 ? off_h0 + mt * step : off_h1 + (mt - MA0) * step;
+        const unsigned off = mt < MA0 ? off_h0 + mt * step : off_h1 + (mt - MA0) * step;
 #pragma unroll
         for (int run = 0; run < 2; ++run) {
-            const int nb = n0 + run * 128;
-            if (nb >= N) continue;
+            const unsigned drop = run ? drop1 : 0u;
             if (run == 1 && NB1 == 1) {               // a 16-column second half has no partner n-tile: the 8-byte store (columns 128 + 16 wc + 4 fq ..)
                 const f32x4 v = acc[2][mt] + bias[2];
                 const bf16x4 o = {(bf16)act_apply_t<ACT>(v[0]), (bf16)act_apply_t<ACT>(v[1]), (bf16)act_apply_t<ACT>(v[2]), (bf16)act_apply_t<ACT>(v[3])};
                 typedef __attribute__((ext_vector_type(2))) int i32x2;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, o), rs, off + (128 - wc * 16 - fq * 4) * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, o), rs, (int)((off + (unsigned)(128 - wc * 16 - fq * 4) * 2u) | drop), 0, 0);
                 continue;
             }
             const f32x4 va = acc[2 * run][mt] + bias[2 * run], vb = acc[2 * run + 1][mt] + bias[2 * run + 1];
@@ -165,9 +178,10 @@ __device__ __forceinline__ void epilogue256_wide(const f32x4 (&acc)[2 + NB1][MA0
             auto t0 = __builtin_amdgcn_permlane16_swap((unsigned)s0[0], (unsigned)s0[1], false, false);
             auto t1 = __builtin_amdgcn_permlane16_swap((unsigned)s1[0], (unsigned)s1[1], false, false);
             const i32x4 o = {(int)t0[0], (int)t1[0], (int)t0[1], (int)t1[1]};       // columns 8 fq .. 8 fq + 7 of the run
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs, off + run * 256, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs, (int)((off + run * 256u) | drop), 0, 0);
         }
     }
+    UFV_EPI_MARK("END wide");
 }
 
 // SwiGLU epilogue with 16-byte stores (round 4).  A lane holds 4 output columns (8 bytes of bf16) per (accumulator row, half): columns 4 fq .. 4 fq + 3 of the
@@ -179,22 +193,23 @@ template <int MA0, int MA1>
 __device__ __forceinline__ void epilogue256_swiglu_wide(const f32x4 (&acc)[4][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc, int frow, int fq) {
     static_assert(MA0 % 2 == 0 && MA1 % 2 == 0, "accumulator rows are stored in pairs inside each A half");
     constexpr int MT = MA0 + MA1;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, M * e.ldc * 2, 0x20000);
-    const int step2 = 64 * e.ldc;                                                                  // bytes between accumulator-row pairs (32 matrix rows)
-    const int col0 = (n0 >> 1) + wc * 16 + 8 * (fq >> 1);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (int)((unsigned)M * (unsigned)e.ldc * 2u), 0x20000);
+    const unsigned step2 = 64u * (unsigned)e.ldc;                                                  // bytes between accumulator-row pairs (32 matrix rows)
+    const unsigned col0 = (n0 >> 1) + wc * 16 + 8 * (fq >> 1);
     const int rsel = 16 * (fq & 1);                                                                // lane rows 1 / 3 carry accumulator row mt + 1
-    const int off_h0 = ((m0 + wr * 16 * MA0 + frow + rsel) * e.ldc + col0) * 2;
-    const int off_h1 = ((m0 + 32 * MA0 + wr * 16 * MA1 + frow + rsel) * e.ldc + col0) * 2;
+    const unsigned off_h0 = ((unsigned)(m0 + wr * 16 * MA0 + frow + rsel) * (unsigned)e.ldc + col0) * 2u;
+    const unsigned off_h1 = ((unsigned)(m0 + 32 * MA0 + wr * 16 * MA1 + frow + rsel) * (unsigned)e.ldc + col0) * 2u;
     auto pack2 = [&](float a, float b) -> unsigned {
         const bf16x2 p = {(bf16)a, (bf16)b};
         return __builtin_bit_cast(unsigned, p);
     };
+    const unsigned drop1 = n0 + 128 >= N ? 0x80000000u : 0u;   // as in epilogue256_wide: a half past N is stored to a dropped offset, every store is issued
+    UFV_EPI_MARK("BEGIN swiglu_wide");
 #pragma unroll
     for (int mp = 0; mp < MT; mp += 2) {
-        const int off = mp < MA0 ? off_h0 + (mp >> 1) * step2 : off_h1 + ((mp - MA0) >> 1) * step2;
+        const unsigned off = mp < MA0 ? off_h0 + (mp >> 1) * step2 : off_h1 + ((mp - MA0) >> 1) * step2;
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
-            if (n0 + nh * 128 >= N) continue;
             unsigned x[2], y[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -204,9 +219,10 @@ __device__ __forceinline__ void epilogue256_swiglu_wide(const f32x4 (&acc)[4][MA
             auto t0 = __builtin_amdgcn_permlane16_swap(x[0], y[0], false, false);
             auto t1 = __builtin_amdgcn_permlane16_swap(x[1], y[1], false, false);
             const i32x4 o = {(int)t0[0], (int)t1[0], (int)t0[1], (int)t1[1]};
-            __builtin_amdgcn_raw_buffer_store_b128(o, rs, off + nh * 128, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o, rs, (int)((off + nh * 128u) | (nh ? drop1 : 0u)), 0, 0);
         }
     }
+    UFV_EPI_MARK("END swiglu_wide");
 }
 
 // acc[nt][mt][j] = C[m0 + row(mt)][n0 + col(nt) + fq*4 + j] with
@@ -216,6 +232,7 @@ template <bool OUT_F32, bool SWIGLU, int ACT, bool DUMP, int MA0, int MA1, int N
 __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2 + NB1][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc,
                                             int frow, int fq, const f32x4 (&bias)[2 + NB1]) {
     static_assert(!SWIGLU || NB1 == 2, "the SwiGLU epilogue pairs n-tiles (gate, up) inside each half");
+    UFV_EPI_MARK("BEGIN plain");
 #pragma unroll
     for (int mt = 0; mt < MA0 + MA1; ++mt) {
         const int m = m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow;
@@ -244,6 +261,7 @@ __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2 + NB1][MA0 + MA
             }
         }
     }
+    UFV_EPI_MARK("END plain");
 }
 
 // Split-K part of a tile (KSPL kernels): out (+)= acc in TURN order part 0, 1, ... (deterministic sum).  Part 0 stores acc + bias + residual;
@@ -542,10 +560,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     constexpr int NSTS = MT;                                 // the 16-byte SwiGLU epilogue: one store per accumulator-row pair and half
     // INVARIANT the relaxed waits rest on: the epilogue that ran last issued EXACTLY this many vector-memory instructions after the next tile's prologue DMA.
     // epilogue256_resid issues its loads / stores from inline asm (count fixed by construction, every store issued on edge tiles too); epilogue256_wide and
-    // epilogue256_swiglu_wide issue one __builtin_amdgcn_raw_buffer_store per (row, run) / (row pair, half) -- 16-byte buffer stores of different rows, which
-    // hipcc can neither merge nor predicate away (rows >= M are dropped by the descriptor, a tile cut in N takes the strict waits); the plain epilogue256
-    // relaxes only on interior tiles.  A toolchain that changed one of these counts would under-wait the first K-tile: the bit-identity tests against the
-    // 128-wide kernel (tests/test_kernels_gpu.py) are the guard, and tools/lab/gemm_tile_lab.hip the place to re-count (`grep -c buffer_store` in the -S output).
+    // epilogue256_swiglu_wide issue one __builtin_amdgcn_raw_buffer_store per (row, run) / (row pair, half) -- buffer stores of different rows with no branch
+    // between them (rows >= M and a half past N are dropped by the descriptor); the plain epilogue256 relaxes only on interior tiles.  A toolchain that changed one
+    // of these counts would under-wait the first K-tile: tests/test_isa_epilogue_stores.py (CPU) compiles the kernels to assembly and counts the vector-memory
+    // instructions on every path between the UFV_EPI_MARK comments of each epilogue form against NST / NSTW / NSTS; the bit-identity tests against the 128-wide
+    // kernel (tests/test_kernels_gpu.py) are the second guard.
     constexpr int NSTW = 2 * MT;
     constexpr bool RELAX_OK = PH2 && !SKT && !KSPL && (L_ALL + NST <= 63);
     int relax = 0;                                           // 0: strict waits; 1: NST stores may stay in flight; 2: NSTW; 3: NSTS
@@ -921,10 +940,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             relax = RELAX_OK ? 1 : 0;                             // this form issues every store instruction, edge tiles included
         } else if (swide) {
             if constexpr (!OUT_F32 && SWIGLU && MA0 % 2 == 0 && MA1 % 2 == 0 && NB1 == 2) epilogue256_swiglu_wide<MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq);
-            relax = RELAX_OK && cn0 + BN <= N ? 3 : 0;
+            relax = RELAX_OK ? 3 : 0;                             // every store instruction is issued on every tile (round 5: dropped offsets, no branches)
         } else if (wide) {
             if constexpr (!OUT_F32 && !SWIGLU) { UFV_ACT_SWITCH(e.act, (epilogue256_wide<ACT_, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias))) }
-            relax = RELAX_OK && cn0 + BN <= N ? 2 : 0;            // buffer stores: every store instruction is issued on row-edge tiles too (the hardware drops rows >= M)
+            relax = RELAX_OK ? 2 : 0;                             // buffer stores: every store instruction is issued on row- and column-edge tiles too (rows >= M and a half past N are dropped by the descriptor)
         } else {
             UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_, false, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias)))
             relax = RELAX_OK && interior ? 1 : 0;

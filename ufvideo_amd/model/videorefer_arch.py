@@ -275,35 +275,35 @@ class VideoReferMetaForCausalLM(ABC):
             return proj(frames_features)
         raise Exception(f"Unsupported projector type {kind}!!!")
 
-    def _host_copy(self, t, slot):
-        """t.tolist(), remembered per tensor OBJECT and version: a caller that passes the same (unmodified) prompt tensor again -- a serving loop over clips with
-        one instruction, bench.py's steps -- does not pay a device-to-host copy, which is also a full stream synchronisation, per call (0.25 ms of idle GPU
-        between two clips in the rocprofv3 trace).  Any in-place write bumps `_version` and a different tensor is a different object: both miss the cache."""
-        import weakref
-        cache = self.__dict__.setdefault("_host_copies", {})
-        hit = cache.get(slot)
-        if hit is not None and hit[0]() is t and hit[1] == t._version:
-            return hit[2]
-        val = t.tolist()
-        try:
-            cache[slot] = (weakref.ref(t), t._version, val)
-        except TypeError:
-            pass
+    @staticmethod
+    def _host_lists(t, host, what):
+        """The prompt as host lists for the splice plan.  `host` (extension, optional): the caller's own host copy of `t` -- a CPU tensor or nested lists, what a
+        caller that tokenised on the host still has (mm_infer does: the ids are built on the CPU and then moved) -- used instead of reading the device tensor back,
+        which is a device-to-host copy AND a full stream synchronisation per call.  No cache: rounds 3-4 remembered `t.tolist()` per tensor object and `_version`,
+        which a write through `.data`, DLPack, shared numpy memory or this library's own raw-pointer kernels does not bump (a stale plan, silently), and which
+        only ever hit for a loop that passes the same tensor again.  The host copy is the CALLER's statement of what the device tensor holds; its shape is checked."""
+        if host is None:
+            return t.tolist()
+        val = host.tolist() if torch.is_tensor(host) else [list(r) for r in host]
+        if len(val) != t.shape[0] or any(len(r) != t.shape[1] for r in val):
+            raise ValueError(f"{what}_host has shape {len(val)} x {len(val[0]) if val else 0}, the device tensor {tuple(t.shape)}")
         return val
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, attention_mask, past_key_values, labels, images, masks, frame,
-                                             ann_indices, frame_nums, video_file="", mm_features=None, region_stash=None):
+                                             ann_indices, frame_nums, video_file="", mm_features=None, region_stash=None,
+                                             input_ids_host=None, attention_mask_host=None):
         """-> (None, attention_mask, past_key_values, inputs_embeds [B,S,D] fp32, labels, mark_mm_token_indices)
         (ref :218-370).  `mm_features` (extension): visual tokens computed elsewhere, e.g. by
-        parallel.encode_frame_sharded, skip the local encode."""
+        parallel.encode_frame_sharded, skip the local encode.  `input_ids_host` / `attention_mask_host` (extension): the caller's host copies of the
+        two prompt tensors (CPU tensors or nested lists); without them the device tensors are read back -- one synchronising copy per call."""
         vision_tower = self.get_vision_tower()
         if vision_tower is None or images is None or input_ids.shape[1] == 1:
             return input_ids, attention_mask, past_key_values, None, labels, None
         model = self.get_model()
         # the ids come to the host BEFORE the encoder is queued (the copy synchronises: at this point the stream is idle); the
         # splice plan below is then built while the GPU is still busy with the tower, instead of stalling it after the encoder
-        ids_host = self._host_copy(input_ids, "ids")
-        am_host = self._host_copy(attention_mask, "am") if attention_mask is not None else None
+        ids_host = self._host_lists(input_ids, input_ids_host, "input_ids")
+        am_host = self._host_lists(attention_mask, attention_mask_host, "attention_mask") if attention_mask is not None else None
         if mm_features is None:
             mm_features = self.encode_images_or_videos(images)                   # [n_mm, tok, D] fp32
         if frame is not None:

@@ -578,6 +578,8 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
                  offset=None, masks_list=None, label_list=None, inference=True, **kwargs):
         position_ids = kwargs.pop("position_ids", None)
         attention_mask = kwargs.pop("attention_mask", None)
+        # extension: the caller's host copies of the prompt tensors (mm_infer has them: it tokenises on the host), so the splice plan needs no device read-back
+        ids_host, am_host = kwargs.pop("input_ids_host", None), kwargs.pop("attention_mask_host", None)
         if "inputs_embeds" in kwargs:
             raise NotImplementedError("`inputs_embeds` is not supported")
         batch_size, num_frames_sam = images_sam.shape[:2]
@@ -590,10 +592,16 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
             (input_ids, attention_mask, past_key_values, inputs_embeds, _, mark_mm_token_index) = \
                 self.prepare_inputs_labels_for_multimodal(input_ids=inputs, attention_mask=attention_mask, past_key_values=None,
                                                           labels=None, images=images, masks=masks, frame=frame,
-                                                          ann_indices=ann_indices, frame_nums=frame_nums)
+                                                          ann_indices=ann_indices, frame_nums=frame_nums,
+                                                          input_ids_host=ids_host, attention_mask_host=am_host)
         else:
             raise NotImplementedError("generate() without images is not used by the reference's callers")
-        if bool(seg_token_mask.any()):
+        if ids_host is not None:            # the same test on the caller's host copy: no device read-back
+            rows_h = ids_host.tolist() if torch.is_tensor(ids_host) else ids_host
+            has_seg = seg_id is not None and any(v == seg_id for r in rows_h for v in r[1:])
+        else:
+            has_seg = bool(seg_token_mask.any())
+        if has_seg:
             # [SEG] already in the prompt (ref :461-518): one forward, embeddings from the trailing text segment
             logits, cache, hs, normed = self._decode_batch(inputs_embeds, attention_mask, None, True, 0)
             mm_feat_index, mm_input = mark_mm_token_index[0][0], mark_mm_token_index[0][1]
