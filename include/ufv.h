@@ -130,6 +130,17 @@ int ufv_rope_kv(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const floa
 int ufv_rope_table(const float* inv_freq, int pos0, int S, int hd, float* table, void* stream);
 int ufv_rope_kv_table(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, const float* table, int pos0, void* kv_cache, int ldkv,
                       void* stream);
+/* The three calls above as ONE launch for the prefill (round 5): q / k / v Linear + bias, rotate-half RoPE of the q and k heads with the cos | sin table of
+ * ufv_rope_table, append of the k / v rows to the KV cache (modeling_qwen2.py:176-205 under videorefer_qwen2.py:187-197).  A, W, bias as for ufv_gemm with
+ * W = [q | k | v] rows ((Hq + 2 Hkv) * hd, K); q_out bf16 [S, ldq] receives the rotated q heads (Hq * hd columns); row s of the cache, kv_row0 + s * ldkv
+ * (bf16, [Hkv * hd k | Hkv * hd v]), receives the rotated k heads and the v heads -- kv_row0 is the cache row of the call's FIRST position, which is also
+ * row 0 of `rope_table` (f32 [S, hd]).  Bit-identical to ufv_gemm (bf16 output) followed by ufv_rope_kv_table: the same operations in the same order, the
+ * rounding to bf16 between them included.  Built for head_dim 128 and S >= 256 at the tile shape 1332 (192 x 256); ufv_gemm_qkv_rope_shape returns the shape it
+ * would run (host arithmetic only) or 0 when the caller should issue the unfused pair (also when the environment variable UFV_NO_FUSED_ROPE is set);
+ * shape = 0 lets the call choose. */
+int ufv_gemm_qkv_rope_shape(int S, int Hq, int Hkv, int hd, int K);
+int ufv_gemm_qkv_rope(const void* A, int lda, const void* W, int ldw, const float* bias, void* q_out, int ldq, void* kv_row0, int ldkv, int S, int Hq,
+                      int Hkv, int hd, int K, const float* rope_table, int shape, void* stream);
 
 /* Conv2d(k=s=P, valid) as im2col: pixels [T,C,H,W] (dtype id) -> bf16 [T*(H/P)*(W/P), Kpad],
  * k = c*P*P + py*P + px, zero-filled to Kpad (modeling_siglip.py:124-130,178-179). */

@@ -3,7 +3,7 @@
 The K loop's first waits of a tile are `s_waitcnt vmcnt(L + NSTx)`: they leave the PREVIOUS tile's epilogue stores in flight, which is right only if that
 epilogue issued exactly NSTx vector-memory stores behind the next tile's prologue DMA.  A toolchain that merged, split or predicated those stores would make
 the first K-tile read LDS that has not landed -- wrong sums that the short-K GPU tests can miss (round 4 saw exactly that with another invariant).  Here
-the three translation units that instantiate the kernel are compiled to assembly and every path through every epilogue form (bracketed by UFV_EPI_MARK
+the translation units that instantiate the kernel are compiled to assembly and every path through every epilogue form (bracketed by UFV_EPI_MARK
 comments) is walked and its vector-memory instructions counted (tools/isa_epilogue_stores.py).  A toolchain bump that changes a count fails HERE, on the CPU."""
 import os
 import re
@@ -15,7 +15,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 HIPCC = "/opt/rocm/bin/hipcc"
-SOURCES = ("gemm256.hip", "gemm256_b.hip", "gemm256_q.hip")       # 256x256 (+ SwiGLU), the named bf16 tile shapes, the e4m3 shapes
+SOURCES = ("gemm256.hip", "gemm256_b.hip", "gemm256_q.hip", "gemm256_r.hip")       # 256x256 (+ SwiGLU), the named bf16 tile shapes, the e4m3 shapes, the fused QKV + RoPE form
 
 
 @pytest.fixture(scope="module")
@@ -24,7 +24,7 @@ def listings(tmp_path_factory):
         pytest.skip("hipcc not installed")
     d = tmp_path_factory.mktemp("isa")
     procs = []
-    for src in SOURCES:                                           # the three compiles run side by side (about a minute of wall time)
+    for src in SOURCES:                                           # the compiles run side by side (about a minute of wall time)
         out = d / (src + ".s")
         procs.append((src, out, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S",
                                                   "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "ufvideo_amd", "csrc", src)],
@@ -48,6 +48,7 @@ def test_every_epilogue_path_issues_the_store_count_the_relaxed_waits_assume(lis
     assert seen["gemm256.hip"][0] >= 60 and {"wide", "swiglu_wide", "resid", "plain"} <= seen["gemm256.hip"][1], seen
     assert seen["gemm256_b.hip"][0] >= 100 and {"wide", "resid", "plain"} <= seen["gemm256_b.hip"][1], seen
     assert seen["gemm256_q.hip"][0] >= 100 and {"wide", "plain"} <= seen["gemm256_q.hip"][1], seen
+    assert seen["gemm256_r.hip"] == (1, {"rope"}), seen
 
 
 def test_the_wide_epilogues_are_straight_line_code(listings):

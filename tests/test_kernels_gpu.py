@@ -741,3 +741,46 @@ def test_sample_top_p_vs_oracle_distribution(V, T, k, p):
     assert (toks[:256] == exp_tok).float().mean() > 0.98                                 # fp32 vs fp64 running sums at bin edges
     emp = torch.bincount(toks, minlength=V).float() / n
     assert 0.5 * float((emp - ref).abs().sum()) < 0.05 + 0.5 * float((ref > 0).sum()) / n
+
+
+@pytest.mark.parametrize("S,pos0,Hq,Hkv", [(256, 0, 28, 4), (383, 5, 28, 4), (2399, 0, 28, 4), (1000, 37, 6, 1), (640, 0, 3, 2)])
+def test_fused_qkv_rope_kv_append_bit_identical_to_gemm_then_rope(S, pos0, Hq, Hkv):
+    """ufv_gemm_qkv_rope (round 5: q / k / v Linear + bias, RoPE and the KV-cache append in ONE launch, csrc/gemm256_kernel.h epilogue256_rope) against
+    the unfused pair ufv_gemm + ufv_rope_kv_table on the same operands: torch.equal on the rotated q heads and on the cache rows, rows outside
+    [pos0, pos0 + S) untouched.  Shapes: the decoder's (28 / 4 heads of 128, S = 2399 -> 13 row tiles, the last one ragged), an S one past a tile
+    boundary, a position offset, and head counts that leave half a 256-column tile past N ((6 + 2) * 128 = 1024 is even; (3 + 4) * 128 = 896 is not)."""
+    hd, K = 128, 3584 if Hq == 28 else 512
+    g = torch.Generator().manual_seed(S + pos0)
+    N = (Hq + 2 * Hkv) * hd
+    a = (torch.randn(S, K, generator=g)).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    inv_freq = (1.0 / (1e6 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(DEV)
+    table = ops.rope_table(inv_freq, pos0, S, hd)
+    rows = pos0 + S + 3
+    kv0 = torch.full((rows, 2 * Hkv * hd), 7.0, device=DEV, dtype=torch.bfloat16)
+    kv1 = kv0.clone()
+    qkv = ops.gemm(a, w, bias=bias)
+    ops.rope_kv(qkv, S, Hq, Hkv, hd, inv_freq, pos0, kv0, table=table)
+    assert ops.qkv_rope_shape(2399, 28, 4, 128, 3584) == 1332           # the bench shape takes the fused kernel
+    q = ops.gemm_qkv_rope(a, w, bias, Hq, Hkv, hd, table, kv1, pos0, shape=1332)
+    assert torch.equal(q, qkv[:, :Hq * hd])
+    assert torch.equal(kv1, kv0)
+    assert bool((kv1[:pos0] == 7.0).all()) and bool((kv1[pos0 + S:] == 7.0).all())
+    # no bias, and a q buffer wider than Hq * hd (the stage call hands the front of its qkv buffer)
+    q2buf = torch.zeros(S, N, device=DEV, dtype=torch.bfloat16)
+    qkv_nb = ops.gemm(a, w)
+    kv2, kv3 = kv0.clone(), kv0.clone()
+    ops.rope_kv(qkv_nb, S, Hq, Hkv, hd, inv_freq, pos0, kv2, table=table)
+    ops.gemm_qkv_rope(a, w, None, Hq, Hkv, hd, table, kv3, pos0, q_out=q2buf, shape=1332)
+    assert torch.equal(q2buf[:, :Hq * hd], qkv_nb[:, :Hq * hd]) and bool((q2buf[:, Hq * hd:] == 0).all()) and torch.equal(kv3, kv2)
+
+
+def test_fused_qkv_rope_refuses_what_it_is_not_built_for():
+    assert ops.qkv_rope_shape(2399, 28, 4, 64, 3584) == 0 and ops.qkv_rope_shape(100, 28, 4, 128, 3584) == 0 and ops.qkv_rope_shape(2399, 28, 4, 128, 3500) == 0
+    a = torch.zeros(100, 512, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(8 * 128, 512, device=DEV, dtype=torch.bfloat16)
+    kv = torch.zeros(100, 2 * 128, device=DEV, dtype=torch.bfloat16)
+    tab = torch.zeros(100, 128, device=DEV)
+    with pytest.raises(_lib.UfvError, match="no fused kernel"):
+        ops.gemm_qkv_rope(a, w, None, 6, 1, 128, tab, kv, 0)

@@ -10,6 +10,7 @@ STORES and LOADS over all paths.
 expected (MT = MA0 + MA1 accumulator rows, NT = 2 + NB1 n-tiles, from the kernel's template arguments in its mangled name):
   wide         stores == 2 MT on EVERY path (NSTW), no loads
   swiglu_wide  stores == MT on every path (NSTS), no loads
+  rope         stores == 2 MT on every path (NSTW), no loads (the cos / sin rows are fetched before the next tile's prologue DMA, outside the region)
   resid        stores == MT NT on every path (NST), loads == MT NT (all retired by counted waits inside the form)
   plain        stores <= NST = (SWIGLU ? 2 MT : MT NT) with equality on the all-in-range path (the form relaxes on interior tiles only)
 usage: python tools/isa_epilogue_stores.py file.s"""
@@ -18,7 +19,7 @@ import sys
 
 VM_STORE = re.compile(r'^(buffer_store|global_store|flat_store|scratch_store)')
 VM_LOAD = re.compile(r'^(buffer_load|global_load|flat_load|scratch_load)')
-KERNEL = re.compile(r'gemm_nt_256ILb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)E')
+KERNEL = re.compile(r'gemm_nt_256ILb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)E')
 
 
 def kernels(listing):
@@ -33,7 +34,7 @@ def kernels(listing):
                 body = body[:j + 1]
                 break
         m = KERNEL.search(name)
-        t = dict(zip(("OUT_F32", "SWIGLU", "FP8", "SKT", "MA0", "MA1", "NB1", "PH2", "KSPL"), (int(x) for x in m.groups())))
+        t = dict(zip(("OUT_F32", "SWIGLU", "FP8", "SKT", "MA0", "MA1", "NB1", "PH2", "KSPL", "ROPE"), (int(x) for x in m.groups())))
         out.append((name, t, body))
     return out
 
@@ -137,6 +138,8 @@ def expected(form, t):
         return dict(stores=(2 * MT, 2 * MT), loads=(0, 0))
     if form == "swiglu_wide":
         return dict(stores=(MT, MT), loads=(0, 0))
+    if form == "rope":                             # the fused QKV + RoPE + KV-append epilogue: (MT / 2 row pairs) x (2 heads) x (2 n-tiles) = 2 MT = NSTW
+        return dict(stores=(2 * MT, 2 * MT), loads=(0, 0))
     if form == "resid":
         return dict(stores=(MT * NT, MT * NT), loads=(MT * NT, MT * NT))
     if form == "plain":

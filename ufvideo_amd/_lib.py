@@ -30,6 +30,7 @@ SIGNATURES = {
     "ufv_rope_kv": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
     "ufv_rope_table": [_p, _i, _i, _i, _p, _p],
     "ufv_rope_kv_table": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
+    "ufv_gemm_qkv_rope": [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "ufv_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ufv_dwconv3x3_ln_silu": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "ufv_colmean": [_p, _p, _i, _i, _i, _p],
@@ -105,7 +106,7 @@ SIGNATURES = {
     "ufv_attention_bwd_fused": [_p, _l, _p, _p, _l, _p, _l, _p, _l, _p, _p, _l, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p],
 }
 # entry points that return a size instead of a status
-SIZE_FUNCS = {"ufv_argmax_ws_bytes": ([], _l), "ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l), "ufv_attention_decode_fused_ws_bytes": ([_i, _i, _i], _l), "ufv_gemm_timing_read": ([_p, _p, _i], _i), "ufv_gemm_choice": ([_i, _i, _i, _i, _i, _i], _i), "ufv_gemm_set_splitk": ([_i], _i), "ufv_gemm_error_state": ([], _i),
+SIZE_FUNCS = {"ufv_argmax_ws_bytes": ([], _l), "ufv_attention_decode_ws_bytes": ([_i, _i, _i, _i], _i), "ufv_qwen2_decode_ws_bytes": ([_p], _l), "ufv_attention_decode_fused_ws_bytes": ([_i, _i, _i], _l), "ufv_gemm_timing_read": ([_p, _p, _i], _i), "ufv_gemm_choice": ([_i, _i, _i, _i, _i, _i], _i), "ufv_gemm_set_splitk": ([_i], _i), "ufv_gemm_qkv_rope_shape": ([_i, _i, _i, _i, _i], _i), "ufv_gemm_error_state": ([], _i),
               "ufv_qwen2_prefill_ws_bytes": ([_p, _i], _l), "ufv_vit_forward_ws_bytes": ([_p, _i], _l), "ufv_stc_forward_ws_bytes": ([_p, _i, _i], _l),
               "ufv_rmsnorm_bwd_ws_bytes": ([_i], _l), "ufv_attention_bwd_ws_bytes": ([_i, _i, _i, _i], _l), "ufv_attention_bwd_fused_ws_bytes": ([_i, _i], _l),
               "ufv_layernorm_bwd_ws_bytes": ([_i], _l), "ufv_dwconv3x3_dw_ws_bytes": ([_i], _l), "ufv_mask_dot_bwd_ws_bytes": ([_i, _i], _l)}

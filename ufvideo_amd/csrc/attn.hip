@@ -1417,7 +1417,9 @@ __global__ __launch_bounds__(256) void attn_decode_fused(const bf16* __restrict_
             const float ang = (float)pos * (j < 4 ? fr0[j & 3] : fr1[j & 3]);
             const float c = cosf(ang), sn = sinf(ang);
             const float x1 = lo ? (float)mine[j] : (float)other[j], x2 = lo ? (float)other[j] : (float)mine[j];
-            r[j] = lo ? (bf16)(x1 * c - x2 * sn) : (bf16)(x2 * c + x1 * sn);
+            float r1, r2;
+            rope_pair(x1, x2, c, sn, r1, r2);
+            r[j] = lo ? (bf16)r1 : (bf16)r2;
         }
         return r;
     };

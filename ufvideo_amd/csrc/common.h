@@ -110,6 +110,15 @@ __device__ __forceinline__ float act_apply_t(float x) {
         default: { constexpr int ACT_ = ACT_NONE; __VA_ARGS__; } break;                   \
     }
 
+// Rotate-half RoPE of one (x1, x2) = (dim i, dim i + hd/2) pair, in the ONE operation order every forward kernel uses (the prefill table kernel, the
+// on-the-fly forms, the decode steps and the QKV GEMM's fused epilogue): y1 = fma(x1, c, -(x2 s)), y2 = fma(x1, s, x2 c).  Written with explicit fmas so that
+// the compiler's contraction choice cannot differ from kernel to kernel -- the fused and unfused prefill paths are bit-identical by construction
+// (modeling_qwen2.py apply_rotary_pos_emb: q cos + rotate_half(q) sin).
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float sn, float& y1, float& y2) {
+    y1 = __builtin_fmaf(x1, c, -(x2 * sn));
+    y2 = __builtin_fmaf(x1, sn, x2 * c);
+}
+
 // ---- wave-level reductions (wave = 64 lanes) --------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

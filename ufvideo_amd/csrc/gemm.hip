@@ -643,10 +643,12 @@ constexpr PPShape PP_SHAPES[] = {{1442, 4, 4, 2}, {1432, 4, 3, 2}, {1332, 3, 3, 
 // split-K forms (aligned split, gemm256_kernel.h KSPL; fp32 output without activation only): items = tiles x parts in rounds of 256, a part's seam
 // carries the turn-ordered read-modify-write of its tile (+12000 ticks); taken when the model sees at least 5 % over the best unsplit kernel --
 // in practice the decoder's `down` projection (M = 2399: 140 tiles of 256x256 for 296 K-tiles; 348 -> ~270 us) and its 64-frame form.
-inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool can_split = false) {
+// rope_cost (optional out): the model's ticks of the shape the fused QKV + RoPE kernel is built for (1332) and that shape's code in rope_pick
+inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool can_split = false, double* best_cost = nullptr, double* rope_cost = nullptr,
+                         int* rope_pick = nullptr) {
     const double nk = K / 64.0, c_out = out_f32 ? 0.21 : 0.183;      // (fp32 + residual: 0.33 before the row-pipelined residual epilogue of round 3)
-    double best = 1e30;
-    int pick = 0;
+    double best = 1e30, rbest = 1e30;
+    int pick = 0, rpick = 0;
     for (int mt = 4; mt <= 6; ++mt) {
         const long t = (long)cdiv(M, 32 * mt) * (N / BN);
         const double area = 32.0 * mt * 128;
@@ -666,7 +668,11 @@ inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool ca
         const double tk = 2.0 * ((pa > fl ? pa : fl) + (pb > fl ? pb : fl));
         const double c = (double)((t + 255) / 256) * (nk * tk + 2500.0 + (double)bm * bn * c_out);
         if (c < best) { best = c; pick = s.code; }
+        if (s.code == 1332 && c < rbest) { rbest = c; rpick = s.code; }
     }
+    if (best_cost) *best_cost = best;
+    if (rope_cost) *rope_cost = rbest;
+    if (rope_pick) *rope_pick = rpick;
     // Long-K fp32 products whose 192x192 tiling fills the chip (the decoder's `down` at S = 2399: 247 tiles for 256 CUs; 475 at 64 frames): since the
     // row-pipelined residual epilogue (round 3) the unsplit 192x192 kernel beats both the split-K form and the 128-wide kernel there (292 us against
     // 314 / 353, tools/gemm_shapes.py); the tick model above still carries the old epilogue's K-tile floor for small tiles, so this case is decided here.
@@ -820,6 +826,40 @@ extern "C" int ufv_gemm_choice(int M, int N, int K, int out_f32, int swiglu, int
 }
 
 extern "C" int ufv_gemm_set_splitk(int enable) { return g_splitk.exchange(enable != 0 ? 1 : 0); }
+
+// ---- fused QKV projection + RoPE + KV-cache append (round 5) ------------------------------------------------------------------------------
+// Which tile shape the fused kernel would run for S rows, or 0 when the unfused pair (ufv_gemm, ufv_rope_kv_table) is the better or the only choice:
+// head_dim 128 (a 256-column tile = two heads), S >= 256, K a multiple of 64, and the cost model (choose_kernel) must not see the fused kernel's best
+// shape (192 x 256) more than ~12 us (17 k ticks: what the separate RoPE launch costs at S = 2399) behind the shape AUTO would take.
+extern "C" int ufv_gemm_qkv_rope_shape(int S, int Hq, int Hkv, int hd, int K) {
+    if (hd != 128 || S < 256 || Hq < 1 || Hkv < 1 || K % BK != 0 || getenv("UFV_NO_FUSED_ROPE") != nullptr) return 0;
+    const int N = (Hq + 2 * Hkv) * hd;
+    double best = 0, rc = 0;
+    int rp = 0;
+    (void)choose_kernel(S, N, K, false, false, false, &best, &rc, &rp);
+    const double rope_ticks = 17000.0 * (double)S / 2399.0;
+    return (rp != 0 && rc <= best + rope_ticks) ? rp : 0;
+}
+
+extern "C" int ufv_gemm_qkv_rope(const void* A, int lda, const void* W, int ldw, const float* bias, void* q_out, int ldq, void* kv_row0, int ldkv, int S,
+                                 int Hq, int Hkv, int hd, int K, const float* rope_table, int shape, void* stream) {
+    UFV_REQUIRE(A && W && q_out && kv_row0 && rope_table && S > 0 && K > 0, "ufv_gemm_qkv_rope: bad arguments");
+    if (shape == 0) shape = ufv_gemm_qkv_rope_shape(S, Hq, Hkv, hd, K);
+    UFV_REQUIRE(shape == 1332, "ufv_gemm_qkv_rope: no fused kernel for S=%d heads %d/%d head_dim %d K=%d (ufv_gemm_qkv_rope_shape returned 0: "
+                "use ufv_gemm + ufv_rope_kv_table)", S, Hq, Hkv, hd, K);
+    UFV_REQUIRE(hd == 128 && S >= 256 && K % BK == 0, "ufv_gemm_qkv_rope: needs head_dim 128, S >= 256, K %% 64 == 0 (S=%d hd=%d K=%d)", S, hd, K);
+    const int N = (Hq + 2 * Hkv) * hd;
+    UFV_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && (lda % 8 == 0) && (ldw % 8 == 0) && ((uintptr_t)q_out % 16 == 0) && ((uintptr_t)kv_row0 % 16 == 0) &&
+                (ldq % 8 == 0) && (ldkv % 8 == 0) && ((uintptr_t)rope_table % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0),
+                "ufv_gemm_qkv_rope: operands, outputs and the table must be 16-byte aligned, pitches multiples of 8");
+    UFV_REQUIRE(ldq >= Hq * hd && ldkv >= 2 * Hkv * hd && (int64_t)S * ldq < (1ll << 30) && (int64_t)S * ldkv < (1ll << 30),
+                "ufv_gemm_qkv_rope: q / kv pitches too small or an output beyond 2^31 bytes (S=%d ldq=%d ldkv=%d)", S, ldq, ldkv);
+    Epi e;
+    e.bias = bias; e.resid = nullptr; e.out = q_out; e.ldr = 0; e.ldc = ldq; e.act = ACT_NONE; e.resid_rows = 0;
+    e.scale_m = nullptr; e.scale_n = nullptr; e.dump_f32 = 0; e.ksplit = 0;
+    e.rope_tab = rope_table; e.out_kv = kv_row0; e.ldkv = ldkv; e.rope_hq = Hq; e.rope_hkv = Hkv;
+    return ufv_launch_pp_rope(A, W, e, S, N, K, lda, ldw, shape, reinterpret_cast<hipStream_t>(stream));
+}
 
 extern "C" int ufv_gemm_timing(int enable) {
     g_timing = enable < 0 ? 0 : enable;

@@ -225,6 +225,65 @@ __device__ __forceinline__ void epilogue256_swiglu_wide(const f32x4 (&acc)[4][MA
     UFV_EPI_MARK("END swiglu_wide");
 }
 
+// Fused QKV projection + rotary embedding + KV-cache append (round 5; modeling_qwen2.py:176-205: q / k / v Linear, apply_rotary_pos_emb, cache update).
+// ROPE kernels read their B fragments so that n-tile 2 h + t of a wave holds head-dims t * 64 + wc * 16 .. + 15 of the tile's head h (h = 0, 1: a 256-column
+// tile is two heads of 128): the rotate-half partners (i, i + 64) of a head sit in ONE lane, accumulators acc[2 h][mt][j] and acc[2 h + 1][mt][j].  Nothing
+// about W changes -- which LDS rows a wave multiplies is the wave's own choice.  Per (row pair, head, t): bias, round to bf16 (the value the unfused path stored
+// and read back), RoPE with the row's cos / sin (the table ufv_rope_kv_table reads), round, regroup the pair's two rows with one v_permlane16_swap per register
+// (as epilogue256_swiglu_wide) into 16-byte runs and store: q heads to `out` [M, Hq * 128], k / v heads to the KV cache row, v untouched.  Same operations in the
+// same order as ufv_gemm + ufv_rope_kv_table: bit-identical.  2 MT store instructions per wave and tile (= NSTW), every one issued on every path.
+template <int MA0, int MA1>
+__device__ __forceinline__ void epilogue256_rope(const f32x4 (&acc)[4][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc, int frow, int fq,
+                                                 const f32x4 (&bias)[4], const f32x4 (&rcos)[MA0 + MA1], const f32x4 (&rsin)[MA0 + MA1]) {
+    constexpr int MT = MA0 + MA1;
+    static_assert(MT % 2 == 0, "accumulator rows are stored in pairs");
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (int)((unsigned)M * (unsigned)e.ldc * 2u), 0x20000);
+    const __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc(e.out_kv, 0, (int)((unsigned)M * (unsigned)e.ldkv * 2u), 0x20000);
+    auto row_of = [&](int mt) { return m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow; };
+    auto pack2 = [&](float a, float b) -> unsigned {
+        const bf16x2 p = {(bf16)a, (bf16)b};
+        return __builtin_bit_cast(unsigned, p);
+    };
+    auto rt = [](float v) { return (float)(bf16)v; };             // the bf16 the unfused GEMM stored
+    const int head0 = n0 >> 7;
+    const unsigned colw = wc * 16 + 8 * (fq >> 1);                 // this lane's 8-column run inside a 16-column n-tile, after the regroup
+    UFV_EPI_MARK("BEGIN rope");
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        const int head = head0 + nh;
+        const bool is_q = head < e.rope_hq, roped = head < e.rope_hq + e.rope_hkv;
+        const __amdgpu_buffer_rsrc_t rs = is_q ? rs_q : rs_kv;
+        const unsigned ld = is_q ? (unsigned)e.ldc : (unsigned)e.ldkv;
+        const unsigned colbase = (unsigned)(is_q ? head : head - e.rope_hq) * 128u + colw;      // kv row = [k heads | v heads]: head - Hq indexes both
+        const unsigned drop = n0 + nh * 128 >= N ? 0x80000000u : 0u;
+#pragma unroll
+        for (int mp = 0; mp < MT; mp += 2) {
+            const unsigned row = (unsigned)((fq & 1) ? row_of(mp + 1) : row_of(mp));             // lane rows 1 / 3 carry accumulator row mp + 1 after the swap
+            float lo[2][4], hi[2][4];                                                            // [row of the pair][j]: dims i and i + 64
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x1 = rt(acc[2 * nh][mp + r][j] + bias[2 * nh][j]), x2 = rt(acc[2 * nh + 1][mp + r][j] + bias[2 * nh + 1][j]);
+                    float y1, y2;
+                    rope_pair(x1, x2, rcos[mp + r][j], rsin[mp + r][j], y1, y2);
+                    lo[r][j] = roped ? y1 : x1;
+                    hi[r][j] = roped ? y2 : x2;
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float (&v)[2][4] = t ? hi : lo;
+                const unsigned x0 = pack2(v[0][0], v[0][1]), x1 = pack2(v[0][2], v[0][3]), y0 = pack2(v[1][0], v[1][1]), y1 = pack2(v[1][2], v[1][3]);
+                auto t0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                auto t1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                const i32x4 o = {(int)t0[0], (int)t1[0], (int)t0[1], (int)t1[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs, (int)(((row * ld + colbase + t * 64u) * 2u) | drop), 0, 0);
+            }
+        }
+    }
+    UFV_EPI_MARK("END rope");
+}
+
 // acc[nt][mt][j] = C[m0 + row(mt)][n0 + col(nt) + fq*4 + j] with
 //   row(mt) = mt < MA0 ? wr*16*MA0 + mt*16 + frow : 32*MA0 + wr*16*MA1 + (mt-MA0)*16 + frow
 //   col(nt) = nt < 2 ? wc*32 + nt*16 : 128 + wc*16*NB1 + (nt-2)*16
@@ -390,7 +449,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // are (part, tile) in part-major order, every part a contiguous range of K-tiles, so the blocks of a round run the SAME K range of
 // neighbouring tiles and keep sharing A / W panels in L2 (free-running stream-K ranges do not: they re-read every panel from HBM).  The parts of
 // a tile add into the fp32 output in turn order (epilogue_split) -- deterministic, no workspace; needs act == none and one block per CU.
-template <bool OUT_F32, bool SWIGLU, bool FP8, bool SKT, int MA0 = 4, int MA1 = 4, int NB1 = 2, bool PH2 = false, bool KSPL = false>
+// ROPE: the fused QKV + RoPE + KV-append form (epilogue256_rope): B fragments re-mapped so that the rotate-half partners of a head share a lane.
+template <bool OUT_F32, bool SWIGLU, bool FP8, bool SKT, int MA0 = 4, int MA1 = 4, int NB1 = 2, bool PH2 = false, bool KSPL = false, bool ROPE = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ Av, const void* __restrict__ Wv, Epi e, int M,
                                                        int N, int K, int lda, int ldw, StreamK sk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -399,6 +459,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     constexpr int MT = T::MT, NT = T::NT, BM = T::BM, BN = T::BN;
     static_assert(!SKT || (MA0 == 4 && MA1 == 4 && NB1 == 2), "the stream-K fix-up is written for the 256x256 tile image");
     static_assert(!KSPL || (OUT_F32 && !SWIGLU && !FP8 && !SKT && PH2), "split-K parts accumulate into an fp32 output");
+    static_assert(!ROPE || (!OUT_F32 && !SWIGLU && !FP8 && !SKT && !KSPL && PH2 && NB1 == 2 && (MA0 + MA1) % 2 == 0),
+                  "the fused RoPE epilogue: bf16 output, 256-column tiles (two heads of 128), accumulator rows in pairs");
     const char* A = reinterpret_cast<const char*>(Av);
     const char* W = reinterpret_cast<const char*>(Wv);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -545,7 +607,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
 
     const int frow = lane & 15, fq = lane >> 4, fx = lane & 7;
     const int a_row_off[2] = {(wr * 16 * MA0 + frow) * 128, (wr * 16 * MA1 + frow) * 128};     // + i*2048 inside the half
-    const int b_row_off[2] = {(wc * 32 + frow) * 128, (wc * 16 * NB1 + frow) * 128};
+    // ROPE: n-tile i of a half = rows wc * 16 + 64 i .. (head-dims wc * 16 + 64 i ..): the rotate-half partners land in one lane (epilogue256_rope)
+    const int b_row_off[2] = {ROPE ? (wc * 16 + frow) * 128 : (wc * 32 + frow) * 128, ROPE ? (wc * 16 + frow) * 128 : (wc * 16 * NB1 + frow) * 128};
+    constexpr int BSTR = ROPE ? 8192 : 2048;                  // bytes between a wave's two n-tiles of a half (64 rows | 16 rows)
     // bf16: k-step kk reads chunk 4*kk + fq;  fp8: the lane's 32 bytes are chunks 2*fq and 2*fq + 1
     const int coff0 = ((FP8 ? 2 * fq : fq) ^ fx) << 4, coff1 = ((FP8 ? 2 * fq + 1 : 4 + fq) ^ fx) << 4;
 
@@ -590,8 +654,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         constexpr int h = decltype(hsel)::value, d0 = PH2 ? 2 * h : 0;
 #pragma unroll
         for (int i = 0; i < (h ? NB1 : 2); ++i) {
-            bfr[d0 + i][0] = *reinterpret_cast<const bf16x8*>(half + b_row_off[h] + i * 2048 + coff0);
-            bfr[d0 + i][1] = *reinterpret_cast<const bf16x8*>(half + b_row_off[h] + i * 2048 + coff1);
+            bfr[d0 + i][0] = *reinterpret_cast<const bf16x8*>(half + b_row_off[h] + i * BSTR + coff0);
+            bfr[d0 + i][1] = *reinterpret_cast<const bf16x8*>(half + b_row_off[h] + i * BSTR + coff1);
         }
     };
     using H0 = std::integral_constant<int, 0>;
@@ -640,7 +704,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     auto rd_b = [&](auto pc, const char* stg, int r) {
         constexpr int P = decltype(pc)::value;
         const int j = r >> 1;
-        const char* half = j < 2 ? stg + OB0 + b_row_off[0] + j * 2048 : stg + OB1 + b_row_off[1] + (j - 2) * 2048;
+        const char* half = j < 2 ? stg + OB0 + b_row_off[0] + j * BSTR : stg + OB1 + b_row_off[1] + (j - 2) * BSTR;
         bF[FPL == 2 ? P : 0][FPF ? j : 0][r & 1] = *reinterpret_cast<const bf16x8*>(half + ((r & 1) ? coff1 : coff0));
     };
 #define UFV_MMA_STEP(AF, BF, MTB, MCNT, S0, S1, S2, ISSUE, TAILWAIT)                                                    \
@@ -844,6 +908,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     auto row_of = [&](int mt) { return (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow; };
     // column of n-tile nt (clamped so that a half-tile past N reads valid memory; its outputs are not stored)
     auto col_of = [&](int nt) {
+        if constexpr (ROPE) return min(n0 + (nt >> 1) * 128, N - 128) + (nt & 1) * 64 + wc * 16 + fq * 4;
         return nt < 2 ? min(n0, N - 128) + wc * 32 + nt * 16 + fq * 4 : min(n0 + 128, N - 64 * NB1) + wc * 16 * NB1 + (nt - 2) * 16 + fq * 4;
     };
     if constexpr (FP8) {     // de-quantise in place: acc *= scale_m[row] * scale_n[col]; per element, so it distributes over
@@ -872,6 +937,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         // 61 k-tick tile where the chip's write rate allows 4.8 k).
         if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3])::"memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2])::"memory");
+    }
+    // ROPE: cos / sin of this lane's accumulator rows (dims wc * 16 + fq * 4 .. + 3), requested -- like the bias -- BEFORE the next tile's prologue DMA so that no
+    // ordinary load queues behind it, and handed on as asm outputs so that the compiler puts no wait of its own in front of their first use in the epilogue
+    f32x4 rcos[ROPE ? MT : 1], rsin[ROPE ? MT : 1];
+    if constexpr (ROPE) {
+        const bool any_roped = (n0 >> 7) < e.rope_hq + e.rope_hkv;          // a tile of two v heads rotates nothing
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            rcos[mt] = f32x4{1.f, 1.f, 1.f, 1.f}; rsin[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (any_roped) {
+                const float* tr = e.rope_tab + (size_t)min(m0 + row_of(mt), M - 1) * 128 + wc * 16 + fq * 4;
+                rcos[mt] = *reinterpret_cast<const f32x4*>(tr);
+                rsin[mt] = *reinterpret_cast<const f32x4*>(tr + 64);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(rcos[mt]), "+v"(rsin[mt]));
     }
     const int cm0 = m0, cn0 = n0, cpart = item_part, ctile = item_tile, clen = len;
     UFV_TSTAMP(8);
@@ -935,7 +1018,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         bool wide = false;
         if constexpr (!OUT_F32 && !SWIGLU) wide = e.resid == nullptr && e.ldc % 8 == 0 && ((uintptr_t)e.out & 15) == 0 && (int64_t)M * e.ldc < (1ll << 30);
         const bool interior = cm0 + BM <= M && cn0 + BN <= N;     // every store instruction of the epilogue is issued
-        if (by_rows) {
+        if constexpr (ROPE) {
+            epilogue256_rope<MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias, rcos, rsin);
+            relax = RELAX_OK ? 2 : 0;                             // 2 MT sixteen-byte buffer stores, every one issued on every tile
+        } else if (by_rows) {
             if constexpr (!SWIGLU && !FP8) epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
             relax = RELAX_OK ? 1 : 0;                             // this form issues every store instruction, edge tiles included
         } else if (swide) {
@@ -964,10 +1050,10 @@ static inline int pp_n_cu() { return ufv_dev_n_cu(); }
 // made its XCDs fetch 16 W panels per round instead of 4; 1203 -> 1244 TF/s on gate/up), else ~8 in equal groups
 static inline int pp_group(int tiles_m) { return tiles_m <= 16 ? tiles_m : cdiv(tiles_m, cdiv(tiles_m, 8)); }
 
-template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false>
+template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false, bool ROPE = false>
 static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st, int ksplit = 1) {
     UFV_ONCE_PER_DEVICE(
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM256);
     );
     using T = PP<MA0, MA1, NB1>;
@@ -990,7 +1076,7 @@ static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, i
         sk.ksplit = ksplit;
         items = tiles * ksplit;
     }
-    hipLaunchKernelGGL((gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL>), dim3(items < n_cu ? items : n_cu), dim3(512), SMEM256, st, A, W, e, M, N, K,
+    hipLaunchKernelGGL((gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE>), dim3(items < n_cu ? items : n_cu), dim3(512), SMEM256, st, A, W, e, M, N, K,
                        lda, ldw, sk);
     UFV_CHECK_LAUNCH();
     return UFV_OK;

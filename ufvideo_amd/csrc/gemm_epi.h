@@ -12,6 +12,10 @@ struct Epi {
     const float* scale_n;
     int dump_f32;          // stream-K only: store the raw accumulators as fp32 whatever the output type (partial tile dump)
     int ksplit;            // > 1: split-K launch (gridDim.y = ksplit), partial tiles are added to the fp32 output atomically
+    // fused QKV projection + RoPE + KV-cache append (gemm_nt_256<..., ROPE = true>, epilogue256_rope): `out` / `ldc` is the q buffer [M, Hq * 128]
+    const float* rope_tab = nullptr; // f32 [M, 128]: cos (64) | sin (64) of every row's position (ufv_rope_table)
+    void* out_kv = nullptr;          // bf16 KV-cache row of the call's first position: row m = [Hkv * 128 k | Hkv * 128 v] at out_kv + m * ldkv
+    int ldkv = 0, rope_hq = 0, rope_hkv = 0;
 };
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -77,3 +81,5 @@ __device__ __forceinline__ void epi_store4b(const Epi& e, int m, int n, float v0
 
 int ufv_launch_gemm256(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
                        bool swiglu, bool fp8, bool streamk, int shape, hipStream_t st);
+// gemm256_r.hip: the fused QKV + RoPE + KV-append instantiations of the ping-pong kernel (shape 1332)
+int ufv_launch_pp_rope(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int shape, hipStream_t st);

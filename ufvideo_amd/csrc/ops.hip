@@ -280,8 +280,10 @@ __global__ __launch_bounds__(256) void rope_kv_k(bf16* qkv, int ldqkv, int S, in
                 const float ang = pos * inv_freq[i0 + j];
                 const float c = cosf(ang), sn = sinf(ang);
                 const float x1 = (float)a[j], x2 = (float)b2[j];
-                y1[j] = (bf16)(x1 * c - x2 * sn);
-                y2[j] = (bf16)(x2 * c + x1 * sn);
+                float r1, r2;
+                rope_pair(x1, x2, c, sn, r1, r2);
+                y1[j] = (bf16)r1;
+                y2[j] = (bf16)r2;
             }
             bf16* d = (hh < Hq) ? p : kv + (int64_t)(pos0 + s) * ldkv + (hh - Hq) * hd;
             *reinterpret_cast<bf16x8*>(d + i0) = y1;
@@ -331,8 +333,10 @@ __global__ __launch_bounds__(256) void rope_kv_tab_k(bf16* qkv, int ldqkv, int S
             for (int j = 0; j < 8; ++j) {
                 const float c = j < 4 ? c0[j & 3] : c1[j & 3], sn = j < 4 ? s0[j & 3] : s1[j & 3];
                 const float x1 = (float)a[j], x2 = (float)b2[j];
-                y1[j] = (bf16)(x1 * c - x2 * sn);
-                y2[j] = (bf16)(x2 * c + x1 * sn);
+                float r1, r2;
+                rope_pair(x1, x2, c, sn, r1, r2);
+                y1[j] = (bf16)r1;
+                y2[j] = (bf16)r2;
             }
             bf16* d = (hh < Hq) ? p : kv + (int64_t)(pos0 + s) * ldkv + (hh - Hq) * hd;
             *reinterpret_cast<bf16x8*>(d + i0) = y1;
@@ -361,8 +365,10 @@ __global__ void rope_kv1_dev_k(bf16* qkv, int Hq, int Hkv, int hd, const float* 
             const float c = cosf(ang), sn = sinf(ang);
             const float x1 = (float)p[i], x2 = (float)p[half + i];
             bf16* d = (hh < Hq) ? p : kv + (int64_t)pos * ldkv + (hh - Hq) * hd;
-            d[i] = (bf16)(x1 * c - x2 * sn);
-            d[half + i] = (bf16)(x2 * c + x1 * sn);
+            float r1, r2;
+            rope_pair(x1, x2, c, sn, r1, r2);
+            d[i] = (bf16)r1;
+            d[half + i] = (bf16)r2;
         } else {
             const int hv = hh - Hq - Hkv;
             const bf16* p = qkv + (Hq + Hkv) * hd + hv * hd;
@@ -388,7 +394,8 @@ __global__ void rope_kv_scalar_k(bf16* qkv, int ldqkv, int S, int Hq, int Hkv, i
             const float c = cosf(ang), sn = sinf(ang);
             bf16* p = row + hh * hd;
             const float x1 = (float)p[i], x2 = (float)p[i + half];
-            const float y1 = x1 * c - x2 * sn, y2 = x2 * c + x1 * sn;
+            float y1, y2;
+            rope_pair(x1, x2, c, sn, y1, y2);
             bf16* d = (hh < Hq) ? p : kv + (int64_t)(pos0 + s) * ldkv + (hh - Hq) * hd;
             d[i] = (bf16)y1;
             d[i + half] = (bf16)y2;

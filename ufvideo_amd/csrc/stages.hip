@@ -46,13 +46,22 @@ extern "C" int ufv_qwen2_prefill(const ufv_qwen2_model* m, float* x, int S, int 
     void* nrow_bf = p;
     const float scale = 1.0f / sqrtf((float)hd);
     UFV_TRY(ufv_rope_table(m->inv_freq, pos0, S, hd, table, stream));
+    // round 5: q / k / v projection, RoPE and the KV append as ONE launch where the fused kernel is built (head_dim 128, S >= 256; bit-identical to the three
+    // calls of the else branch: tests/test_stages_gpu.py); q then lives compactly in the front of the qkv buffer, [S, H * hd]
+    const int fused = ufv_gemm_qkv_rope_shape(S, H, KV, hd, D);
     for (int l = 0; l < m->n_layers; ++l) {
         const ufv_qwen2_layer& L = m->layers[l];
         char* kv = reinterpret_cast<char*>(L.kv_cache);
         UFV_TRY(ufv_rmsnorm(x, D, h, 0, D, L.ln1, S, D, m->eps, stream));
-        UFV_TRY(ufv_gemm(h, D, L.wqkv, D, qkv, qkv_n, 0, S, qkv_n, D, L.bqkv, UFV_ACT_NONE, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
-        UFV_TRY(ufv_rope_kv_table(qkv, qkv_n, S, H, KV, hd, table, pos0, kv, m->ldkv, stream));
-        UFV_TRY(ufv_attention(qkv, 0, qkv_n, kv, 0, m->ldkv, kv + 2 * (size_t)KV * hd, 0, m->ldkv, o, 0, (int64_t)H * hd, 1, H, KV, S, pos0 + S, hd,
+        int q_ss = qkv_n;
+        if (fused) {
+            q_ss = H * hd;
+            UFV_TRY(ufv_gemm_qkv_rope(h, D, L.wqkv, D, L.bqkv, qkv, q_ss, kv + 2 * (size_t)pos0 * m->ldkv, m->ldkv, S, H, KV, hd, D, table, fused, stream));
+        } else {
+            UFV_TRY(ufv_gemm(h, D, L.wqkv, D, qkv, qkv_n, 0, S, qkv_n, D, L.bqkv, UFV_ACT_NONE, nullptr, 0, 0, 0, UFV_GEMM_AUTO, stream));
+            UFV_TRY(ufv_rope_kv_table(qkv, qkv_n, S, H, KV, hd, table, pos0, kv, m->ldkv, stream));
+        }
+        UFV_TRY(ufv_attention(qkv, 0, q_ss, kv, 0, m->ldkv, kv + 2 * (size_t)KV * hd, 0, m->ldkv, o, 0, (int64_t)H * hd, 1, H, KV, S, pos0 + S, hd,
                               scale, 1, pos0, 0, stream));
         UFV_TRY(ufv_gemm(o, H * hd, L.wo, H * hd, x, D, 1, S, D, H * hd, nullptr, UFV_ACT_NONE, x, D, 0, 0, UFV_GEMM_AUTO, stream));
         UFV_TRY(ufv_rmsnorm(x, D, h, 0, D, L.ln2, S, D, m->eps, stream));

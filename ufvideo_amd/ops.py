@@ -220,6 +220,25 @@ def rope_kv(qkv, S, Hq, Hkv, hd, inv_freq, pos0, kv_cache, table=None):
               kv_cache.stride(0), _stream())
 
 
+def qkv_rope_shape(S, Hq, Hkv, hd, K):
+    """tile shape the fused QKV + RoPE + KV-append GEMM would run, or 0: issue gemm + rope_kv (host arithmetic, include/ufv.h ufv_gemm_qkv_rope_shape)"""
+    return int(_lib.load().ufv_gemm_qkv_rope_shape(S, Hq, Hkv, hd, K))
+
+
+def gemm_qkv_rope(a, w, bias, Hq, Hkv, hd, table, kv_cache, pos0, q_out=None, shape=0):
+    """q / k / v projection + RoPE + KV append of S = a.shape[0] prefill rows in ONE launch (ufv_gemm_qkv_rope): returns q [S, Hq * hd] (rotated); the
+    rotated k heads and the v heads go to kv_cache rows pos0 .. pos0 + S - 1.  `table` = rope_table(inv_freq, pos0, S, hd).  Bit-identical to
+    gemm(a, w, bias) followed by rope_kv(..., table=table)."""
+    _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w"); _chk(kv_cache, torch.bfloat16, "kv_cache"); _chk(table, torch.float32, "table")
+    S, K = a.shape
+    assert w.shape == ((Hq + 2 * Hkv) * hd, K) and table.shape == (S, hd) and kv_cache.shape[0] >= pos0 + S
+    if q_out is None:
+        q_out = torch.empty((S, Hq * hd), device=a.device, dtype=torch.bfloat16)
+    _lib.call("ufv_gemm_qkv_rope", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), bias.data_ptr() if bias is not None else None, q_out.data_ptr(),
+              q_out.stride(0), kv_cache[pos0:].data_ptr(), kv_cache.stride(0), S, Hq, Hkv, hd, K, table.data_ptr(), shape, _stream())
+    return q_out
+
+
 def patchify(pixels, P, Kpad):
     _chk(pixels, name="pixels"); assert pixels.is_contiguous()
     T, Cc, H, W = pixels.shape
