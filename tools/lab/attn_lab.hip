@@ -84,6 +84,46 @@ int main(int argc, char** argv) {
         for (size_t r = 0; r < ho.size() / D; ++r) { int nb = 0; for (int c = 0; c < D; ++c) nb += fabs(bf2f(ho[r * D + c]) - bf2f(h2[r * D + c])) > 0.02; if (nb) printf(" %zu(%d)", r, nb); }
         printf("\n");
     }
+#ifdef UFV_VIT_P2_CLOCK
+    if (kernel == 14 && getenv("LAB_P2_CLOCK")) {
+        // In-kernel clock of the ViT attention kernel (MI355X_MICROARCH.md, DVFS give-back item 6): >= 2 s of back-to-back launches on the random operands, then
+        // the stamps of the LAST launch: per wave d(s_memtime) / d(s_memrealtime) x 100 MHz, median over the waves; the wall time per launch of the same run by
+        // HIP events; MFMA-busy cycles per SIMD from the instruction stream (one wave per SIMD: 81 periods x 22 v_mfma_f32_32x32x16_bf16 x 32 cycles).
+        const int nw = B * H / 2 * 4;
+        unsigned long long* cb; hipMalloc(&cb, (size_t)nw * 32); hipMemset(cb, 0, (size_t)nw * 32);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_vit_p2_clock), &cb, sizeof(cb));
+        hipEvent_t c0, c1; hipEventCreate(&c0); hipEventCreate(&c1);
+        int launches = 0; float tot_ms = 0;
+        while (tot_ms < 2500.f) {
+            hipEventRecord(c0);
+            for (int i = 0; i < 2000; ++i) run();
+            hipEventRecord(c1); hipEventSynchronize(c1);
+            float m; hipEventElapsedTime(&m, c0, c1); tot_ms += m; launches += 2000;
+        }
+        hipEventRecord(c0);
+        for (int i = 0; i < 2000; ++i) run();
+        hipEventRecord(c1); hipEventSynchronize(c1);
+        float m; hipEventElapsedTime(&m, c0, c1);
+        const double wall_us = m * 1000.0 / 2000;
+        std::vector<unsigned long long> hc((size_t)nw * 4);
+        hipMemcpy(hc.data(), cb, hc.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> ghz, cyc;
+        for (int w = 0; w < nw; ++w) {
+            const double dt = (double)(hc[w * 4 + 1] - hc[w * 4]), dr = (double)(hc[w * 4 + 3] - hc[w * 4 + 2]);
+            if (dr > 0) { ghz.push_back(dt / dr * 0.1); cyc.push_back(dt); }
+        }
+        std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+        const double g_med = ghz[ghz.size() / 2], c_med = cyc[cyc.size() / 2];
+        const double mfma_busy = 81.0 * 22.0 * 32.0;
+        printf("clock: %d launches warm, then 2000 timed: wall %.2f us / launch; in-kernel clock median %.3f GHz (min %.3f max %.3f over %zu waves); pass loop median %.0f cycles "
+               "(max %.0f)\n", launches, wall_us, g_med, ghz.front(), ghz.back(), ghz.size(), c_med, cyc.back());
+        printf("clock: MFMA busy %.0f cycles per SIMD = %.3f of wall x clock (%.0f cycles), %.3f of the wave's own pass loop\n", mfma_busy, mfma_busy / (wall_us * 1e3 * g_med),
+               wall_us * 1e3 * g_med, mfma_busy / c_med);
+        printf("{\"kernel\": \"attn_fwd_vit72_p2\", \"wall_us\": %.3f, \"clock_ghz_median\": %.4f, \"clock_ghz_min\": %.4f, \"clock_ghz_max\": %.4f, \"pass_loop_cycles_median\": %.0f, "
+               "\"mfma_busy_cycles_per_simd\": %.0f, \"mfma_busy_over_wall_x_clock\": %.4f, \"mfma_busy_over_pass_loop\": %.4f, \"waves\": %zu}\n",
+               wall_us, g_med, ghz.front(), ghz.back(), c_med, mfma_busy, mfma_busy / (wall_us * 1e3 * g_med), mfma_busy / c_med, ghz.size());
+    }
+#endif
     if (kernel == 14 && getenv("LAB_P2_STAMPS")) {       // per-period cycle anatomy of the generated kernel (built with gen_attn_p2.py --stamps)
         const int nw = B * H / 2 * 4;
         unsigned* sb; hipMalloc(&sb, (size_t)nw * 512); hipMemset(sb, 0, (size_t)nw * 512);

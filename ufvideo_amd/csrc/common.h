@@ -110,6 +110,28 @@ __device__ __forceinline__ float act_apply_t(float x) {
         default: { constexpr int ACT_ = ACT_NONE; __VA_ARGS__; } break;                   \
     }
 
+// Row-norm arithmetic with a PINNED operation order, shared by the norm kernels of ops.hip (rmsnorm_k, layernorm_k, layernorm_pipe_k -- which must agree bit
+// for bit -- and whatever computes the same norm elsewhere): which multiply-adds hipcc contracts into an fma is otherwise its own choice per kernel (round 5: the
+// same source lines compiled as multiply-then-add in ops.hip and as fmas inside a GEMM epilogue experiment, one bf16 ulp apart in places).
+// Sums of squares: products rounded, then added left to right; the LayerNorm output: ONE fma of the scaled deviation with weight and bias.
+__device__ __forceinline__ float norm_sumsq4(f32x4 v) {
+#pragma clang fp contract(off)
+    return v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+}
+__device__ __forceinline__ float norm_var_acc(float q, float x, float mean) {
+#pragma clang fp contract(off)
+    const float d = x - mean;
+    return q + d * d;
+}
+__device__ __forceinline__ float norm_ln_out(float x, float mean, float rstd, float w, float b) {
+    float t;
+    {
+#pragma clang fp contract(off)
+        t = (x - mean) * rstd;
+    }
+    return __builtin_fmaf(t, w, b);
+}
+
 // Rotate-half RoPE of one (x1, x2) = (dim i, dim i + hd/2) pair, in the ONE operation order every forward kernel uses (the prefill table kernel, the
 // on-the-fly forms, the decode steps and the QKV GEMM's fused epilogue): y1 = fma(x1, c, -(x2 s)), y2 = fma(x1, s, x2 c).  Written with explicit fmas so that
 // the compiler's contraction choice cannot differ from kernel to kernel -- the fused and unfused prefill paths are bit-identical by construction

@@ -67,6 +67,9 @@ template <int MA0, int MA1, int NB1> struct PP {
 // the K loop (NST / NSTW / NSTS below) are exact only if the epilogue that ran last issued EXACTLY that many vector-memory stores; the CPU test compiles the kernels
 // to gfx950 assembly, walks every path between a BEGIN and its END and counts the vector-memory instructions on it.  ("memory": nothing that touches memory moves
 // across a marker; the markers emit no instruction.)
+#ifndef UFV_RESID_SC
+#define UFV_RESID_SC ""        /* lab (tools/lab/build_variant_lib.sh): " sc0 sc1" = write-through stores of the fp32 stream; measured free (LABNOTES round 5) */
+#endif
 #define UFV_EPI_MARK(text) asm volatile("; UFV_EPI_" text ::: "memory")
 
 template <bool OUT_F32, int MA0, int MA1, int NB1>
@@ -117,7 +120,7 @@ __device__ __forceinline__ void epilogue256_resid(const f32x4 (&acc)[2 + NB1][MA
             const bool ok = m < M && nok[nt];
             if constexpr (OUT_F32) {
                 float* pp = reinterpret_cast<float*>(e.out) + (size_t)min(m, M - 1) * e.ldc + ncol[nt];
-                asm volatile("s_mov_b64 s[2:3], exec\n\ts_and_b64 exec, exec, %2\n\tglobal_store_dwordx4 %0, %1, off\n\ts_mov_b64 exec, s[2:3]\n\ts_nop 1"
+                asm volatile("s_mov_b64 s[2:3], exec\n\ts_and_b64 exec, exec, %2\n\tglobal_store_dwordx4 %0, %1, off" UFV_RESID_SC "\n\ts_mov_b64 exec, s[2:3]\n\ts_nop 1"
                              ::"v"(pp), "v"(v), "s"(__builtin_amdgcn_ballot_w64(ok)) : "memory", "s2", "s3", "scc");
             } else {
                 bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};

@@ -58,10 +58,7 @@ __device__ __forceinline__ void ln_stats(const f32x4* x, int nv, int lane, int D
     for (int i = 0; i < MAXV; ++i)
         if (lane + 64 * i < nv) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = x[i][j] - mean;
-                q += d * d;
-            }
+            for (int j = 0; j < 4; ++j) q = norm_var_acc(q, x[i][j], mean);
         }
     rstd = rsqrtf(wave_sum(q) / D + eps);
 }
@@ -88,10 +85,7 @@ __global__ __launch_bounds__(256) void layernorm_k(const void* x, int ldx, void*
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < nv)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = v[i][j] - mean;
-                q += d * d;
-            }
+            for (int j = 0; j < 4; ++j) q = norm_var_acc(q, v[i][j], mean);
     const float rstd = rsqrtf(wave_sum(q) / D + eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -102,7 +96,7 @@ __global__ __launch_bounds__(256) void layernorm_k(const void* x, int ldx, void*
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float t = (v[i][j] - mean) * rstd * ww[j] + bb[j];
+                const float t = norm_ln_out(v[i][j], mean, rstd, ww[j], bb[j]);
                 o[j] = ACT >= 0 ? act_apply_t<(ACT >= 0 ? ACT : 0)>(t) : act_apply(t, act);
             }
             store4<YF32>(y, (int64_t)row * ldy + c, o);
@@ -147,10 +141,7 @@ __global__ __launch_bounds__(256) void layernorm_pipe_k(const void* x, int ldx, 
         for (int i = 0; i < NV; ++i)
             if (lane + 64 * i < nv)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float d = v[i][j] - mean;
-                    q += d * d;
-                }
+                for (int j = 0; j < 4; ++j) q = norm_var_acc(q, v[i][j], mean);
         const float rstd = rsqrtf(wave_sum(q) / D + eps);
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -160,7 +151,7 @@ __global__ __launch_bounds__(256) void layernorm_pipe_k(const void* x, int ldx, 
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(ln_wb + D + c);
                 f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * ww[j] + bb[j];
+                for (int j = 0; j < 4; ++j) o[j] = norm_ln_out(v[i][j], mean, rstd, ww[j], bb[j]);
                 store4<YF32>(y, (int64_t)row * ldy + c, o);
             }
 #pragma unroll
@@ -241,7 +232,7 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const float* x, int ldx, void* 
     for (int i = 0; i < MAXV; ++i)
         if (lane + 64 * i < nv) {
             v[i] = load4<UFV_DT_F32>(x, (int64_t)row * ldx + 4 * (lane + 64 * i));
-            q += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+            q += norm_sumsq4(v[i]);
         }
     const float r = rsqrtf(wave_sum(q) / D + eps);
 #pragma unroll
