@@ -273,6 +273,8 @@ def test_config4_training_step_16_frames_7b_dims():
     assert float(r["loss"]) == losses[0] and float(r["grad_norm"]) == norms[0]       # bit-reproducible
 
 
+CONFIG4_STEP_FLOOR_MS = 153.0      # recorded on MI355X with this tree (profiles/r05/perf_floors.json): the step is held to this + 10 %
+
 CONFIG4_28_CHILD = r'''
 import gc, os, sys
 sys.path.insert(0, os.environ["UFV_ROOT"]); sys.path.insert(0, os.path.join(os.environ["UFV_ROOT"], "tests"))
@@ -290,6 +292,18 @@ for b in tr.layers:
     assert bool(torch.isfinite(b.g).all())
 peak = torch.cuda.max_memory_allocated() / 1e9
 print(f"CONFIG4 28 layers: losses {losses}, grad norms {norms}, peak HBM {peak:.1f} GB", flush=True)
+# perf floor of the config-#4 step (tower + trained projector + 28 decoder layers forward / backward + clip + AdamW on ONE 16-frame clip): median of three, printed,
+# and held to the recorded figure + 10 % on an MI355X (tests/test_perf_floor_gpu.py has the other next-row floors)
+import time
+ts = []
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    tr.train_step(**batch)
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+ts.sort()
+FLOOR = float(os.environ.get("UFV_CONFIG4_FLOOR_MS", "0"))
+print(f"PERF_FLOOR config4_train_step_ms: measured {ts[1]:.1f} ms, recorded {FLOOR:.1f} ms, limit {FLOOR * 1.10:.1f} ms", flush=True)
+assert FLOOR == 0 or ts[1] <= FLOOR * 1.10, f"config #4 training step {ts[1]:.1f} ms is more than 10 % over the recorded {FLOOR:.1f} ms"
 tr.detach()
 del model, tr, batch, r
 gc.collect(); torch.cuda.empty_cache()
@@ -317,6 +331,7 @@ def test_config4_training_step_at_its_real_depth_28_layers():
         pytest.skip("needs the 288 GB of an MI355X")
     assert free > 200e9, f"only {free / 1e9:.0f} GB of HBM are free: earlier tests of this process hold the rest"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", CONFIG4_28_CHILD], env=dict(os.environ, UFV_ROOT=root), capture_output=True, text=True, timeout=1200)
-    print(r.stdout[-600:])
+    r = subprocess.run([sys.executable, "-c", CONFIG4_28_CHILD], env=dict(os.environ, UFV_ROOT=root, UFV_CONFIG4_FLOOR_MS=str(CONFIG4_STEP_FLOOR_MS)),
+                       capture_output=True, text=True, timeout=1200)
+    print(r.stdout[-900:])
     assert r.returncode == 0 and "CONFIG4_28_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
