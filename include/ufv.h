@@ -339,6 +339,19 @@ int ufv_quantize_fp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_t l
 int ufv_layernorm_fp8(const void* x, int x_dtype, int ldx, void* q, int64_t ldq, float* scale, const float* w, const float* b, int M,
                       int D, float eps, void* stream);
 int ufv_rmsnorm_fp8(const float* x, int ldx, void* q, int64_t ldq, float* scale, const float* w, int M, int D, float eps, void* stream);
+/* MX-style block quantisation (round 5; OCP microscaling layout as v_mfma_scale_f32_16x16x128_f8f6f4 consumes it): x [M, K] -> e4m3 codes q [M, K] + one e8m0
+ * scale byte per (row, 32 consecutive elements), bscale [M, ldb >= K / 32]: scale = 2^(byte - 127) = amax / 448 of the block rounded UP to a power of two
+ * (no element saturates), code = rne_e4m3(x / scale).  K % 32 == 0.  The e4m3 GEMM epilogues emit the same format (ufv_gemm_fp8_mx). */
+int ufv_quantize_mx(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, void* bscale, int64_t ldb, int M, int K, void* stream);
+int ufv_dequantize_mx(const void* q, int64_t ldq, const void* bscale, int64_t ldb, float* out, int64_t ldo, int M, int K, void* stream);
+/* ufv_gemm_fp8 with block scales on the activation side: exactly one of a_scale (fp32 per row) / a_bscale (e8m0 per row and 32 K-elements, pitch ld_abs bytes);
+ * out_bscale != NULL: C receives e4m3 codes (ldc = byte pitch) and out_bscale [M, ld_obs] their block scales, written by the GEMM's epilogue -- the A operand of the
+ * next e4m3 GEMM without a quantise launch in between (modeling_siglip.py:310-322 fc1 -> fc2, modeling_qwen2.py:35-48 gate/up -> down).  With `swiglu` the 32-column
+ * blocks of an output row are stored in a fixed permutation inside every group of 128 columns (physical column 32 w + 16 h + c holds logical column 64 h + 16 w + c,
+ * w < 4, h < 2, c < 16): the consumer's weight carries the same permutation on its K axis (ufvideo_amd.ops.Fp8Weight(..., mx_swiglu_cols=True)).
+ * M >= 256, N % 128 == 0 (N % 256 == 0 for an MX output), K % 128 == 0. */
+int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, const void* a_bscale, int ld_abs, const void* W, int ldw, const float* w_scale, void* C, int ldc,
+                    int out_f32, void* out_bscale, int ld_obs, int M, int N, int K, const float* bias, int act, const float* resid, int ldr, int swiglu, void* stream);
 int ufv_dequantize_fp8(const void* q, int64_t ldq, const float* scale, float* out, int64_t ldo, int M, int K, void* stream);
 /* ufv_gemm with e4m3 A [M,K] (a_scale [M]) and W [N,K] (w_scale [N]):  C = epilogue((Aq Wq^T) * a_scale[m] * w_scale[n]).
  * v_mfma_f32_16x16x128_f8f6f4 tiles (N % 128 == 0, K % 128 == 0) or the fp8 GEMV (M <= 64, K % 16 == 0); same epilogues. */

@@ -1153,6 +1153,35 @@ def gemm_fp8(a: torch.Tensor, w: torch.Tensor, bias=None):
     return y if bias is None else y + bias.float()
 
 
+def mx_quantize(x: torch.Tensor):
+    """MX-style block quantisation as the HIP path defines it (csrc/common.h mx_scale_byte; round 5): per (row, 32 consecutive elements) one e8m0 byte
+    e = biased exponent of amax / 448, + 1 when its mantissa is not zero (amax / 448 rounded UP to a power of two: no element saturates), clamped to [1, 253];
+    codes = round-to-nearest-even e4m3fn(x * 2^(127 - e)).  The layout is the OCP microscaling one that v_mfma_scale_f32_16x16x128_f8f6f4 consumes; the scale
+    choice (round up instead of the spec's floor(log2 amax) - 8, which lets the block maximum saturate) is this builder's and is restated, not pinned.
+    -> (dequantised values fp32 [M, K], scale bytes uint8 [M, K / 32], codes uint8 [M, K])"""
+    x = x.float()
+    M, K = x.shape
+    assert K % 32 == 0
+    xb = x.view(M, K // 32, 32)
+    amax = xb.abs().amax(dim=2)
+    bits = (amax * (1.0 / 448.0)).view(torch.int32)
+    e = (bits >> 23) + ((bits & 0x7FFFFF) != 0).to(torch.int32)
+    e = e.clamp(1, 253)
+    inv = ((254 - e) << 23).view(torch.float32)                     # 2^(127 - e)
+    q8 = (xb * inv[:, :, None]).to(torch.float8_e4m3fn)
+    scale = (e << 23).view(torch.float32)                            # 2^(e - 127)
+    deq = (q8.float() * scale[:, :, None]).view(M, K)
+    return deq, e.to(torch.uint8), q8.view(torch.uint8).view(M, K)
+
+
+def gemm_fp8_mx(a: torch.Tensor, w: torch.Tensor, bias=None):
+    """(mx(a) q(w)^T) * sw[n] (+ bias): MX block-scaled activations, per-output-channel e4m3 weights, fp32 accumulation (ufv_gemm_fp8_mx with a_bscale)."""
+    qa, _, _ = mx_quantize(a)
+    qw, sw, _ = quantize_fp8_rows(w)
+    y = (qa @ qw.t()) * sw[None, :]
+    return y if bias is None else y + bias.float()
+
+
 class fp8_linear_mode:
     """Context manager: inside it every `F.linear` of this module whose weight fits the fp8 MFMA tiles (N % 128 == 0,
     K % 128 == 0 -- the rule `PackedModule.gw` applies) runs the W8A8 restatement `gemm_fp8`; activations are first rounded

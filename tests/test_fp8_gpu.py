@@ -8,6 +8,7 @@ pytestmark = pytest.mark.gpu
 from conftest import rel_err  # noqa: E402
 from oracle import ref_cpu as O  # noqa: E402
 from ufvideo_amd import ops, _lib  # noqa: E402
+from ufvideo_amd.model.videorefer_qwen2 import pack_swiglu  # noqa: E402
 
 DEV = "cuda"
 
@@ -277,3 +278,90 @@ def test_sam2_trunk_runs_its_gemms_in_fp8_under_set_gemm_dtype():
     errs = [float((a - b).norm() / b.norm()) for a, b in zip(q1, ref)]
     print("SAM2-L trunk fp8 vs bf16, rel-L2 of the FPN levels:", [round(e, 3) for e in errs])
     assert all(torch.isfinite(a).all() for a in q1) and max(errs) < 0.2            # measured 0.041 / 0.080 / 0.129 (highest resolution first)
+
+
+# ---- MX block scales (round 5) ------------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("M,K", [(7, 64), (300, 4352), (2399, 18944)])
+def test_mx_quantise_codes_and_scale_bytes_bit_exact_vs_oracle(M, K):
+    """ufv_quantize_mx == oracle.mx_quantize: every e4m3 code and every e8m0 scale byte, incl. an all-zero block, a block of one huge value and tiny values"""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g) * 2)
+    x[0, :32] = 0
+    x[min(1, M - 1), 32:64] = 0; x[min(1, M - 1), 40] = 3e4
+    x[min(2, M - 1), :32] *= 1e-30
+    xb = x.to(torch.bfloat16)
+    deq, e, codes = O.mx_quantize(xb.float())
+    a = ops.quantize_mx(xb.to(DEV))
+    assert torch.equal(a.bscale.cpu(), e) and torch.equal(a.q.cpu(), codes)
+    assert torch.equal(ops.dequantize_mx(a).cpu(), deq)
+    a32 = ops.quantize_mx(x.to(DEV))
+    deq32, e32, codes32 = O.mx_quantize(x)
+    assert torch.equal(a32.bscale.cpu(), e32) and torch.equal(a32.q.cpu(), codes32)
+
+
+@pytest.mark.parametrize("M,N,K,f32", [(2399, 3584, 18944, True), (1000, 1152, 4352, True), (512, 1024, 512, False), (300, 3584, 3584, False)])
+def test_gemm_with_mx_scaled_activations_vs_oracle(M, N, K, f32):
+    """ufv_gemm_fp8_mx, block-scaled A operand (v_mfma_scale_f32_16x16x128_f8f6f4 with the scale bytes staged per K-tile): against oracle.gemm_fp8_mx (fp32 sums of
+    the same dequantised operands: only the accumulation order differs), with bias and the fp32 residual epilogue; and equal to itself run twice"""
+    g = torch.Generator().manual_seed(N + K)
+    a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(1, K, generator=g))).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    ref = O.gemm_fp8_mx(a.float(), w.float(), bias)
+    am = ops.quantize_mx(a.to(DEV))
+    wq = ops.Fp8Weight(w.to(DEV))
+    if f32:
+        x0 = torch.randn(M, N, generator=g)
+        x = x0.clone().to(DEV)
+        ops.gemm_fp8_mx(am, wq, bias=bias.to(DEV), resid=x, out=x)
+        got, want = x.cpu(), ref + x0
+    else:
+        got, want = ops.gemm_fp8_mx(am, wq, bias=bias.to(DEV)).float().cpu(), ref
+    err = (got - want).abs().max() / want.abs().max()
+    assert err < (2e-4 if f32 else 6e-3), float(err)           # (fp32 sums of 18 944 products in another order; the MFMA applies the block scale to partial sums)
+
+
+@pytest.mark.parametrize("M,swiglu", [(2399, False), (2399, True), (18432, False), (300, True)])
+def test_mx_emitting_epilogues_vs_oracle(M, swiglu):
+    """The GELU / SwiGLU epilogues that write e4m3 codes + block scales (the next GEMM's A operand, no quantise launch): dequantised, they must equal
+    oracle.mx_quantize of the bf16-free fp32 epilogue value to within one e4m3 step of the block (the GEMM's fp32 sums differ from the oracle's in the last bits,
+    so codes can move by one where a value sits on a rounding boundary; the scale bytes by one where the block maximum does); and the chain
+    producer -> consumer (fc1 -> fc2, gate/up -> down with the permuted K axis) against the oracle's two GEMMs."""
+    g = torch.Generator().manual_seed(M)
+    K, N, N2 = (3584, 2 * 1024, 3584) if swiglu else (1152, 4352, 1152)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w1 = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16)
+    n_mid = N // 2 if swiglu else N
+    w2 = (torch.randn(N2, n_mid, generator=g) * n_mid ** -0.5).to(torch.bfloat16)
+    b1 = None if swiglu else torch.randn(N, generator=g)
+    # oracle: per-row-quantised a, per-channel w1 -> activation -> MX -> second GEMM
+    h = O.gemm_fp8(a.float(), w1.float(), b1)
+    h = torch.nn.functional.silu(h[:, :N // 2]) * h[:, N // 2:] if swiglu else torch.nn.functional.gelu(h, approximate="tanh")
+    deq_ref, e_ref, _ = O.mx_quantize(h)
+    y_ref = (deq_ref @ O.quantize_fp8_rows(w2.float())[0].t()) * O.quantize_fp8_rows(w2.float())[1][None, :]
+    # HIP
+    aq, sa = ops.quantize_fp8(a.to(DEV))
+    w1d = w1.to(DEV)
+    w1q = ops.Fp8Weight(pack_swiglu(w1d[:N // 2], w1d[N // 2:]) if swiglu else w1d)
+    hm = ops.gemm_fp8_mx(ops.QAct(aq, sa), w1q, bias=None if b1 is None else b1.to(DEV), act=None if swiglu else "gelu_pytorch_tanh", swiglu=swiglu, mx_out=True)
+    deq = ops.dequantize_mx(hm).cpu()
+    if swiglu:
+        perm = ops.mx_swiglu_perm(n_mid)
+        logical = torch.empty_like(deq); logical[:, perm] = deq
+        deq = logical
+        eb = hm.bscale.cpu()                                  # physical block p of a group of 4 holds logical 16-column groups (p, 4 + p): compare through values
+    assert (deq - deq_ref).abs().max() <= 0.0725 * deq_ref.abs().max()          # one e4m3 step (2^-3 relative) of the largest block
+    assert ((deq - deq_ref).abs() > 1e-6).float().mean() < 0.02                 # and all but a few codes agree exactly
+    w2q = ops.Fp8Weight(w2.to(DEV), mx_swiglu_cols=swiglu)
+    x0 = torch.randn(M, N2, generator=g)
+    x = x0.clone().to(DEV)
+    ops.gemm_fp8_mx(hm, w2q, resid=x, out=x)
+    # the consumer alone: against fp32 sums of the codes the producer actually wrote (in logical column order) ...
+    qw2, sw2, _ = O.quantize_fp8_rows(w2.float())
+    y_own = (deq @ qw2.t()) * sw2[None, :] + x0
+    err = (x.cpu() - y_own).abs().max() / y_own.abs().max()
+    assert err < 2e-4, float(err)
+    # ... and the chain against the oracle's two GEMMs (a code one step off moves its product by 2^-3 of itself)
+    err = (x.cpu() - (y_ref + x0)).abs().max() / (y_ref + x0).abs().max()
+    assert err < 1e-2, float(err)

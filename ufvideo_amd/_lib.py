@@ -30,6 +30,9 @@ SIGNATURES = {
     "ufv_rope_kv": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
     "ufv_rope_table": [_p, _i, _i, _i, _p, _p],
     "ufv_rope_kv_table": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
+    "ufv_quantize_mx": [_p, _i, _l, _p, _l, _p, _l, _i, _i, _p],
+    "ufv_dequantize_mx": [_p, _l, _p, _l, _p, _l, _i, _i, _p],
+    "ufv_gemm_fp8_mx": [_p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p],
     "ufv_gemm_qkv_rope": [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "ufv_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "ufv_dwconv3x3_ln_silu": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],

@@ -132,6 +132,16 @@ __device__ __forceinline__ float norm_ln_out(float x, float mean, float rstd, fl
     return __builtin_fmaf(t, w, b);
 }
 
+// MX block scale (round 5): the e8m0 byte of a block of e4m3 activations whose largest magnitude is amax: amax / 448 rounded UP to a power of two, so that no element of
+// the block saturates (byte = biased exponent, + 1 when the mantissa is not zero; clamped to [1, 253]; an all-zero block takes 1).  scale = 2^(byte - 127),
+// codes = rne_e4m3(x * 2^(127 - byte)).  One definition for the GEMM epilogues (gemm256_kernel.h) and ufv_quantize_mx (quant.hip); oracle.mx_quantize restates it.
+__device__ __forceinline__ unsigned mx_scale_byte(float amax) {
+    const unsigned b = __builtin_bit_cast(unsigned, amax * (1.0f / 448.0f));
+    unsigned e = (b >> 23) + ((b & 0x7fffffu) ? 1u : 0u);
+    e = e < 1u ? 1u : (e > 253u ? 253u : e);
+    return e;
+}
+
 // Rotate-half RoPE of one (x1, x2) = (dim i, dim i + hd/2) pair, in the ONE operation order every forward kernel uses (the prefill table kernel, the
 // on-the-fly forms, the decode steps and the QKV GEMM's fused epilogue): y1 = fma(x1, c, -(x2 s)), y2 = fma(x1, s, x2 c).  Written with explicit fmas so that
 // the compiler's contraction choice cannot differ from kernel to kernel -- the fused and unfused prefill paths are bit-identical by construction

@@ -963,6 +963,41 @@ extern "C" int ufv_gemm_fp8(const void* A, int lda, const float* a_scale, const 
                             stream);
 }
 
+// ---- W8A8 with MX block scales on the activation side (round 5) -------------------------------------------------------------------------------------
+// a_bscale != NULL: A carries one e8m0 scale byte per (row, 32 K-elements) instead of a_scale's fp32 per row.  out_bscale != NULL: C receives e4m3 codes
+// (1 byte per element, ldc in bytes) and out_bscale their block scales [M, ld_obs] -- the input of the next e4m3 GEMM, written by this GEMM's own epilogue
+// (256 x 256 tile; swiglu: the 32-column blocks are the permuted ones of epilogue256_swiglu_mx).  w_scale: fp32 per output channel, as in ufv_gemm_fp8.
+extern "C" int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, const void* a_bscale, int ld_abs, const void* W, int ldw, const float* w_scale, void* C,
+                               int ldc, int out_f32, void* out_bscale, int ld_obs, int M, int N, int K, const float* bias, int act, const float* resid, int ldr,
+                               int swiglu, void* stream) {
+    UFV_REQUIRE(A && W && C && w_scale && M > 0 && N > 0 && K > 0 && ((a_scale != nullptr) != (a_bscale != nullptr)),
+                "ufv_gemm_fp8_mx: give exactly one of a_scale (fp32 per row) / a_bscale (e8m0 per row and 32 elements) (M=%d N=%d K=%d)", M, N, K);
+    UFV_REQUIRE(a_bscale || out_bscale, "ufv_gemm_fp8_mx: neither a block-scaled input nor a block-scaled output: use ufv_gemm_fp8");
+    UFV_REQUIRE(!(a_bscale && out_bscale), "ufv_gemm_fp8_mx: block scales on BOTH sides of one GEMM are not built (register budget of the 256 x 256 tile)");
+    UFV_REQUIRE(M >= 256 && N % 128 == 0 && K % 128 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && lda % 16 == 0 && ldw % 16 == 0 &&
+                ((uintptr_t)C % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0) && ((uintptr_t)w_scale % 16 == 0),
+                "ufv_gemm_fp8_mx: needs M >= 256, N %% 128 == 0, K %% 128 == 0 and 16-byte aligned operands (M=%d N=%d K=%d)", M, N, K);
+    UFV_REQUIRE(!a_bscale || (ld_abs % 4 == 0 && ld_abs >= K / 32 && (uintptr_t)a_bscale % 4 == 0), "ufv_gemm_fp8_mx: A block scales: pitch %% 4 == 0, >= K / 32");
+    UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemm_fp8_mx: swiglu epilogue takes no bias/activation");
+    Epi e;
+    e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = 0;
+    e.scale_m = a_scale; e.scale_n = w_scale; e.dump_f32 = 0; e.ksplit = 0;
+    e.a_bscale = reinterpret_cast<const unsigned char*>(a_bscale); e.ld_abs = ld_abs;
+    e.out_bscale = reinterpret_cast<unsigned char*>(out_bscale); e.ld_obs = ld_obs;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (out_bscale) {
+        const int n_out = swiglu ? N / 2 : N;
+        UFV_REQUIRE(!out_f32 && !resid && N % 256 == 0 && ldc % 8 == 0 && ldc >= n_out && ld_obs >= n_out / 32 && (int64_t)M * ldc < (1ll << 31),
+                    "ufv_gemm_fp8_mx: the MX-emitting epilogue needs N %% 256 == 0, no residual, a byte pitch %% 8 == 0 (N=%d ldc=%d)", N, ldc);
+        return ufv_launch_pp_mx(A, W, e, M, N, K, lda, ldw, false, swiglu != 0, 1442, 2, st);
+    }
+    UFV_REQUIRE(!swiglu, "ufv_gemm_fp8_mx: SwiGLU with a block-scaled input is not built");
+    UFV_REQUIRE(e.ldc % 4 == 0 && (!resid || ((uintptr_t)resid % 16 == 0 && ldr % 4 == 0)), "ufv_gemm_fp8_mx: output / residual pitch %% 4 == 0");
+    int pick = choose_kernel(M, N, K / 2, out_f32 != 0, false, false);
+    if (pick == 0 || pick >= 10000) pick = 1442;
+    return ufv_launch_pp_mx(A, W, e, M, N, K, lda, ldw, out_f32 != 0, false, pick, 1, st);
+}
+
 extern "C" int ufv_gemv1(const void* a, const float* x, const float* ln_w, float eps, const void* W, int ldw, const float* w_scale,
                          void* C, int out_f32, int N, int K, const float* bias, int act, const float* resid, int swiglu, void* stream) {
     UFV_REQUIRE(W && C && N > 0 && K > 0 && ((a != nullptr) != (x != nullptr)), "ufv_gemv1: give exactly one of a (bf16 row) / x (fp32 row)");

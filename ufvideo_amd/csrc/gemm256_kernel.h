@@ -287,6 +287,84 @@ __device__ __forceinline__ void epilogue256_rope(const f32x4 (&acc)[4][MA0 + MA1
     UFV_EPI_MARK("END rope");
 }
 
+// ---- MX-emitting epilogues (e4m3 kernels, 256 x 256 tile; round 5) --------------------------------------------------------------------------------------
+// The consumer of these activations is another e4m3 GEMM: instead of a bf16 tensor that a separate kernel reads back, scans for the row maximum and quantises
+// (3.8 ms of stand-alone quantise launches per W8A8 clip), the epilogue stores e4m3 codes with ONE power-of-two scale per (row, 32 consecutive columns) -- the
+// block a lane of v_mfma_scale_f32_16x16x128_f8f6f4 owns.  A wave's 32-column run of an accumulator row sits in its four 16-lane rows: block maximum = in-lane
+// maximum of 8 values + two cross-row exchanges; scale byte e = biased exponent of amax / 448 rounded UP to a power of two (no value saturates;
+// oracle.mx_quantize restates it bit for bit); codes = rne_e4m3(v * 2^(127 - e)); one v_permlane32_swap + one v_permlane16_swap leave lane row r with bytes
+// 8 r .. 8 r + 7 of the run: ONE 8-byte store per (row, run) + ONE scale-byte store (lane row 0; the other rows' go to a dropped offset): 4 MT store
+// instructions per wave and tile (NSTM), every one issued on every path.
+__device__ __forceinline__ void mx_store_run(const float (&va)[4], const float (&vb)[4], const __amdgpu_buffer_rsrc_t rs_q, const __amdgpu_buffer_rsrc_t rs_s,
+                                             unsigned off_q, unsigned off_s, int fq) {
+    float am = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) am = fmaxf(am, fmaxf(fabsf(va[j]), fabsf(vb[j])));
+    am = fmaxf(am, __shfl_xor(am, 16, 64));
+    am = fmaxf(am, __shfl_xor(am, 32, 64));
+    const unsigned e = mx_scale_byte(am);
+    const float inv = __builtin_bit_cast(float, (254u - e) << 23);                           // 2^(127 - e)
+    int x = 0, y = 0;
+    x = __builtin_amdgcn_cvt_pk_fp8_f32(va[0] * inv, va[1] * inv, x, false);
+    x = __builtin_amdgcn_cvt_pk_fp8_f32(va[2] * inv, va[3] * inv, x, true);
+    y = __builtin_amdgcn_cvt_pk_fp8_f32(vb[0] * inv, vb[1] * inv, y, false);
+    y = __builtin_amdgcn_cvt_pk_fp8_f32(vb[2] * inv, vb[3] * inv, y, true);
+    // rows after the swaps: A = [x.r0, x.r2, y.r0, y.r2], B = [x.r1, x.r3, y.r1, y.r3]: lane row r holds bytes 8 r .. 8 r + 7 of the 32-byte run as {A, B}
+    auto s = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)y, false, false);
+    auto t = __builtin_amdgcn_permlane16_swap((unsigned)s[0], (unsigned)s[1], false, false);
+    typedef __attribute__((ext_vector_type(2))) int i32x2;
+    const i32x2 o = {(int)t[0], (int)t[1]};
+    __builtin_amdgcn_raw_buffer_store_b64(o, rs_q, (int)off_q, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, rs_s, (int)(off_s | (fq ? 0x80000000u : 0u)), 0, 0);
+}
+
+// plain / activation form: the run = the wave's two adjacent n-tiles (32 consecutive columns), as in epilogue256_wide
+template <int ACT, int MA0, int MA1>
+__device__ __forceinline__ void epilogue256_wide_mx(const f32x4 (&acc)[4][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc, int frow, int fq,
+                                                    const f32x4 (&bias)[4]) {
+    constexpr int MT = MA0 + MA1;
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (int)((unsigned)M * (unsigned)e.ldc), 0x20000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(e.out_bscale, 0, (int)((unsigned)M * (unsigned)e.ld_obs), 0x20000);
+    const unsigned drop1 = n0 + 128 >= N ? 0x80000000u : 0u;
+    UFV_EPI_MARK("BEGIN wide_mx");
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const unsigned row = (unsigned)(m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow);
+#pragma unroll
+        for (int run = 0; run < 2; ++run) {
+            const f32x4 a4 = acc[2 * run][mt] + bias[2 * run], b4 = acc[2 * run + 1][mt] + bias[2 * run + 1];
+            float va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { va[j] = act_apply_t<ACT>(a4[j]); vb[j] = act_apply_t<ACT>(b4[j]); }
+            const unsigned col = (unsigned)(n0 + run * 128 + wc * 32);
+            mx_store_run(va, vb, rs_q, rs_s, (row * (unsigned)e.ldc + col + 8u * fq) | (run ? drop1 : 0u), (row * (unsigned)e.ld_obs + (col >> 5)) | (run ? drop1 : 0u), fq);
+        }
+    }
+    UFV_EPI_MARK("END wide_mx");
+}
+
+// SwiGLU form.  A wave's outputs of an accumulator row are 16 columns per half (nh): 32 values, but 64 columns apart in the natural order (n0 / 2 + nh * 64 +
+// wc * 16).  They are stored as ONE 32-column block at physical column n0 / 2 + wc * 32 + nh * 16: a fixed permutation of the activation's columns inside every
+// group of 128, which the consumer's weight matrix (down_proj) carries on its K axis (ops.Fp8Weight(..., mx_swiglu_cols=True)) -- the product does not change.
+template <int MA0, int MA1>
+__device__ __forceinline__ void epilogue256_swiglu_mx(const f32x4 (&acc)[4][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc, int frow, int fq) {
+    constexpr int MT = MA0 + MA1;
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (int)((unsigned)M * (unsigned)e.ldc), 0x20000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(e.out_bscale, 0, (int)((unsigned)M * (unsigned)e.ld_obs), 0x20000);
+    const unsigned drop1 = n0 + 128 >= N ? 0x80000000u : 0u;      // (half a tile past N: both halves feed one block, so the whole block is dropped -- N % 256 == 0 is required by the host)
+    UFV_EPI_MARK("BEGIN swiglu_mx");
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const unsigned row = (unsigned)(m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow);
+        float va[4], vb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[j] = swiglu_f(acc[0][mt][j], acc[1][mt][j]); vb[j] = swiglu_f(acc[2][mt][j], acc[3][mt][j]); }
+        const unsigned col = (unsigned)((n0 >> 1) + wc * 32);
+        mx_store_run(va, vb, rs_q, rs_s, (row * (unsigned)e.ldc + col + 8u * fq) | drop1, (row * (unsigned)e.ld_obs + (col >> 5)) | drop1, fq);
+    }
+    UFV_EPI_MARK("END swiglu_mx");
+}
+
 // acc[nt][mt][j] = C[m0 + row(mt)][n0 + col(nt) + fq*4 + j] with
 //   row(mt) = mt < MA0 ? wr*16*MA0 + mt*16 + frow : 32*MA0 + wr*16*MA1 + (mt-MA0)*16 + frow
 //   col(nt) = nt < 2 ? wc*32 + nt*16 : 128 + wc*16*NB1 + (nt-2)*16
@@ -453,7 +531,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // neighbouring tiles and keep sharing A / W panels in L2 (free-running stream-K ranges do not: they re-read every panel from HBM).  The parts of
 // a tile add into the fp32 output in turn order (epilogue_split) -- deterministic, no workspace; needs act == none and one block per CU.
 // ROPE: the fused QKV + RoPE + KV-append form (epilogue256_rope): B fragments re-mapped so that the rotate-half partners of a head share a lane.
-template <bool OUT_F32, bool SWIGLU, bool FP8, bool SKT, int MA0 = 4, int MA1 = 4, int NB1 = 2, bool PH2 = false, bool KSPL = false, bool ROPE = false>
+// MX (e4m3 operands only): bit 0 = the A operand carries MX block scales (one e8m0 byte per row and 32 K-elements, staged per K-tile beside the operand tiles and
+// handed to v_mfma_scale_f32_16x16x128_f8f6f4, whose lanes own exactly one such block each); bit 1 = the epilogue emits e4m3 codes + block scales (epilogue256_*_mx).
+template <bool OUT_F32, bool SWIGLU, bool FP8, bool SKT, int MA0 = 4, int MA1 = 4, int NB1 = 2, bool PH2 = false, bool KSPL = false, bool ROPE = false, int MX = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ Av, const void* __restrict__ Wv, Epi e, int M,
                                                        int N, int K, int lda, int ldw, StreamK sk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -462,6 +542,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     constexpr int MT = T::MT, NT = T::NT, BM = T::BM, BN = T::BN;
     static_assert(!SKT || (MA0 == 4 && MA1 == 4 && NB1 == 2), "the stream-K fix-up is written for the 256x256 tile image");
     static_assert(!KSPL || (OUT_F32 && !SWIGLU && !FP8 && !SKT && PH2), "split-K parts accumulate into an fp32 output");
+    static_assert(MX == 0 || (FP8 && PH2 && !SKT && !KSPL && !ROPE), "MX block scales belong to the e4m3 kernels");
+    static_assert(!(MX & 2) || (!OUT_F32 && MA0 == 4 && MA1 == 4 && NB1 == 2), "the MX-emitting epilogues are built for the 256 x 256 tile");
+    constexpr bool MXA = (MX & 1) != 0;
+    constexpr int SCL_OFF = 131072;                                  // MXA: two 1 KiB stages of A-operand block scales (256 rows x 4 bytes per K-tile) above the operand ring
     static_assert(!ROPE || (!OUT_F32 && !SWIGLU && !FP8 && !SKT && !KSPL && PH2 && NB1 == 2 && (MA0 + MA1) % 2 == 0),
                   "the fused RoPE epilogue: bf16 output, 256-column tiles (two heads of 128), accumulator rows in pairs");
     const char* A = reinterpret_cast<const char*>(Av);
@@ -554,6 +638,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // what FPF rests on: the leading group (waves 0-3) reads A rows [0, 16 MA) of each half, and waves 0-3 stage rows [0, 32 LA) of it
     static_assert(!FPF || (16 * MA0 <= 32 * T::LA0 && 16 * MA1 <= 32 * T::LA1), "fragment prefetch: the leading group's A rows must be staged by its own waves");
     const char* src[4][2];
+    const unsigned char* ssrc = nullptr;           // MXA: this lane's row of the A block scales (rows 64 (wave & 3) + lane of the tile; waves 4-7 stage the same bytes again)
     auto set_src = [&](int m0_, int n0_) {
         if constexpr (X2) {
 #pragma unroll
@@ -565,6 +650,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             }
             return;
         }
+        if constexpr (MXA) ssrc = e.a_bscale + (size_t)min(m0_ + (wave & 3) * 64 + lane, M - 1) * e.ld_abs;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -586,6 +672,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             }
             return;
         }
+        if constexpr (MXA) {
+            if (which == 4) {                      // the K-tile's 4 scale bytes of 64 rows per wave: one dword per lane
+                if (kt < kend) __builtin_amdgcn_global_load_lds(GLB_PTR(ssrc + kt * 4), LDS_PTR(smem + SCL_OFF + d * 1024 + (wave & 3) * 256), 4, 0, 0);
+                return;
+            }
+        }
         const int l = which == 0 ? T::LA0 : which == 1 ? T::LA1 : which == 2 ? T::LB0 : T::LB1;
         if (kt < kend) {
             char* dst = smem + d * 65536 + which * 16384 + wave * (1024 * l);
@@ -594,12 +686,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         }
     };
     auto prologue_loads = [&]() {      // first K-tile of the item complete + A0/B1 (PH2: A0/B0/B1) of its second K-tile
-        stage(0, 0, kbeg); stage(0, 2, kbeg); stage(0, 3, kbeg); stage(0, 1, kbeg);
+        stage(0, 0, kbeg); stage(0, 2, kbeg); stage(0, 3, kbeg);
+        if constexpr (MXA) stage(0, 4, kbeg);      // (the scales travel with the [A0 B0 B1] group of their K-tile: one more piece per wave in every counted wait)
+        stage(0, 1, kbeg);
         stage(1, 0, kbeg + 1);
         if constexpr (PH2) stage(1, 2, kbeg + 1);
         stage(1, 3, kbeg + 1);
+        if constexpr (MXA) stage(1, 4, kbeg + 1);
     };
-    constexpr int L_ALL = T::LA0 + T::LA1 + T::LB0 + T::LB1;      // PH2: DMA instructions in flight behind the half-tiles that are needed next
+    constexpr int L_ALL = T::LA0 + T::LA1 + T::LB0 + T::LB1 + (MXA ? 1 : 0);      // PH2: DMA instructions in flight behind the half-tiles that are needed next
     // the counted wait that leaves exactly the last two staged half-tiles (A0, B1 of the K-tile after next) in flight
 #define UFV_WAIT_KEEP_A0_B1()                                                                              \
     do {                                                                                                     \
@@ -614,7 +709,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     const int b_row_off[2] = {ROPE ? (wc * 16 + frow) * 128 : (wc * 32 + frow) * 128, ROPE ? (wc * 16 + frow) * 128 : (wc * 16 * NB1 + frow) * 128};
     constexpr int BSTR = ROPE ? 8192 : 2048;                  // bytes between a wave's two n-tiles of a half (64 rows | 16 rows)
     // bf16: k-step kk reads chunk 4*kk + fq;  fp8: the lane's 32 bytes are chunks 2*fq and 2*fq + 1
-    const int coff0 = ((FP8 ? 2 * fq : fq) ^ fx) << 4, coff1 = ((FP8 ? 2 * fq + 1 : 4 + fq) ^ fx) << 4;
+    // MXA: the scaled MFMA applies lane group g's scale byte to K-block g, and its K-block j is the FIRST 16 bytes of lane groups 2 (j & 1), 2 (j & 1) + 1 for j < 2 and their
+    // SECOND 16 bytes for j >= 2 (measured with one non-zero element per position, tools/scratch history in LABNOTES round 5): block j = chunks 2 j, 2 j + 1 of the row when lane
+    // group g reads chunks g and 4 + g -- the bf16 mapping.  (Without scales any K order shared by both operands is right, which is all the plain e4m3 path needs.)
+    constexpr bool CH_BF16 = !FP8 || MXA;
+    const int coff0 = ((CH_BF16 ? fq : 2 * fq) ^ fx) << 4, coff1 = ((CH_BF16 ? 4 + fq : 2 * fq + 1) ^ fx) << 4;
 
     int m0, n0, k0, k1;
     bool have = next_item(m0, n0, k0, k1);
@@ -633,6 +732,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // instructions on every path between the UFV_EPI_MARK comments of each epilogue form against NST / NSTW / NSTS; the bit-identity tests against the 128-wide
     // kernel (tests/test_kernels_gpu.py) are the second guard.
     constexpr int NSTW = 2 * MT;
+    constexpr int NSTM = SWIGLU ? 2 * MT : 4 * MT;           // the MX-emitting epilogues: a code store + a scale-byte store per (row, run) | per row
     constexpr bool RELAX_OK = PH2 && !SKT && !KSPL && (L_ALL + NST <= 63);
     int relax = 0;                                           // 0: strict waits; 1: NST stores may stay in flight; 2: NSTW; 3: NSTS
     UFV_TSTAMP_DECL
@@ -645,6 +745,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 afr[4][2], bfr[PH2 ? 4 : 2][2];
+    int asc[MXA ? MT : 1];                                    // MXA: e8m0 block scale of each A fragment's row for this lane's 32-element K block (low byte)
     auto read_a = [&](const char* half, auto hsel) {
         constexpr int h = decltype(hsel)::value;
 #pragma unroll
@@ -674,6 +775,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     if constexpr (FP8) {                                                                                     \
         _Pragma("unroll") for (int n_ = 0; n_ < NCNT; ++n_)                                                  \
             _Pragma("unroll") for (int m_ = 0; m_ < MCNT; ++m_)                                              \
+                if constexpr (MXA)                                                                           \
+                    acc[NTB + n_][MTB + m_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(              \
+                        cat8(bfr[n_][0], bfr[n_][1]), cat8(afr[m_][0], afr[m_][1]), acc[NTB + n_][MTB + m_], 0, 0, 0, 0x7f, 0, asc[MTB + m_]); \
+                else                                                                                         \
                 acc[NTB + n_][MTB + m_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                  \
                     cat8(bfr[n_][0], bfr[n_][1]), cat8(afr[m_][0], afr[m_][1]), acc[NTB + n_][MTB + m_], 0, 0, 0, 0, 0, 0); \
     } else {                                                                                                 \
@@ -750,6 +855,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             if (RELAX_OK && relax == 1) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
             else if (RELAX_OK && relax == 3) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
+            else if (RELAX_OK && relax == 4) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? L_ALL + NSTM : L_ALL>();
             else wait_vmcnt<L_ALL>();
         } else wait_vmcnt<T::LA1>();
     } else {
@@ -840,6 +946,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         read_b(buf + 32768, H0{});
         read_a(buf, H0{});
         read_b(buf + 49152, H1{});
+        if constexpr (MXA) {
+            // the block scales of ALL of this wave's A fragments (both halves) are read here, in phase A: the slot is re-staged in phase B, which the lagging wave
+            // group enters one barrier later -- a read in phase B would race the leading group's DMA.  Lane (frow, fq) takes byte fq of its row's dword.
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int trow = mt < MA0 ? wr * 16 * MA0 + mt * 16 + frow : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16 + frow;
+                asc[mt] = (int)(*reinterpret_cast<const unsigned*>(smem + SCL_OFF + d * 1024 + trow * 4) >> (8 * fq));
+            }
+        }
         UFV_GSTAMP(9);
         stage(d ^ 1, 1, t + 1);
         UFV_GSTAMP(10);
@@ -847,6 +962,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
             else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
+            else if (RELAX_OK && relax == 4 && tt == 0) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? L_ALL + NSTM : L_ALL>();
             else wait_vmcnt<L_ALL>();
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, 0, MA0, 1, 2, 3)
@@ -857,11 +973,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         stage(d, 0, t + 2);
         stage(d, 2, t + 2);
         stage(d, 3, t + 2);
+        if constexpr (MXA) stage(d, 4, t + 2);
         UFV_GSTAMP(12);
         if (tt + 2 < len) {                            // behind them: A1[t+1] and A0/B0/B1[t+2]
             if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
             else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
+            else if (RELAX_OK && relax == 4 && tt == 0) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? L_ALL + NSTM : L_ALL>();
             else wait_vmcnt<L_ALL>();
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, MA0, MA1, 5, 6, 7)
@@ -920,7 +1038,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         for (int nt = 0; nt < NT; ++nt) sn[nt] = *reinterpret_cast<const f32x4*>(e.scale_n + col_of(nt));
         float sm[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) sm[mt] = e.scale_m[min(m0 + row_of(mt), M - 1)];
+        for (int mt = 0; mt < MT; ++mt) sm[mt] = MXA ? 1.0f : e.scale_m[min(m0 + row_of(mt), M - 1)];      // (MXA: the block scales were applied by the MFMAs)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -1024,6 +1142,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         if constexpr (ROPE) {
             epilogue256_rope<MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias, rcos, rsin);
             relax = RELAX_OK ? 2 : 0;                             // 2 MT sixteen-byte buffer stores, every one issued on every tile
+        } else if constexpr ((MX & 2) != 0) {
+            if constexpr (SWIGLU) epilogue256_swiglu_mx<MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq);
+            else { UFV_ACT_SWITCH(e.act, (epilogue256_wide_mx<ACT_, MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias))) }
+            relax = RELAX_OK ? 4 : 0;
         } else if (by_rows) {
             if constexpr (!SWIGLU && !FP8) epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
             relax = RELAX_OK ? 1 : 0;                             // this form issues every store instruction, edge tiles included
@@ -1053,11 +1175,12 @@ static inline int pp_n_cu() { return ufv_dev_n_cu(); }
 // made its XCDs fetch 16 W panels per round instead of 4; 1203 -> 1244 TF/s on gate/up), else ~8 in equal groups
 static inline int pp_group(int tiles_m) { return tiles_m <= 16 ? tiles_m : cdiv(tiles_m, cdiv(tiles_m, 8)); }
 
-template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false, bool ROPE = false>
+template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false, bool ROPE = false, int MX = 0>
 static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st, int ksplit = 1) {
+    constexpr int SMEM = SMEM256 + ((MX & 1) ? 2048 : 0);          // MX & 1: two stages of A block scales above the operand ring
     UFV_ONCE_PER_DEVICE(
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE, MX>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     );
     using T = PP<MA0, MA1, NB1>;
     const int rem = N % T::BN;
@@ -1079,7 +1202,7 @@ static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, i
         sk.ksplit = ksplit;
         items = tiles * ksplit;
     }
-    hipLaunchKernelGGL((gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE>), dim3(items < n_cu ? items : n_cu), dim3(512), SMEM256, st, A, W, e, M, N, K,
+    hipLaunchKernelGGL((gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE, MX>), dim3(items < n_cu ? items : n_cu), dim3(512), SMEM, st, A, W, e, M, N, K,
                        lda, ldw, sk);
     UFV_CHECK_LAUNCH();
     return UFV_OK;

@@ -16,6 +16,10 @@ struct Epi {
     const float* rope_tab = nullptr; // f32 [M, 128]: cos (64) | sin (64) of every row's position (ufv_rope_table)
     void* out_kv = nullptr;          // bf16 KV-cache row of the call's first position: row m = [Hkv * 128 k | Hkv * 128 v] at out_kv + m * ldkv
     int ldkv = 0, rope_hq = 0, rope_hkv = 0;
+    // MX-style block scales of e4m3 activations (gemm_nt_256<..., MX>): one e8m0 byte per (row, 32 consecutive K / N elements), value 2^(byte - 127)
+    const unsigned char* a_bscale = nullptr;   // MX & 1: scales of the A operand, [M, ld_abs] bytes (K / 32 per row); scale_m is not used then
+    unsigned char* out_bscale = nullptr;       // MX & 2: the epilogue writes e4m3 codes to `out` and their block scales here, [M, ld_obs] bytes
+    int ld_abs = 0, ld_obs = 0;
 };
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -81,5 +85,7 @@ __device__ __forceinline__ void epi_store4b(const Epi& e, int m, int n, float v0
 
 int ufv_launch_gemm256(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32,
                        bool swiglu, bool fp8, bool streamk, int shape, hipStream_t st);
+// gemm256_m.hip / gemm256_m2.hip: the MX instantiations (mx & 1: block-scaled A operand at every named shape; mx & 2: 256 x 256 tiles whose epilogue emits MX)
+int ufv_launch_pp_mx(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32, bool swiglu, int shape, int mx, hipStream_t st);
 // gemm256_r.hip: the fused QKV + RoPE + KV-append instantiations of the ping-pong kernel (shape 1332)
 int ufv_launch_pp_rope(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int shape, hipStream_t st);

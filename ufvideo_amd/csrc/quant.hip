@@ -237,7 +237,65 @@ __global__ void dequantize_fp8_k(const uint8_t* __restrict__ q, int64_t ldq, con
     out[(int64_t)m * ldo + k] = __builtin_amdgcn_cvt_f32_fp8(byte, 0) * scale[m];
 }
 
+// MX block quantisation: one thread per (row, 32-element block): 32 values -> amax -> scale byte -> 32 codes (8 dword stores)
+template <int DT>
+__global__ __launch_bounds__(256) void quantize_mx_k(const void* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q, int64_t ldq, uint8_t* __restrict__ bs,
+                                                     int64_t ldb, int M, int nb) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)M * nb) return;
+    const int m = (int)(id / nb), b = (int)(id % nb);
+    f32x4 v[8];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = ld4<DT>(x, (int64_t)m * ldx + b * 32 + 4 * i);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i][0]), fabsf(v[i][1]))), fmaxf(fabsf(v[i][2]), fabsf(v[i][3])));
+    }
+    const unsigned e = mx_scale_byte(amax);
+    const float inv = __builtin_bit_cast(float, (254u - e) << 23);
+    bs[(int64_t)m * ldb + b] = (uint8_t)e;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w, true);
+        *reinterpret_cast<int*>(q + (int64_t)m * ldq + b * 32 + 4 * i) = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void dequantize_mx_k(const uint8_t* __restrict__ q, int64_t ldq, const uint8_t* __restrict__ bs, int64_t ldb, float* __restrict__ out,
+                                                       int64_t ldo, int M, int K) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)M * (K >> 2)) return;
+    const int m = (int)(id / (K >> 2)), k = (int)(id % (K >> 2)) * 4;
+    const int w = *reinterpret_cast<const int*>(q + (int64_t)m * ldq + k);
+    const float sc = __builtin_bit_cast(float, (unsigned)bs[(int64_t)m * ldb + (k >> 5)] << 23);
+    f32x4 o = {__builtin_amdgcn_cvt_f32_fp8(w, 0) * sc, __builtin_amdgcn_cvt_f32_fp8(w, 1) * sc, __builtin_amdgcn_cvt_f32_fp8(w, 2) * sc, __builtin_amdgcn_cvt_f32_fp8(w, 3) * sc};
+    *reinterpret_cast<f32x4*>(out + (int64_t)m * ldo + k) = o;
+}
+
 }  // namespace
+
+extern "C" int ufv_quantize_mx(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, void* bscale, int64_t ldb, int M, int K, void* stream) {
+    UFV_REQUIRE(x && q && bscale && M > 0 && K > 0 && K % 32 == 0 && ldx % 4 == 0 && ldq % 4 == 0 && ldb >= K / 32 && (uintptr_t)q % 4 == 0 && (uintptr_t)x % 8 == 0,
+                "ufv_quantize_mx: K %% 32 == 0, row pitches multiples of 4, ldb >= K / 32 (K=%d)", K);
+    const int nb = K / 32;
+    const int64_t total = (int64_t)M * nb;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (x_dtype == UFV_DT_F32) hipLaunchKernelGGL((quantize_mx_k<UFV_DT_F32>), grid, dim3(256), 0, ST(stream), x, ldx, (uint8_t*)q, ldq, (uint8_t*)bscale, ldb, M, nb);
+    else if (x_dtype == UFV_DT_BF16) hipLaunchKernelGGL((quantize_mx_k<UFV_DT_BF16>), grid, dim3(256), 0, ST(stream), x, ldx, (uint8_t*)q, ldq, (uint8_t*)bscale, ldb, M, nb);
+    else { ufv_set_error("ufv_quantize_mx: unsupported dtype %d", x_dtype); return UFV_EINVAL; }
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
+
+extern "C" int ufv_dequantize_mx(const void* q, int64_t ldq, const void* bscale, int64_t ldb, float* out, int64_t ldo, int M, int K, void* stream) {
+    UFV_REQUIRE(q && bscale && out && M > 0 && K > 0 && K % 32 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && (uintptr_t)q % 4 == 0 && (uintptr_t)out % 16 == 0, "ufv_dequantize_mx: bad arguments");
+    const int64_t total = (int64_t)M * (K / 4);
+    hipLaunchKernelGGL(dequantize_mx_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), (const uint8_t*)q, ldq, (const uint8_t*)bscale, ldb, out, ldo, M, K);
+    UFV_CHECK_LAUNCH();
+    return UFV_OK;
+}
 
 extern "C" int ufv_quantize_fp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, float* scale, int M, int K, void* stream) {
     UFV_REQUIRE(x && q && scale && M > 0 && K > 0, "ufv_quantize_fp8: bad arguments");

@@ -96,14 +96,77 @@ class QAct:
         self.shape = tuple(q.shape)
 
 
+class MxAct:
+    """A block-quantised activation (round 5): e4m3 codes [M, K] + one e8m0 scale byte per (row, 32 elements) [M, K / 32] -- what the MX-emitting GEMM epilogues
+    write and `gemm` consumes with an Fp8Weight through ufv_gemm_fp8_mx.  `swiglu_cols`: the columns are in the SwiGLU epilogue's block order (see ufv.h)."""
+
+    def __init__(self, q, bscale, swiglu_cols=False):
+        self.q, self.bscale, self.swiglu_cols = q, bscale, swiglu_cols
+        self.shape = tuple(q.shape)
+
+
+def mx_swiglu_perm(n, device=None):
+    """physical -> logical column of the SwiGLU MX epilogue's output: inside every group of 128, physical 32 w + 16 h + c holds logical 64 h + 16 w + c"""
+    p = torch.arange(n, device=device)
+    g, r = p // 128, p % 128
+    w, h, c = r // 32, (r % 32) // 16, r % 16
+    return g * 128 + 64 * h + 16 * w + c
+
+
+def quantize_mx(x):
+    """x [M, K] bf16|f32 -> MxAct (ufv_quantize_mx): the stand-alone form of what the MX-emitting epilogues do"""
+    _chk(x, name="x")
+    M, K = x.shape
+    q = torch.empty((M, K), device=x.device, dtype=torch.uint8)
+    bs = torch.empty((M, K // 32), device=x.device, dtype=torch.uint8)
+    _lib.call("ufv_quantize_mx", x.data_ptr(), _DT[x.dtype], x.stride(0), q.data_ptr(), q.stride(0), bs.data_ptr(), bs.stride(0), M, K, _stream())
+    return MxAct(q, bs)
+
+
+def dequantize_mx(a):
+    M, K = a.q.shape
+    out = torch.empty((M, K), device=a.q.device, dtype=torch.float32)
+    _lib.call("ufv_dequantize_mx", a.q.data_ptr(), a.q.stride(0), a.bscale.data_ptr(), a.bscale.stride(0), out.data_ptr(), out.stride(0), M, K, _stream())
+    return out
+
+
+def gemm_fp8_mx(a, w, bias=None, act=None, resid=None, out=None, out_dtype=torch.bfloat16, swiglu=False, mx_out=False):
+    """e4m3 GEMM with MX block scales on the activation side (ufv_gemm_fp8_mx).  a: MxAct (block-scaled input) or QAct (per-row scales); w: Fp8Weight.
+    mx_out=True: the epilogue writes the result as an MxAct (codes + block scales) -- the input of the next e4m3 GEMM, no quantise launch in between."""
+    M, K = a.q.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    n_out = N // 2 if swiglu else N
+    is_mx = isinstance(a, MxAct)
+    if mx_out:
+        q = torch.empty((M, n_out), device=a.q.device, dtype=torch.uint8)
+        bs = torch.empty((M, n_out // 32), device=a.q.device, dtype=torch.uint8)
+        _lib.call("ufv_gemm_fp8_mx", a.q.data_ptr(), a.q.stride(0), None if is_mx else a.scale.data_ptr(), a.bscale.data_ptr() if is_mx else None,
+                  a.bscale.stride(0) if is_mx else 0, w.q.data_ptr(), w.q.stride(0), w.scale.data_ptr(), q.data_ptr(), q.stride(0), 0, bs.data_ptr(), bs.stride(0),
+                  M, N, K, _ptr(bias), ACT[act], None, 0, int(swiglu), _stream())
+        return MxAct(q, bs, swiglu_cols=swiglu)
+    assert is_mx
+    if out is None:
+        out = torch.empty((M, n_out), device=a.q.device, dtype=out_dtype)
+    ldr = resid.stride(0) if resid is not None else 0
+    _lib.call("ufv_gemm_fp8_mx", a.q.data_ptr(), a.q.stride(0), None, a.bscale.data_ptr(), a.bscale.stride(0), w.q.data_ptr(), w.q.stride(0), w.scale.data_ptr(),
+              out.data_ptr(), out.stride(0), int(out.dtype == torch.float32), None, 0, M, N, K, _ptr(bias), ACT[act], _ptr(resid), ldr, int(swiglu), _stream())
+    return out
+
+
 class Fp8Weight:
     """A weight matrix [N, K] held as e4m3 bytes + one fp32 scale per output channel.  Passing it to `gemm` in place of a
     bf16 weight selects the W8A8 path: the activation is quantised per token on the fly."""
 
-    def __init__(self, w):
+    def __init__(self, w, mx_swiglu_cols=False):
+        """mx_swiglu_cols: the K axis (columns) is stored in the block order of the SwiGLU MX epilogue's output (mx_swiglu_perm): the weight of the GEMM that
+        consumes that activation (down_proj behind a fused gate/up); per-channel scales and the product are unchanged by a permutation of K"""
+        if mx_swiglu_cols:
+            w = w[:, mx_swiglu_perm(w.shape[1], w.device)]
         self.q, self.scale = quantize_fp8(w.contiguous())
         self.shape = tuple(w.shape)
         self.dtype = torch.uint8
+        self.mx_swiglu_cols = mx_swiglu_cols
 
     def stride(self, i):
         return self.q.stride(i)
