@@ -339,9 +339,13 @@ int ufv_quantize_fp8(const void* x, int x_dtype, int64_t ldx, void* q, int64_t l
 int ufv_layernorm_fp8(const void* x, int x_dtype, int ldx, void* q, int64_t ldq, float* scale, const float* w, const float* b, int M,
                       int D, float eps, void* stream);
 int ufv_rmsnorm_fp8(const float* x, int ldx, void* q, int64_t ldq, float* scale, const float* w, int M, int D, float eps, void* stream);
-/* MX-style block quantisation (round 5; OCP microscaling layout as v_mfma_scale_f32_16x16x128_f8f6f4 consumes it): x [M, K] -> e4m3 codes q [M, K] + one e8m0
- * scale byte per (row, 32 consecutive elements), bscale [M, ldb >= K / 32]: scale = 2^(byte - 127) = amax / 448 of the block rounded UP to a power of two
- * (no element saturates), code = rne_e4m3(x / scale).  K % 32 == 0.  The e4m3 GEMM epilogues emit the same format (ufv_gemm_fp8_mx). */
+/* MX-style block quantisation (round 5; OCP microscaling blocks as v_mfma_scale_f32_16x16x128_f8f6f4 consumes them): x [M, K] -> e4m3 codes q [M, K] + one e8m0
+ * scale byte per (row, 32 consecutive elements): scale = 2^(byte - 127) = amax / 448 of the block rounded UP to a power of two (no element saturates),
+ * code = rne_e4m3(x / scale).  The scale bytes are stored as bscale [ceil(M / 64)][ceil(K / 512)][64 rows][16] (ldb = bytes per 64-row block >= 1024 ceil(K / 512)):
+ * per (row, group of four 128-element K-tiles) 16 bytes, byte 4 f + t = the scale of block f (0..3) of K-tile t (0..3) of the group.  64 rows of a group are one
+ * contiguous KiB (one LDS-DMA piece per wave and four K-tiles), the groups of a row block follow each other along K (the GEMM's scale stream stays inside a few
+ * pages), and a lane of the scaled MFMA finds the four K-tiles of its block f in one dword.  K % 128 == 0; the buffer holds ceil(M / 64) * ldb bytes.  The e4m3 GEMM epilogues emit the same
+ * format (ufv_gemm_fp8_mx). */
 int ufv_quantize_mx(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, void* bscale, int64_t ldb, int M, int K, void* stream);
 int ufv_dequantize_mx(const void* q, int64_t ldq, const void* bscale, int64_t ldb, float* out, int64_t ldo, int M, int K, void* stream);
 /* ufv_gemm_fp8 with block scales on the activation side: exactly one of a_scale (fp32 per row) / a_bscale (e8m0 per row and 32 K-elements, pitch ld_abs bytes);

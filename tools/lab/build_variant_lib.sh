@@ -7,7 +7,7 @@ D=$R/tools/scratch/var_$name
 mkdir -p $D
 C=$R/ufvideo_amd/csrc
 FL="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -I$R/include"
-for f in gemm256 gemm256_b gemm256_q gemm256_s gemm256_r gemm; do
+for f in gemm256 gemm256_b gemm256_q gemm256_s gemm256_r gemm256_m gemm256_m2 gemm; do
   ( /opt/rocm/bin/hipcc $FL "$@" -c $C/$f.hip -o $D/$f.o 2> $D/$f.err || echo FAILED $f ) &
 done
 wait

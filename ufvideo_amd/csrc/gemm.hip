@@ -964,7 +964,7 @@ extern "C" int ufv_gemm_fp8(const void* A, int lda, const float* a_scale, const 
 }
 
 // ---- W8A8 with MX block scales on the activation side (round 5) -------------------------------------------------------------------------------------
-// a_bscale != NULL: A carries one e8m0 scale byte per (row, 32 K-elements) instead of a_scale's fp32 per row.  out_bscale != NULL: C receives e4m3 codes
+// a_bscale != NULL: A carries one e8m0 scale byte per (row, 32 K-elements) instead of a_scale's fp32 per row, stored as [M / 64][K / 512][64][16] (ld_abs bytes per 64-row block; include/ufv.h ufv_quantize_mx).  out_bscale != NULL: C receives e4m3 codes
 // (1 byte per element, ldc in bytes) and out_bscale their block scales [M, ld_obs] -- the input of the next e4m3 GEMM, written by this GEMM's own epilogue
 // (256 x 256 tile; swiglu: the 32-column blocks are the permuted ones of epilogue256_swiglu_mx).  w_scale: fp32 per output channel, as in ufv_gemm_fp8.
 extern "C" int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, const void* a_bscale, int ld_abs, const void* W, int ldw, const float* w_scale, void* C,
@@ -977,7 +977,8 @@ extern "C" int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, con
     UFV_REQUIRE(M >= 256 && N % 128 == 0 && K % 128 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && lda % 16 == 0 && ldw % 16 == 0 &&
                 ((uintptr_t)C % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0) && ((uintptr_t)w_scale % 16 == 0),
                 "ufv_gemm_fp8_mx: needs M >= 256, N %% 128 == 0, K %% 128 == 0 and 16-byte aligned operands (M=%d N=%d K=%d)", M, N, K);
-    UFV_REQUIRE(!a_bscale || (ld_abs % 4 == 0 && ld_abs >= K / 32 && (uintptr_t)a_bscale % 4 == 0), "ufv_gemm_fp8_mx: A block scales: pitch %% 4 == 0, >= K / 32");
+    UFV_REQUIRE(!a_bscale || (ld_abs % 1024 == 0 && ld_abs >= 1024 * ((K + 511) / 512) && (uintptr_t)a_bscale % 16 == 0),
+                "ufv_gemm_fp8_mx: A block scales [M / 64][K / 512][64][16]: block pitch %% 1024 == 0, >= 1024 ceil(K / 512)");
     UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemm_fp8_mx: swiglu epilogue takes no bias/activation");
     Epi e;
     e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = 0;
@@ -987,14 +988,17 @@ extern "C" int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, con
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (out_bscale) {
         const int n_out = swiglu ? N / 2 : N;
-        UFV_REQUIRE(!out_f32 && !resid && N % 256 == 0 && ldc % 8 == 0 && ldc >= n_out && ld_obs >= n_out / 32 && (int64_t)M * ldc < (1ll << 31),
+        UFV_REQUIRE(!out_f32 && !resid && N % 256 == 0 && ldc % 8 == 0 && ldc >= n_out && ld_obs % 1024 == 0 && ld_obs >= 1024 * ((n_out + 511) / 512) && (int64_t)M * ldc < (1ll << 31) &&
+                    (int64_t)((M + 63) / 64) * ld_obs < (1ll << 31),
                     "ufv_gemm_fp8_mx: the MX-emitting epilogue needs N %% 256 == 0, no residual, a byte pitch %% 8 == 0 (N=%d ldc=%d)", N, ldc);
         return ufv_launch_pp_mx(A, W, e, M, N, K, lda, ldw, false, swiglu != 0, 1442, 2, st);
     }
     UFV_REQUIRE(!swiglu, "ufv_gemm_fp8_mx: SwiGLU with a block-scaled input is not built");
     UFV_REQUIRE(e.ldc % 4 == 0 && (!resid || ((uintptr_t)resid % 16 == 0 && ldr % 4 == 0)), "ufv_gemm_fp8_mx: output / residual pitch %% 4 == 0");
     int pick = choose_kernel(M, N, K / 2, out_f32 != 0, false, false);
-    if (pick == 0 || pick >= 10000) pick = 1442;
+    // (the block-scaled A operand costs 14 registers: the 256 x 256 and 224 x 256 tiles spill with it -- 124 / 8 bytes of scratch -- and are not offered)
+    if (pick == 0 || pick >= 10000 || pick == 1442) pick = N % 192 == 0 || N % 192 == 128 ? 1441 : 1332;
+    if (pick == 1432) pick = 1332;
     return ufv_launch_pp_mx(A, W, e, M, N, K, lda, ldw, out_f32 != 0, false, pick, 1, st);
 }
 

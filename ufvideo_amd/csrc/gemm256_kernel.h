@@ -67,6 +67,9 @@ template <int MA0, int MA1, int NB1> struct PP {
 // the K loop (NST / NSTW / NSTS below) are exact only if the epilogue that ran last issued EXACTLY that many vector-memory stores; the CPU test compiles the kernels
 // to gfx950 assembly, walks every path between a BEGIN and its END and counts the vector-memory instructions on it.  ("memory": nothing that touches memory moves
 // across a marker; the markers emit no instruction.)
+#ifndef UFV_MX_LAB
+#define UFV_MX_LAB 0           /* lab: 1 = the MX-A kernels issue the UNSCALED MFMA (wrong sums): what the scale operand itself costs */
+#endif
 #ifndef UFV_RESID_SC
 #define UFV_RESID_SC ""        /* lab (tools/lab/build_variant_lib.sh): " sc0 sc1" = write-through stores of the fp32 stream; measured free (LABNOTES round 5) */
 #endif
@@ -293,15 +296,23 @@ __device__ __forceinline__ void epilogue256_rope(const f32x4 (&acc)[4][MA0 + MA1
 // block a lane of v_mfma_scale_f32_16x16x128_f8f6f4 owns.  A wave's 32-column run of an accumulator row sits in its four 16-lane rows: block maximum = in-lane
 // maximum of 8 values + two cross-row exchanges; scale byte e = biased exponent of amax / 448 rounded UP to a power of two (no value saturates;
 // oracle.mx_quantize restates it bit for bit); codes = rne_e4m3(v * 2^(127 - e)); one v_permlane32_swap + one v_permlane16_swap leave lane row r with bytes
-// 8 r .. 8 r + 7 of the run: ONE 8-byte store per (row, run) + ONE scale-byte store (lane row 0; the other rows' go to a dropped offset): 4 MT store
+// 8 r .. 8 r + 7 of the run: ONE 8-byte store per (row, run).  The scale bytes of FOUR accumulator rows go out in one store: after the block maximum every lane of a
+// row's four (fq = 0..3) holds the byte, so lane row fq takes accumulator row 4 g + fq -- the CU's write-out is paced by store INSTRUCTIONS (37 cycles each with
+// every CU storing, LABNOTES round 4): a byte store per (row, run) made fc1's MX epilogue 11 us slower than the bf16 one.  2 MT + MT / 4 (SwiGLU: MT + MT / 4) store
 // instructions per wave and tile (NSTM), every one issued on every path.
-__device__ __forceinline__ void mx_store_run(const float (&va)[4], const float (&vb)[4], const __amdgpu_buffer_rsrc_t rs_q, const __amdgpu_buffer_rsrc_t rs_s,
-                                             unsigned off_q, unsigned off_s, int fq) {
+__device__ __forceinline__ unsigned mx_store_run(const float (&va)[4], const float (&vb)[4], const __amdgpu_buffer_rsrc_t rs_q, unsigned off_q) {
     float am = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) am = fmaxf(am, fmaxf(fabsf(va[j]), fabsf(vb[j])));
-    am = fmaxf(am, __shfl_xor(am, 16, 64));
-    am = fmaxf(am, __shfl_xor(am, 32, 64));
+    {   // maximum over the four 16-lane rows without the LDS crossbar (two __shfl_xor = two ds_bpermute round trips per run, 32 per tile, each behind its own wait:
+        // the MX epilogue of fc1 ran 10 us over the bf16 one): v_permlane16_swap(a, a) = ([r0 r0 r2 r2], [r1 r1 r3 r3]), v_permlane32_swap(c, c) = ([c0 c1 c0 c1], [c2 c3 c2 c3])
+        const unsigned ab = __builtin_bit_cast(unsigned, am);
+        auto p = __builtin_amdgcn_permlane16_swap(ab, ab, false, false);
+        const float c = fmaxf(__builtin_bit_cast(float, (unsigned)p[0]), __builtin_bit_cast(float, (unsigned)p[1]));
+        const unsigned cb = __builtin_bit_cast(unsigned, c);
+        auto q = __builtin_amdgcn_permlane32_swap(cb, cb, false, false);
+        am = fmaxf(__builtin_bit_cast(float, (unsigned)q[0]), __builtin_bit_cast(float, (unsigned)q[1]));
+    }
     const unsigned e = mx_scale_byte(am);
     const float inv = __builtin_bit_cast(float, (254u - e) << 23);                           // 2^(127 - e)
     int x = 0, y = 0;
@@ -315,7 +326,7 @@ __device__ __forceinline__ void mx_store_run(const float (&va)[4], const float (
     typedef __attribute__((ext_vector_type(2))) int i32x2;
     const i32x2 o = {(int)t[0], (int)t[1]};
     __builtin_amdgcn_raw_buffer_store_b64(o, rs_q, (int)off_q, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)e, rs_s, (int)(off_s | (fq ? 0x80000000u : 0u)), 0, 0);
+    return e;                                                  // every lane of the row's four holds the block's scale byte: the caller stores four rows' at once
 }
 
 // plain / activation form: the run = the wave's two adjacent n-tiles (32 consecutive columns), as in epilogue256_wide
@@ -324,21 +335,34 @@ __device__ __forceinline__ void epilogue256_wide_mx(const f32x4 (&acc)[4][MA0 + 
                                                     const f32x4 (&bias)[4]) {
     constexpr int MT = MA0 + MA1;
     const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (int)((unsigned)M * (unsigned)e.ldc), 0x20000);
-    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(e.out_bscale, 0, (int)((unsigned)M * (unsigned)e.ld_obs), 0x20000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(e.out_bscale, 0, (int)((unsigned)((M + 63) >> 6) * (unsigned)e.ld_obs), 0x20000);   // [ceil(M / 64)][ceil(N / 512)][64][16]
     const unsigned drop1 = n0 + 128 >= N ? 0x80000000u : 0u;
     UFV_EPI_MARK("BEGIN wide_mx");
+    static_assert(MT % 4 == 0, "the scale bytes of four accumulator rows leave in one store");
+    auto row_of = [&](int mt) { return (unsigned)(m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow); };
+    const unsigned col0 = (unsigned)(n0 + wc * 32);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const unsigned row = (unsigned)(m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow);
+    for (int g4 = 0; g4 < MT / 4; ++g4) {
+        unsigned es = 0;                                       // this lane's pick of the group's scale bytes: row 4 g4 + fq, run 0 | run 1 << 8
 #pragma unroll
-        for (int run = 0; run < 2; ++run) {
-            const f32x4 a4 = acc[2 * run][mt] + bias[2 * run], b4 = acc[2 * run + 1][mt] + bias[2 * run + 1];
-            float va[4], vb[4];
+        for (int k = 0; k < 4; ++k) {
+            const int mt = 4 * g4 + k;
+            const unsigned row = row_of(mt);
+            unsigned e2 = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { va[j] = act_apply_t<ACT>(a4[j]); vb[j] = act_apply_t<ACT>(b4[j]); }
-            const unsigned col = (unsigned)(n0 + run * 128 + wc * 32);
-            mx_store_run(va, vb, rs_q, rs_s, (row * (unsigned)e.ldc + col + 8u * fq) | (run ? drop1 : 0u), (row * (unsigned)e.ld_obs + (col >> 5)) | (run ? drop1 : 0u), fq);
+            for (int run = 0; run < 2; ++run) {
+                const f32x4 a4 = acc[2 * run][mt] + bias[2 * run], b4 = acc[2 * run + 1][mt] + bias[2 * run + 1];
+                float va[4], vb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { va[j] = act_apply_t<ACT>(a4[j]); vb[j] = act_apply_t<ACT>(b4[j]); }
+                e2 |= mx_store_run(va, vb, rs_q, (row * (unsigned)e.ldc + col0 + run * 128u + 8u * fq) | (run ? drop1 : 0u)) << (8 * run);
+            }
+            es = fq == k ? e2 : es;
         }
+        // run 0 / run 1 = K-tiles (n0 >> 7) & 3 (even) and + 1 of the consumer: adjacent bytes 4 wc + t of the row's 16 (a half past N: its byte is written too, nobody reads it)
+        const unsigned row = row_of(4 * g4 + fq);
+        const unsigned off_s = (row >> 6) * (unsigned)e.ld_obs + (col0 >> 9) * 1024u + (row & 63u) * 16u + ((col0 >> 5) & 3u) * 4u + ((col0 >> 7) & 3u);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)es, rs_s, (int)(off_s | (row >= (unsigned)M ? 0x80000000u : 0u)), 0, 0);
     }
     UFV_EPI_MARK("END wide_mx");
 }
@@ -350,17 +374,27 @@ template <int MA0, int MA1>
 __device__ __forceinline__ void epilogue256_swiglu_mx(const f32x4 (&acc)[4][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc, int frow, int fq) {
     constexpr int MT = MA0 + MA1;
     const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(e.out, 0, (int)((unsigned)M * (unsigned)e.ldc), 0x20000);
-    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(e.out_bscale, 0, (int)((unsigned)M * (unsigned)e.ld_obs), 0x20000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(e.out_bscale, 0, (int)((unsigned)((M + 63) >> 6) * (unsigned)e.ld_obs), 0x20000);   // [ceil(M / 64)][ceil(N_out / 512)][64][16]
     const unsigned drop1 = n0 + 128 >= N ? 0x80000000u : 0u;      // (half a tile past N: both halves feed one block, so the whole block is dropped -- N % 256 == 0 is required by the host)
     UFV_EPI_MARK("BEGIN swiglu_mx");
+    static_assert(MT % 4 == 0, "the scale bytes of four accumulator rows leave in one store");
+    auto row_of = [&](int mt) { return (unsigned)(m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow); };
+    const unsigned col = (unsigned)((n0 >> 1) + wc * 32);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const unsigned row = (unsigned)(m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow);
-        float va[4], vb[4];
+    for (int g4 = 0; g4 < MT / 4; ++g4) {
+        unsigned es = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { va[j] = swiglu_f(acc[0][mt][j], acc[1][mt][j]); vb[j] = swiglu_f(acc[2][mt][j], acc[3][mt][j]); }
-        const unsigned col = (unsigned)((n0 >> 1) + wc * 32);
-        mx_store_run(va, vb, rs_q, rs_s, (row * (unsigned)e.ldc + col + 8u * fq) | drop1, (row * (unsigned)e.ld_obs + (col >> 5)) | drop1, fq);
+        for (int k = 0; k < 4; ++k) {
+            const int mt = 4 * g4 + k;
+            float va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { va[j] = swiglu_f(acc[0][mt][j], acc[1][mt][j]); vb[j] = swiglu_f(acc[2][mt][j], acc[3][mt][j]); }
+            const unsigned e1 = mx_store_run(va, vb, rs_q, (row_of(mt) * (unsigned)e.ldc + col + 8u * fq) | drop1);
+            es = fq == k ? e1 : es;
+        }
+        const unsigned row = row_of(4 * g4 + fq);
+        const unsigned off_s = (row >> 6) * (unsigned)e.ld_obs + (col >> 9) * 1024u + (row & 63u) * 16u + ((col >> 5) & 3u) * 4u + ((col >> 7) & 3u);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)es, rs_s, (int)(off_s | drop1 | (row >= (unsigned)M ? 0x80000000u : 0u)), 0, 0);
     }
     UFV_EPI_MARK("END swiglu_mx");
 }
@@ -545,7 +579,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     static_assert(MX == 0 || (FP8 && PH2 && !SKT && !KSPL && !ROPE), "MX block scales belong to the e4m3 kernels");
     static_assert(!(MX & 2) || (!OUT_F32 && MA0 == 4 && MA1 == 4 && NB1 == 2), "the MX-emitting epilogues are built for the 256 x 256 tile");
     constexpr bool MXA = (MX & 1) != 0;
-    constexpr int SCL_OFF = 131072;                                  // MXA: two 1 KiB stages of A-operand block scales (256 rows x 4 bytes per K-tile) above the operand ring
+    // MXA: two 4 KiB slots of A-operand block scales (256 rows x 16 bytes per FOUR K-tiles).  NB1 == 1 shapes: in the unused upper half of the B1 half-tile slots of the
+    // operand ring (slot s at s * 65536 + 57344); else above the ring
+    constexpr int SCL_OFF = NB1 == 1 ? 57344 : 131072, SCL_STRIDE = NB1 == 1 ? 65536 : 4096;
     static_assert(!ROPE || (!OUT_F32 && !SWIGLU && !FP8 && !SKT && !KSPL && PH2 && NB1 == 2 && (MA0 + MA1) % 2 == 0),
                   "the fused RoPE epilogue: bf16 output, 256-column tiles (two heads of 128), accumulator rows in pairs");
     const char* A = reinterpret_cast<const char*>(Av);
@@ -650,7 +686,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             }
             return;
         }
-        if constexpr (MXA) ssrc = e.a_bscale + (size_t)min(m0_ + (wave & 3) * 64 + lane, M - 1) * e.ld_abs;
+        // block scales are stored in GROUPS OF FOUR K-TILES, 16 bytes per (row, group), byte 4 fq + (kt & 3) of a row = the scale of its K-block fq of K-tile kt: the 64
+        // rows a wave stages are 1 KiB contiguous, ONE piece per four K-tiles (row-major [M][K / 32], 64 lanes fetched 64 different cache lines per K-tile: the scale
+        // piece cost more address work than an operand half-tile; and one piece per K-tile was still +8 % on the 192 x 192 kernel), and a lane's four K-tile scales
+        // of a fragment row are ONE dword (one ds_read_b32 per fragment per four K-tiles + a shift per K-tile)
+        // ... and per BLOCK OF 64 ROWS all K-groups follow each other, [M / 64][K / 512][64 rows][16]: the pieces a wave fetches along K are consecutive KiBs.  (With the
+        // groups as outer planes, [K / 512][M][16], every piece of an item touched a new page 16 M bytes further on: 0.75 us per piece, 6 us for the prologue's -- fc2 ran
+        // 125 instead of 101 us, lab 5 / 6 / 7.)
+        if constexpr (MXA) {
+            const int srow = min(m0_ + (wave & 3) * 64 + lane, M - 1);
+            ssrc = e.a_bscale + (size_t)(srow >> 6) * e.ld_abs + (srow & 63) * 16;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -674,7 +720,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         }
         if constexpr (MXA) {
             if (which == 4) {                      // the K-tile's 4 scale bytes of 64 rows per wave: one dword per lane
-                if (kt < kend) __builtin_amdgcn_global_load_lds(GLB_PTR(ssrc + kt * 4), LDS_PTR(smem + SCL_OFF + d * 1024 + (wave & 3) * 256), 4, 0, 0);
+                // one piece = the scales of FOUR K-tiles (kt .. kt + 3, kt % 4 == 0) of 64 rows per wave, 16 bytes per row; slot = (kt / 4) & 1
+                if (kt < kend) __builtin_amdgcn_global_load_lds(GLB_PTR(ssrc + (size_t)(kt >> 2) * 1024), LDS_PTR(smem + SCL_OFF + ((kt >> 2) & 1) * SCL_STRIDE + (wave & 3) * 1024), 16, 0, 0);
                 return;
             }
         }
@@ -686,15 +733,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         }
     };
     auto prologue_loads = [&]() {      // first K-tile of the item complete + A0/B1 (PH2: A0/B0/B1) of its second K-tile
+        if constexpr (MXA) stage(0, 4, kbeg);      // the scales of K-tiles 0 .. 3 FIRST: the item's first wait needs them (every MX-A item starts at K-tile 0): the first wait of the item needs them (every MXA item starts at K-tile 0)
         stage(0, 0, kbeg); stage(0, 2, kbeg); stage(0, 3, kbeg);
-        if constexpr (MXA) stage(0, 4, kbeg);      // (the scales travel with the [A0 B0 B1] group of their K-tile: one more piece per wave in every counted wait)
         stage(0, 1, kbeg);
         stage(1, 0, kbeg + 1);
         if constexpr (PH2) stage(1, 2, kbeg + 1);
         stage(1, 3, kbeg + 1);
-        if constexpr (MXA) stage(1, 4, kbeg + 1);
     };
-    constexpr int L_ALL = T::LA0 + T::LA1 + T::LB0 + T::LB1 + (MXA ? 1 : 0);      // PH2: DMA instructions in flight behind the half-tiles that are needed next
+    constexpr int L_ALL = T::LA0 + T::LA1 + T::LB0 + T::LB1;      // PH2: DMA instructions in flight behind the half-tiles that are needed next
     // the counted wait that leaves exactly the last two staged half-tiles (A0, B1 of the K-tile after next) in flight
 #define UFV_WAIT_KEEP_A0_B1()                                                                              \
     do {                                                                                                     \
@@ -712,8 +758,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // MXA: the scaled MFMA applies lane group g's scale byte to K-block g, and its K-block j is the FIRST 16 bytes of lane groups 2 (j & 1), 2 (j & 1) + 1 for j < 2 and their
     // SECOND 16 bytes for j >= 2 (measured with one non-zero element per position, tools/scratch history in LABNOTES round 5): block j = chunks 2 j, 2 j + 1 of the row when lane
     // group g reads chunks g and 4 + g -- the bf16 mapping.  (Without scales any K order shared by both operands is right, which is all the plain e4m3 path needs.)
-    constexpr bool CH_BF16 = !FP8 || MXA;
-    const int coff0 = ((CH_BF16 ? fq : 2 * fq) ^ fx) << 4, coff1 = ((CH_BF16 ? 4 + fq : 2 * fq + 1) ^ fx) << 4;
+    // The plain e4m3 kernels take the same order (round 5; they used chunks 2 fq, 2 fq + 1 -- 32 contiguous bytes per lane): any K order shared by both operands gives the
+    // same sums, and this one reads LDS faster -- the 16 lanes of a row group then cover 8 different 16-byte chunks per read instead of pairs of adjacent ones
+    // (fc2 18432 x 1152 x 4352: 112 -> 101 us; down: 185 -> 177 us, lab 4 / 7).
+    const int coff0 = (fq ^ fx) << 4, coff1 = ((4 + fq) ^ fx) << 4;
 
     int m0, n0, k0, k1;
     bool have = next_item(m0, n0, k0, k1);
@@ -732,7 +780,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // instructions on every path between the UFV_EPI_MARK comments of each epilogue form against NST / NSTW / NSTS; the bit-identity tests against the 128-wide
     // kernel (tests/test_kernels_gpu.py) are the second guard.
     constexpr int NSTW = 2 * MT;
-    constexpr int NSTM = SWIGLU ? 2 * MT : 4 * MT;           // the MX-emitting epilogues: a code store + a scale-byte store per (row, run) | per row
+    constexpr int NSTM = (SWIGLU ? MT : 2 * MT) + MT / 4;     // the MX-emitting epilogues: a code store per (row, run) | per row + one scale store per four rows
     constexpr bool RELAX_OK = PH2 && !SKT && !KSPL && (L_ALL + NST <= 63);
     int relax = 0;                                           // 0: strict waits; 1: NST stores may stay in flight; 2: NSTW; 3: NSTS
     UFV_TSTAMP_DECL
@@ -745,7 +793,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 afr[4][2], bfr[PH2 ? 4 : 2][2];
-    int asc[MXA ? MT : 1];                                    // MXA: e8m0 block scale of each A fragment's row for this lane's 32-element K block (low byte)
+    int asc[MXA ? MT : 1];                                    // MXA: e8m0 block scale of each A fragment's row for this lane's 32-element K block of THIS K-tile (low byte)
+    unsigned asc_raw[MXA ? MT : 1];                           //      ... of four K-tiles, one byte each
+    int asc_sh = 0;
     auto read_a = [&](const char* half, auto hsel) {
         constexpr int h = decltype(hsel)::value;
 #pragma unroll
@@ -773,9 +823,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     __builtin_amdgcn_sched_barrier(0);                                                                       \
     __builtin_amdgcn_s_setprio(1);                                                                           \
     if constexpr (FP8) {                                                                                     \
+        if constexpr (MXA && (MTB) == 0) {                                                                   \
+            _Pragma("unroll") for (int m_ = 0; m_ < MT; ++m_) asc[m_] = (int)(asc_raw[m_] >> asc_sh);        \
+        }                                                                                                    \
         _Pragma("unroll") for (int n_ = 0; n_ < NCNT; ++n_)                                                  \
             _Pragma("unroll") for (int m_ = 0; m_ < MCNT; ++m_)                                              \
-                if constexpr (MXA)                                                                           \
+                if constexpr (MXA && UFV_MX_LAB == 0)                                                        \
                     acc[NTB + n_][MTB + m_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(              \
                         cat8(bfr[n_][0], bfr[n_][1]), cat8(afr[m_][0], afr[m_][1]), acc[NTB + n_][MTB + m_], 0, 0, 0, 0x7f, 0, asc[MTB + m_]); \
                 else                                                                                         \
@@ -787,6 +840,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             _Pragma("unroll") for (int m_ = 0; m_ < MCNT; ++m_)                                              \
                 acc[NTB + n_][MTB + m_] =                                                                    \
                     __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[n_][kk], afr[m_][kk], acc[NTB + n_][MTB + m_], 0, 0, 0); \
+    }                                                                                                        \
+    if constexpr (MXA) {                                                                                     \
+        /* anchor: with the scale shifts in front of them hipcc placed this step's MFMAs BEHIND the closing barrier, at the end of the next load step (the    */ \
+        /* listing showed `s_setprio 1; s_setprio 0` with nothing between: both wave groups then multiply and wait in the same phases).  An empty volatile asm */ \
+        /* that names the accumulators keeps their producers in front of it. */ \
+        _Pragma("unroll") for (int n_ = 0; n_ < NCNT; ++n_)                                                  \
+            _Pragma("unroll") for (int m_ = 0; m_ < MCNT; ++m_) asm volatile("" : "+v"(acc[NTB + n_][MTB + m_]));  \
     }                                                                                                        \
     __builtin_amdgcn_s_setprio(0);                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -938,7 +998,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         if (tt + 1 < len) ktile(P1{}, tt + 1);
     }
     } else if constexpr (PH2) {
-    for (int tt = 0; tt < len; ++tt) {
+    // One K-tile.  Q = t & 3 as a COMPILE-TIME value in the MX-A kernels (the loop below is unrolled by four there), -1 elsewhere.  MX-A: every fourth K-tile the scales
+    // of the next four join the [A0 B0 B1] group two K-tiles ahead (Q == 2) as its YOUNGEST piece; that phase's wait and the next phase A's (Q == 3) keep one more
+    // operation in flight.  Why compile-time: with `if ((t + 2) & 3 == 0) stage(...)` as a run-time branch inside the load step hipcc split the step's basic block and
+    // SANK phase A's MFMAs below the next load step's waits -- the two wave groups then multiplied at the same time and waited at the same time (fc2: 101 -> 130 us;
+    // the listing showed `s_setprio 1; s_setprio 0` with nothing between them).  Left uncounted the piece made two waits per four K-tiles retire an operand piece issued
+    // one phase earlier: a memory latency each.
+    auto ktile2 = [&](auto qc, int tt) {
+        constexpr int Q = decltype(qc)::value;
         const int t = k0 + tt, d = tt & 1;
         const char* buf = smem + d * 65536;
         // phase A: A0, B0, B1 -> top half; prefetch A1[t+1]; retire A1[t]
@@ -947,13 +1014,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         read_a(buf, H0{});
         read_b(buf + 49152, H1{});
         if constexpr (MXA) {
-            // the block scales of ALL of this wave's A fragments (both halves) are read here, in phase A: the slot is re-staged in phase B, which the lagging wave
-            // group enters one barrier later -- a read in phase B would race the leading group's DMA.  Lane (frow, fq) takes byte fq of its row's dword.
+            // every fourth K-tile: the dword of each A fragment's row (this lane's K-block, four K-tiles) from the slot of the group; read HERE, in phase A -- the slot is
+            // re-staged in a phase B, which the lagging wave group enters one barrier later.  The byte of THIS K-tile is shifted down behind the barrier (asc, in
+            // UFV_SYNC_THEN_MMA): a vector instruction that depends on an LDS read, placed in the load step, would pull the compiler's lgkmcnt wait for every fragment
+            // read in front of the DMA issue (measured: 159 -> 219 us on the 192 x 192 kernel).
+            if constexpr (Q == 0) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int trow = mt < MA0 ? wr * 16 * MA0 + mt * 16 + frow : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16 + frow;
-                asc[mt] = (int)(*reinterpret_cast<const unsigned*>(smem + SCL_OFF + d * 1024 + trow * 4) >> (8 * fq));
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int trow = mt < MA0 ? wr * 16 * MA0 + mt * 16 + frow : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16 + frow;
+                    asc_raw[mt] = *reinterpret_cast<const unsigned*>(smem + SCL_OFF + ((t >> 2) & 1) * SCL_STRIDE + trow * 16 + fq * 4);
+                }
             }
+            asc_sh = 8 * (Q < 0 ? 0 : Q);
         }
         UFV_GSTAMP(9);
         stage(d ^ 1, 1, t + 1);
@@ -963,7 +1035,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
             else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
             else if (RELAX_OK && relax == 4 && tt == 0) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? L_ALL + NSTM : L_ALL>();
-            else wait_vmcnt<L_ALL>();
+            else wait_vmcnt<L_ALL + ((MXA && Q == 3) ? 1 : 0)>();          // (Q == 3: the scale piece that joined [A0 B0 B1][t+1]; it was issued iff tt + 1 < len)
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, 0, MA0, 1, 2, 3)
         // phase B: A1 -> bottom half; prefetch A0 / B0 / B1 [t+2]; retire A0 / B0 / B1 [t+1]
@@ -973,18 +1045,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         stage(d, 0, t + 2);
         stage(d, 2, t + 2);
         stage(d, 3, t + 2);
-        if constexpr (MXA) stage(d, 4, t + 2);
+        if constexpr (MXA && Q == 2) stage(d, 4, t + 2);           // K-tiles t + 2 .. t + 5 (issued iff t + 2 < kend, i.e. tt + 2 < len: the branch of the wait below)
         UFV_GSTAMP(12);
         if (tt + 2 < len) {                            // behind them: A1[t+1] and A0/B0/B1[t+2]
             if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
             else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
             else if (RELAX_OK && relax == 4 && tt == 0) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? L_ALL + NSTM : L_ALL>();
-            else wait_vmcnt<L_ALL>();
+            else wait_vmcnt<L_ALL + ((MXA && Q == 2) ? 1 : 0)>();
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, MA0, MA1, 5, 6, 7)
         UFV_GSTAMP(8);
         UFV_TSTAMP_K(tt);
+    };
+    if constexpr (MXA) {
+        for (int tt = 0; tt < len; tt += 4) {           // (every MX-A item starts at K-tile 0: tt & 3 == t & 3)
+            ktile2(std::integral_constant<int, 0>{}, tt);
+            if (tt + 1 < len) ktile2(std::integral_constant<int, 1>{}, tt + 1);
+            if (tt + 2 < len) ktile2(std::integral_constant<int, 2>{}, tt + 2);
+            if (tt + 3 < len) ktile2(std::integral_constant<int, 3>{}, tt + 3);
+        }
+    } else {
+        for (int tt = 0; tt < len; ++tt) ktile2(std::integral_constant<int, -1>{}, tt);
     }
     } else {
     for (int tt = 0; tt < len; ++tt) {
@@ -1177,7 +1259,7 @@ static inline int pp_group(int tiles_m) { return tiles_m <= 16 ? tiles_m : cdiv(
 
 template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false, bool ROPE = false, int MX = 0>
 static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st, int ksplit = 1) {
-    constexpr int SMEM = SMEM256 + ((MX & 1) ? 2048 : 0);          // MX & 1: two stages of A block scales above the operand ring
+    constexpr int SMEM = SMEM256 + (((MX & 1) && NB1 != 1) ? 8192 : 0);          // MX & 1: two slots of A block scales (four K-tiles each) above the operand ring unless they fit inside it
     UFV_ONCE_PER_DEVICE(
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE, MX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);

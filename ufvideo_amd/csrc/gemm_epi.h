@@ -16,9 +16,11 @@ struct Epi {
     const float* rope_tab = nullptr; // f32 [M, 128]: cos (64) | sin (64) of every row's position (ufv_rope_table)
     void* out_kv = nullptr;          // bf16 KV-cache row of the call's first position: row m = [Hkv * 128 k | Hkv * 128 v] at out_kv + m * ldkv
     int ldkv = 0, rope_hq = 0, rope_hkv = 0;
-    // MX-style block scales of e4m3 activations (gemm_nt_256<..., MX>): one e8m0 byte per (row, 32 consecutive K / N elements), value 2^(byte - 127)
-    const unsigned char* a_bscale = nullptr;   // MX & 1: scales of the A operand, [M, ld_abs] bytes (K / 32 per row); scale_m is not used then
-    unsigned char* out_bscale = nullptr;       // MX & 2: the epilogue writes e4m3 codes to `out` and their block scales here, [M, ld_obs] bytes
+    // MX-style block scales of e4m3 activations (gemm_nt_256<..., MX>): one e8m0 byte per (row, 32 consecutive K / N elements), value 2^(byte - 127), stored
+    // as [ceil(M / 64)][ceil(K / 512)][64 rows][16]: per (row, group of four K-tiles) 16 bytes, byte 4 (b & 3) + (b >> 2) = block b of the group (b & 3 = the 32-element
+    // block inside its K-tile); the groups of a 64-row block follow each other (include/ufv.h ufv_quantize_mx)
+    const unsigned char* a_bscale = nullptr;   // MX & 1: scales of the A operand; ld_abs = bytes per 64-row block (= 1024 ceil(K / 512)); scale_m is not used then
+    unsigned char* out_bscale = nullptr;       // MX & 2: the epilogue writes e4m3 codes to `out` and their block scales here, ld_obs bytes per 64-row block
     int ld_abs = 0, ld_obs = 0;
 };
 

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void quantize_mx_k(const void* __restrict__ x,
     }
     const unsigned e = mx_scale_byte(amax);
     const float inv = __builtin_bit_cast(float, (254u - e) << 23);
-    bs[(int64_t)m * ldb + b] = (uint8_t)e;
+    bs[(int64_t)(m >> 6) * ldb + (int64_t)(b >> 4) * 1024 + (m & 63) * 16 + (b & 3) * 4 + ((b >> 2) & 3)] = (uint8_t)e;      // [M / 64][K / 512][64][16], byte 4 (block in K-tile) + (K-tile in group)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         int w = 0;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void dequantize_mx_k(const uint8_t* __restrict
     if (id >= (int64_t)M * (K >> 2)) return;
     const int m = (int)(id / (K >> 2)), k = (int)(id % (K >> 2)) * 4;
     const int w = *reinterpret_cast<const int*>(q + (int64_t)m * ldq + k);
-    const float sc = __builtin_bit_cast(float, (unsigned)bs[(int64_t)m * ldb + (k >> 5)] << 23);
+    const float sc = __builtin_bit_cast(float, (unsigned)bs[(int64_t)(m >> 6) * ldb + (int64_t)(k >> 9) * 1024 + (m & 63) * 16 + ((k >> 5) & 3) * 4 + ((k >> 7) & 3)] << 23);
     f32x4 o = {__builtin_amdgcn_cvt_f32_fp8(w, 0) * sc, __builtin_amdgcn_cvt_f32_fp8(w, 1) * sc, __builtin_amdgcn_cvt_f32_fp8(w, 2) * sc, __builtin_amdgcn_cvt_f32_fp8(w, 3) * sc};
     *reinterpret_cast<f32x4*>(out + (int64_t)m * ldo + k) = o;
 }
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void dequantize_mx_k(const uint8_t* __restrict
 }  // namespace
 
 extern "C" int ufv_quantize_mx(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, void* bscale, int64_t ldb, int M, int K, void* stream) {
-    UFV_REQUIRE(x && q && bscale && M > 0 && K > 0 && K % 32 == 0 && ldx % 4 == 0 && ldq % 4 == 0 && ldb >= K / 32 && (uintptr_t)q % 4 == 0 && (uintptr_t)x % 8 == 0,
-                "ufv_quantize_mx: K %% 32 == 0, row pitches multiples of 4, ldb >= K / 32 (K=%d)", K);
+    UFV_REQUIRE(x && q && bscale && M > 0 && K > 0 && K % 128 == 0 && ldx % 4 == 0 && ldq % 4 == 0 && ldb % 1024 == 0 && ldb >= 1024 * ((K + 511) / 512) && (uintptr_t)q % 4 == 0 && (uintptr_t)x % 8 == 0,
+                "ufv_quantize_mx: K %% 128 == 0, row pitches multiples of 4, ldb = bytes per 64-row block >= 1024 ceil(K / 512) (K=%d)", K);
     const int nb = K / 32;
     const int64_t total = (int64_t)M * nb;
     const dim3 grid((unsigned)((total + 255) / 256));
@@ -290,7 +290,7 @@ extern "C" int ufv_quantize_mx(const void* x, int x_dtype, int64_t ldx, void* q,
 }
 
 extern "C" int ufv_dequantize_mx(const void* q, int64_t ldq, const void* bscale, int64_t ldb, float* out, int64_t ldo, int M, int K, void* stream) {
-    UFV_REQUIRE(q && bscale && out && M > 0 && K > 0 && K % 32 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && (uintptr_t)q % 4 == 0 && (uintptr_t)out % 16 == 0, "ufv_dequantize_mx: bad arguments");
+    UFV_REQUIRE(q && bscale && out && M > 0 && K > 0 && K % 128 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && (uintptr_t)q % 4 == 0 && (uintptr_t)out % 16 == 0, "ufv_dequantize_mx: bad arguments");
     const int64_t total = (int64_t)M * (K / 4);
     hipLaunchKernelGGL(dequantize_mx_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), (const uint8_t*)q, ldq, (const uint8_t*)bscale, ldb, out, ldo, M, K);
     UFV_CHECK_LAUNCH();

@@ -162,8 +162,14 @@ class _VitBody(PackedModule):
             ops.gemm(o, L["wo"], bias=L["bo"], resid=x, out=x)
             hq = (ops.layernorm(x, L["ln2"][0], L["ln2"][1], cfg.layer_norm_eps, quant=True) if q8
                   else ops.layernorm(x, L["ln2"][0], L["ln2"][1], cfg.layer_norm_eps, out=h))
-            ops.gemm(hq, L["w1"], bias=L["b1"], act=cfg.hidden_act, out=ff)
-            ops.gemm(ff, L["w2"], bias=L["b2"], resid=x, out=x)
+            if (q8 and isinstance(L["w1"], ops.Fp8Weight) and isinstance(L["w2"], ops.Fp8Weight) and M >= 256 and pk["Ip"] % 256 == 0
+                    and os.environ.get("UFV_FP8_NO_MX") is None):
+                # W8A8, fused (round 5): fc1's GELU epilogue writes e4m3 codes + MX block scales, fc2 takes them as its block-scaled A operand: no quantise launch
+                ffm = ops.gemm_fp8_mx(hq, L["w1"], bias=L["b1"], act=cfg.hidden_act, mx_out=True)
+                ops.gemm_fp8_mx(ffm, L["w2"], bias=L["b2"], resid=x, out=x)
+            else:
+                ops.gemm(hq, L["w1"], bias=L["b1"], act=cfg.hidden_act, out=ff)
+                ops.gemm(ff, L["w2"], bias=L["b2"], resid=x, out=x)
         return x, S
 
 

@@ -179,6 +179,11 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
             if self.gemm_dtype == "fp8":          # prefill GEMMs in W8A8; the bf16 copies stay for the one-call decode step
                 for k in ("wqkv", "wo", "wgu", "wd"):
                     layers[-1][k + "8"] = self.gw(layers[-1][k])
+                # round 5: the prefill's gate/up GEMM emits its SwiGLU output as e4m3 codes + MX block scales (no quantise launch in front of down_proj); that
+                # output's columns are in the epilogue's block order, which down_proj's weight carries on its K axis (a second e4m3 copy: 68 MB per layer at 7B)
+                wd8 = layers[-1]["wd8"]
+                if isinstance(wd8, ops.Fp8Weight) and layers[-1]["wd"].shape[1] % 128 == 0 and os.environ.get("UFV_FP8_NO_MX") is None:
+                    layers[-1]["wd8m"] = ops.Fp8Weight(layers[-1]["wd"], mx_swiglu_cols=True)
         pk["layers"] = layers
         return pk
 
@@ -225,8 +230,13 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
                               (0, kvb.stride(0)), causal=True, q_pos0=p0, out=o[off:off + n])
             ops.gemm(o, L["wo"], resid=x, out=x)
             hq = ops.rmsnorm(x, L["ln2"], eps, quant=True) if q8 else ops.rmsnorm(x, L["ln2"], eps, out=h)
-            ops.gemm(hq, L["wgu"], swiglu=True, out=act)
-            ops.gemm(act, L["wd"], resid=x, out=x)
+            if q8 and "wd8m" in L and S >= 256 and isinstance(L["wgu"], ops.Fp8Weight) and L["wgu"].shape[0] % 256 == 0:
+                # W8A8, fused: gate/up (SwiGLU epilogue -> e4m3 + MX block scales) -> down (block-scaled A operand); ufv_gemm_fp8_mx
+                actm = ops.gemm_fp8_mx(hq, L["wgu"], swiglu=True, mx_out=True)
+                ops.gemm_fp8_mx(actm, L["wd8m"], resid=x, out=x)
+            else:
+                ops.gemm(hq, L["wgu"], swiglu=True, out=act)
+                ops.gemm(act, L["wd"], resid=x, out=x)
             if collect_hidden is not None and li < len(pk["layers"]) - 1:
                 collect_hidden.append(x.clone())
         for _, n, c, p0 in segs:

@@ -97,12 +97,19 @@ class QAct:
 
 
 class MxAct:
-    """A block-quantised activation (round 5): e4m3 codes [M, K] + one e8m0 scale byte per (row, 32 elements) [M, K / 32] -- what the MX-emitting GEMM epilogues
+    """A block-quantised activation (round 5): e4m3 codes [M, K] + one e8m0 scale byte per (row, 32 elements), as [ceil(M / 64), ceil(K / 512), 64, 16] (include/ufv.h) -- what the MX-emitting GEMM epilogues
     write and `gemm` consumes with an Fp8Weight through ufv_gemm_fp8_mx.  `swiglu_cols`: the columns are in the SwiGLU epilogue's block order (see ufv.h)."""
 
     def __init__(self, q, bscale, swiglu_cols=False):
         self.q, self.bscale, self.swiglu_cols = q, bscale, swiglu_cols
         self.shape = tuple(q.shape)
+
+    def scales_row_major(self):
+        """[M, K / 32] uint8: the scale bytes in row-major block order (tests / the oracle's layout)"""
+        M, K = self.q.shape
+        nb, G = self.bscale.shape[:2]
+        g = self.bscale.view(nb, G, 64, 4, 4).permute(0, 2, 1, 4, 3)         # [row block, row, group, K-tile in group, block in K-tile]
+        return g.reshape(nb * 64, -1)[:M, :K // 32]
 
 
 def mx_swiglu_perm(n, device=None):
@@ -118,7 +125,7 @@ def quantize_mx(x):
     _chk(x, name="x")
     M, K = x.shape
     q = torch.empty((M, K), device=x.device, dtype=torch.uint8)
-    bs = torch.empty((M, K // 32), device=x.device, dtype=torch.uint8)
+    bs = torch.empty(((M + 63) // 64, (K + 511) // 512, 64, 16), device=x.device, dtype=torch.uint8)           # include/ufv.h ufv_quantize_mx
     _lib.call("ufv_quantize_mx", x.data_ptr(), _DT[x.dtype], x.stride(0), q.data_ptr(), q.stride(0), bs.data_ptr(), bs.stride(0), M, K, _stream())
     return MxAct(q, bs)
 
@@ -140,7 +147,7 @@ def gemm_fp8_mx(a, w, bias=None, act=None, resid=None, out=None, out_dtype=torch
     is_mx = isinstance(a, MxAct)
     if mx_out:
         q = torch.empty((M, n_out), device=a.q.device, dtype=torch.uint8)
-        bs = torch.empty((M, n_out // 32), device=a.q.device, dtype=torch.uint8)
+        bs = torch.empty(((M + 63) // 64, (n_out + 511) // 512, 64, 16), device=a.q.device, dtype=torch.uint8)
         _lib.call("ufv_gemm_fp8_mx", a.q.data_ptr(), a.q.stride(0), None if is_mx else a.scale.data_ptr(), a.bscale.data_ptr() if is_mx else None,
                   a.bscale.stride(0) if is_mx else 0, w.q.data_ptr(), w.q.stride(0), w.scale.data_ptr(), q.data_ptr(), q.stride(0), 0, bs.data_ptr(), bs.stride(0),
                   M, N, K, _ptr(bias), ACT[act], None, 0, int(swiglu), _stream())
