@@ -204,7 +204,16 @@ def test_every_fp8_gemm_inside_the_model_is_exact_for_its_own_input():
         y = orig(aq, a_scale, w, bias=bias, act=act, resid=resid, resid_rows=resid_rows, out=out, out_dtype=out_dtype, swiglu=swiglu, kernel=kernel)
         calls.append(dict(aq=aq.clone(), sa=a_scale.clone(), w=w, bias=bias, act=act, resid=r0, resid_rows=resid_rows, swiglu=swiglu, y=y.clone()))
         return y
+    mx_calls = []
+    orig_mx = ops.gemm_fp8_mx
+
+    def spy_mx(a, w, bias=None, act=None, resid=None, out=None, out_dtype=torch.bfloat16, swiglu=False, mx_out=False):
+        r0 = resid.clone() if resid is not None else None
+        y = orig_mx(a, w, bias=bias, act=act, resid=resid, out=out, out_dtype=out_dtype, swiglu=swiglu, mx_out=mx_out)
+        mx_calls.append(dict(a=a, w=w, bias=bias, act=act, resid=r0, swiglu=swiglu, mx_out=mx_out, y=y if mx_out else y.clone()))
+        return y
     ops.gemm_fp8 = spy
+    ops.gemm_fp8_mx = spy_mx
     try:
         cfg = dict(vocab_size=512, hidden_size=3584, intermediate_size=18944, num_hidden_layers=1, num_attention_heads=28, num_key_value_heads=4,
                    rope_theta=1e6, rms_norm_eps=1e-6)
@@ -224,7 +233,9 @@ def test_every_fp8_gemm_inside_the_model_is_exact_for_its_own_input():
         tower(torch.randn(1, 3, 336, 336, generator=torch.Generator().manual_seed(13)).to(DEV))
     finally:
         ops.gemm_fp8 = orig
-    assert n_llm == 4 and len(calls) == 4 + 2 * 4, (n_llm, len(calls))            # qkv, o, gate/up, down; per ViT layer qkv, out, fc1, fc2
+        ops.gemm_fp8_mx = orig_mx
+    # per-row-scaled GEMMs: qkv, o (+ per ViT layer qkv, out); the fused MX chain (round 5): gate/up -> down (+ per ViT layer fc1 -> fc2)
+    assert n_llm == 2 and len(calls) == 2 + 2 * 2 and len(mx_calls) == 2 + 2 * 2, (n_llm, len(calls), len(mx_calls))
     acts = {None: lambda v: v, "gelu_pytorch_tanh": lambda v: F.gelu(v, approximate="tanh"), "gelu_tanh": lambda v: F.gelu(v, approximate="tanh"),
             "gelu": F.gelu, "silu": F.silu}
     for i, c in enumerate(calls):
@@ -248,6 +259,38 @@ def test_every_fp8_gemm_inside_the_model_is_exact_for_its_own_input():
         tol = (2.0 ** -8 + 1e-4) if c["y"].dtype == torch.bfloat16 else (2e-6 * K ** 0.5 + 1e-5)
         err = float((y - ref).abs().max()) / top
         assert err <= tol, (i, tuple(ref.shape), K, c["y"].dtype, err, tol)
+
+
+    # the MX chain: the producer's output (codes + block scales, dequantised) against oracle.mx_quantize of the fp64 restatement of ITS input, the consumer against
+    # fp64 sums of the codes it was handed (a SwiGLU producer's columns and its consumer's weight carry the same permutation: the products are taken as stored)
+    for i, c in enumerate(mx_calls):
+        w = ops.dequantize_fp8(c["w"].q, c["w"].scale).double()
+        if c["mx_out"]:
+            a = ops.dequantize_fp8(c["a"].q, c["a"].scale).double()
+            ref = a @ w.t()
+            if c["swiglu"]:
+                Mr, N2 = ref.shape
+                r4 = ref.view(Mr, N2 // 32, 2, 16)
+                ref = (F.silu(r4[:, :, 0]) * r4[:, :, 1]).reshape(Mr, N2 // 2)
+                ref = ref[:, ops.mx_swiglu_perm(N2 // 2, ref.device)]                 # physical column order of the epilogue
+            else:
+                ref = acts[c["act"]](ref + c["bias"][: ref.shape[1]].double())
+            want, _, _ = O.mx_quantize(ref.float().cpu())
+            got = ops.dequantize_mx(c["y"]).cpu()
+            assert float((got - want).abs().max()) <= 0.0725 * float(want.abs().max()), i      # one e4m3 step of the largest block
+            assert float(((got - want).abs() > 1e-6).float().mean()) < 0.02, i
+        else:
+            a = ops.dequantize_mx(c["a"]).double()
+            ref = a @ w.t()
+            if c["bias"] is not None:
+                ref = ref + c["bias"][: ref.shape[1]].double()
+            if c["resid"] is not None:
+                ref = ref + c["resid"].double()
+            y = c["y"].double()
+            K = a.shape[1]
+            tol = (2.0 ** -8 + 1e-4) if c["y"].dtype == torch.bfloat16 else (2e-6 * K ** 0.5 + 1e-5)
+            err = float((y - ref).abs().max()) / float(ref.abs().max())
+            assert err <= tol, (i, tuple(ref.shape), K, err, tol)
 
 
 def test_sam2_trunk_runs_its_gemms_in_fp8_under_set_gemm_dtype():

@@ -15,7 +15,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 HIPCC = "/opt/rocm/bin/hipcc"
-SOURCES = ("gemm256.hip", "gemm256_b.hip", "gemm256_q.hip", "gemm256_r.hip")       # 256x256 (+ SwiGLU), the named bf16 tile shapes, the e4m3 shapes, the fused QKV + RoPE form
+SOURCES = ("gemm256.hip", "gemm256_b.hip", "gemm256_q.hip", "gemm256_r.hip", "gemm256_m.hip", "gemm256_m2.hip")       # 256x256 (+ SwiGLU), the named bf16 / e4m3 shapes, the fused QKV + RoPE form, the MX forms
 
 
 @pytest.fixture(scope="module")
@@ -49,6 +49,8 @@ def test_every_epilogue_path_issues_the_store_count_the_relaxed_waits_assume(lis
     assert seen["gemm256_b.hip"][0] >= 100 and {"wide", "resid", "plain"} <= seen["gemm256_b.hip"][1], seen
     assert seen["gemm256_q.hip"][0] >= 100 and {"wide", "plain"} <= seen["gemm256_q.hip"][1], seen
     assert seen["gemm256_r.hip"] == (1, {"rope"}), seen
+    assert seen["gemm256_m.hip"][0] >= 60 and "plain" in seen["gemm256_m.hip"][1], seen          # block-scaled A operand: the per-row kernels' epilogues
+    assert seen["gemm256_m2.hip"][0] >= 8 and {"wide_mx", "swiglu_mx"} <= seen["gemm256_m2.hip"][1], seen
 
 
 def test_the_wide_epilogues_are_straight_line_code(listings):

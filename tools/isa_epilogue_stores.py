@@ -10,6 +10,8 @@ STORES and LOADS over all paths.
 expected (MT = MA0 + MA1 accumulator rows, NT = 2 + NB1 n-tiles, from the kernel's template arguments in its mangled name):
   wide         stores == 2 MT on EVERY path (NSTW), no loads
   swiglu_wide  stores == MT on every path (NSTS), no loads
+  wide_mx      stores == 2 MT + MT / 4 on every path (NSTM: e4m3 codes per (row, run) + the scale bytes of four rows per store), no loads
+  swiglu_mx    stores == MT + MT / 4 on every path, no loads
   rope         stores == 2 MT on every path (NSTW), no loads (the cos / sin rows are fetched before the next tile's prologue DMA, outside the region)
   resid        stores == MT NT on every path (NST), loads == MT NT (all retired by counted waits inside the form)
   plain        stores <= NST = (SWIGLU ? 2 MT : MT NT) with equality on the all-in-range path (the form relaxes on interior tiles only)
@@ -19,7 +21,7 @@ import sys
 
 VM_STORE = re.compile(r'^(buffer_store|global_store|flat_store|scratch_store)')
 VM_LOAD = re.compile(r'^(buffer_load|global_load|flat_load|scratch_load)')
-KERNEL = re.compile(r'gemm_nt_256ILb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)E')
+KERNEL = re.compile(r'gemm_nt_256ILb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELi(\d)E')
 
 
 def kernels(listing):
@@ -34,7 +36,7 @@ def kernels(listing):
                 body = body[:j + 1]
                 break
         m = KERNEL.search(name)
-        t = dict(zip(("OUT_F32", "SWIGLU", "FP8", "SKT", "MA0", "MA1", "NB1", "PH2", "KSPL", "ROPE"), (int(x) for x in m.groups())))
+        t = dict(zip(("OUT_F32", "SWIGLU", "FP8", "SKT", "MA0", "MA1", "NB1", "PH2", "KSPL", "ROPE", "MX"), (int(x) for x in m.groups())))
         out.append((name, t, body))
     return out
 
@@ -138,6 +140,10 @@ def expected(form, t):
         return dict(stores=(2 * MT, 2 * MT), loads=(0, 0))
     if form == "swiglu_wide":
         return dict(stores=(MT, MT), loads=(0, 0))
+    if form == "wide_mx":                          # MX-emitting epilogue: a code store per (row, run) + one scale store per four rows (NSTM)
+        return dict(stores=(2 * MT + MT // 4, 2 * MT + MT // 4), loads=(0, 0))
+    if form == "swiglu_mx":
+        return dict(stores=(MT + MT // 4, MT + MT // 4), loads=(0, 0))
     if form == "rope":                             # the fused QKV + RoPE + KV-append epilogue: (MT / 2 row pairs) x (2 heads) x (2 n-tiles) = 2 MT = NSTW
         return dict(stores=(2 * MT, 2 * MT), loads=(0, 0))
     if form == "resid":
@@ -153,6 +159,8 @@ def relax_ok(t):
     MT, NT = t["MA0"] + t["MA1"], 2 + t["NB1"]
     la0, la1 = (2 if t["MA0"] > 2 else 1), (2 if t["MA1"] > 2 else 1)
     l_all = la0 + la1 + 2 + t["NB1"]
+    if t.get("MX", 0) & 2:
+        return bool(t["PH2"]) and l_all + (MT if t["SWIGLU"] else 2 * MT) + MT // 4 <= 63
     nst = 2 * MT if t["SWIGLU"] else MT * NT
     return bool(t["PH2"]) and not t["SKT"] and not t["KSPL"] and l_all + nst <= 63
 
