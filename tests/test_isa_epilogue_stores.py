@@ -89,3 +89,15 @@ def test_the_check_sees_a_missing_and_an_extra_store(listings):
     s = next(i for i in range(b, len(lines)) if re.match(r"\s*global_store_dwordx", lines[i]))
     bad, _, _ = I.check("\n".join(lines[:s] + [lines[s]] + lines[s:]))
     assert bad and bad[0][1] == "resid" and bad[0][2] == "stores"
+
+
+def test_no_mfma_step_is_empty(listings):
+    """Every MFMA step of the ping-pong K loop is bracketed by `s_setprio 1` ... `s_setprio 0` between two barriers: one wave group multiplies while the other
+    loads.  hipcc once moved a step's MFMAs BEHIND its closing barrier (round 5, the block-scaled e4m3 kernels: a shift in front of the MFMAs was enough; the
+    listing showed the two s_setprio back to back, the two groups then multiplied and waited in the same phases and the kernel ran 25 % slower -- every numerics
+    test green).  The listing must hold no such empty step."""
+    for src, text in listings.items():
+        lines = [l.strip() for l in text.split("\n") if l.strip() and not l.strip().startswith(";")]
+        empty = sum(1 for a, b in zip(lines, lines[1:]) if a.startswith("s_setprio 1") and b.startswith("s_setprio 0"))
+        steps = sum(1 for a in lines if a.startswith("s_setprio 1"))
+        assert steps > 0 and empty == 0, (src, steps, empty)
