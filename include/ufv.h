@@ -139,6 +139,9 @@ int ufv_rope_kv_table(void* qkv, int ldqkv, int S, int Hq, int Hkv, int hd, cons
  * would run (host arithmetic only) or 0 when the caller should issue the unfused pair (also when the environment variable UFV_NO_FUSED_ROPE is set);
  * shape = 0 lets the call choose. */
 int ufv_gemm_qkv_rope_shape(int S, int Hq, int Hkv, int hd, int K);
+/* the W8A8 form (e4m3 codes + fp32 row scales of A, per-channel scales of W, as ufv_gemm_fp8): same epilogue behind the de-quantising scale; head_dim 128, S >= 256 */
+int ufv_gemm_qkv_rope_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, const float* bias, void* q_out, int ldq,
+                          void* kv_row0, int ldkv, int S, int Hq, int Hkv, int hd, int K, const float* rope_table, void* stream);
 int ufv_gemm_qkv_rope(const void* A, int lda, const void* W, int ldw, const float* bias, void* q_out, int ldq, void* kv_row0, int ldkv, int S, int Hq,
                       int Hkv, int hd, int K, const float* rope_table, int shape, void* stream);
 

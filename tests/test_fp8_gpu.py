@@ -154,7 +154,10 @@ def test_fulldim_siglip_fp8_vs_restatement():
     y8 = tower(x.to(DEV)).float().cpu()
     with O.fp8_linear_mode():
         ref = O.siglip_tower(sd, vit, x)
-    assert rms_rel(y8, ref) < rms_rel(y8, y16) < 0.15, (rms_rel(y8, ref), rms_rel(y8, y16))
+    # Round 5: the HIP W8A8 tower keeps out_proj in bf16 and hands fc1 -> fc2 an MX block-scaled activation, while oracle.fp8_linear_mode quantises every linear whose
+    # shape fits per token: the two schemes are no longer the same point set, so HIP need not be closer to that restatement than to bf16 (it is more accurate than it).
+    # Both distances stay at the e4m3 level; what pins the kernels is test_every_fp8_gemm_inside_the_model_is_exact_for_its_own_input.
+    assert rms_rel(y8, ref) < 0.15 and rms_rel(y8, y16) < 0.15, (rms_rel(y8, ref), rms_rel(y8, y16))
 
 
 def test_gemv1_fp8_and_decode_step_fp8():
@@ -214,6 +217,8 @@ def test_every_fp8_gemm_inside_the_model_is_exact_for_its_own_input():
         return y
     ops.gemm_fp8 = spy
     ops.gemm_fp8_mx = spy_mx
+    import os
+    os.environ["UFV_NO_FUSED_ROPE"] = "1"            # the q / k / v GEMM through ops.gemm_fp8 (its fused RoPE form is compared with this one bit for bit below)
     try:
         cfg = dict(vocab_size=512, hidden_size=3584, intermediate_size=18944, num_hidden_layers=1, num_attention_heads=28, num_key_value_heads=4,
                    rope_theta=1e6, rms_norm_eps=1e-6)
@@ -234,8 +239,9 @@ def test_every_fp8_gemm_inside_the_model_is_exact_for_its_own_input():
     finally:
         ops.gemm_fp8 = orig
         ops.gemm_fp8_mx = orig_mx
-    # per-row-scaled GEMMs: qkv, o (+ per ViT layer qkv, out); the fused MX chain (round 5): gate/up -> down (+ per ViT layer fc1 -> fc2)
-    assert n_llm == 2 and len(calls) == 2 + 2 * 2 and len(mx_calls) == 2 + 2 * 2, (n_llm, len(calls), len(mx_calls))
+        os.environ.pop("UFV_NO_FUSED_ROPE", None)
+    # per-row-scaled GEMMs: qkv (+ per ViT layer qkv); o_proj / out_proj stay bf16; the fused MX chain (round 5): gate/up -> down (+ per ViT layer fc1 -> fc2)
+    assert n_llm == 1 and len(calls) == 1 + 2 * 1 and len(mx_calls) == 2 + 2 * 2, (n_llm, len(calls), len(mx_calls))
     acts = {None: lambda v: v, "gelu_pytorch_tanh": lambda v: F.gelu(v, approximate="tanh"), "gelu_tanh": lambda v: F.gelu(v, approximate="tanh"),
             "gelu": F.gelu, "silu": F.silu}
     for i, c in enumerate(calls):
@@ -408,3 +414,23 @@ def test_mx_emitting_epilogues_vs_oracle(M, swiglu):
     # ... and the chain against the oracle's two GEMMs (a code one step off moves its product by 2^-3 of itself)
     err = (x.cpu() - (y_ref + x0)).abs().max() / (y_ref + x0).abs().max()
     assert err < 1e-2, float(err)
+
+
+@pytest.mark.parametrize("S,pos0", [(2399, 0), (300, 11)])
+def test_fused_qkv_rope_fp8_bit_identical_to_gemm_fp8_then_rope(S, pos0):
+    """ufv_gemm_qkv_rope_fp8 (the W8A8 q / k / v projection with RoPE and the KV append in its epilogue) == ufv_gemm_fp8 + ufv_rope_kv_table on the same codes"""
+    Hq, Hkv, hd, K = 28, 4, 128, 3584
+    g = torch.Generator().manual_seed(S)
+    N = (Hq + 2 * Hkv) * hd
+    a = torch.randn(S, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = ops.Fp8Weight((torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV))
+    bias = torch.randn(N, generator=g).to(DEV)
+    aq, sa = ops.quantize_fp8(a)
+    inv_freq = (1.0 / (1e6 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(DEV)
+    table = ops.rope_table(inv_freq, pos0, S, hd)
+    kv0 = torch.full((pos0 + S + 2, 2 * Hkv * hd), 3.0, device=DEV, dtype=torch.bfloat16)
+    kv1 = kv0.clone()
+    qkv = ops.gemm_fp8(aq, sa, w, bias=bias)
+    ops.rope_kv(qkv, S, Hq, Hkv, hd, inv_freq, pos0, kv0, table=table)
+    q = ops.gemm_qkv_rope_fp8(ops.QAct(aq, sa), w, bias, Hq, Hkv, hd, table, kv1, pos0)
+    assert torch.equal(q, qkv[:, :Hq * hd]) and torch.equal(kv1, kv0)

@@ -1,16 +1,18 @@
 #!/bin/bash
 # Launches per TIMED STEP of every kernel of bench.py, by differencing two rocprofv3 --stats runs (4 and 14 timed steps, same warm-up): what the model
 # build and the warm-up launch drops out.  Prints every at::native / rocclr row that still has a per-step count and writes gpurun_out/<tag>/per_step.json.
-# usage (GPU box): tools/native_per_step.sh <tag>
+# usage (GPU box): [UFV_BENCH_ARGS=--fp8] tools/native_per_step.sh <tag> [out-name]    (out-name: per_step | per_step_fp8 ...)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r04}
-OUT=$R/gpurun_out/$TAG/perstep
+TAG=${1:-r05}
+NAME=${2:-per_step}
+ARGS=${UFV_BENCH_ARGS:-}
+OUT=$R/gpurun_out/$TAG/$NAME.d
 mkdir -p $OUT
 for K in 4 14; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k$K -- python3 $R/bench.py --steps $K --warmup 2 --no-cpu-baseline > $OUT/k$K.json 2> $OUT/k$K.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k$K -- python3 $R/bench.py --steps $K --warmup 2 --no-cpu-baseline $ARGS > $OUT/k$K.json 2> $OUT/k$K.err
 done
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" "$R/gpurun_out/$TAG/$NAME.json" <<'PY'
 import csv, glob, json, sys
 out = sys.argv[1]
 def load(k):
@@ -24,7 +26,7 @@ for n in sorted(set(a) | set(b)):
     if per > 0:
         rows.append({"kernel": n[:160], "launches_per_step": per, "us_per_step": round(us, 2)})
 rows.sort(key=lambda r: -r["us_per_step"])
-json.dump(rows, open(f"{out}/../per_step.json", "w"), indent=1)
+json.dump(rows, open(sys.argv[2], "w"), indent=1)
 nat = [r for r in rows if "at::native" in r["kernel"] or "rocclr" in r["kernel"]]
 print("kernels per timed step:", sum(r["launches_per_step"] for r in rows), " us:", round(sum(r["us_per_step"] for r in rows), 1))
 print("at::native / rocclr rows with a per-step count:", len(nat))

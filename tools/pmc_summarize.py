@@ -7,9 +7,11 @@ memory side (Infinity-Cache hits included); GRBM_GUI_ACTIVE sums the 8 XCDs (/ 8
 1024 SIMDs (/ 1024 = busy cycles of one matrix pipe)."""
 import collections, csv, glob, json, os, re, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+sub = sys.argv[2] if len(sys.argv) > 2 else "pmc"          # "pmc" (bf16 bench) | "pmc_fp8" (bench.py --fp8): the sub-directory tools/pmc_bench.sh wrote
+fp8 = sub.endswith("fp8")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", tag, "pmc")
+src = os.path.join(root, "gpurun_out", tag, sub)
 
 
 def short(name):
@@ -69,18 +71,19 @@ sys.path.insert(0, root)
 import bench as _bench          # noqa: E402  (only for the source fingerprint; nothing of it runs)
 res = {"gemm_sources_sha256": _bench.gemm_sources_sha256(),
        "source": f"tools/pmc_bench.sh {tag}: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, one pass each, no trace "
-                 "domains, on `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`; summarised by tools/pmc_summarize.py",
+                 "domains, on `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline" + (" --fp8" if fp8 else "") + "`; summarised by tools/pmc_summarize.py",
        "correction": "gfx950: FETCH_SIZE (KB) reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE (KB) exact; counters sit on the "
                      "L2's memory side: Infinity-Cache hits included.  GRBM_GUI_ACTIVE sums the 8 XCDs -> / 8 = elapsed shader cycles (reads high on launches shorter than "
                      "~0.3 ms); SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs",
        "per_kernel_means": means}
 M, N, K = 2399, 37888, 3584
-res["gate_up"] = summary(lambda k: k.startswith("gemm_nt_256<false, true"), f"gemm_nt_256<bf16, swiglu, 256x256, two-phase> M={M} N={N} K={K}",
-                         alg_bytes=(M * K + N * K + M * (N // 2)) * 2)
+# (--fp8: e4m3 operands, 1 byte per element; the SwiGLU output is e4m3 + block scales in the fused MX chain)
+res["gate_up"] = summary(lambda k: k.startswith("gemm_nt_256<false, true"), f"gemm_nt_256<{'e4m3' if fp8 else 'bf16'}, swiglu, 256x256, two-phase> M={M} N={N} K={K}",
+                         alg_bytes=(M * K + N * K + M * (N // 2)) * (1 if fp8 else 2))
 res["vit_attention"] = summary(lambda k: "attn_fwd_vit72" in k, "ViT attention B=32 H=16 S=576 hd=72", alg_bytes=32 * 576 * 1152 * 2 * 4)
 res["llm_attention"] = summary(lambda k: "attn_fwd_c128" in k or "attn_fwd_mfma<128" in k, "causal attention S=2399 28/4 heads hd=128 (attn_fwd_c128)")
 out = os.path.join(root, "profiles", tag)
 os.makedirs(out, exist_ok=True)
-json.dump(res, open(os.path.join(out, "pmc_bench.json"), "w"), indent=1, sort_keys=True)
+json.dump(res, open(os.path.join(out, "pmc_bench_fp8.json" if fp8 else "pmc_bench.json"), "w"), indent=1, sort_keys=True)
 for k in ("gate_up", "vit_attention", "llm_attention"):
     print(k, json.dumps(res[k]))

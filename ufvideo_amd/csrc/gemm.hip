@@ -841,6 +841,23 @@ extern "C" int ufv_gemm_qkv_rope_shape(int S, int Hq, int Hkv, int hd, int K) {
     return (rp != 0 && rc <= best + rope_ticks) ? rp : 0;
 }
 
+// e4m3 operands: A codes [S, K] with fp32 row scales, W codes with fp32 per-channel scales (ufv_gemm_fp8's operands); the same fused epilogue after the de-quantising scale
+extern "C" int ufv_gemm_qkv_rope_fp8(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, const float* bias, void* q_out, int ldq,
+                                     void* kv_row0, int ldkv, int S, int Hq, int Hkv, int hd, int K, const float* rope_table, void* stream) {
+    UFV_REQUIRE(A && a_scale && W && w_scale && q_out && kv_row0 && rope_table && S >= 256 && hd == 128 && K % 128 == 0,
+                "ufv_gemm_qkv_rope_fp8: needs head_dim 128, S >= 256, K %% 128 == 0 (S=%d hd=%d K=%d)", S, hd, K);
+    const int N = (Hq + 2 * Hkv) * hd;
+    UFV_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)W % 16 == 0) && (lda % 16 == 0) && (ldw % 16 == 0) && ((uintptr_t)q_out % 16 == 0) && ((uintptr_t)kv_row0 % 16 == 0) &&
+                (ldq % 8 == 0) && (ldkv % 8 == 0) && ((uintptr_t)rope_table % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0) && ((uintptr_t)w_scale % 16 == 0) &&
+                ldq >= Hq * hd && ldkv >= 2 * Hkv * hd && (int64_t)S * ldq < (1ll << 30) && (int64_t)S * ldkv < (1ll << 30),
+                "ufv_gemm_qkv_rope_fp8: alignment / pitch (S=%d ldq=%d ldkv=%d)", S, ldq, ldkv);
+    Epi e;
+    e.bias = bias; e.resid = nullptr; e.out = q_out; e.ldr = 0; e.ldc = ldq; e.act = ACT_NONE; e.resid_rows = 0;
+    e.scale_m = a_scale; e.scale_n = w_scale; e.dump_f32 = 0; e.ksplit = 0;
+    e.rope_tab = rope_table; e.out_kv = kv_row0; e.ldkv = ldkv; e.rope_hq = Hq; e.rope_hkv = Hkv;
+    return ufv_launch_pp_rope_fp8(A, W, e, S, N, K, lda, ldw, 1332, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int ufv_gemm_qkv_rope(const void* A, int lda, const void* W, int ldw, const float* bias, void* q_out, int ldq, void* kv_row0, int ldkv, int S,
                                  int Hq, int Hkv, int hd, int K, const float* rope_table, int shape, void* stream) {
     UFV_REQUIRE(A && W && q_out && kv_row0 && rope_table && S > 0 && K > 0, "ufv_gemm_qkv_rope: bad arguments");

@@ -581,12 +581,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     static_assert(!SKT || (MA0 == 4 && MA1 == 4 && NB1 == 2), "the stream-K fix-up is written for the 256x256 tile image");
     static_assert(!KSPL || (OUT_F32 && !SWIGLU && !FP8 && !SKT && PH2), "split-K parts accumulate into an fp32 output");
     static_assert(MX == 0 || (FP8 && PH2 && !SKT && !KSPL && !ROPE), "MX block scales belong to the e4m3 kernels");
+    static_assert(!(ROPE && FP8) || MX == 0, "the fused RoPE form of the e4m3 QKV GEMM takes per-row-scaled activations");
     static_assert(!(MX & 2) || (!OUT_F32 && MA0 == 4 && MA1 == 4 && NB1 == 2), "the MX-emitting epilogues are built for the 256 x 256 tile");
     constexpr bool MXA = (MX & 1) != 0;
     // MXA: two 4 KiB slots of A-operand block scales (256 rows x 16 bytes per FOUR K-tiles).  NB1 == 1 shapes: in the unused upper half of the B1 half-tile slots of the
     // operand ring (slot s at s * 65536 + 57344); else above the ring
     constexpr int SCL_OFF = NB1 == 1 ? 57344 : 131072, SCL_STRIDE = NB1 == 1 ? 65536 : 4096;
-    static_assert(!ROPE || (!OUT_F32 && !SWIGLU && !FP8 && !SKT && !KSPL && PH2 && NB1 == 2 && (MA0 + MA1) % 2 == 0),
+    static_assert(!ROPE || (!OUT_F32 && !SWIGLU && !SKT && !KSPL && PH2 && NB1 == 2 && (MA0 + MA1) % 2 == 0),
                   "the fused RoPE epilogue: bf16 output, 256-column tiles (two heads of 128), accumulator rows in pairs");
     const char* A = reinterpret_cast<const char*>(Av);
     const char* W = reinterpret_cast<const char*>(Wv);

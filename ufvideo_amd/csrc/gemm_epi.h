@@ -91,3 +91,4 @@ int ufv_launch_gemm256(const void* A, const void* W, const Epi& e, int M, int N,
 int ufv_launch_pp_mx(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, bool out_f32, bool swiglu, int shape, int mx, hipStream_t st);
 // gemm256_r.hip: the fused QKV + RoPE + KV-append instantiations of the ping-pong kernel (shape 1332)
 int ufv_launch_pp_rope(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int shape, hipStream_t st);
+int ufv_launch_pp_rope_fp8(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, int shape, hipStream_t st);

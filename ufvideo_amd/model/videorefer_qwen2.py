@@ -219,11 +219,24 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
         tabs = [ops.rope_table(pk["inv_freq"], p0, n, hd) if n > 1 and hd % 16 == 0 else None for _, n, _, p0 in segs]
         for li, L in enumerate(pk["layers"]):
             if "wqkv8" in L:
-                L = dict(L, wqkv=L["wqkv8"], wo=L["wo8"], wgu=L["wgu8"], wd=L["wd8"])
+                # W8A8 prefill.  o_proj stays bf16 (round 5): its input is the attention kernel's bf16 output, and quantising that in a launch of its own (14.6 us) plus
+                # the e4m3 GEMM (44 us) is no faster than the bf16 GEMM (64 us) -- one stand-alone quantise kernel per layer less, a bf16-exact projection more.
+                # (wo8 exists for the decode step, which streams weights: half the bytes.)
+                L = dict(L, wqkv=L["wqkv8"], wgu=L["wgu8"], wd=L["wd8"])
             q8 = isinstance(L["wqkv"], ops.Fp8Weight)          # W8A8 prefill: the norms emit e4m3 + row scale directly
             hq = ops.rmsnorm(x, L["ln1"], eps, quant=True) if q8 else ops.rmsnorm(x, L["ln1"], eps, out=h)
-            ops.gemm(hq, L["wqkv"], bias=L["bqkv"], out=qkv)
+            fused_qkv = q8 and segments is None and S >= 256 and hd == 128 and tabs[0] is not None and os.environ.get("UFV_NO_FUSED_ROPE") is None
+            if fused_qkv:                                      # q / k / v projection + RoPE + KV append in one launch (ufv_gemm_qkv_rope_fp8)
+                c, p0 = segs[0][2], segs[0][3]
+                qc = qkv.view(-1)[:S * H * hd].view(S, H * hd)
+                ops.gemm_qkv_rope_fp8(hq, L["wqkv"], L["bqkv"], H, KV, hd, tabs[0], c.buf[li], p0, q_out=qc)
+                kvb = c.buf[li]
+                ops.attention(qc, kvb, kvb[:, KV * hd:], 1, H, KV, S, p0 + S, hd, (0, qc.stride(0)), (0, kvb.stride(0)), (0, kvb.stride(0)), causal=True, q_pos0=p0, out=o)
+            else:
+                ops.gemm(hq, L["wqkv"], bias=L["bqkv"], out=qkv)
             for (off, n, c, p0), tab in zip(segs, tabs):
+                if fused_qkv:
+                    break
                 kvb, qs = c.buf[li], qkv[off:off + n]
                 ops.rope_kv(qs, n, H, KV, hd, pk["inv_freq"], p0, kvb, table=tab)
                 ops.attention(qs, kvb, kvb[:, KV * hd:], 1, H, KV, n, p0 + n, hd, (0, qkv.stride(0)), (0, kvb.stride(0)),

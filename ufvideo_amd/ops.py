@@ -309,6 +309,17 @@ def gemm_qkv_rope(a, w, bias, Hq, Hkv, hd, table, kv_cache, pos0, q_out=None, sh
     return q_out
 
 
+def gemm_qkv_rope_fp8(a, w, bias, Hq, Hkv, hd, table, kv_cache, pos0, q_out=None):
+    """gemm_qkv_rope with e4m3 operands: a QAct (codes + row scales), w Fp8Weight (ufv_gemm_qkv_rope_fp8)"""
+    S, K = a.q.shape
+    assert w.shape == ((Hq + 2 * Hkv) * hd, K) and table.shape == (S, hd) and kv_cache.shape[0] >= pos0 + S
+    if q_out is None:
+        q_out = torch.empty((S, Hq * hd), device=a.q.device, dtype=torch.bfloat16)
+    _lib.call("ufv_gemm_qkv_rope_fp8", a.q.data_ptr(), a.q.stride(0), a.scale.data_ptr(), w.q.data_ptr(), w.q.stride(0), w.scale.data_ptr(), _ptr(bias), q_out.data_ptr(),
+              q_out.stride(0), kv_cache[pos0:].data_ptr(), kv_cache.stride(0), S, Hq, Hkv, hd, K, table.data_ptr(), _stream())
+    return q_out
+
+
 def patchify(pixels, P, Kpad):
     _chk(pixels, name="pixels"); assert pixels.is_contiguous()
     T, Cc, H, W = pixels.shape
