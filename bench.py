@@ -42,9 +42,9 @@ MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICRO
 FLOPS = dict(vit=15.89e12, proj=4.69e12, llm=32.48e12)
 
 
-PMC_FILE = "profiles/r04/pmc_bench.json"
+PMC_FILE = "profiles/r05/pmc_bench.json"            # (--fp8: pmc_bench_fp8.json beside it)
 GEMM_SOURCES = ("ufvideo_amd/csrc/gemm256_kernel.h", "ufvideo_amd/csrc/gemm256.hip", "ufvideo_amd/csrc/gemm_epi.h", "ufvideo_amd/csrc/gemm.hip",
-                "ufvideo_amd/csrc/common.h")
+                "ufvideo_amd/csrc/common.h", "ufvideo_amd/csrc/gemm256_m.hip", "ufvideo_amd/csrc/gemm256_m2.hip")
 
 
 def gemm_sources_sha256():
@@ -285,9 +285,10 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
             ach = ks["flops"] / (ks["mean_ms"] * 1e-3) / 1e12
             traffic = None
             peak = 2 * MFMA_PEAK_TFLOPS if args.fp8 else MFMA_PEAK_TFLOPS
-            pmc = os.path.join(ROOT, PMC_FILE)
-            busy, pmc_note = None, f"{PMC_FILE} (tools/pmc_bench.sh: rocprofv3 --pmc passes of this command, not re-measured per run)"
-            if os.path.exists(pmc) and not args.fp8:
+            pmc_file = PMC_FILE.replace("pmc_bench.json", "pmc_bench_fp8.json") if args.fp8 else PMC_FILE
+            pmc = os.path.join(ROOT, pmc_file)
+            busy, pmc_note = None, f"{pmc_file} (tools/pmc_bench.sh: rocprofv3 --pmc passes of this command, not re-measured per run)"
+            if os.path.exists(pmc):
                 rec = json.load(open(pmc))
                 have, want = rec.get("gemm_sources_sha256"), gemm_sources_sha256()
                 if have == want:
@@ -295,7 +296,7 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
                     traffic, busy = gu.get("hbm_bytes_per_launch"), gu.get("mfma_busy_fraction")
                 else:
                     # counters of a DIFFERENT build of the kernel are not quoted: null, and say so where the driver's log shows it
-                    pmc_note = (f"STALE, not quoted: {PMC_FILE} was measured on GEMM sources {str(have)[:12]}, this tree has {want[:12]}; "
+                    pmc_note = (f"STALE, not quoted: {pmc_file} was measured on GEMM sources {str(have)[:12]}, this tree has {want[:12]}; "
                                 f"re-run tools/pmc_bench.sh")
                     print("bench.py: " + pmc_note, file=sys.stderr, flush=True)
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_256<%s,swiglu> gate/up M=%d N=%d K=%d" % ("fp8" if args.fp8 else "bf16", ks["M"], ks["N"], ks["K"]),

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Everything the round's evidence directory holds, in one GPU call (run on the GPU box; outputs under gpurun_out/<tag>/, copied into profiles/<tag>/ afterwards by
+# tools/evidence_collect.py, which also runs tools/pmc_summarize.py on the merged counter files).   usage: tools/evidence_round.sh <tag>
+TAG=${1:-r05}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+bash $R/tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
+bash $R/tools/native_per_step.sh $TAG per_step > $OUT/per_step.log 2>&1
+UFV_BENCH_ARGS=--fp8 bash $R/tools/native_per_step.sh $TAG per_step_fp8 > $OUT/per_step_fp8.log 2>&1
+rm -rf $OUT/per_step.d $OUT/per_step_fp8.d
+bash $R/tools/pmc_bench.sh $TAG pmc > $OUT/pmc.log 2>&1
+UFV_BENCH_ARGS=--fp8 bash $R/tools/pmc_bench.sh $TAG pmc_fp8 > $OUT/pmc_fp8.log 2>&1
+bash $R/tools/profile_aux.sh $TAG > $OUT/profile_aux.log 2>&1
+cd $R
+python3 tools/probe_blaslt.py $TAG > $OUT/gemm_vs_vendor.log 2>&1
+LAB_P2_CLOCK=1 tools/lab/attn_lab_clock 14 > $OUT/attn_vit_clock.txt 2>&1
+UFV_PARITY_REPORT=$OUT/parity_table_bench.json UFV_PARITY_FULL=1 python3 -m pytest tests/test_bench_workload_gpu.py -m gpu -q > $OUT/parity_full.log 2>&1
+(time python3 -m pytest tests -m gpu -q -s 2>&1 | grep -E "PERF_FLOOR|passed|failed|error" ) > $OUT/pytest_gpu_tail.txt 2>&1
+tail -3 $OUT/pytest_gpu_tail.txt

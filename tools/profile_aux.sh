@@ -1,14 +1,15 @@
 #!/bin/bash
 # Evidence for the paths outside the headline metric (GPU box): rocprofv3 kernel-trace stats + the tools' own timing lines for greedy decode, the SAM2-L
 # segmentation path and the decoder training step, all at full dimensions.  usage: tools/profile_aux.sh <tag>  -> gpurun_out/<tag>/{decode,sam2,train}_*
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for name in decode sam2 train; do
+for name in decode decode_fp8 sam2 train; do
   case $name in
     decode) SCRIPT="$R/tools/bench_decode.py";;
+    decode_fp8) SCRIPT="$R/tools/bench_decode.py --fp8";;
     sam2)   SCRIPT="$R/tools/bench_sam2.py";;
     train)  SCRIPT="$R/tools/bench_train.py --steps 3 --warmup 1";;
   esac
