@@ -82,6 +82,18 @@ res["gate_up"] = summary(lambda k: k.startswith("gemm_nt_256<false, true"), f"ge
                          alg_bytes=(M * K + N * K + M * (N // 2)) * (1 if fp8 else 2))
 res["vit_attention"] = summary(lambda k: "attn_fwd_vit72" in k, "ViT attention B=32 H=16 S=576 hd=72", alg_bytes=32 * 576 * 1152 * 2 * 4)
 res["llm_attention"] = summary(lambda k: "attn_fwd_c128" in k or "attn_fwd_mfma<128" in k, "causal attention S=2399 28/4 heads hd=128 (attn_fwd_c128)")
+# the in-kernel clock of the ViT attention kernel (diagnostic build, tools/lab/attn_lab.hip LAB_P2_CLOCK; MI355X_MICROARCH.md DVFS item 6): settles which denominator
+# the MFMA-busy figure gets -- GRBM_GUI_ACTIVE / 8 reads high on a 74 us dispatch (it implies 2.3-2.5 GHz), the stamps give the clock the kernel really ran at
+clock_file = os.path.join(root, "gpurun_out", tag, "attn_vit_clock.txt")
+if res.get("vit_attention") and os.path.exists(clock_file):
+    for line in open(clock_file):
+        if line.startswith("{"):
+            ck = json.loads(line)
+            res["vit_attention"]["in_kernel_clock"] = dict(
+                ck, source="tools/lab/attn_lab_clock 14 (LAB_P2_CLOCK=1): >= 2 s of back-to-back launches on random operands, then s_memtime / s_memrealtime stamped once "
+                           "around every wave's pass loop of the last launch; MFMA-busy cycles per SIMD = 81 periods x 22 v_mfma_f32_32x32x16_bf16 x 32 cycles = what "
+                           "SQ_VALU_MFMA_BUSY_CYCLES / 1024 counts")
+            res["vit_attention"]["mfma_busy_fraction_measured_clock"] = ck["mfma_busy_over_wall_x_clock"]
 out = os.path.join(root, "profiles", tag)
 os.makedirs(out, exist_ok=True)
 json.dump(res, open(os.path.join(out, "pmc_bench_fp8.json" if fp8 else "pmc_bench.json"), "w"), indent=1, sort_keys=True)
