@@ -7,7 +7,8 @@
     28 decoder layers (fp32 leg only; +32 TFLOP of CPU work).  Reference: videorefer_arch.py:168-191, projector.py:189-238, videorefer_qwen2.py:357-459.
 (b) `test_teacher_forced_every_tower_layer` / `..._decoder_layer`: for EVERY one of the 26 + 28 layer indices, the HIP layer's output against the mirror's
     layer applied to the HIP path's own layer input (no chain in front of the layer), at d 1152 / 16 x 72 / 4304 and 3584 / 28:4 x 128 / 18944.
-Both write their figures into the table UFV_PARITY_REPORT names (committed as profiles/r04/parity_table.json)."""
+Both write their figures into the table UFV_PARITY_REPORT_BENCH (or UFV_PARITY_REPORT) names (committed as profiles/<round>/parity_table_bench.json; the
+UFV_PARITY_FULL=1 run as parity_table_bench_full.json)."""
 import json
 import os
 import sys
@@ -171,8 +172,11 @@ def test_bench_workload_stage_by_stage_vs_oracle(bench_model):
     assert r_p["rel_l2_vs_mirror"] <= 2.5e-2 and r_p["rel_l2_vs_fp32"] <= 2e-2, r_p                 # 1.3e-2 / 1.0e-2 (1.0e-2)
     assert r_p["vs_fp32"] <= 1.5 * r_p["mirror_vs_fp32"] + 1e-3, r_p
     assert r_ptf["vs_bf16_mirror"] <= 2.2e-2, r_ptf                                                    # 1.1e-2 (48 storage points, the connector's noise floor)
-    assert r_n["rel_l2_vs_fp32"] <= 2.8e-2 and r_l["rel_l2_vs_fp32"] <= 1.2e-2, (r_n, r_l)          # 1.4e-2 (1.35e-2) / 6.0e-3 (5.8e-3)
-    assert r_n["vs_fp32"] <= 1.5 * r_n["mirror_vs_fp32"] + 1e-3 and r_l["vs_fp32"] <= 1.5 * r_l["mirror_vs_fp32"] + 1e-3, (r_n, r_l)
+    if do_mirror:
+        assert r_n["rel_l2_vs_fp32"] <= 2.8e-2 and r_l["rel_l2_vs_fp32"] <= 1.2e-2, (r_n, r_l)      # 1.4e-2 (1.35e-2) / 6.0e-3 (5.8e-3)
+        assert r_n["vs_fp32"] <= 1.5 * r_n["mirror_vs_fp32"] + 1e-3 and r_l["vs_fp32"] <= 1.5 * r_l["mirror_vs_fp32"] + 1e-3, (r_n, r_l)
+    else:                                                                                              # UFV_PARITY_FULL=1: 28 layers, fp32 leg only (no mirror to bound against)
+        assert r_n["rel_l2_vs_fp32"] <= 5e-2 and r_l["rel_l2_vs_fp32"] <= 2.3e-2, (r_n, r_l)        # measured 2.47e-2 / 1.13e-2 (profiles/r05/parity_table_bench_full.json)
     if margin > 3.0 * err:                                                                             # measured: margin 0.150, error 0.031 -> decided, equal
         assert bool(g.argmax() == lg_32.argmax())
     assert t5 >= 4                                                                                     # 5 of 5
@@ -310,7 +314,7 @@ def test_teacher_forced_every_decoder_layer(bench_model):
 
 
 def test_zz_write_report():
-    path = os.environ.get("UFV_PARITY_REPORT_BENCH")
+    path = os.environ.get("UFV_PARITY_REPORT_BENCH") or os.environ.get("UFV_PARITY_REPORT")
     if path and REPORT:
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         with open(path, "w") as f:
