@@ -395,6 +395,79 @@ __global__ __launch_bounds__(256) void gemv_nt(const bf16* __restrict__ A, const
     }
 }
 
+// ---- small-M product on the matrix cores (8 < M <= 64: the connector's squeeze-excite 32 x 3584 -> 896 -> 3584) ----------------------------
+// A block owns 16 output columns and 32 rows; its NW waves split K into contiguous parts and stream both operands straight from global memory into
+// v_mfma_f32_16x16x32_bf16 fragments (a lane's 16 bytes = 8 consecutive k of one row: no LDS staging, every load of a wave is independent of the others, so
+// the whole K range of the wave is in flight at once).  The partial tiles meet in LDS and wave 0 adds them in wave order (deterministic).  The one-wave-per-
+// column gemv_nt above spent 19 us on each of these products in a chain of K / 512 dependent round trips per wave.
+template <bool OUT_F32, int NW, int UB>
+__global__ __launch_bounds__(64 * NW) void gemm_small_m(const bf16* __restrict__ A, const bf16* __restrict__ W, Epi e, int M, int N, int K, int lda, int ldw) {
+    __shared__ float part[NW - 1][2][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 16, r0 = blockIdx.y * 32;
+    const int ksteps = K >> 5, per = (ksteps + NW - 1) / NW;
+    const int s0 = wave * per, s1 = min(ksteps, s0 + per);
+    const int lr = lane & 15, kq = (lane >> 4) * 8;
+    const bf16* wp = W + (size_t)min(n0 + lr, N - 1) * ldw + kq;
+    const bf16* ap0 = A + (size_t)min(r0 + lr, M - 1) * lda + kq;
+    const bf16* ap1 = A + (size_t)min(r0 + 16 + lr, M - 1) * lda + kq;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    int s = s0;
+    for (; s + UB <= s1; s += UB) {
+        bf16x8 wv[UB], a0[UB], a1[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            wv[u] = *reinterpret_cast<const bf16x8*>(wp + (s + u) * 32);
+            a0[u] = *reinterpret_cast<const bf16x8*>(ap0 + (s + u) * 32);
+            a1[u] = *reinterpret_cast<const bf16x8*>(ap1 + (s + u) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // all 3 UB loads issued before the first product waits (the scheduler otherwise interleaves them in groups)
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[u], a0[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[u], a1[u], acc1, 0, 0, 0);
+        }
+    }
+    for (; s < s1; ++s) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(wp + s * 32);
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap0 + s * 32), a1 = *reinterpret_cast<const bf16x8*>(ap1 + s * 32);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, a0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, a1, acc1, 0, 0, 0);
+    }
+    if (wave > 0) {
+        *reinterpret_cast<f32x4*>(part[wave - 1][0][lane]) = acc0;
+        *reinterpret_cast<f32x4*>(part[wave - 1][1][lane]) = acc1;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(part[w][0][lane]), p1 = *reinterpret_cast<const f32x4*>(part[w][1][lane]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc0[i] += p0[i]; acc1[i] += p1[i]; }
+    }
+    // lane holds out[m = r0 + 16 h + (lane & 15)][n0 + 4 (lane >> 4) + i], i = 0..3
+    const int nb = n0 + (lane >> 4) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = r0 + 16 * h + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = nb + i;
+            if (n >= N) continue;
+            float v = h ? acc1[i] : acc0[i];
+            if (e.bias) v += e.bias[n];
+            v = act_apply(v, e.act);
+            if (e.resid) v += e.resid[(size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n];
+            if (OUT_F32)
+                reinterpret_cast<float*>(e.out)[(size_t)m * e.ldc + n] = v;
+            else
+                reinterpret_cast<bf16*>(e.out)[(size_t)m * e.ldc + n] = (bf16)v;
+        }
+    }
+}
+
 // ---- GEMV with fp8 operands (M <= 64): weights streamed once, 16 e4m3 bytes per lane per load; dequantised in registers
 template <bool OUT_F32, bool SWIGLU, int MR>
 __global__ __launch_bounds__(256) void gemv_nt_fp8(const uint8_t* __restrict__ A, const uint8_t* __restrict__ W, Epi e, int M, int N,
@@ -740,6 +813,17 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
             return UFV_EUNSUPPORTED;
         }
         const int n_out = S ? N / 2 : N;
+        if constexpr (!Q && !S) {
+            static const bool no_small_m = getenv("UFV_NO_SMALL_M") != nullptr;          // lab switch (same-box A/B)
+            if (M > 8 && K % 32 == 0 && !no_small_m) {
+                if (K >= 2048)          // 8 waves x 14 K-steps in flight each: the whole K range of the block requested at once
+                    hipLaunchKernelGGL((gemm_small_m<F, 8, 14>), dim3(cdiv(N, 16), cdiv(M, 32)), dim3(512), 0, st, (const bf16*)A, (const bf16*)W, e, M, N, K, lda, ldw);
+                else
+                    hipLaunchKernelGGL((gemm_small_m<F, 4, 7>), dim3(cdiv(N, 16), cdiv(M, 32)), dim3(256), 0, st, (const bf16*)A, (const bf16*)W, e, M, N, K, lda, ldw);
+                UFV_CHECK_LAUNCH();
+                return UFV_OK;
+            }
+        }
         if constexpr (Q)
             hipLaunchKernelGGL((gemv_nt_fp8<F, S, 8>), dim3(cdiv(n_out, 4), cdiv(M, 8)), dim3(256), 0, st, (const uint8_t*)A,
                                (const uint8_t*)W, e, M, N, K, lda, ldw);

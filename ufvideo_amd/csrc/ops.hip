@@ -434,13 +434,23 @@ __global__ __launch_bounds__(256) void patchify_k(const void* px, bf16* out, int
 // wave w owns a quarter of the 8-channel chunks, so every weight chunk is loaded once per 4 pixels and every input
 // column is loaded once for the 3 horizontal taps that use it; LayerNorm statistics are combined across the waves in LDS.
 // -------------------------------------------------------------------------------------------------
+// Block order: the hardware deals consecutive workgroups round-robin over the 8 XCDs, each with its own L2.  An output row reads three input rows and a segment two
+// halo columns of its neighbours, so with REMAP block b works on logical index (b % 8) * (n / 8) + b / 8: every XCD walks its own contiguous range of
+// (frame, row, segment) and finds the rows its previous blocks fetched in ITS L2 instead of fetching them again over the fabric.
+template <int PX, bool REMAP>
 __global__ __launch_bounds__(256) void dwconv_ln_silu_k(const bf16* __restrict__ x, bf16* __restrict__ y, const float* __restrict__ w9,
                                                         const float* __restrict__ lnw, const float* __restrict__ lnb, int F, int H, int W,
-                                                        int C, float eps) {
-    constexpr int PX = 4, MAXI = 2;                     // C <= 4096 -> <= 128 chunks per wave -> <= 2 per lane
+                                                        int C, float eps, int nblk) {
+    constexpr int MAXI = 2;                             // C <= 4096 -> <= 128 chunks per wave -> <= 2 per lane
     __shared__ float red[2][4][PX];
     const int nseg = (W + PX - 1) / PX;
-    const int seg = blockIdx.x % nseg, py = (blockIdx.x / nseg) % H, f = blockIdx.x / (nseg * H);
+    int bid = blockIdx.x;
+    if (REMAP) {
+        const int per = (nblk + 7) >> 3;
+        bid = (bid & 7) * per + (bid >> 3);
+        if (bid >= nblk) return;
+    }
+    const int seg = bid % nseg, py = (bid / nseg) % H, f = bid / (nseg * H);
     const int x0 = seg * PX, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nc = C >> 3, cpw = (nc + 3) >> 2;
     int cidx[MAXI];
@@ -1089,8 +1099,18 @@ extern "C" int ufv_dwconv3x3_ln_silu(const void* x, void* y, const float* w9, co
                                      int W, int C, float eps, void* stream) {
     UFV_REQUIRE(x && y && w9 && lnw && lnb && F > 0, "ufv_dwconv3x3_ln_silu: bad arguments");
     UFV_REQUIRE(C % 8 == 0 && C <= 4096, "ufv_dwconv3x3_ln_silu: C=%d must be a multiple of 8 and <= 4096", C);
-    hipLaunchKernelGGL(dwconv_ln_silu_k, dim3(F * H * cdiv(W, 4)), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F,
-                       H, W, C, eps);
+    static const int lab = getenv("UFV_DWCONV_LAB") ? atoi(getenv("UFV_DWCONV_LAB")) : 1;          // lab: bit 0 = remap, bit 1 = 8 pixels per block
+#define UFV_DWCONV_LAUNCH(PX_, RM_)                                                                                                          \
+    do {                                                                                                                                     \
+        const int nblk = F * H * cdiv(W, PX_);                                                                                               \
+        hipLaunchKernelGGL((dwconv_ln_silu_k<PX_, RM_>), dim3(RM_ ? cdiv(nblk, 8) * 8 : nblk), dim3(256), 0, ST(stream), (const bf16*)x,     \
+                           (bf16*)y, w9, lnw, lnb, F, H, W, C, eps, nblk);                                                                   \
+    } while (0)
+    if (lab == 3) UFV_DWCONV_LAUNCH(8, true);
+    else if (lab == 2) UFV_DWCONV_LAUNCH(8, false);
+    else if (lab == 1) UFV_DWCONV_LAUNCH(4, true);
+    else UFV_DWCONV_LAUNCH(4, false);
+#undef UFV_DWCONV_LAUNCH
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
