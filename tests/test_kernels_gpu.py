@@ -102,6 +102,22 @@ def test_gemv(M):
     assert rel(out, ref) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,act", [(32, 896, 3584, "silu"), (32, 3584, 896, "sigmoid"), (33, 1000, 2048, None), (9, 40, 4096, "relu"), (64, 16, 32, None),
+                                         (17, 72, 2080, "gelu_tanh")])
+def test_small_m_products_on_the_matrix_cores(M, N, K, act):
+    """8 < M <= 64 (the connector's squeeze-excite products): gemm_small_m -- 16 columns per block, K split over 4 or 8 waves, partial sums added in wave order.
+    Covers both wave counts (K >= 2048 -> 8), ragged M (second row block partly or wholly empty), N not a multiple of 16, bf16 and fp32 outputs."""
+    a, w = bf(g(M, K, seed=21)), bf(g(N, K, seed=22, scale=0.03))
+    bias = g(N, seed=23)
+    z = a.float() @ w.float().t() + bias
+    ref = ACTS[act](z)
+    out = ops.gemm(a, w, bias=bias, act=act, out_dtype=torch.float32)
+    assert rel(out, ref) < 1e-4
+    out16 = ops.gemm(a, w, bias=bias, act=act)
+    assert out16.dtype == torch.bfloat16 and torch.equal(out16, out.to(torch.bfloat16)), "bf16 output = the rounded fp32 output"
+    assert torch.equal(out, ops.gemm(a, w, bias=bias, act=act, out_dtype=torch.float32)), "deterministic (fixed order of the waves' partial sums)"
+
+
 def test_gemm_strided_a_and_errors():
     buf = bf(g(300, 512, seed=14))
     a = buf[:, 128:384]

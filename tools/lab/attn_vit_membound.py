@@ -35,5 +35,20 @@ def main():
         print(f"{name:40s} {t:7.1f} us")
 
 
+def pair_major():
+    """the same work with q / k / v stored [frame x head pair][token][2 heads x 72]: the rows a block streams are 288 contiguous bytes that no other block shares"""
+    B, H, S, hd = 32, 16, 576, 72
+    dev = torch.device("cuda", 0)
+    q, k, v = [torch.randn(B * H // 2, S, 2 * hd, device=dev).to(torch.bfloat16) for _ in range(3)]
+    out = torch.empty(B * H // 2 * S, 2 * hd, device=dev, dtype=torch.bfloat16)
+    st = (S * 2 * hd, 2 * hd)
+    t = timed(lambda: ops.attention(q, k, v, B * H // 2, 2, 2, S, S, hd, st, st, st, out=out))
+    print(f"{'pair-major q / k / v / o':40s} {t:7.1f} us")
+    out2 = torch.empty(B * S, H * hd, device=dev, dtype=torch.bfloat16)       # token-major o as the product needs it (one frame's worth of address pattern per 8 pairs is not expressible: pitch only)
+    t = timed(lambda: ops.attention(q, k, v, B * H // 2, 2, 2, S, S, hd, st, st, st, out=out2.view(B * H // 2 * S, 2 * hd)))
+    print(f"{'pair-major q / k / v, o other buffer':40s} {t:7.1f} us")
+
+
 if __name__ == "__main__":
+    pair_major()
     main()
