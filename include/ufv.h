@@ -85,6 +85,12 @@ int ufv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, i
              const float* bias, int act, const float* resid, int ldr, int resid_rows, int swiglu, int kernel,
              void* stream);
 
+/* x[M,N] = bf16(A[M,K] * W[N,K]^T + bias[n] + float(x[M,N])), x bf16 updated in place: the residual add of a bf16 module on its bf16 hidden states
+ * (modeling_siglip.py:371-383 `hidden_states = residual + hidden_states` with the tower loaded in bfloat16, as videorefer_arch.py builds it).  One rounding
+ * per element, of the fp32 sum -- the torch bf16 add rounds the projection first; the stream's storage points are the reference's. */
+int ufv_gemm_stream_bf16(const void* A, int lda, const void* W, int ldw, void* x, int ldx, int M, int N, int K, const float* bias, int kernel,
+                         void* stream);
+
 /* y = act(LayerNorm(x) * w + b) per row (nn.LayerNorm: modeling_siglip.py:329-331; timm LayerNorm2d in
  * NHWC).  x fp32 or bf16 (x_dtype), y bf16 (or fp32 when y_f32). */
 int ufv_layernorm(const void* x, int x_dtype, int ldx, void* y, int y_f32, int ldy, const float* w, const float* b,

@@ -194,8 +194,10 @@ _ACT = {"gelu_pytorch_tanh": gelu_tanh, "quick_gelu": quick_gelu, "gelu": F.gelu
 # --------------------------------------------------------------------------------------
 # SigLIP / CLIP vision tower
 # --------------------------------------------------------------------------------------
-def vit_encoder_layer(sd: SD, p: str, x: torch.Tensor, heads: int, eps: float, act: str) -> torch.Tensor:
-    """One pre-LN encoder layer (modeling_siglip.py:325-357; CLIP's layer is the same graph)."""
+def vit_encoder_layer(sd: SD, p: str, x: torch.Tensor, heads: int, eps: float, act: str, stream_bf16: bool = False) -> torch.Tensor:
+    """One pre-LN encoder layer (modeling_siglip.py:325-357; CLIP's layer is the same graph).  stream_bf16 (mirror mode only): the residual stream is stored
+    in bf16 after both adds -- the product's opt-in UFV_TOWER_STREAM=bf16 (ufv_gemm_stream_bf16: one rounding of the fp32 sum), what a bf16 HF tower keeps."""
+    rs = (lambda t: _rb(t)) if stream_bf16 else (lambda t: t)
     B, N, D = x.shape
     hd = D // heads
     h = _rb(F.layer_norm(x, (D,), _g(sd, p, "layer_norm1.weight"), _g(sd, p, "layer_norm1.bias"), eps))
@@ -207,12 +209,12 @@ def vit_encoder_layer(sd: SD, p: str, x: torch.Tensor, heads: int, eps: float, a
     v = v.view(B, N, heads, hd).transpose(1, 2)
     o = _rb(attention_noncausal(q, k, v, hd ** -0.5)).transpose(1, 2).reshape(B, N, D)   # :237-247 (fp32 softmax)
     o = F.linear(o, _g(sd, p, "self_attn.out_proj.weight"), _g(sd, p, "self_attn.out_proj.bias"))
-    x = x + o
+    x = rs(x + o)
     h = _rb(F.layer_norm(x, (D,), _g(sd, p, "layer_norm2.weight"), _g(sd, p, "layer_norm2.bias"), eps))
     h = F.linear(h, _g(sd, p, "mlp.fc1.weight"), _g(sd, p, "mlp.fc1.bias"))
     h = _rb(_ACT[act](h))
     h = F.linear(h, _g(sd, p, "mlp.fc2.weight"), _g(sd, p, "mlp.fc2.bias"))
-    return x + h
+    return rs(x + h)
 
 
 def siglip_embeddings(sd: SD, p: str, pixel_values: torch.Tensor, patch: int) -> torch.Tensor:
@@ -225,7 +227,7 @@ def siglip_embeddings(sd: SD, p: str, pixel_values: torch.Tensor, patch: int) ->
 
 
 def siglip_tower(sd: SD, cfg: dict, pixel_values: torch.Tensor, prefix: str = "",
-                 select_layer: int = -2, return_all: bool = False):
+                 select_layer: int = -2, return_all: bool = False, stream_bf16: bool = False):
     """SiglipVisionTower.forward + feature_select (encoder.py:126-146).
 
     HF ``hidden_states`` = [embeddings, layer1 out, ..., layerL out]; the reference picks
@@ -235,11 +237,13 @@ def siglip_tower(sd: SD, cfg: dict, pixel_values: torch.Tensor, prefix: str = ""
     p = prefix
     L = cfg["num_hidden_layers"]
     x = siglip_embeddings(sd, p, pixel_values, cfg["patch_size"])
+    if stream_bf16:
+        x = _rb(x)
     hs = [x]
     n_run = L if return_all else (L + 1 + select_layer if select_layer < 0 else select_layer)
     for i in range(n_run):
         x = vit_encoder_layer(sd, f"{p}encoder.layers.{i}.", x, cfg["num_attention_heads"],
-                              cfg.get("layer_norm_eps", 1e-6), cfg.get("hidden_act", "gelu_pytorch_tanh"))
+                              cfg.get("layer_norm_eps", 1e-6), cfg.get("hidden_act", "gelu_pytorch_tanh"), stream_bf16)
         hs.append(x)
     if return_all:
         return hs

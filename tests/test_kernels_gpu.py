@@ -118,6 +118,19 @@ def test_small_m_products_on_the_matrix_cores(M, N, K, act):
     assert torch.equal(out, ops.gemm(a, w, bias=bias, act=act, out_dtype=torch.float32)), "deterministic (fixed order of the waves' partial sums)"
 
 
+@pytest.mark.parametrize("M,N,K", [(18432, 1152, 1152), (1000, 1152, 4352), (300, 256, 192), (20, 128, 64), (2399, 3584, 3584)])
+def test_gemm_stream_bf16_in_place_update(M, N, K):
+    """ufv_gemm_stream_bf16: x <- bf16(a w^T + bias + float(x)) in place on a bf16 stream (the opt-in reference-dtype residual stream of the tower): the same
+    accumulators and element order as the fp32-residual epilogue, so the result is EXACTLY the rounded output of the fp32 form fed float(x)"""
+    a, w = bf(g(M, K, seed=31)), bf(g(N, K, seed=32, scale=0.05))
+    bias = g(N, seed=33)
+    x = bf(g(M, N, seed=34))
+    ref = ops.gemm(a, w, bias=bias, resid=x.float(), out_dtype=torch.float32).to(torch.bfloat16)
+    y = x.clone()
+    ops.gemm_stream_bf16(a, w, y, bias=bias)
+    assert torch.equal(y, ref)
+
+
 def test_gemm_strided_a_and_errors():
     buf = bf(g(300, 512, seed=14))
     a = buf[:, 128:384]

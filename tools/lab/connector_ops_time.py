@@ -1,6 +1,6 @@
 """Lab (GPU box): the connector's elementwise kernels at the bench clip's stage-1 shape (32 frames x 24 x 24 tokens x 3584 channels), timed in a chain that
 mimics the block (the input of each kernel was written by the launch before it) and one by one over rotating buffers (cold).  Prints us per launch and a
-checksum of every output so that variants (UFV_DWCONV_LAB=0..3) can be compared bit for bit.   usage: python3 tools/lab/connector_ops_time.py [F H W C]"""
+checksum of every output so that variants (UFV_DWCONV_NO_REMAP=1) can be compared bit for bit.   usage: python3 tools/lab/connector_ops_time.py [F H W C]"""
 import os
 import sys
 import hashlib
@@ -43,7 +43,7 @@ def main():
     def rot():
         k[0] = (k[0] + 1) % NB
         return xs[k[0]]
-    print("shape", F, H, W, C, "UFV_DWCONV_LAB", os.environ.get("UFV_DWCONV_LAB"))
+    print("shape", F, H, W, C, "UFV_DWCONV_NO_REMAP", os.environ.get("UFV_DWCONV_NO_REMAP"))
     y = ops.dwconv3x3_ln_silu(xs[0], w9, lw, lb, F, H, W, C, 1e-5)
     print("dwconv digest", digest(y))
     print("dwconv same-buffer  %.1f us" % timed(lambda: ops.dwconv3x3_ln_silu(xs[0], w9, lw, lb, F, H, W, C, 1e-5)))

@@ -23,6 +23,7 @@ SIGNATURES = {
     "ufv_resize_bilinear_bwd": [_p, _p, _i, _i, _i, _i, _i, _p],
     "ufv_mask_loss_bwd": [_p, _p, _p, _f, _p, _i, _l, _p],
     "ufv_gemm": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _p],
+    "ufv_gemm_stream_bf16": [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p],
     "ufv_layernorm": [_p, _i, _i, _p, _i, _i, _p, _p, _i, _i, _f, _i, _p],
     "ufv_ln_add_silu": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "ufv_rmsnorm": [_p, _i, _p, _i, _i, _p, _i, _i, _f, _p],

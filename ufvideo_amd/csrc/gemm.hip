@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_128(const void* __restrict__ A
     }
     // ---- epilogue (activation resolved once so the body stays unrolled)
     if constexpr (!SWIGLU) {
-        if (e.resid != nullptr && e.act == ACT_NONE) {
+        if (e.resid != nullptr && e.act == ACT_NONE && !e.resid_bf16) {
             epilogue128_resid<OUT_F32, MT>(acc, e, M, m0, n0, wm, wn, frow, fq);
             return;
         }
@@ -331,7 +331,7 @@ __global__ void gemm_nt_generic(const bf16* __restrict__ A, const bf16* __restri
         if (e.bias) v += e.bias[n];
         v = act_apply(v, e.act);
     }
-    if (e.resid) v += e.resid[(size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n];
+    if (e.resid) v += resid_load1(e, (size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n);
     if (OUT_F32)
         reinterpret_cast<float*>(e.out)[(size_t)m * e.ldc + n] = v;
     else
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void gemv_nt(const bf16* __restrict__ A, const
         }
         if (lane == 0) {
             const int m = r0 + r;
-            if (e.resid) v += e.resid[(size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n];
+            if (e.resid) v += resid_load1(e, (size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n);
             if (OUT_F32)
                 reinterpret_cast<float*>(e.out)[(size_t)m * e.ldc + n] = v;
             else
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_m(const bf16* __restrict__
             float v = h ? acc1[i] : acc0[i];
             if (e.bias) v += e.bias[n];
             v = act_apply(v, e.act);
-            if (e.resid) v += e.resid[(size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n];
+            if (e.resid) v += resid_load1(e, (size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n);
             if (OUT_F32)
                 reinterpret_cast<float*>(e.out)[(size_t)m * e.ldc + n] = v;
             else
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void gemv_nt_fp8(const uint8_t* __restrict__ A
             v = act_apply(v, e.act);
         }
         if (lane == 0) {
-            if (e.resid) v += e.resid[(size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n];
+            if (e.resid) v += resid_load1(e, (size_t)(e.resid_rows > 0 ? m % e.resid_rows : m) * e.ldr + n);
             if (OUT_F32)
                 reinterpret_cast<float*>(e.out)[(size_t)m * e.ldc + n] = v;
             else
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void gemv1_nt(const bf16* __restrict__ a, cons
             v = act_apply(v, e.act);
         }
         if (lane == 0 && n < n_out) {
-            if (e.resid) v += e.resid[n];
+            if (e.resid) v += resid_load1(e, n);
             if (OUT_F32) reinterpret_cast<float*>(e.out)[n] = v;
             else reinterpret_cast<bf16*>(e.out)[n] = (bf16)v;
         }
@@ -876,9 +876,9 @@ static std::vector<TimedLaunch>& timed_launches() { static std::vector<TimedLaun
 template <bool Q>
 int gemm_entry(const void* A, int lda, const float* a_scale, const void* W, int ldw, const float* w_scale, void* C, int ldc, int out_f32,
                int M, int N, int K, const float* bias, int act, const float* resid, int ldr, int resid_rows, int swiglu, int kernel,
-               void* stream) {
+               void* stream, int resid_bf16 = 0) {
     Epi e;
-    e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = resid_rows;
+    e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = resid_rows; e.resid_bf16 = resid_bf16;
     e.scale_m = a_scale; e.scale_n = w_scale; e.dump_f32 = 0; e.ksplit = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     TimedLaunch tl{};
@@ -993,6 +993,13 @@ extern "C" int ufv_gemm(const void* A, int lda, const void* W, int ldw, void* C,
     UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemm: swiglu epilogue takes no bias/activation");
     return gemm_entry<false>(A, lda, nullptr, W, ldw, nullptr, C, ldc, out_f32, M, N, K, bias, act, resid, ldr, resid_rows, swiglu, kernel,
                              stream);
+}
+
+extern "C" int ufv_gemm_stream_bf16(const void* A, int lda, const void* W, int ldw, void* x, int ldx, int M, int N, int K, const float* bias, int kernel,
+                                    void* stream) {
+    UFV_REQUIRE(A && W && x && M > 0 && N > 0 && K > 0 && ldx % 4 == 0 && (uintptr_t)x % 16 == 0, "ufv_gemm_stream_bf16: bad arguments (M=%d N=%d K=%d ldx=%d)", M, N, K,
+                ldx);
+    return gemm_entry<false>(A, lda, nullptr, W, ldw, nullptr, x, ldx, 0, M, N, K, bias, ACT_NONE, reinterpret_cast<const float*>(x), ldx, 0, 0, kernel, stream, 1);
 }
 
 // C[M,N] (+)= A[M,K] * W[N,K]^T with the K range split over up to `nsplit` blocks per output tile: for products whose output

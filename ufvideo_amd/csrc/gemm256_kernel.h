@@ -75,7 +75,9 @@ template <int MA0, int MA1, int NB1> struct PP {
 #endif
 #define UFV_EPI_MARK(text) asm volatile("; UFV_EPI_" text ::: "memory")
 
-template <bool OUT_F32, int MA0, int MA1, int NB1>
+// RB: the residual is bf16 (Epi::resid_bf16: the stream of a bf16 module, updated in place as bf16 -- the reference's own `residual + hidden_states` on bf16
+// tensors); 8-byte loads, same number of load and store instructions as the fp32 form (the counted waits do not change).
+template <bool OUT_F32, int MA0, int MA1, int NB1, bool RB = false>
 __device__ __forceinline__ void epilogue256_resid(const f32x4 (&acc)[2 + NB1][MA0 + MA1], const Epi& e, int M, int N, int m0, int n0, int wr, int wc,
                                                   int frow, int fq, const f32x4 (&bias)[2 + NB1]) {
     constexpr int MT = MA0 + MA1, NT = 2 + NB1;
@@ -89,18 +91,25 @@ __device__ __forceinline__ void epilogue256_resid(const f32x4 (&acc)[2 + NB1][MA
     }
     auto row_of = [&](int mt) { return m0 + (mt < MA0 ? wr * 16 * MA0 + mt * 16 : 32 * MA0 + wr * 16 * MA1 + (mt - MA0) * 16) + frow; };
     UFV_EPI_MARK("BEGIN resid");
-    f32x4 r[2][NT];
-    auto request = [&](int mt, f32x4 (&dst)[NT]) {
+    typedef typename std::conditional<RB, u32x2, f32x4>::type rvec;          // what one residual load returns: 4 bf16 or 4 floats
+    rvec r[2][NT];
+    auto request = [&](int mt, rvec (&dst)[NT]) {
         const int m = min(row_of(mt), M - 1);
         const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
-        const float* rp = e.resid + (size_t)mr * e.ldr;
+        if constexpr (RB) {
+            const bf16* rp = reinterpret_cast<const bf16*>(e.resid) + (size_t)mr * e.ldr;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[nt]) : "v"(rp + ncol[nt]) : "memory");
+            for (int nt = 0; nt < NT; ++nt) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[nt]) : "v"(rp + ncol[nt]) : "memory");
+        } else {
+            const float* rp = e.resid + (size_t)mr * e.ldr;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[nt]) : "v"(rp + ncol[nt]) : "memory");
+        }
     };
     request(0, r[0]);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        f32x4 (&cur)[NT] = r[mt & 1];
+        rvec (&cur)[NT] = r[mt & 1];
         if (mt + 1 < MT) request(mt + 1, r[(mt + 1) & 1]);
         // in flight behind row mt's loads: the stores of row mt - 1 (NT, when there was one) and the loads of row mt + 1 (NT, when there is one)
         if (mt == 0) {
@@ -118,7 +127,14 @@ __device__ __forceinline__ void epilogue256_resid(const f32x4 (&acc)[2 + NB1][MA
         for (int nt = 0; nt < NT; ++nt) {
             // the element order of epi_store4b: (acc + bias) then + resid
             f32x4 v = acc[nt][mt] + bias[nt];
-            v += cur[nt];
+            if constexpr (RB) {
+                const u32x2 c = cur[nt];
+                const f32x4 rf = {__builtin_bit_cast(float, c[0] << 16), __builtin_bit_cast(float, c[0] & 0xffff0000u), __builtin_bit_cast(float, c[1] << 16),
+                                  __builtin_bit_cast(float, c[1] & 0xffff0000u)};
+                v += rf;
+            } else {
+                v += cur[nt];
+            }
             // stores are ALWAYS issued (the wait counts above rely on it); rows / half-tiles past the edge go to a clamped address with no lane enabled
             const bool ok = m < M && nok[nt];
             if constexpr (OUT_F32) {
@@ -1234,7 +1250,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             else { UFV_ACT_SWITCH(e.act, (epilogue256_wide_mx<ACT_, MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias))) }
             relax = RELAX_OK ? 4 : 0;
         } else if (by_rows) {
-            if constexpr (!SWIGLU && !FP8) epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
+            if constexpr (!SWIGLU && !FP8) {
+                if constexpr (!OUT_F32) {
+                    if (e.resid_bf16) epilogue256_resid<OUT_F32, MA0, MA1, NB1, true>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
+                    else epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
+                } else {
+                    epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
+                }
+            }
             relax = RELAX_OK ? 1 : 0;                             // this form issues every store instruction, edge tiles included
         } else if (swide) {
             if constexpr (!OUT_F32 && SWIGLU && MA0 % 2 == 0 && MA1 % 2 == 0 && NB1 == 2) epilogue256_swiglu_wide<MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq);

@@ -8,6 +8,7 @@ struct Epi {
     void* out;             // bf16 or fp32
     int ldr, ldc, act;
     int resid_rows;        // >0: residual row = m % resid_rows (broadcast table, e.g. position embeddings)
+    int resid_bf16 = 0;    // the residual is bf16 [M, ldr] (bf16 outputs only): the in-place update of a bf16 residual stream, out = bf16(acc + bias + float(resid))
     const float* scale_m;  // fp8 operands only: per-row scale of A [M] and per-row scale of W [N]; acc *= scale_m[m] * scale_n[n]
     const float* scale_n;
     int dump_f32;          // stream-K only: store the raw accumulators as fp32 whatever the output type (partial tile dump)
@@ -25,6 +26,20 @@ struct Epi {
 };
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// four / one residual value(s) at element index idx of the residual buffer, whatever its type
+__device__ __forceinline__ f32x4 resid_load4(const Epi& e, size_t idx) {
+    if (e.resid_bf16) {
+        const u32x2 c = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16*>(e.resid) + idx);
+        return f32x4{__builtin_bit_cast(float, c[0] << 16), __builtin_bit_cast(float, c[0] & 0xffff0000u), __builtin_bit_cast(float, c[1] << 16),
+                     __builtin_bit_cast(float, c[1] & 0xffff0000u)};
+    }
+    return *reinterpret_cast<const f32x4*>(e.resid + idx);
+}
+__device__ __forceinline__ float resid_load1(const Epi& e, size_t idx) {
+    return e.resid_bf16 ? (float)reinterpret_cast<const bf16*>(e.resid)[idx] : e.resid[idx];
+}
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 template <bool OUT_F32, int ACT>
@@ -40,7 +55,7 @@ __device__ __forceinline__ void epi_store4(const Epi& e, int m, int n, float v0,
     for (int j = 0; j < 4; ++j) v[j] = act_apply_t<ACT>(v[j]);
     if (e.resid) {
         const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
-        const f32x4 r = *reinterpret_cast<const f32x4*>(e.resid + (size_t)mr * e.ldr + n);
+        const f32x4 r = resid_load4(e, (size_t)mr * e.ldr + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += r[j];
     }
@@ -72,7 +87,7 @@ __device__ __forceinline__ void epi_store4b(const Epi& e, int m, int n, float v0
     for (int j = 0; j < 4; ++j) v[j] = act_apply_t<ACT>(v[j] + b[j]);
     if (e.resid) {
         const int mr = e.resid_rows > 0 ? m % e.resid_rows : m;
-        const f32x4 r = *reinterpret_cast<const f32x4*>(e.resid + (size_t)mr * e.ldr + n);
+        const f32x4 r = resid_load4(e, (size_t)mr * e.ldr + n);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += r[j];
     }

@@ -1099,18 +1099,13 @@ extern "C" int ufv_dwconv3x3_ln_silu(const void* x, void* y, const float* w9, co
                                      int W, int C, float eps, void* stream) {
     UFV_REQUIRE(x && y && w9 && lnw && lnb && F > 0, "ufv_dwconv3x3_ln_silu: bad arguments");
     UFV_REQUIRE(C % 8 == 0 && C <= 4096, "ufv_dwconv3x3_ln_silu: C=%d must be a multiple of 8 and <= 4096", C);
-    static const int lab = getenv("UFV_DWCONV_LAB") ? atoi(getenv("UFV_DWCONV_LAB")) : 1;          // lab: bit 0 = remap, bit 1 = 8 pixels per block
-#define UFV_DWCONV_LAUNCH(PX_, RM_)                                                                                                          \
-    do {                                                                                                                                     \
-        const int nblk = F * H * cdiv(W, PX_);                                                                                               \
-        hipLaunchKernelGGL((dwconv_ln_silu_k<PX_, RM_>), dim3(RM_ ? cdiv(nblk, 8) * 8 : nblk), dim3(256), 0, ST(stream), (const bf16*)x,     \
-                           (bf16*)y, w9, lnw, lnb, F, H, W, C, eps, nblk);                                                                   \
-    } while (0)
-    if (lab == 3) UFV_DWCONV_LAUNCH(8, true);
-    else if (lab == 2) UFV_DWCONV_LAUNCH(8, false);
-    else if (lab == 1) UFV_DWCONV_LAUNCH(4, true);
-    else UFV_DWCONV_LAUNCH(4, false);
-#undef UFV_DWCONV_LAUNCH
+    // round 5 lab: 8 pixels per block (halves the weight re-reads) lost to the occupancy it costs (192 registers: 151 -> 172 us); the XCD-aware order alone: 151 -> 132 us
+    static const bool no_remap = getenv("UFV_DWCONV_NO_REMAP") != nullptr;          // same-box A/B switch
+    const int nblk = F * H * cdiv(W, 4);
+    if (no_remap)
+        hipLaunchKernelGGL((dwconv_ln_silu_k<4, false>), dim3(nblk), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F, H, W, C, eps, nblk);
+    else
+        hipLaunchKernelGGL((dwconv_ln_silu_k<4, true>), dim3(cdiv(nblk, 8) * 8), dim3(256), 0, ST(stream), (const bf16*)x, (bf16*)y, w9, lnw, lnb, F, H, W, C, eps, nblk);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }

@@ -134,12 +134,16 @@ class _VitBody(PackedModule):
         if n != pk["pos"].shape[0]:
             raise ValueError(f"vision tower built for {pk['pos'].shape[0]} patches, got {n} (image {tuple(pixels.shape[-2:])})")
         hd = D // H
+        # UFV_TOWER_STREAM=bf16 (opt-in, NOT the default): the residual stream kept in bf16 as the reference's bf16 tower keeps it -- in-place updates through
+        # ufv_gemm_stream_bf16, half the stream traffic of out_proj / fc2 / the LayerNorms (-0.67 ms per 32-frame clip, same box) for twice the distance from the
+        # fp32 oracle (LABNOTES round 5, tests/test_kernels_gpu.py::test_tower_bf16_stream_option); the default stream is fp32
+        sb = os.environ.get("UFV_TOWER_STREAM") == "bf16" and not self.clip
         if (not self.clip and not any(isinstance(L["wqkv"], ops.Fp8Weight) for L in pk["layers"][:n_layers])
-                and os.environ.get("UFV_STAGE_CALLS", "1") != "0"):
+                and os.environ.get("UFV_STAGE_CALLS", "1") != "0" and not sb):
             # the whole tower as ONE C call (ufv_vit_forward, csrc/stages.hip): the same launches in the same order, bit-identical
             return self._encode_c(pixels.contiguous(), n_layers, n), n
         cols = ops.patchify(pixels.contiguous(), P, pk["Kp"])
-        x = ops.gemm(cols, pk["patch_w"], bias=pk["patch_b"], resid=pk["pos"], resid_rows=n, out_dtype=torch.float32)
+        x = ops.gemm(cols, pk["patch_w"], bias=pk["patch_b"], resid=pk["pos"], resid_rows=n, out_dtype=torch.bfloat16 if sb else torch.float32)
         S = n
         if self.clip:                     # [CLS] row + patches, then pre-LN (in place on the fp32 stream)
             S = n + 1
@@ -161,7 +165,10 @@ class _VitBody(PackedModule):
                   else ops.layernorm(x, L["ln1"][0], L["ln1"][1], cfg.layer_norm_eps, out=h))
             ops.gemm(hq, L["wqkv"], bias=L["bqkv"], out=qkv)
             ops.attention(qkv, qkv[:, D:], qkv[:, 2 * D:], T, H, H, S, S, hd, st, st, st, out=o)
-            ops.gemm(o, L["wo"], bias=L["bo"], resid=x, out=x)
+            if sb:
+                ops.gemm_stream_bf16(o, L["wo"], x, bias=L["bo"])
+            else:
+                ops.gemm(o, L["wo"], bias=L["bo"], resid=x, out=x)
             hq = (ops.layernorm(x, L["ln2"][0], L["ln2"][1], cfg.layer_norm_eps, quant=True) if q8
                   else ops.layernorm(x, L["ln2"][0], L["ln2"][1], cfg.layer_norm_eps, out=h))
             if (q8 and isinstance(L["w1"], ops.Fp8Weight) and isinstance(L["w2"], ops.Fp8Weight) and M >= 256 and pk["Ip"] % 256 == 0
@@ -171,7 +178,10 @@ class _VitBody(PackedModule):
                 ops.gemm_fp8_mx(ffm, L["w2"], bias=L["b2"], resid=x, out=x)
             else:
                 ops.gemm(hq, L["w1"], bias=L["b1"], act=cfg.hidden_act, out=ff)
-                ops.gemm(ff, L["w2"], bias=L["b2"], resid=x, out=x)
+                if sb:
+                    ops.gemm_stream_bf16(ff, L["w2"], x, bias=L["b2"])
+                else:
+                    ops.gemm(ff, L["w2"], bias=L["b2"], resid=x, out=x)
         return x, S
 
 

@@ -53,6 +53,17 @@ def gemm(a, w, bias=None, act=None, resid=None, resid_rows=0, out=None, out_dtyp
     return out
 
 
+def gemm_stream_bf16(a, w, x, bias=None, kernel=GEMM_AUTO):
+    """x += a @ w^T + bias, x the bf16 residual stream [M, N] updated in place (one rounding of the fp32 sum per element); include/ufv.h ufv_gemm_stream_bf16"""
+    _chk(a, torch.bfloat16, "a"); _chk(w, torch.bfloat16, "w"); _chk(x, torch.bfloat16, "x")
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.stride(1) == 1 and a.shape[1] == w.shape[1] and x.shape == (a.shape[0], w.shape[0]) and x.stride(1) == 1
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+    _lib.call("ufv_gemm_stream_bf16", a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), x.data_ptr(), x.stride(0), a.shape[0], w.shape[0], a.shape[1], _ptr(bias),
+              kernel, _stream())
+    return x
+
+
 def gemv1(w, a=None, x=None, ln_w=None, eps=1e-6, bias=None, act=None, resid=None, swiglu=False, out=None, out_dtype=torch.bfloat16):
     """One-row GEMV (decode): a bf16 [K] row, or x fp32 [K] + RMSNorm weight (norm fused into the kernel).  w bf16 [N,K] or
     an Fp8Weight (then the row is quantised in the kernel: W8A8).  -> [N(/2)]"""
