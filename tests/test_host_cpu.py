@@ -378,6 +378,9 @@ def test_gemm_kernel_choice_at_the_config2_shapes():
     assert pick(1200, 3584, 18944, 1, 0, 0) < 10000                       # ... never split under an activation
     assert pick(1200, 3584, 18944, 0, 0, 1) < 10000                       # ... or into a bf16 output
     assert pick(100, 3584, 3584, 1, 0, 1) == 0 and pick(2399, 3500, 3584, 1, 0, 1) == 0      # small / unaligned shapes: not the ping-pong kernel
+    # the connector: stage-2 1x1 convolutions / readout and the Conv3d sampler as a GEMM (bf16 outputs, 2304 rows): 192x192, 228 tiles = one round
+    assert pick(2304, 3584, 3584, 0, 0, 1) == 1331 and pick(2304, 3584, 28672, 0, 0, 1) == 1331
+    assert pick(18432, 3584, 3584, 0, 0, 1) == 1442                       # stage-1 1x1 convolutions: 1008 tiles of 256x256
 
 
 def test_generated_kernel_bodies_are_what_their_generators_emit(tmp_path):

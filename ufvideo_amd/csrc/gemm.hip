@@ -750,7 +750,9 @@ inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool ca
     // row-pipelined residual epilogue (round 3) the unsplit 192x192 kernel beats both the split-K form and the 128-wide kernel there (292 us against
     // 314 / 353, tools/gemm_shapes.py); the tick model above still carries the old epilogue's K-tile floor for small tiles, so this case is decided here.
     // (round 4: bf16 outputs too -- the connector's Conv3d as a GEMM, 2304 x 3584 x 28672, 228 tiles: 427 us against 580 on the 128-wide kernel the model picked)
-    if (!swiglu && K >= 8192 && M >= 256 && (N % 192 == 0 || N % 192 == 128)) {
+    // (round 5: bf16 outputs from K = 2048 when ONE round of 192 x 192 tiles fills the chip -- the connector's stage-2 1x1 convolutions and readout, 2304 x 3584 x 3584,
+    // 228 tiles: 57.2 us against 61.3 on the 128-wide kernel the model picked, tools/gemm_shapes.py proj_ro)
+    if (!swiglu && K >= (out_f32 ? 8192 : 2048) && M >= 256 && (N % 192 == 0 || N % 192 == 128)) {
         const long t = (long)cdiv(M, 192) * cdiv(N, 192);
         if ((out_f32 || t <= 256) && (double)t / (256.0 * ((t + 255) / 256)) >= (out_f32 ? 0.9 : 0.85)) return 1331;
     }
