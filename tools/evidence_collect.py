@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEEP = [
     "bench_line.json", "bench_line_fp8.json", "bench_line_64f.json", "bench_line_profiled.json", "bench_line_fp8_profiled.json",
-    "bench_kernel_stats.csv", "bench_fp8_kernel_stats.csv", "per_step.json", "per_step_fp8.json",
+    "bench_kernel_stats.csv", "bench_fp8_kernel_stats.csv", "per_step.json", "per_step_fp8.json", "step_timeline.json",
     "decode_timings.txt", "decode_kernel_stats.csv", "decode_fp8_timings.txt", "decode_fp8_kernel_stats.csv",
     "sam2_timings.txt", "sam2_kernel_stats.csv", "train_timings.txt", "train_kernel_stats.csv",
     "gemm_vs_vendor.json", "attn_vit_clock.txt", "pytest_gpu_tail.txt",

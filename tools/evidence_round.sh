@@ -9,6 +9,8 @@ bash $R/tools/profile_round.sh $TAG > $OUT/profile_round.log 2>&1
 bash $R/tools/native_per_step.sh $TAG per_step > $OUT/per_step.log 2>&1
 UFV_BENCH_ARGS=--fp8 bash $R/tools/native_per_step.sh $TAG per_step_fp8 > $OUT/per_step_fp8.log 2>&1
 rm -rf $OUT/per_step.d $OUT/per_step_fp8.d
+python3 $R/tools/step_timeline.py $OUT/tl $OUT/step_timeline.json > $OUT/step_timeline.log 2>&1
+rm -rf $OUT/tl
 bash $R/tools/pmc_bench.sh $TAG pmc > $OUT/pmc.log 2>&1
 UFV_BENCH_ARGS=--fp8 bash $R/tools/pmc_bench.sh $TAG pmc_fp8 > $OUT/pmc_fp8.log 2>&1
 bash $R/tools/profile_aux.sh $TAG > $OUT/profile_aux.log 2>&1
