@@ -102,11 +102,12 @@ def test_gemv(M):
     assert rel(out, ref) < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K,act", [(32, 896, 3584, "silu"), (32, 3584, 896, "sigmoid"), (33, 1000, 2048, None), (9, 40, 4096, "relu"), (64, 16, 32, None),
-                                         (17, 72, 2080, "gelu_tanh")])
+@pytest.mark.parametrize("M,N,K,act", [(32, 896, 3584, "silu"), (32, 3584, 896, "sigmoid"), (33, 1000, 2048, None), (9, 520, 4096, "relu"), (64, 512, 512, None),
+                                         (17, 600, 2080, "gelu_tanh"), (1, 896, 3584, "silu"), (2, 3584, 896, None)])
 def test_small_m_products_on_the_matrix_cores(M, N, K, act):
-    """8 < M <= 64 (the connector's squeeze-excite products): gemm_small_m -- 16 columns per block, K split over 4 or 8 waves, partial sums added in wave order.
-    Covers both wave counts (K >= 2048 -> 8), ragged M (second row block partly or wholly empty), N not a multiple of 16, bf16 and fp32 outputs."""
+    """M <= 64 with 512 <= N <= 8192, K >= 512 (the connector's squeeze-excite products): gemm_small_m -- 16 columns per block, K split over 4 or 8 waves, partial
+    sums added in wave order.  Covers both wave counts (K >= 2048 -> 8), ragged M (second row block partly or wholly empty), N not a multiple of 16, bf16 and fp32
+    outputs, and that a row's result does not depend on how many rows travel with it (frame chunks of a video)."""
     a, w = bf(g(M, K, seed=21)), bf(g(N, K, seed=22, scale=0.03))
     bias = g(N, seed=23)
     z = a.float() @ w.float().t() + bias
@@ -116,6 +117,9 @@ def test_small_m_products_on_the_matrix_cores(M, N, K, act):
     out16 = ops.gemm(a, w, bias=bias, act=act)
     assert out16.dtype == torch.bfloat16 and torch.equal(out16, out.to(torch.bfloat16)), "bf16 output = the rounded fp32 output"
     assert torch.equal(out, ops.gemm(a, w, bias=bias, act=act, out_dtype=torch.float32)), "deterministic (fixed order of the waves' partial sums)"
+    for m0, m1 in ((0, 1), (M // 2, M), (M - 1, M)):
+        if m1 > m0:
+            assert torch.equal(ops.gemm(a[m0:m1].contiguous(), w, bias=bias, act=act, out_dtype=torch.float32), out[m0:m1]), "rows are independent of the batch they arrive in"
 
 
 @pytest.mark.parametrize("M,N,K", [(18432, 1152, 1152), (1000, 1152, 4352), (300, 256, 192), (20, 128, 64), (2399, 3584, 3584)])

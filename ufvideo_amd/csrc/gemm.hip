@@ -817,7 +817,9 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
         const int n_out = S ? N / 2 : N;
         if constexpr (!Q && !S) {
             static const bool no_small_m = getenv("UFV_NO_SMALL_M") != nullptr;          // lab switch (same-box A/B)
-            if (M > 8 && K % 32 == 0 && !no_small_m) {
+            // chosen by (N, K) alone, never by M: a frame chunk of a video (M = its frames) must get the arithmetic the whole video gets (frame-sharded encode is
+            // bit-identical to the single-process pass); products with a small weight matrix (the SAM heads' 256-wide layers) and the vocabulary-sized lm_head row stay on the GEMV
+            if (K % 32 == 0 && N >= 512 && K >= 512 && N <= 8192 && !no_small_m) {
                 if (K >= 2048)          // 8 waves x 14 K-steps in flight each: the whole K range of the block requested at once
                     hipLaunchKernelGGL((gemm_small_m<F, 8, 14>), dim3(cdiv(N, 16), cdiv(M, 32)), dim3(512), 0, st, (const bf16*)A, (const bf16*)W, e, M, N, K, lda, ldw);
                 else
