@@ -269,7 +269,12 @@ def test_vit72_third_generation_bit_identical_and_rescale_paths():
         new = ops.attention(q, k, v, B, H, H, S, S, hd, *st, kernel=14)
         old = ops.attention(q, k, v, B, H, H, S, S, hd, *st, kernel=11)
         auto = ops.attention(q, k, v, B, H, H, S, S, hd, *st)
-        assert torch.equal(new, old) and torch.equal(auto, old), (B, H, int((new != old).sum()))
+        if not (torch.equal(new, old) and torch.equal(auto, old)):
+            # seen ONCE in round 5 (1 of 7 suite runs, not reproduced in 1240 directed launches, tools/lab/attn_vit_flake*.py): say which kernel is unstable and where
+            new2, old2 = ops.attention(q, k, v, B, H, H, S, S, hd, *st, kernel=14), ops.attention(q, k, v, B, H, H, S, S, hd, *st, kernel=11)
+            d = (new != old).nonzero()
+            raise AssertionError(dict(B=B, H=H, new_vs_old=int(d.shape[0]), first=d[:4].tolist(), last=d[-1:].tolist(), auto_vs_old=int((auto != old).sum()),
+                                      kernel14_repeatable=bool(torch.equal(new2, new)), kernel11_repeatable=bool(torch.equal(old2, old)), rerun_equal=bool(torch.equal(new2, old2))))
         assert torch.isfinite(new.float()).all() and rel(new, attn_ref(q, k, v, False)) <= 2 * ATTN_TOL
     q, k, v = bf(g(1, 288, 2, hd, seed=60)), bf(g(1, 288, 2, hd, seed=61)), bf(g(1, 288, 2, hd, seed=62))
     with pytest.raises(_lib.UfvError):
