@@ -291,8 +291,11 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
             if os.path.exists(pmc):
                 rec = json.load(open(pmc))
                 have, want = rec.get("gemm_sources_sha256"), gemm_sources_sha256()
-                if have == want:
-                    gu = rec.get("gate_up", {})
+                gu = rec.get("gate_up", {})
+                if have == want and f"M={ks['M']} " not in str(gu.get("kernel", "")) + " ":
+                    # the counters were taken on the default workload (32 frames, M = 2399); another M is another launch: not quoted
+                    pmc_note = f"not quoted: {pmc_file} holds the counters of {gu.get('kernel')}, this run's dominant launch has M={ks['M']}"
+                elif have == want:
                     traffic, busy = gu.get("hbm_bytes_per_launch"), gu.get("mfma_busy_fraction")
                 else:
                     # counters of a DIFFERENT build of the kernel are not quoted: null, and say so where the driver's log shows it

@@ -1,2 +1,9 @@
+cd $GRAFT_REPO_ROOT; OUT=$GRAFT_REPO_ROOT/gpurun_out/r05; mkdir -p $OUT
+bash tools/pmc_bench.sh r05 pmc > $OUT/pmc.log 2>&1
+UFV_BENCH_ARGS=--fp8 bash tools/pmc_bench.sh r05 pmc_fp8 > $OUT/pmc_fp8.log 2>&1
 cd $GRAFT_REPO_ROOT
-python3 -m pytest tests/test_seg_train_gpu.py tests/test_configs_gpu.py::test_config3_64_frames_token_count_and_8_way_chunks tests/test_fullsize_gpu.py::test_encoder_is_independent_per_aligned_frame_chunk tests/test_parallel_gpu.py tests/test_kernels_gpu.py -m gpu -q 2>&1 | tail -3
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
+python3 bench.py --steps 10 --warmup 3 --fp8 --no-cpu-baseline > $OUT/bench_line_fp8.json 2>> $OUT/bench.err
+python3 bench.py --steps 5 --warmup 2 --frames 64 --no-cpu-baseline > $OUT/bench_line_64f.json 2>> $OUT/bench.err
+python3 -m pytest tests/test_fp8_gpu.py tests/test_bench_gpu.py -m gpu -q 2>&1 | tail -2
+for f in bench_line.json bench_line_fp8.json bench_line_64f.json; do tail -1 $OUT/$f | cut -c1-120; done

@@ -1103,7 +1103,17 @@ extern "C" int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, con
         UFV_REQUIRE(!out_f32 && !resid && N % 256 == 0 && ldc % 8 == 0 && ldc >= n_out && ld_obs % 1024 == 0 && ld_obs >= 1024 * ((n_out + 511) / 512) && (int64_t)M * ldc < (1ll << 31) &&
                     (int64_t)((M + 63) / 64) * ld_obs < (1ll << 31),
                     "ufv_gemm_fp8_mx: the MX-emitting epilogue needs N %% 256 == 0, no residual, a byte pitch %% 8 == 0 (N=%d ldc=%d)", N, ldc);
-        return ufv_launch_pp_mx(A, W, e, M, N, K, lda, ldw, false, swiglu != 0, 1442, 2, st);
+        // bench.py's roofline entry for --fp8: the same every-n-th-launch HIP event bracket ufv_gemm puts around the bf16 gate/up GEMM (ufv_gemm_timing)
+        TimedLaunch tl{};
+        const bool timed = g_timing > 0 && swiglu && (g_timing_seen++ % (unsigned)g_timing) == 0 && hipEventCreate(&tl.s) == hipSuccess && hipEventCreate(&tl.e) == hipSuccess;
+        if (timed) (void)hipEventRecord(tl.s, st);
+        const int rc = ufv_launch_pp_mx(A, W, e, M, N, K, lda, ldw, false, swiglu != 0, 1442, 2, st);
+        if (timed) {
+            (void)hipEventRecord(tl.e, st);
+            tl.M = M; tl.N = N; tl.K = K;
+            timed_launches().push_back(tl);
+        }
+        return rc;
     }
     UFV_REQUIRE(!swiglu, "ufv_gemm_fp8_mx: SwiGLU with a block-scaled input is not built");
     UFV_REQUIRE(e.ldc % 4 == 0 && (!resid || ((uintptr_t)resid % 16 == 0 && ldr % 4 == 0)), "ufv_gemm_fp8_mx: output / residual pitch %% 4 == 0");
