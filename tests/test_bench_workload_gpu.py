@@ -129,7 +129,7 @@ def test_bench_workload_stage_by_stage_vs_oracle(bench_model):
         cos, sin = O.rope_cos_sin(torch.arange(S), 128, 1e6)
         bias = torch.zeros(S, S).masked_fill(torch.arange(S)[None, :] > torch.arange(S)[:, None], torch.finfo(torch.float32).min)[None, None]
         xm, x32 = emb_m.clone(), emb_32.clone()
-        do_mirror = n_dec <= 4
+        do_mirror = n_dec <= 4 or os.environ.get("UFV_PARITY_FULL") == "mirror"        # UFV_PARITY_FULL=mirror: the 28-layer chain with BOTH legs (+ ~3 min of host time)
         for i in range(n_dec):
             p = f"model.layers.{i}."
             lsd = layer_sd(msd, p)
@@ -173,7 +173,10 @@ def test_bench_workload_stage_by_stage_vs_oracle(bench_model):
     assert r_p["vs_fp32"] <= 1.5 * r_p["mirror_vs_fp32"] + 1e-3, r_p
     assert r_ptf["vs_bf16_mirror"] <= 2.2e-2, r_ptf                                                    # 1.1e-2 (48 storage points, the connector's noise floor)
     if do_mirror:
-        assert r_n["rel_l2_vs_fp32"] <= 2.8e-2 and r_l["rel_l2_vs_fp32"] <= 1.2e-2, (r_n, r_l)      # 1.4e-2 (1.35e-2) / 6.0e-3 (5.8e-3)
+        if n_dec <= 4:
+            assert r_n["rel_l2_vs_fp32"] <= 2.8e-2 and r_l["rel_l2_vs_fp32"] <= 1.2e-2, (r_n, r_l)  # 1.4e-2 (1.35e-2) / 6.0e-3 (5.8e-3)
+        else:
+            assert r_n["rel_l2_vs_fp32"] <= 5e-2 and r_l["rel_l2_vs_fp32"] <= 2.3e-2, (r_n, r_l)    # 28 layers: 2.47e-2 / 1.08e-2
         assert r_n["vs_fp32"] <= 1.5 * r_n["mirror_vs_fp32"] + 1e-3 and r_l["vs_fp32"] <= 1.5 * r_l["mirror_vs_fp32"] + 1e-3, (r_n, r_l)
     else:                                                                                              # UFV_PARITY_FULL=1: 28 layers, fp32 leg only (no mirror to bound against)
         assert r_n["rel_l2_vs_fp32"] <= 5e-2 and r_l["rel_l2_vs_fp32"] <= 2.3e-2, (r_n, r_l)        # measured 2.47e-2 / 1.13e-2 (profiles/r05/parity_table_bench_full.json)

@@ -17,7 +17,7 @@ bash $R/tools/profile_aux.sh $TAG > $OUT/profile_aux.log 2>&1
 cd $R
 python3 tools/probe_blaslt.py $TAG > $OUT/gemm_vs_vendor.log 2>&1
 LAB_P2_CLOCK=1 tools/lab/attn_lab_clock 14 > $OUT/attn_vit_clock.txt 2>&1
-UFV_PARITY_REPORT_BENCH=$OUT/parity_table_bench_full.json UFV_PARITY_FULL=1 python3 -m pytest tests/test_bench_workload_gpu.py -m gpu -q -s > $OUT/parity_full.log 2>&1
+UFV_PARITY_REPORT_BENCH=$OUT/parity_table_bench_full.json UFV_PARITY_FULL=mirror python3 -m pytest tests/test_bench_workload_gpu.py -m gpu -q -s > $OUT/parity_full.log 2>&1
 UFV_PARITY_REPORT_BENCH=$OUT/parity_table_bench.json python3 -m pytest tests/test_bench_workload_gpu.py -m gpu -q -s > $OUT/parity_bench.log 2>&1
 UFV_PARITY_REPORT=$OUT/parity_table.json python3 -m pytest tests/test_parity_bf16_gpu.py -m gpu -q -s > $OUT/parity_bf16.log 2>&1
 (time python3 -m pytest tests -m gpu -q -s 2>&1 | grep -E "PERF_FLOOR|TOWER_STREAM|passed|failed|FAILED|error|AssertionError" ) > $OUT/pytest_gpu_tail.txt 2>&1
