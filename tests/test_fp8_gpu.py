@@ -240,8 +240,9 @@ def test_every_fp8_gemm_inside_the_model_is_exact_for_its_own_input():
         ops.gemm_fp8 = orig
         ops.gemm_fp8_mx = orig_mx
         os.environ.pop("UFV_NO_FUSED_ROPE", None)
-    # per-row-scaled GEMMs: qkv (+ per ViT layer qkv); o_proj / out_proj stay bf16; the fused MX chain (round 5): gate/up -> down (+ per ViT layer fc1 -> fc2)
-    assert n_llm == 1 and len(calls) == 1 + 2 * 1 and len(mx_calls) == 2 + 2 * 2, (n_llm, len(calls), len(mx_calls))
+    # per-row-scaled GEMMs: qkv (+ per ViT layer qkv); the tower's out_proj stays bf16; block-scaled (round 5): o_proj behind its MX quantise launch, the fused chain
+    # gate/up -> down (+ per ViT layer fc1 -> fc2)
+    assert n_llm == 1 and len(calls) == 1 + 2 * 1 and len(mx_calls) == 3 + 2 * 2, (n_llm, len(calls), len(mx_calls))
     acts = {None: lambda v: v, "gelu_pytorch_tanh": lambda v: F.gelu(v, approximate="tanh"), "gelu_tanh": lambda v: F.gelu(v, approximate="tanh"),
             "gelu": F.gelu, "silu": F.silu}
     for i, c in enumerate(calls):

@@ -219,9 +219,9 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
         tabs = [ops.rope_table(pk["inv_freq"], p0, n, hd) if n > 1 and hd % 16 == 0 else None for _, n, _, p0 in segs]
         for li, L in enumerate(pk["layers"]):
             if "wqkv8" in L:
-                # W8A8 prefill.  o_proj stays bf16 (round 5): its input is the attention kernel's bf16 output, and quantising that in a launch of its own (14.6 us) plus
-                # the e4m3 GEMM (44 us) is no faster than the bf16 GEMM (64 us) -- one stand-alone quantise kernel per layer less, a bf16-exact projection more.
-                # (wo8 exists for the decode step, which streams weights: half the bytes.)
+                # W8A8 prefill.  o_proj's input is the attention kernel's bf16 output: with the per-row quantise launch (14.6 us) the e4m3 GEMM (44 us) was no faster than
+                # the bf16 GEMM (64 us); with the one-pass MX quantise (ufv_quantize_mx, ~6 us) and the block-scaled A operand it is: -0.45 ms per clip (same box, three
+                # alternations: 32.75 -> 32.3 ms).  UFV_FP8_O_BF16=1 keeps the bf16 projection (same-box A/B).
                 L = dict(L, wqkv=L["wqkv8"], wgu=L["wgu8"], wd=L["wd8"])
             q8 = isinstance(L["wqkv"], ops.Fp8Weight)          # W8A8 prefill: the norms emit e4m3 + row scale directly
             hq = ops.rmsnorm(x, L["ln1"], eps, quant=True) if q8 else ops.rmsnorm(x, L["ln1"], eps, out=h)
@@ -241,7 +241,10 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
                 ops.rope_kv(qs, n, H, KV, hd, pk["inv_freq"], p0, kvb, table=tab)
                 ops.attention(qs, kvb, kvb[:, KV * hd:], 1, H, KV, n, p0 + n, hd, (0, qkv.stride(0)), (0, kvb.stride(0)),
                               (0, kvb.stride(0)), causal=True, q_pos0=p0, out=o[off:off + n])
-            ops.gemm(o, L["wo"], resid=x, out=x)
+            if q8 and isinstance(L.get("wo8"), ops.Fp8Weight) and S >= 256 and (H * hd) % 128 == 0 and os.environ.get("UFV_FP8_O_BF16") is None:
+                ops.gemm_fp8_mx(ops.quantize_mx(o), L["wo8"], resid=x, out=x)
+            else:
+                ops.gemm(o, L["wo"], resid=x, out=x)
             hq = ops.rmsnorm(x, L["ln2"], eps, quant=True) if q8 else ops.rmsnorm(x, L["ln2"], eps, out=h)
             if q8 and "wd8m" in L and S >= 256 and isinstance(L["wgu"], ops.Fp8Weight) and L["wgu"].shape[0] % 256 == 0:
                 # W8A8, fused: gate/up (SwiGLU epilogue -> e4m3 + MX block scales) -> down (block-scaled A operand); ufv_gemm_fp8_mx
