@@ -321,7 +321,7 @@ def test_fulldim_siglip_layers_vs_oracle():
 def test_tower_bf16_stream_option(monkeypatch):
     """UFV_TOWER_STREAM=bf16 (opt-in; model/encoder.py): the residual stream stored in bf16, as the reference's bf16 tower stores it.  9 layers at SigLIP-so400m
     dimensions: the option follows ITS mirror (oracle stream_bf16=True) as closely as the default follows the fp32-stream mirror, and the price against the fp32
-    oracle is printed and bounded (26 layers, oracle only, tests/eval_bf16_stream.py: rel-L2 6.9e-3 -> 1.3e-2) -- the reason it is not the default."""
+    oracle is printed and bounded (26 layers, oracle only, tools/lab/eval_bf16_stream.py: rel-L2 6.9e-3 -> 1.3e-2) -- the reason it is not the default."""
     cfg = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=10, num_attention_heads=16, image_size=336, patch_size=14)
     sd = O.make_siglip_weights(cfg, seed=17)
     tower = SiglipVisionTower("siglip", Args(), vision_config=cfg)

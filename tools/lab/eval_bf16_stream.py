@@ -1,7 +1,7 @@
 """Lab (CPU, oracle only): what a bf16 residual stream in the ViT tower would cost in parity.  The 26-layer SigLIP-so400m-dims tower on one 336 x 336 frame:
 the fp32 oracle, the bf16 mirror as built (fp32 stream) and the mirror with the stream rounded to bf16 after both residual adds of every layer (what a
 bf16 tower keeps, and what would halve the in-place update traffic of out_proj / fc2).  Result (round 4): rel-L2 vs fp32 6.9e-3 -> 1.3e-2, max norm 8.1e-3 -> 2.5e-2."""
-import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 from oracle import ref_cpu as O
 torch.manual_seed(0)
