@@ -502,6 +502,64 @@ def test_gradient_accumulation_equals_sum_of_micro_batches():
             assert torch.allclose(b.view(x12, n), s_, rtol=1e-4, atol=1e-6 * float(s_.abs().max() + 1)), n
 
 
+@pytest.mark.parametrize("lora", [None, dict(r=4, alpha=8, seed=3)])
+def test_gradient_checkpointing_is_bit_identical_and_keeps_one_stash(lora):
+    """DecoderTrainer(gradient_checkpointing=True) -- the reference's --gradient_checkpointing True (scripts/train/train_1121v1.sh; transformers wraps every decoder
+    layer in torch.utils.checkpoint): per layer only the input stream is kept, a layer's backward first re-runs its forward into the ONE shared stash.  Same launches on
+    the same inputs: loss, every gradient and d(inputs_embeds) are `torch.equal` to the stashing form; the activation buffers shrink from n_layers stashes to one."""
+    a, _ = load_golden("train_grad_tiny")
+    emb = t(a["inputs_embeds"])[0].to(DEV)
+    labels = _shift(t(a["labels"])[0])
+    eids = spliced_embed_ids(a["ids"][0], emb.shape[0])
+    res = []
+    for ck in (False, True):
+        m, _, _ = tiny_model()
+        tr = DecoderTrainer(m, lora=lora, gradient_checkpointing=ck)
+        if lora is not None:                                             # B = 0 at init would leave the adapters' A without gradient: give B values
+            tr.lora_bucket.w.copy_(torch.randn(tr.lora_bucket.w.shape, generator=torch.Generator().manual_seed(5)).to(tr.lora_bucket.w) * 0.05)
+            tr._refresh_lora()
+        tr.zero_grad()
+        loss, dx = tr.forward_backward(emb, labels, embed_ids=eids)
+        loss2, dx2 = tr.forward_backward(emb * 0.5, labels, embed_ids=eids)          # a second micro-batch accumulates through the same path
+        stash_ptrs = {st["gu"].data_ptr() for st in tr.st}
+        x_ptrs = {st["x_in"].data_ptr() for st in tr.st}
+        res.append((float(loss), float(loss2), dx.clone(), dx2.clone(), [b.g.clone() for b in tr.buckets()], len(stash_ptrs), len(x_ptrs)))
+        tr.detach()
+    (l0, l0b, d0, d0b, g0, n0, x0), (l1, l1b, d1, d1b, g1, n1, x1) = res
+    assert l0 == l1 and l0b == l1b and torch.equal(d0, d1) and torch.equal(d0b, d1b)
+    assert len(g0) == len(g1) and all(torch.equal(x, y) for x, y in zip(g0, g1))
+    assert n0 == x0 == x1 and n0 > 1 and n1 == 1, (n0, n1, x0, x1)        # one stash for all layers, an input stream per layer
+
+
+def test_hf_gradient_checkpointing_switch_selects_the_recomputing_engine():
+    """transformers' Trainer calls model.gradient_checkpointing_enable() under --gradient_checkpointing True and the reference then asks for
+    enable_input_require_grads() (ufvideo/train.py:820-826): both exist on the drop-in model; the autograd path's engine is re-built with the re-computing backward and
+    `.grad` comes out bit-identical."""
+    a, _ = load_golden("train_grad_tiny")
+    m, arrs, _ = tiny_model()
+    ids, labels = t(a["ids"]).to(DEV), t(a["labels_in"]).to(DEV)
+    batch = dict(input_ids=ids, labels=labels, attention_mask=torch.ones_like(ids), images=[(t(arrs["video"]).to(DEV), "video")],
+                 images_sam=torch.zeros(1, 4, 3, 8, 8, device=DEV), offset=[0, 1], masks_list=[torch.zeros(0, 56, 56)], label_list=[torch.zeros(56, 56)])
+    names = [n for n, _ in m.named_parameters() if n.startswith(("model.layers.", "model.norm.", "lm_head."))]
+    own = dict(m.named_parameters())
+    for n in names:
+        own[n].requires_grad_(True)
+    assert m.supports_gradient_checkpointing and not m.is_gradient_checkpointing
+    m(**batch)["loss"].backward()
+    plain = {n: own[n].grad.clone() for n in names}
+    assert not m._engine[1].gradient_checkpointing
+    for n in names:
+        own[n].grad = None
+    m.gradient_checkpointing_enable()
+    m.enable_input_require_grads()
+    assert m.is_gradient_checkpointing
+    m(**batch)["loss"].backward()
+    assert m._engine[1].gradient_checkpointing and len({st["gu"].data_ptr() for st in m._engine[1].st}) == 1
+    assert all(torch.equal(own[n].grad, plain[n]) for n in names)
+    m.gradient_checkpointing_disable()
+    m.release_grad_engine()
+
+
 def test_train_step_on_the_collator_batch_contract():
     """train_step(**batch) with the reference collator's keys: loss = the reference's ce_loss on the same sample (our tower +
     projector feed the splice), and repeated steps on the sample drive it down."""

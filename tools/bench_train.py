@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--adapter-only", action="store_true",
                     help="the reference's tune_mm_mlp_adapter stage: decoder frozen (dL/dx only), STC-v35 projector trained on 32 x 24 x 24 tower tokens")
+    ap.add_argument("--gradient-checkpointing", action="store_true", help="the reference's --gradient_checkpointing True: per layer only the input stream is kept")
+    ap.add_argument("--micro-batches", type=int, default=1, help="samples per step and rank (gradient accumulation): the reference's per-device batch is 2 x 32 frames")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     dist = None
@@ -47,7 +49,7 @@ def main():
         model.get_model().mm_projector = STCConnectorV35(PCfg(), device=dev)
         tr = DecoderTrainer(model, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0, train_projector=True, train_decoder=False)
     else:
-        tr = DecoderTrainer(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
+        tr = DecoderTrainer(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0, gradient_checkpointing=args.gradient_checkpointing)
     S, D, V = args.seq, cfg.hidden_size, cfg.vocab_size
     g = torch.Generator(device=dev).manual_seed(1237 + rank)
     emb = torch.randn(S, D, device=dev, generator=g) * 0.02
@@ -74,7 +76,8 @@ def main():
                 name = "mm_projector." + name
                 tr.proj_bucket.view(tr.proj_bucket.g, name).add_(gval.reshape(tr.proj_params[name].shape))
         else:
-            loss, _ = tr.forward_backward(emb, labels, embed_ids=eids, last=True)
+            for mb in range(args.micro_batches):
+                loss, _ = tr.forward_backward(emb, labels, embed_ids=eids, last=mb == args.micro_batches - 1)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         tr.step()
         sync(); t2 = time.perf_counter()
@@ -87,17 +90,18 @@ def main():
     H, KV, hd, I, L = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size, args.layers
     lin = 2.0 * S * D * ((H + 2 * KV) * hd + H * hd + 3 * I) * L + 2.0 * S * D * V          # projections + lm_head (all positions)
     att = 2.0 * 2 * H * S * S * hd / 2 * L                                                     # causal QK^T + PV
-    flops = 3.0 * lin + 3.5 * att                                                              # bwd = 2x linear, 2.5x attention
+    flops = (3.0 * lin + 3.5 * att) * args.micro_batches                                       # bwd = 2x linear, 2.5x attention (a re-run forward is not counted as useful work)
     if args.adapter_only:
         flops = 2.0 * lin + 3.5 * att                                                          # no weight gradients in the decoder (projector not counted)
     if rank == 0:
         print(json.dumps({"metric": ("adapter-only training tokens/s (projector trained, decoder frozen)" if args.adapter_only else
-                                     "decoder training tokens/s (fwd+bwd+AdamW), Qwen2-7B dims"), "value": round(world * S / dt, 1),
+                                     "decoder training tokens/s (fwd+bwd+AdamW), Qwen2-7B dims"), "value": round(world * S * args.micro_batches / dt, 1),
                           "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "ms_per_step": round(dt * 1e3, 1),
                           "ms_fwd_bwd": round(t_fb / args.steps * 1e3, 1), "ms_exchange_adamw": round(t_opt / args.steps * 1e3, 1),
                           "loss": round(float(loss), 4), "step_tflops": round(flops / dt / 1e12, 1), "seq_len": S, "layers": L,
                           "hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1), "dtype": "bf16 (fp32 master / grads)",
-                          "parallelism": f"zero2-dp{world}", "data": "synthetic"}), flush=True)
+                          "parallelism": f"zero2-dp{world}", "micro_batches": args.micro_batches,
+                          "gradient_checkpointing": bool(args.gradient_checkpointing), "data": "synthetic"}), flush=True)
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
 

@@ -18,3 +18,7 @@ for name in decode decode_fp8 sam2 train; do
   rm -rf $OUT/prof_$name
   echo "== $name"; tail -8 $OUT/${name}_timings.txt
 done
+# the reference's per-device training shape (scripts/train/train_1121v1.sh: batch 2 x 32 frames, --gradient_checkpointing True): two micro-batches of S = 2399 per step
+python3 $R/tools/bench_train.py --steps 3 --warmup 1 --micro-batches 2 >> $OUT/train_timings.txt 2>> $OUT/train.err
+python3 $R/tools/bench_train.py --steps 3 --warmup 1 --micro-batches 2 --gradient-checkpointing >> $OUT/train_timings.txt 2>> $OUT/train.err
+tail -2 $OUT/train_timings.txt

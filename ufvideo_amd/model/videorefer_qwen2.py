@@ -495,18 +495,37 @@ class VideoReferQwen2ForCausalLM(VideoReferMetaForCausalLM, PackedModule):
         dec = any(p.requires_grad for n, p in self.named_parameters() if n.startswith(("model.layers.", "model.norm.", "lm_head.")))
         emb = bool(inner.embed_tokens.weight.requires_grad)
         key = (dec or emb, emb, req(getattr(inner, "mm_projector", None)), req(getattr(inner, "region_encoder", None)),
-               req(getattr(inner, "text_hidden_fcs", None)) and getattr(inner, "mask_encoder", None) is not None)
+               req(getattr(inner, "text_hidden_fcs", None)) and getattr(inner, "mask_encoder", None) is not None, bool(getattr(self, "_gradient_checkpointing", False)))
         eng = getattr(self, "_engine", None)
         if eng is not None and eng[0] != key:
             eng[1].detach()
             eng = None
         if eng is None:
-            if not any(key):
+            if not any(key[:5]):
                 raise RuntimeError("forward(inference=False): no supported parameter group requires grad (the vision tower is frozen, as in the reference)")
             tr = DecoderTrainer(self, train_decoder=key[0], train_embed=key[1], train_projector=key[2], train_region_encoder=key[3], train_seg_head=key[4],
-                                optimizer_states=False)
+                                optimizer_states=False, gradient_checkpointing=key[5])
             eng = self._engine = [key, tr, None]
         return eng
+
+    # ---- HF's gradient-checkpointing switches (transformers Trainer calls gradient_checkpointing_enable() when --gradient_checkpointing True, as the reference's
+    #      scripts/train/*.sh set it; ufvideo/train.py:820-826 then asks for enable_input_require_grads()).  Here the switch selects the engine's re-computing
+    #      backward (train.DecoderTrainer(gradient_checkpointing=True)): per layer only the input stream is kept, results bit-identical. -------------------------
+    supports_gradient_checkpointing = True
+
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        self._gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self._gradient_checkpointing = False
+
+    @property
+    def is_gradient_checkpointing(self):
+        return bool(getattr(self, "_gradient_checkpointing", False))
+
+    def enable_input_require_grads(self):
+        """HF needs the embedding output to require grad so that checkpointed segments get a graph; the HIP engine differentiates by construction: nothing to do"""
+        return None
 
     def release_grad_engine(self):
         """drops the autograd path's engine and gives the decoder's packed weights back to the model (they are re-packed from the nn.Parameters)"""

@@ -107,8 +107,12 @@ class DecoderTrainer:
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, group=None,
                  train_embed=True, train_projector=False, train_region_encoder=False, train_decoder=True, mm_projector_lr=None,
-                 train_seg_head=False, lora=None, optimizer_states=True):
-        """optimizer_states=False: the forward + backward engine only -- no fp32 masters / Adam moments are allocated and step() raises; the gradients are
+                 train_seg_head=False, lora=None, optimizer_states=True, gradient_checkpointing=False):
+        """gradient_checkpointing=True (the reference's --gradient_checkpointing True, scripts/train/train_1121v1.sh; HF `gradient_checkpointing_enable()` wraps every
+        decoder layer): only every layer's INPUT stream is kept from the forward pass; the backward of a layer first re-runs that layer's forward (same kernels, same
+        bits) into ONE stash shared by all layers.  Activation memory n_layers x 420 MB -> 34 MB per layer + one 420 MB stash at S = 2399 (7B dimensions), for one more
+        forward pass of time; losses and gradients are bit-identical to the stashing form (tests/test_train_gpu.py).
+        optimizer_states=False: the forward + backward engine only -- no fp32 masters / Adam moments are allocated and step() raises; the gradients are
         read with export_grad_dict() (this is what `forward(inference=False)` under autograd builds, model/videorefer_qwen2.py: the optimizer is then the
         caller's, e.g. the HF Trainer's, on the model's own nn.Parameters).
         lora = dict(r=8, alpha=16[, seed=0 | init={name: tensor}]): the reference's --lora_enable stage (train.py:829-845: peft LoraConfig over
@@ -129,6 +133,7 @@ class DecoderTrainer:
         self.base_mm_projector_lr = mm_projector_lr
         self.group = group
         self.optimizer_states = bool(optimizer_states)
+        self.gradient_checkpointing = bool(gradient_checkpointing)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         if not self.optimizer_states:
             # The gradient engine of the autograd path is RANK-LOCAL whatever process group exists: under HF Trainer / torchrun / DDP (the reference's
@@ -318,14 +323,21 @@ class DecoderTrainer:
         H, KV, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         Sp = _ru(S, 128)
         bf, f32 = torch.bfloat16, torch.float32
-        self.st = [dict(x_in=torch.empty((S, D), device=dev, dtype=f32), h1=torch.empty((S, D), device=dev, dtype=bf),
-                        qkv=torch.empty((S, self.QW), device=dev, dtype=bf), kv=torch.zeros((Sp, 2 * KV * hd), device=dev, dtype=bf),
-                        o=torch.empty((S, H * hd), device=dev, dtype=bf), x_mid=torch.empty((S, D), device=dev, dtype=f32),
-                        h2=torch.empty((S, D), device=dev, dtype=bf), gu=torch.empty((S, 2 * I), device=dev, dtype=bf),
-                        act=torch.empty((S, I), device=dev, dtype=bf), lse=torch.empty((H, S), device=dev, dtype=f32)) for _ in self.layers]
-        if self.lora_bucket is not None:
-            for st in self.st:
+        def stash():
+            st = dict(h1=torch.empty((S, D), device=dev, dtype=bf),
+                      qkv=torch.empty((S, self.QW), device=dev, dtype=bf), kv=torch.zeros((Sp, 2 * KV * hd), device=dev, dtype=bf),
+                      o=torch.empty((S, H * hd), device=dev, dtype=bf), x_mid=torch.empty((S, D), device=dev, dtype=f32),
+                      h2=torch.empty((S, D), device=dev, dtype=bf), gu=torch.empty((S, 2 * I), device=dev, dtype=bf),
+                      act=torch.empty((S, I), device=dev, dtype=bf), lse=torch.empty((H, S), device=dev, dtype=f32))
+            if self.lora_bucket is not None:
                 st["u"] = torch.empty((S, 2 * self.Rp), device=dev, dtype=bf)              # A x of both adapters, kept for dB
+            return st
+        self.st = None                                                                      # release the old stashes before the new ones are allocated
+        if self.gradient_checkpointing:                  # ONE stash, refilled by the layer's re-run forward in front of its backward; per layer only the input stream
+            shared = stash()
+            self.st = [dict(shared, x_in=torch.empty((S, D), device=dev, dtype=f32)) for _ in self.layers]
+        else:
+            self.st = [dict(stash(), x_in=torch.empty((S, D), device=dev, dtype=f32)) for _ in self.layers]
         # scratch shared by all layers
         W = max(2 * I, self.QW, D, H * hd, 2 * self.Rp if self.lora_bucket is not None else 0)      # (the LoRA backward transposes [S, 2 Rp] into inT / dyT)
         self.sc = dict(dxb=torch.empty((S, D), device=dev, dtype=bf), dxbT=torch.empty((D, Sp), device=dev, dtype=bf),
@@ -370,8 +382,9 @@ class DecoderTrainer:
         x = inputs_embeds.to(torch.float32).contiguous().clone()
         rope_tab = ops.rope_table(self.inv_freq, 0, S, hd) if hd % 16 == 0 else None
         # ---------------- forward (same kernels as inference; gate/up kept un-fused so the pre-activations are stashed)
-        for lf, (L, st) in enumerate(zip(pk["layers"], self.st)):
-            st["x_in"][:S].copy_(x)
+        def layer_forward(lf, x):
+            """one decoder layer on the stream x (fp32 [S, D], updated in place), every intermediate the backward reads written into the layer's stash"""
+            L, st = pk["layers"][lf], self.st[lf]
             h1, qkv, kv, o, h2, gu, act = st["h1"][:S], st["qkv"][:S], st["kv"], st["o"][:S], st["h2"][:S], st["gu"][:S], st["act"][:S]
             ops.rmsnorm(x, L["ln1"], eps, out=h1)
             ops.gemm(h1, L["wqkv"], bias=L["bqkv"], out=qkv)
@@ -393,6 +406,10 @@ class DecoderTrainer:
             ops.gemm(h2, L["wgu"], out=gu)
             ops.swiglu(gu, out=act)
             ops.gemm(act, L["wd"], resid=x, out=x)
+
+        for lf in range(len(self.layers)):
+            self.st[lf]["x_in"][:S].copy_(x)
+            layer_forward(lf, x)
         x_last = x
         hb = ops.rmsnorm(x_last, pk["norm"], eps)                                   # bf16 [S, D]
         lm = self.head.view(self.head.w, "lm_head")
@@ -431,8 +448,12 @@ class DecoderTrainer:
             del dlT
         del dl
         ops.rmsnorm_bwd(x_last, pk["norm"], dh, dx, self.small.view(g_small, "norm"), eps, accumulate=False)
+        xr = torch.empty((S, D), device=self.dev, dtype=torch.float32) if self.gradient_checkpointing else None
         for li in range(len(self.layers) - 1, -1, -1):
             L, st, b, wT = pk["layers"][li], self.st[li], self.layers[li], self.wT[li]
+            if self.gradient_checkpointing and li < len(self.layers) - 1:           # (the last layer's intermediates are still in the shared stash from the forward pass)
+                xr.copy_(st["x_in"][:S])
+                layer_forward(li, xr)                                                # the same launches on the same input: the same bits
             h1, qkv, kv, o, h2, gu, act = st["h1"][:S], st["qkv"][:S], st["kv"], st["o"][:S], st["h2"][:S], st["gu"][:S], st["act"][:S]
             # ---- MLP: x_out = x_mid + down(act)
             ops.convert_into(dx, dxb)
