@@ -173,6 +173,21 @@ def test_layernorm_pipelined_form_bit_identical(M, D, dt):
     assert torch.equal(nob[:50], ops.layernorm(x[:50], w, None, 1e-6))
 
 
+@pytest.mark.parametrize("M,D,act", [(18432, 3584, "silu"), (1001, 3584, None), (7, 2048, "gelu_tanh"), (300, 1288, "silu"), (64, 4096, None)])
+def test_layernorm_packed_row_form_bit_identical(M, D, act):
+    """bf16 rows of more than 1280 elements run layernorm_packed_k (rows packed in registers, parameters from LDS: the connector's LayerNorm + SiLU, 84 -> 62 us);
+    the fp32 copy of the same values runs layernorm_k<fp32>: same element -> lane assignment, same operations in the same order => the same bits."""
+    x = bf(g(M, D, seed=61, scale=2.0) + 0.3)
+    w, b = 1 + 0.1 * g(D, seed=62), 0.1 * g(D, seed=63)
+    for out_dtype in (torch.bfloat16, torch.float32):
+        y_packed = ops.layernorm(x, w, b, 1e-5, act=act, out_dtype=out_dtype)
+        y_plain = ops.layernorm(x.float(), w, b, 1e-5, act=act, out_dtype=out_dtype)
+        assert torch.equal(y_packed, y_plain)
+    ref = ACTS[act](torch.nn.functional.layer_norm(x.float(), (D,), w, b, 1e-5))
+    assert rel(ops.layernorm(x, w, b, 1e-5, act=act, out_dtype=torch.float32), ref) < 1e-5
+    assert torch.equal(ops.layernorm(x, w, None, 1e-5, act=act), ops.layernorm(x.float(), w, None, 1e-5, act=act))       # no bias
+
+
 def test_ln_add_silu():
     M, D = 50, 3584
     a, b = bf(g(M, D, seed=19)), bf(g(M, D, seed=20))

@@ -56,6 +56,9 @@ def main():
     print("ln+add+silu digest", digest(y))
     print("ln+add+silu same    %.1f us" % timed(lambda: ops.ln_add_silu(xs[2], lw, lb, xs[3], None, None, 1e-5)))
     print("ln+add+silu rotating %.1f us" % timed(lambda: ops.ln_add_silu(rot(), lw, lb, rot(), None, None, 1e-5)))
+    y = ops.ln_add_silu(xs[2], lw, lb, xs[3], lw, lb, 1e-5)
+    print("ln+add+silu (two norms) digest", digest(y))
+    print("ln+add+silu (two norms) rotating %.1f us" % timed(lambda: ops.ln_add_silu(rot(), lw, lb, rot(), lw, lb, 1e-5)))
     print("colmean rotating    %.1f us" % timed(lambda: ops.colmean(rot(), F, H * W)))
     print("scale rotating      %.1f us" % timed(lambda: ops.scale_channels(rot(), gate, F, H * W)))
 

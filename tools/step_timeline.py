@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One timed step of bench.py, launch by launch (GPU box): `rocprofv3 --kernel-trace` of a short run, then the dispatches between the last two `patchify_k`
+"""One timed step of bench.py, launch by launch (GPU box): `rocprofv3 --kernel-trace` of a short run, then the dispatches between the last two `patchify*`
 launches (= one whole step: tower, connector, splice, prefill) in start order with their durations and the idle gap in front of each.
 usage: tools/step_timeline.py <trace-dir> <out.json> [bench args...]     (run as: python3 tools/step_timeline.py gpurun_out/r05/tl gpurun_out/r05/step_timeline.json)
 The trace itself is taken by a child process (rocprofv3 ... -- python3 bench.py); this script never touches the GPU."""
@@ -34,7 +34,7 @@ def main():
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if "patchify_k" in r[2]]
+    starts = [i for i, r in enumerate(rows) if "patchify" in r[2]]
     a, b = starts[-2], starts[-1]
     step = rows[a:b]
     tl, prev_end = [], None

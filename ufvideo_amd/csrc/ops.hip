@@ -103,6 +103,72 @@ __global__ __launch_bounds__(256) void layernorm_k(const void* x, int ldx, void*
         }
 }
 
+// layernorm_k for bf16 rows of more than 1280 elements (the connector's LayerNorm + SiLU on 18 432 x 3584): the row stays PACKED in registers (2 per vec4 chunk instead of 4;
+// the three passes convert again, one shift / and per element) and the affine parameters are staged once per block in LDS and read from there by the block's four rows.
+// The element -> lane assignment, every operation and its order are layernorm_k's: bit-identical output (test).  96 -> ~60 registers: 8 waves per SIMD instead of 5.
+template <bool YF32, int ACT, bool LDSW = true>
+__global__ __launch_bounds__(256) void layernorm_packed_k(const bf16* x, int ldx, void* y, int ldy, const float* w, const float* b, int M, int D, float eps, int act) {
+    extern __shared__ __attribute__((aligned(16))) float lnp[];                   // w [D] | b [D]
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nv = D >> 2;
+    const bool rok = row < M;
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    u2 pv[MAXV];
+    if (rok) {
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+            if (lane + 64 * i < nv) pv[i] = *reinterpret_cast<const u2*>(x + (int64_t)row * ldx + 4 * (lane + 64 * i));
+    }
+    if constexpr (LDSW) {
+        for (int i = threadIdx.x; i < nv; i += 256) {
+            reinterpret_cast<f32x4*>(lnp)[i] = reinterpret_cast<const f32x4*>(w)[i];
+            reinterpret_cast<f32x4*>(lnp + D)[i] = b ? reinterpret_cast<const f32x4*>(b)[i] : f32x4{0, 0, 0, 0};
+        }
+        __syncthreads();
+    }
+    if (!rok) return;
+    auto unpack = [](u2 p) { return f32x4{__builtin_bit_cast(float, p[0] << 16), __builtin_bit_cast(float, p[0] & 0xffff0000u), __builtin_bit_cast(float, p[1] << 16),
+                                            __builtin_bit_cast(float, p[1] & 0xffff0000u)}; };
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            const f32x4 v = unpack(pv[i]);
+            s += v[0] + v[1] + v[2] + v[3];
+        }
+    const float mean = wave_sum(s) / D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) asm volatile("" : "+v"(pv[i]));
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            const f32x4 v = unpack(pv[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q = norm_var_acc(q, v[j], mean);
+        }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) asm volatile("" : "+v"(pv[i]));
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+        if (lane + 64 * i < nv) {
+            if constexpr (LDSW) __builtin_amdgcn_sched_barrier(0);
+            const int c = 4 * (lane + 64 * i);
+            const f32x4 v = unpack(pv[i]);
+            f32x4 ww, bb;
+            if constexpr (LDSW) { ww = *reinterpret_cast<const f32x4*>(lnp + c); bb = *reinterpret_cast<const f32x4*>(lnp + D + c); }
+            else { ww = *reinterpret_cast<const f32x4*>(w + c); bb = b ? *reinterpret_cast<const f32x4*>(b + c) : f32x4{0, 0, 0, 0}; }
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = norm_ln_out(v[j], mean, rstd, ww[j], bb[j]);
+                o[j] = ACT >= 0 ? act_apply_t<(ACT >= 0 ? ACT : 0)>(t) : act_apply(t, act);
+            }
+            store4<YF32>(y, (int64_t)row * ldy + c, o);
+        }
+}
+
 // Pipelined form of layernorm_k for long inputs without activation: persistent blocks, a wave walks rows g, g + G, ... and asks for the NEXT row's
 // chunks before it reduces and stores the current one (layernorm_k's waves all load, then all reduce, then all store: with ~2 rounds of blocks per CU the
 // memory system idles through every reduce phase); weight and bias are staged once per block in LDS.  Same per-lane summation order as layernorm_k:
@@ -162,7 +228,8 @@ __global__ __launch_bounds__(256) void layernorm_pipe_k(const void* x, int ldx, 
 
 // rows stay in registers as bf16 (16-byte loads, 8 channels per chunk): half the registers of an fp32 copy, so more waves are
 // resident to hide the three HBM streams (a, b in; out)
-__device__ __forceinline__ void ln_stats8(const bf16x8* x, int nc, int lane, int D, float eps, float& mean, float& rstd) {
+template <bool REPACK = false>
+__device__ __forceinline__ void ln_stats8(bf16x8* x, int nc, int lane, int D, float eps, float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -170,6 +237,10 @@ __device__ __forceinline__ void ln_stats8(const bf16x8* x, int nc, int lane, int
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += (float)x[i][j];
     mean = wave_sum(s) / D;
+    if (REPACK) {                       // the second pass converts again from the packed row instead of keeping 56 fp32 values alive across the reduction
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(x[i]));
+    }
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -182,6 +253,11 @@ __device__ __forceinline__ void ln_stats8(const bf16x8* x, int nc, int lane, int
     rstd = rsqrtf(wave_sum(q) / D + eps);
 }
 
+// REPACK: the two rows stay PACKED (bf16) in registers between the passes.  Left to itself hipcc keeps the fp32 conversions of both rows alive from the statistics to
+// the output loop -- 178 registers, two waves per SIMD for a streaming kernel; an empty asm that "modifies" the packed registers makes every pass convert again (one
+// shift / and per element): 116 registers, four waves per SIMD, 101 -> 86 us on 18 432 x 3584 (113 -> 89 with the shortcut's own norm), bit-identical.  (Staging the
+// affine parameters in LDS on top of that was measured too: 90 us, and 141 us with four vectors -- 56 KB per block leaves two blocks per CU; not kept.)
+template <bool REPACK>
 __global__ __launch_bounds__(256) void ln_add_silu_k(const bf16* a, const float* wa, const float* ba, const bf16* b,
                                                      const float* wb, const float* bb, bf16* out, int M, int D, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -195,8 +271,12 @@ __global__ __launch_bounds__(256) void ln_add_silu_k(const bf16* a, const float*
             vb[i] = *reinterpret_cast<const bf16x8*>(b + (int64_t)row * D + 8 * (lane + 64 * i));
         }
     float ma, ra, mb = 0.f, rb = 1.f;
-    ln_stats8(va, nc, lane, D, eps, ma, ra);
-    if (wb) ln_stats8(vb, nc, lane, D, eps, mb, rb);
+    ln_stats8<REPACK>(va, nc, lane, D, eps, ma, ra);
+    if (wb) ln_stats8<REPACK>(vb, nc, lane, D, eps, mb, rb);
+    if constexpr (REPACK) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(va[i]), "+v"(vb[i]));
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         if (lane + 64 * i < nc) {
@@ -1020,6 +1100,17 @@ extern "C" int ufv_layernorm(const void* x, int x_dtype, int ldx, void* y, int y
         UFV_CHECK_LAUNCH();
         return UFV_OK;
     }
+    static const bool no_packed = getenv("UFV_LN_NO_PACKED") != nullptr;            // same-box A/B switch
+    if (!no_packed && x_dtype == UFV_DT_BF16 && D > 1280 && (uintptr_t)w % 16 == 0 && (!b || (uintptr_t)b % 16 == 0)) {
+        const size_t par = 2 * (size_t)D * sizeof(float);
+        // (the same kernel with the parameters as global loads in the output loop, LDSW = false: 416 us instead of 62 -- hipcc serialises them behind the packed-row fences)
+#define LNP_LAUNCH(YF, ACT_) hipLaunchKernelGGL((layernorm_packed_k<YF, ACT_, true>), g, blk, par, ST(stream), (const bf16*)x, ldx, y, ldy, w, b, M, D, eps, act)
+        if (y_f32) { if (act == ACT_NONE) LNP_LAUNCH(true, ACT_NONE); else if (act == ACT_SILU) LNP_LAUNCH(true, ACT_SILU); else LNP_LAUNCH(true, -1); }
+        else { if (act == ACT_NONE) LNP_LAUNCH(false, ACT_NONE); else if (act == ACT_SILU) LNP_LAUNCH(false, ACT_SILU); else LNP_LAUNCH(false, -1); }
+#undef LNP_LAUNCH
+        UFV_CHECK_LAUNCH();
+        return UFV_OK;
+    }
 #define LN_LAUNCH2(XD, YF, NV_, ACT_) hipLaunchKernelGGL((layernorm_k<XD, YF, NV_, ACT_>), g, blk, 0, ST(stream), x, ldx, y, ldy, w, b, M, D, eps, act)
 #define LN_LAUNCH(XD, YF)                                                         \
     do {                                                                          \
@@ -1042,8 +1133,11 @@ extern "C" int ufv_ln_add_silu(const void* a, const float* wa, const float* ba, 
                                void* out, int M, int D, float eps, void* stream) {
     UFV_REQUIRE(a && wa && ba && b && out && M > 0, "ufv_ln_add_silu: bad arguments");
     UFV_REQUIRE(D % 8 == 0 && D <= 4096, "ufv_ln_add_silu: D=%d must be a multiple of 8 and <= 4096", D);
-    hipLaunchKernelGGL(ln_add_silu_k, dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), (const bf16*)a, wa, ba, (const bf16*)b, wb, bb,
-                       (bf16*)out, M, D, eps);
+    static const bool unpacked = getenv("UFV_LN_ADD_UNPACKED") != nullptr;          // same-box A/B switch: the round-4 form
+    if (unpacked)
+        hipLaunchKernelGGL((ln_add_silu_k<false>), dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), (const bf16*)a, wa, ba, (const bf16*)b, wb, bb, (bf16*)out, M, D, eps);
+    else
+        hipLaunchKernelGGL((ln_add_silu_k<true>), dim3(cdiv(M, 4)), dim3(256), 0, ST(stream), (const bf16*)a, wa, ba, (const bf16*)b, wb, bb, (bf16*)out, M, D, eps);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
 }
