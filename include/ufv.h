@@ -364,7 +364,8 @@ int ufv_dequantize_mx(const void* q, int64_t ldq, const void* bscale, int64_t ld
  * w < 4, h < 2, c < 16): the consumer's weight carries the same permutation on its K axis (ufvideo_amd.ops.Fp8Weight(..., mx_swiglu_cols=True)).
  * M >= 256, N % 128 == 0 (N % 256 == 0 for an MX output), K % 128 == 0. */
 int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, const void* a_bscale, int ld_abs, const void* W, int ldw, const float* w_scale, void* C, int ldc,
-                    int out_f32, void* out_bscale, int ld_obs, int M, int N, int K, const float* bias, int act, const float* resid, int ldr, int swiglu, void* stream);
+                    int out_f32, void* out_bscale, int ld_obs, int M, int N, int K, const float* bias, int act, const void* resid, int ldr, int resid_bf16, int swiglu,
+                    void* stream);          /* resid: fp32 [M, ldr], or bf16 when resid_bf16 (bf16 outputs only: the in-place update of a bf16 residual stream) */
 int ufv_dequantize_fp8(const void* q, int64_t ldq, const float* scale, float* out, int64_t ldo, int M, int K, void* stream);
 /* ufv_gemm with e4m3 A [M,K] (a_scale [M]) and W [N,K] (w_scale [N]):  C = epilogue((Aq Wq^T) * a_scale[m] * w_scale[n]).
  * v_mfma_f32_16x16x128_f8f6f4 tiles (N % 128 == 0, K % 128 == 0) or the fp8 GEMV (M <= 64, K % 16 == 0); same epilogues. */

@@ -33,7 +33,7 @@ SIGNATURES = {
     "ufv_rope_kv_table": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
     "ufv_quantize_mx": [_p, _i, _l, _p, _l, _p, _l, _i, _i, _p],
     "ufv_dequantize_mx": [_p, _l, _p, _l, _p, _l, _i, _i, _p],
-    "ufv_gemm_fp8_mx": [_p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p],
+    "ufv_gemm_fp8_mx": [_p, _i, _p, _p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _p],
     "ufv_gemm_qkv_rope_fp8": [_p, _i, _p, _p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "ufv_gemm_qkv_rope": [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p],
     "ufv_patchify": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -1080,8 +1080,8 @@ extern "C" int ufv_gemm_fp8(const void* A, int lda, const float* a_scale, const 
 // (1 byte per element, ldc in bytes) and out_bscale their block scales [M, ld_obs] -- the input of the next e4m3 GEMM, written by this GEMM's own epilogue
 // (256 x 256 tile; swiglu: the 32-column blocks are the permuted ones of epilogue256_swiglu_mx).  w_scale: fp32 per output channel, as in ufv_gemm_fp8.
 extern "C" int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, const void* a_bscale, int ld_abs, const void* W, int ldw, const float* w_scale, void* C,
-                               int ldc, int out_f32, void* out_bscale, int ld_obs, int M, int N, int K, const float* bias, int act, const float* resid, int ldr,
-                               int swiglu, void* stream) {
+                               int ldc, int out_f32, void* out_bscale, int ld_obs, int M, int N, int K, const float* bias, int act, const void* resid, int ldr,
+                               int resid_bf16, int swiglu, void* stream) {
     UFV_REQUIRE(A && W && C && w_scale && M > 0 && N > 0 && K > 0 && ((a_scale != nullptr) != (a_bscale != nullptr)),
                 "ufv_gemm_fp8_mx: give exactly one of a_scale (fp32 per row) / a_bscale (e8m0 per row and 32 elements) (M=%d N=%d K=%d)", M, N, K);
     UFV_REQUIRE(a_bscale || out_bscale, "ufv_gemm_fp8_mx: neither a block-scaled input nor a block-scaled output: use ufv_gemm_fp8");
@@ -1093,7 +1093,8 @@ extern "C" int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, con
                 "ufv_gemm_fp8_mx: A block scales [M / 64][K / 512][64][16]: block pitch %% 1024 == 0, >= 1024 ceil(K / 512)");
     UFV_REQUIRE(!(swiglu && (bias || act != ACT_NONE)), "ufv_gemm_fp8_mx: swiglu epilogue takes no bias/activation");
     Epi e;
-    e.bias = bias; e.resid = resid; e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = 0;
+    UFV_REQUIRE(!(resid_bf16 && out_f32), "ufv_gemm_fp8_mx: a bf16 residual goes with a bf16 output");
+    e.bias = bias; e.resid = reinterpret_cast<const float*>(resid); e.out = C; e.ldr = ldr; e.ldc = ldc; e.act = act; e.resid_rows = 0; e.resid_bf16 = resid && resid_bf16 ? 1 : 0;
     e.scale_m = a_scale; e.scale_n = w_scale; e.dump_f32 = 0; e.ksplit = 0;
     e.a_bscale = reinterpret_cast<const unsigned char*>(a_bscale); e.ld_abs = ld_abs;
     e.out_bscale = reinterpret_cast<unsigned char*>(out_bscale); e.ld_obs = ld_obs;
@@ -1116,7 +1117,7 @@ extern "C" int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, con
         return rc;
     }
     UFV_REQUIRE(!swiglu, "ufv_gemm_fp8_mx: SwiGLU with a block-scaled input is not built");
-    UFV_REQUIRE(e.ldc % 4 == 0 && (!resid || ((uintptr_t)resid % 16 == 0 && ldr % 4 == 0)), "ufv_gemm_fp8_mx: output / residual pitch %% 4 == 0");
+    UFV_REQUIRE(e.ldc % 4 == 0 && (!resid || ((uintptr_t)resid % 16 == 0 && ldr % (resid_bf16 ? 8 : 4) == 0)), "ufv_gemm_fp8_mx: output / residual pitch %% 4 == 0");
     int pick = choose_kernel(M, N, K / 2, out_f32 != 0, false, false);
     // (the block-scaled A operand costs 14 registers: the 256 x 256 and 224 x 256 tiles spill with it -- 124 / 8 bytes of scratch -- and are not offered)
     if (pick == 0 || pick >= 10000 || pick == 1442) pick = N % 192 == 0 || N % 192 == 128 ? 1441 : 1332;

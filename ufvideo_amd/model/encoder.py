@@ -137,6 +137,7 @@ class _VitBody(PackedModule):
         # UFV_TOWER_STREAM=bf16 (opt-in, NOT the default): the residual stream kept in bf16 as the reference's bf16 tower keeps it -- in-place updates through
         # ufv_gemm_stream_bf16, half the stream traffic of out_proj / fc2 / the LayerNorms (-0.67 ms per 32-frame clip, same box) for twice the distance from the
         # fp32 oracle (LABNOTES round 5, tests/test_kernels_gpu.py::test_tower_bf16_stream_option); the default stream is fp32
+        # (works in the W8A8 mode too -- ufv_gemm_fp8_mx takes a bf16 residual --, where it is worth -0.2 ms: 33.5 -> 33.3, same box)
         sb = os.environ.get("UFV_TOWER_STREAM") == "bf16" and not self.clip
         if (not self.clip and not any(isinstance(L["wqkv"], ops.Fp8Weight) for L in pk["layers"][:n_layers])
                 and os.environ.get("UFV_STAGE_CALLS", "1") != "0" and not sb):

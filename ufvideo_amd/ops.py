@@ -161,14 +161,16 @@ def gemm_fp8_mx(a, w, bias=None, act=None, resid=None, out=None, out_dtype=torch
         bs = torch.empty(((M + 63) // 64, (n_out + 511) // 512, 64, 16), device=a.q.device, dtype=torch.uint8)
         _lib.call("ufv_gemm_fp8_mx", a.q.data_ptr(), a.q.stride(0), None if is_mx else a.scale.data_ptr(), a.bscale.data_ptr() if is_mx else None,
                   a.bscale.stride(0) if is_mx else 0, w.q.data_ptr(), w.q.stride(0), w.scale.data_ptr(), q.data_ptr(), q.stride(0), 0, bs.data_ptr(), bs.stride(0),
-                  M, N, K, _ptr(bias), ACT[act], None, 0, int(swiglu), _stream())
+                  M, N, K, _ptr(bias), ACT[act], None, 0, 0, int(swiglu), _stream())
         return MxAct(q, bs, swiglu_cols=swiglu)
     assert is_mx
     if out is None:
         out = torch.empty((M, n_out), device=a.q.device, dtype=out_dtype)
     ldr = resid.stride(0) if resid is not None else 0
+    rb = resid is not None and resid.dtype == torch.bfloat16            # a bf16 residual stream (updated in place as bf16): bf16 output only
+    assert not rb or out.dtype == torch.bfloat16
     _lib.call("ufv_gemm_fp8_mx", a.q.data_ptr(), a.q.stride(0), None, a.bscale.data_ptr(), a.bscale.stride(0), w.q.data_ptr(), w.q.stride(0), w.scale.data_ptr(),
-              out.data_ptr(), out.stride(0), int(out.dtype == torch.float32), None, 0, M, N, K, _ptr(bias), ACT[act], _ptr(resid), ldr, int(swiglu), _stream())
+              out.data_ptr(), out.stride(0), int(out.dtype == torch.float32), None, 0, M, N, K, _ptr(bias), ACT[act], _ptr(resid), ldr, int(rb), int(swiglu), _stream())
     return out
 
 
