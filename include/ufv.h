@@ -43,8 +43,10 @@ extern "C" {
 #endif
 
 /* 2: ufv_conv3d_scatter gained `pad`; ufv_qwen2_decode_step needs a zero-filled workspace; ufv_gemm_prepare / _set_splitk / _error_state /
- *    _clear_error added.  A binder checks ufv_abi_version() == UFV_ABI_VERSION at load (ufvideo_amd/_lib.py does). */
-#define UFV_ABI_VERSION 2
+ *    _clear_error added.
+ * 3 (round 5): ufv_gemm_qkv_rope / _fp8 / _shape, ufv_quantize_mx / ufv_dequantize_mx / ufv_gemm_fp8_mx (with `resid_bf16`), ufv_gemm_stream_bf16 added; no existing
+ *    entry changed its signature.  A binder checks ufv_abi_version() == UFV_ABI_VERSION at load (ufvideo_amd/_lib.py does). */
+#define UFV_ABI_VERSION 3
 
 /* activation ids (ufv_gemm `act`, ufv_layernorm `act`) */
 #define UFV_ACT_NONE 0

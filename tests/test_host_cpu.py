@@ -144,7 +144,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ufv.h but not exported"
     assert set(_lib.SIGNATURES) | {"ufv_last_error", "ufv_abi_version"} | set(_lib.SIZE_FUNCS) == declared
-    assert _lib.load().ufv_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.load().ufv_abi_version() == _lib.ABI_VERSION == 3
 
 
 def test_ops_fail_loudly_without_gpu_tensors():

@@ -148,7 +148,7 @@ class StcModel(C.Structure):
                [("eps", _f), ("_padf", _f), ("s1", C.POINTER(StcBlock)), ("s2", C.POINTER(StcBlock)), ("samp_w", _p), ("samp_b", _p),
                 ("readout_w", C.POINTER(_p)), ("readout_b", C.POINTER(_p))]
 
-ABI_VERSION = 2          # include/ufv.h UFV_ABI_VERSION
+ABI_VERSION = 3          # include/ufv.h UFV_ABI_VERSION
 _lib = None
 
 
