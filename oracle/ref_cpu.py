@@ -117,8 +117,8 @@ def _flash_pv_mirror(s2: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
 
 
 def _flash_vit72_mirror(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
-    """The second-generation ViT kernel's arithmetic (csrc/attn_vit.inc `attn_fwd_vit72`: head_dim 72, non-causal, query count a
-    multiple of 288), tile for tile: q' = bf16(q * (scale * log2 e)) (one rounding, the product of the two constants taken in
+    """The second-generation ViT kernel's arithmetic (csrc/attn_vit.inc `attn_fwd_vit72`: head_dim 72, non-causal; query counts that are a
+    multiple of 288, and every count above 576 -- 729 tokens at 384 px), tile for tile: q' = bf16(q * (scale * log2 e)) (one rounding, the product of the two constants taken in
     fp32); scores s = q' k^T - m accumulated in fp32 with the running maximum m kept as a bf16 value; tiles of 64 keys, a wave owns 32
     query rows; tile 0 sets m = bf16(row max); afterwards m only moves when SOME row of the wave sees a tile maximum above 2^6
     (then every row takes m <- bf16(m + max(tile max, 0)) and O, l are rescaled by exp2(m_old - m_new) in fp32); P = bf16(exp2(s));
@@ -139,7 +139,12 @@ def _flash_vit72_mirror(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale
             m_new = _rb(m + tmax)
             trig = torch.ones_like(tmax, dtype=torch.bool)
         else:
-            trig = (tmax > 6.0).reshape(lead + (G, 32)).any(dim=-1, keepdim=True).expand(lead + (G, 32)).reshape(lead + (Sq,))
+            # a 32-row unit past the end of the sequence is filled with rows that never trigger on their own (attn_vit.inc repeats row Sq - 1,
+            # the generated kernel reads zeros: q = 0 gives s - m = 0 in every tile)
+            over = tmax > 6.0
+            if G * 32 != Sq:
+                over = torch.cat([over, torch.zeros(lead + (G * 32 - Sq,), dtype=torch.bool)], dim=-1)
+            trig = over.reshape(lead + (G, 32)).any(dim=-1, keepdim=True).expand(lead + (G, 32)).reshape(lead + (G * 32,))[..., :Sq]
             m_new = torch.where(trig, _rb(m + tmax.clamp_min(0.0)), m)
         delta = m_new - m
         if t0:
@@ -171,7 +176,7 @@ def _softmax_pv(scores: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
 def attention_noncausal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float) -> torch.Tensor:
     """softmax(q k^T * scale) v for the vision towers; q, k, v [..., S, hd].  fp32 graph: exactly that (modeling_siglip.py:237-247).
     Mirror mode picks the arithmetic of the kernel `ufv_attention` dispatches to for this shape."""
-    if _MIRROR and q.shape[-1] == 72 and q.shape[-2] % 288 == 0:
+    if _MIRROR and q.shape[-1] == 72 and (q.shape[-2] % 288 == 0 or q.shape[-2] > 576):       # ufv_attention: attn_vit_p2 / attn_fwd_vit72 (729 tokens at 384 px)
         return _flash_vit72_mirror(q, k, v, scale)
     return _softmax_pv(torch.matmul(q, k.transpose(-1, -2)) * scale, v)
 

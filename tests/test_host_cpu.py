@@ -144,6 +144,14 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ufv.h but not exported"
     assert set(_lib.SIGNATURES) | {"ufv_last_error", "ufv_abi_version"} | set(_lib.SIZE_FUNCS) == declared
+    # ... and NOTHING else: -fvisibility=hidden + UFV_API + csrc/ufv_exports.map (no mangled internals, no compiler markers in the dynamic ABI)
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert exported == declared, (sorted(exported - declared)[:10], sorted(declared - exported)[:10])
+    assert all(re.search(r"UFV_API [a-z_0-9\* ]*\b%s\(" % n, hdr) for n in declared)       # every declaration carries the export macro
     assert _lib.load().ufv_abi_version() == _lib.ABI_VERSION == 3
 
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Generator of the third-generation ViT attention kernel body (head_dim 72, non-causal, S = 576): writes
-ufvideo_amd/csrc/attn_vit_p2_asm.inc -- ONE inline-asm statement that owns the whole 512-register file of a wave.
+"""Generator of the third-generation ViT attention kernel body (head_dim 72, non-causal; S = 576 = SigLIP so400m at 336 px, and with
+`--seq 729` the checkpoint's own 384 px geometry): writes ufvideo_amd/csrc/attn_vit_p2_asm.inc (attn_vit_p2_s729_asm.inc) -- ONE inline-asm
+statement that owns the whole 512-register file of a wave.
 
 Structure (cdna_hip_programming.md, 'Fused attention prefill', 4-wave one-wave-per-SIMD form, adapted to hd 72 / S 576):
   * block = 4 waves = 2 heads; wave w works on head w >> 1, query rows [288 (w & 1), +288) in 3 passes of 96 rows (3 units of 32);
@@ -14,6 +15,12 @@ Structure (cdna_hip_programming.md, 'Fused attention prefill', 4-wave one-wave-p
     sums out of the PV MFMAs, deferred rescale at 2^6 decided per 32-query unit -- the outputs are bit-identical.
 
 The order of instructions inside each period is decided here (gap placement tables), not by hipcc.
+
+Other sequence lengths (`--seq S`; built: 729): NT = ceil(S / 64) key tiles per pass (a multiple of 3, so that the ring stage of a tile stays an
+immediate), NPASS = ceil(S / 192) passes of 96 rows per wave (wave 1 starts at row 96 NPASS).  Rows past S are never special-cased: the buffer
+descriptors return zeros for them (q, k, v) and drop their stores (o).  Keys past S sit in the LAST tile only: their scores are overwritten with
+-inf in front of that tile's row maximum (attn_vit.inc masks the same scores the same way; exp2 gives them P = 0).  With S = 576 the generated
+text is byte for byte what the generator wrote before it had the parameter.
 """
 import os
 import sys
@@ -24,12 +31,23 @@ KT = 64 * PK              # 9216
 VOFF = KT                 # V tile right behind the K tile
 KONE_REL = 2 * KT         # 16 bytes {1.0, 0, ...} behind the V tile of EVERY stage (the K fragment of the contraction-padding lanes), + 48 B pad for the
 STG = 2 * KT + 64         # transposed reads of d-tile 2 that run past a row: 18496 per stage
-NSTAGE = 3                # tile j lives in stage j % 3 (9 tiles per pass: the same in every pass, so every LDS offset is an immediate)
+NSTAGE = 3                # tile j lives in stage j % 3 (NT tiles per pass, NT % 3 == 0: the same in every pass, so every LDS offset is an immediate)
 NPIECE = 9                # DMA pieces per wave per tile (a wave loads the K tile or the V tile of its head)
 QPIECES = 9               # staging holds the rows of units 0 and 1 (64 x 144 B = 9 pieces); unit 2's fragments come straight from global memory
 UNIT_BYTES = 32 * PK      # 4608
-NT = 9                    # key tiles per pass (S = 576)
-NPASS = 3
+def _seq_arg():
+    for i, a in enumerate(sys.argv):
+        if a == "--seq":
+            return int(sys.argv[i + 1])
+        if a.startswith("--seq="):
+            return int(a[6:])
+    return 576
+SEQ = _seq_arg()
+NT = (SEQ + 63) // 64     # key tiles per pass (9 at S = 576, 12 at S = 729)
+NPASS = (SEQ + 191) // 192    # passes of 96 query rows per wave (3 / 4)
+REM = SEQ - 64 * (NT - 1)     # keys of the last tile that exist (64: nothing to mask)
+assert NT % 3 == 0 and NT >= 9, "the ring stage of tile j is the immediate j % 3 in every pass: NT must be a multiple of 3 (and the Q staging needs tiles 1..5)"
+NEG_INF = 0xFF800000
 THR = 0x40C00000          # 6.0f
 
 # ---- register map ------------------------------------------------------------------------------------------------------------
@@ -126,6 +144,22 @@ def sm_max(u):
     return o
 
 
+def sm_mask_tail(u):
+    """last key tile of a sequence that is not a multiple of 64: the scores of keys >= REM become -inf (register r of half `hf` holds key
+    32 hf + (r & 3) + 8 (r >> 2) + 4 h, h = lane >> 5: the rows of a 32x32 MFMA result).  T1 is free until sm_max writes it."""
+    if REM == 64:
+        return []
+    o = [f"v_mov_b32 {vr(T1)}, 0x{NEG_INF:08x}"]
+    for hf in range(2):
+        for r in range(16):
+            k0 = 32 * hf + (r & 3) + 8 * (r >> 2)             # the h = 0 lanes' key; the h = 1 lanes hold key k0 + 4
+            if k0 >= REM:
+                o.append(f"v_mov_b32 {vr(S(u, 16 * hf + r))}, {vr(T1)}")
+            elif k0 + 4 >= REM:
+                o.append(f"v_cndmask_b32 {vr(S(u, 16 * hf + r))}, {vr(S(u, 16 * hf + r))}, {vr(T1)}, {sr(S_HM, 2)}")
+    return o
+
+
 def sm_exp_cvt(u):
     """32 exp2 in place + 16 packs; pack k follows its two exps by >= 2 instructions"""
     ex = [f"v_exp_f32 {vr(S(u, r))}, {vr(S(u, r))}" for r in range(32)]
@@ -141,8 +175,12 @@ def sm_exp_cvt(u):
     return out
 
 
-def rescale_math(u, first):
-    """m_new = bf16(m_run + (first ? tmax : max(tmax, 0))); delta = m_new - m_run; returns instrs; leaves delta in TA, m_new in MRUN"""
+def rescale_math(u, first, last_tile=False):
+    """m_new = bf16(m_run + (first ? tmax : max(tmax, 0))); delta = m_new - m_run; returns instrs; leaves delta in TA, m_new in MRUN.
+    last_tile: the rescale of a pass's LAST key tile does not touch the Q fragments -- no QK^T of this pass is left to read -m from them, and unit 2's fragment
+    registers already belong to the NEXT pass's raw rows by then (q2_fetch is issued in the same period, before the softmax can branch here: a v_cndmask that
+    executes after such a load has returned leaves -m in place of 8 bytes of q.  Round 6: seen as intermittent wrong rows of unit 2 whenever the load beat the
+    stub -- few blocks on the chip, L2-resident q, a late-tile spike in a unit-2 row group; the one-in-eight-suites mismatch of round 5 at S = 576.)"""
     o = []
     if first:
         o += [f"v_cvt_pk_bf16_f32 {vr(TB)}, {vr(T0)}, {vr(T0)}", f"v_lshlrev_b32 {vr(TA)}, 16, {vr(TB)}",   # TA = m_new (m_run was 0) = delta
@@ -152,7 +190,8 @@ def rescale_math(u, first):
               f"v_cvt_pk_bf16_f32 {vr(TB)}, {vr(TB)}, {vr(TB)}", f"v_lshlrev_b32 {vr(TB)}, 16, {vr(TB)}",
               f"v_sub_f32 {vr(TA)}, {vr(TB)}, {vr(MRUN(u))}", f"v_mov_b32 {vr(MRUN(u))}, {vr(TB)}"]
     # q'[4][0] of the h = 1 lanes <- bf16(-m_new) (upper half: 0)
-    o += [f"v_cvt_pk_bf16_f32 {vr(TB)}, -{vr(MRUN(u))}, 0", f"v_cndmask_b32 {vr(Q(u, 4))}, {vr(Q(u, 4))}, {vr(TB)}, {sr(S_HM, 2)}"]
+    if not last_tile:
+        o += [f"v_cvt_pk_bf16_f32 {vr(TB)}, -{vr(MRUN(u))}, 0", f"v_cndmask_b32 {vr(Q(u, 4))}, {vr(Q(u, 4))}, {vr(TB)}, {sr(S_HM, 2)}"]
     o += [f"v_sub_f32 {vr(S(u, r))}, {vr(S(u, r))}, {vr(TA)}" for r in range(32)]
     return o
 
@@ -440,7 +479,7 @@ def build(simple=False):
 
     # ================= pass loop =================================================================================================
     def emit_pass(G, carry):
-        """one pass = 27 periods; `carry`: fillers handed over by the previous pass's last period (the second half of tile 1's DMA pieces)"""
+        """one pass = 3 NT periods; `carry`: fillers handed over by the previous pass's last period (the second half of tile 1's DMA pieces)"""
         e = G.e
         e("PASS_LOOP%=:")
         # what was issued before the top of a pass, oldest first: ... tile 1 | unit 2's Q rows | first half of tile 2
@@ -457,13 +496,13 @@ def build(simple=False):
                 carry = []
                 free_bank = S((u + 2) % 3, 0)           # 32 VGPRs nobody owns during period (., u)
                 # ---- softmax of item (j, u)
-                mx = sm_max(u)
+                mx = (sm_mask_tail(u) if j == NT - 1 else []) + sm_max(u)
                 if j == 0:
                     body = mx + rescale_math(u, True)
                 else:
                     stub, back = G.label("RS"), G.label("BK")
                     body = mx + [f"v_cmp_lt_f32 vcc, 0x{THR:08x}, {vr(T0)}", "s_nop 1", f"s_cbranch_vccnz {stub}", f"{back}:"]
-                    G.stubs.append((stub, back, u))
+                    G.stubs.append((stub, back, u, j == NT - 1))
                 ex = sm_exp_cvt(u)
                 if "exp" in DROP:
                     ex = []
@@ -531,11 +570,11 @@ def build(simple=False):
                         qd.append(("TAG", "q_done"))
                     per.put([(10, i) for i in qd] if simple else spread(qd, 13, 18))
                 if "seam" not in DROP:
-                    if j == 8 and u == 1:
+                    if j == NT - 1 and u == 1:
                         per.put([(0, ("VMWAIT", "q_done"))])
                         ql = q_load(0, (free_bank, free_bank + 1))
                         per.put([(22, i) for i in ql] if simple else spread(ql, 1, 22))
-                    if j == 8 and u == 2:
+                    if j == NT - 1 and u == 2:
                         ql = q_load(1, (free_bank, free_bank + 1))
                         per.put([(22, i) for i in ql] if simple else spread(ql, 1, 22))
                         # unit 2's last QK^T of the pass was issued in the period before: its registers take the next pass's raw rows
@@ -544,7 +583,7 @@ def build(simple=False):
                         per.put([(0, ("VMWAIT", "q2"))])
                         ql = q_load(2, (TC, TD))
                         per.put([(21, i) for i in ql] if simple else spread(ql, 1, 21))
-                if j == 8 and u == 2:
+                if j == NT - 1 and u == 2:
                     per.put([(22, f"s_mul_i32 {sr(S_T4)}, {sr(S_SS)}, 96"), (22, f"s_add_u32 {sr(S_QSOFF)}, {sr(S_QSOFF)}, {sr(S_T4)}"),
                              (22, f"s_add_u32 {sr(S_Q2OFF)}, {sr(S_Q2OFF)}, {sr(S_T4)}")])
                 per.emit(G)
@@ -571,9 +610,9 @@ def build(simple=False):
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e("s_branch END%=")
     # ================= out-of-line rescale paths ================================================================================
-    for stub, back, u in G.stubs:
+    for stub, back, u, last_tile in G.stubs:
         e(f"{stub}:")
-        for i in rescale_math(u, False) + rescale_o(u):
+        for i in rescale_math(u, False, last_tile) + rescale_o(u):
             e(i)
         e(f"s_branch {back}")
     e("END%=:")
@@ -587,17 +626,19 @@ def main():
     simple = "--simple" in sys.argv
     lines = build(simple)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = os.environ.get("UFV_P2_OUT") or os.path.join(root, "ufvideo_amd", "csrc", "attn_vit_p2_asm.inc")
+    sfx = "" if SEQ == 576 else f"_s{SEQ}"              # file and macro names of the other sequence lengths carry the length
+    out = os.environ.get("UFV_P2_OUT") or os.path.join(root, "ufvideo_amd", "csrc", f"attn_vit_p2{sfx}_asm.inc")
     clob = [f"v{i}" for i in range(256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(40, 100)] + ["vcc", "memory"]
     with open(out, "w") as f:
-        f.write("// GENERATED by tools/gen_attn_p2.py%s -- do not edit.  %d instructions.\n" % (" --simple" if simple else "", len(lines)))
+        f.write("// GENERATED by tools/gen_attn_p2.py%s%s -- do not edit.  %d instructions.\n" % ("" if SEQ == 576 else f" --seq {SEQ}", " --simple" if simple else "", len(lines)))
         if STAMPS:
             f.write("#define UFV_VIT_P2_STAMPS 1\n")
-        f.write("#define UFV_VIT_P2_ASM \\\n")
+        f.write(f"#define UFV_VIT_P2{sfx.upper()}_ASM \\\n")
         for l in lines:
             f.write('    "%s\\n\\t" \\\n' % l)
         f.write('    ""\n')
-        f.write("#define UFV_VIT_P2_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + "\n")
+        if SEQ == 576:
+            f.write("#define UFV_VIT_P2_CLOBBERS " + ", ".join('"%s"' % c for c in clob) + "\n")
     print(out, len(lines), "lines")
 
 

@@ -1,0 +1,28 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from ufvideo_amd import ops
+hd = 72
+def g(*shape, seed=0):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(*shape, generator=gen).cuda()
+for S in (729, 576):
+  for B, H, seed in ((2, 4, 70), (1, 16, 71), (3, 2, 72)):
+    q, k, v = g(B, S, H, hd, seed=seed), g(B, S, H, hd, seed=seed + 100), g(B, S, H, hd, seed=seed + 200)
+    for row, key, amp in ((5, 70, 3.0), (5, 300, 6.0), (40, S - 1, 5.0), (100, S - 19, 4.0), (200, 450, 6.0), (383, S - 2, 7.0), (384, 70, 4.0), (500, S - 25, 5.0),
+                          (S - 58, 300, 6.0), (S - 57, S - 1, 7.0), (S - 29, 450, 5.0), (S - 1, S - 1, 6.0), (S - 1, 10, 3.0)):
+        k[:, key] = q[:, row] * amp
+    k[:, :64] = -q[:, 150:214].abs().mean(dim=(1, 2), keepdim=True) * torch.sign(q[:, 150:151]) * 2.0
+    x = torch.empty(B * S, 3 * H * hd, device="cuda", dtype=torch.bfloat16)
+    x[:, :H * hd] = q.bfloat16().reshape(B * S, H * hd); x[:, H * hd:2 * H * hd] = k.bfloat16().reshape(B * S, H * hd); x[:, 2 * H * hd:] = v.bfloat16().reshape(B * S, H * hd)
+    st = ((S * 3 * H * hd, 3 * H * hd),) * 3
+    ref = ops.attention(x, x[:, H * hd:], x[:, 2 * H * hd:], B, H, H, S, S, hd, *st, kernel=11).clone()
+    for it in range(12):
+        kern = (14, 0, 11)[it % 3]
+        o = ops.attention(x, x[:, H * hd:], x[:, 2 * H * hd:], B, H, H, S, S, hd, *st, kernel=kern)
+        d = (o != ref).nonzero()
+        if d.shape[0]:
+            rows = sorted(set((d[:, 0] % S).tolist()))
+            print(S, B, H, "it", it, "kern", kern, "diff elems", d.shape[0], "rows", rows[:10], rows[-4:], "heads", sorted(set((d[:, 1] // hd).tolist()))[:8], "frames", sorted(set((d[:, 0] // S).tolist()))[:8],
+                  "maxabs", (o.float() - ref.float()).abs().max().item(), flush=True)
+    print(S, B, H, "done", flush=True)

@@ -1263,6 +1263,14 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         ufv_set_error("ufv_attention: kernel %d is built for head_dim %d (hd=%d)", kernel, kernel == 14 ? 72 : 128, hd);
         return UFV_EUNSUPPORTED;
     }
+#ifndef UFV_LAB_KERNELS
+    // ids 3, 4, 6, 7, 8, 10 name first-generation forms that no AUTO choice can reach (register-staged, lockstep, head-pair and 6-wave ping-pong ViT
+    // kernels: measured, slower, LABNOTES.md): they are compiled into lab builds only (tools/lab/build_variant_lib.sh -DUFV_LAB_KERNELS)
+    if (kernel == 3 || kernel == 4 || kernel == 6 || kernel == 7 || kernel == 8 || kernel == 10) {
+        ufv_set_error("ufv_attention: kernel %d is a lab-only diagnostic form (library built without UFV_LAB_KERNELS)", kernel);
+        return UFV_EUNSUPPORTED;
+    }
+#endif
     if ((kernel == 1 || kernel == 3) && !mfma_ok) {
         ufv_set_error("ufv_attention: MFMA kernel needs hd in {64,72,80,96,128} and 16-byte aligned rows (hd=%d)", hd);
         return UFV_EUNSUPPORTED;
@@ -1272,21 +1280,33 @@ extern "C" int ufv_attention(const void* q, int64_t q_bs, int64_t q_ss, const vo
         const bool six = (Sq % 192 == 0) && (Sq % 128 != 0);     // e.g. 576 ViT tokens: 3 blocks of 6 waves, no idle wave
         switch (hd) {
             case 64: return launch_mfma<64, 4>(a, causal, st);
-            case 72: if (kernel == 3) return launch_mfma<72, 4>(a, causal, st);      // register-staged variant (diagnostic)
+            case 72:
+#ifdef UFV_LAB_KERNELS
+                     if (kernel == 3) return launch_mfma<72, 4>(a, causal, st);      // register-staged variant (diagnostic)
+#endif
                      if (kernel == 14) {
-                         if (causal || !vit72_p2_ok(a)) { ufv_set_error("ufv_attention: kernel 14 is built for non-causal hd 72, S = 576, an even head count and equal q / k / v row pitches"); return UFV_EUNSUPPORTED; }
+                         if (causal || !vit72_p2_ok(a)) { ufv_set_error("ufv_attention: kernel 14 is built for non-causal hd 72, S = 576 or 729, an even head count and equal q / k / v row pitches"); return UFV_EUNSUPPORTED; }
                          return launch_vit72_p2(a, st);
                      }
+#ifdef UFV_LAB_KERNELS
                      // head-pair variants (diagnostic: measured 10-25 % slower than the 9-wave blocks)
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 7) return launch_pair<72, 6, false>(a, st);
                      if (!causal && Sq % 192 == 0 && Hq % 2 == 0 && kernel == 8) return launch_pair<72, 6, true>(a, st);
-                     // third generation (attn_vit_p2.inc): SigLIP at 336 px; bit-identical to the second generation, which stays for other lengths
+#endif
+                     // third generation (attn_vit_p2.inc): SigLIP at 336 px (S = 576) and 384 px (S = 729); bit-identical to the second generation, which stays for other lengths
                      if (!causal && vit72_p2_ok(a) && (kernel == 0 || kernel == 1)) return launch_vit72_p2(a, st);
                      if (!causal && Sq % 288 == 0 && (int64_t)Sk * (k_ss > v_ss ? k_ss : v_ss) * 2 < (1ll << 31) && (kernel == 0 || kernel == 1 || kernel == 11))
                          return launch_vit72<9>(a, st);   // second-generation ViT kernel (attn_vit.inc)
+                     // the same kernel in 6-wave blocks (192 rows; ragged query and key tails are its own: clamped rows, -inf scores) for the lengths above the 336-px
+                     // tower's that are no multiple of 288 -- SigLIP at 384 px: 729 tokens when the generated kernel cannot take the call -- and for id 11 at any length:
+                     // one numerics family (oracle `_flash_vit72_mirror`) for every long ViT sequence
+                     if (!causal && (int64_t)Sk * (k_ss > v_ss ? k_ss : v_ss) * 2 < (1ll << 31) && (kernel == 11 || ((kernel == 0 || kernel == 1) && Sq > 576)))
+                         return launch_vit72<6>(a, st);
+#ifdef UFV_LAB_KERNELS
                      if (Sq % 288 == 0 && kernel == 6) return launch_mfma_dma<72, 9, false>(a, causal, st);   // lockstep variant (diagnostic)
                      if (six && kernel == 10) return launch_mfma_dma<72, 6, true>(a, causal, st);               // 6-wave blocks, ping-pong, 2 blocks / CU (diagnostic)
-                     if (Sq % 288 == 0 && kernel != 4) return launch_mfma_dma<72, 9, true>(a, causal, st);     // 2 blocks of 9 waves (kernel 9: the former default)
+#endif
+                     if (Sq % 288 == 0 && kernel != 4) return launch_mfma_dma<72, 9, true>(a, causal, st);     // 2 blocks of 9 waves (kernel 9: the former default; AUTO's for causal hd 72)
                      return six ? launch_mfma_dma<72, 6, false>(a, causal, st) : launch_mfma_dma<72, 4, false>(a, causal, st);
             case 80: return launch_mfma<80, 4>(a, causal, st);
             case 96: return launch_mfma<96, 4>(a, causal, st);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include "../../include/ufv.h"      // the C ABI: every definition of an entry point sees its UFV_API declaration (-fvisibility=hidden)
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -15,7 +16,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define GLB_PTR(p) ((const void __attribute__((address_space(1)))*)(p))
 
 // ---- error plumbing (ufv_last_error) -------------------------------------------------
-extern "C" const char* ufv_last_error(void);
 void ufv_set_error(const char* fmt, ...);
 #define UFV_OK 0
 #define UFV_EINVAL (-1)
