@@ -38,8 +38,15 @@ T_FRAMES, IMG, PROMPT_LEN, VIDEO_POS = 32, 336, 96, 14
 VISION = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16, image_size=IMG, patch_size=14)
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
-# algorithmic work per clip (2*MACs), SURVEY.md §8(d)
+# algorithmic work per clip (2*MACs); the 384-px row is the released checkpoint's own geometry (siglip-so400m-patch14-384:
+# 729 tokens per frame, 2704 visual tokens, S = 2799) and is reported by `--img 384` as a SECONDARY line, never the headline
 FLOPS = dict(vit=15.89e12, proj=4.69e12, llm=32.48e12)
+FLOPS_384 = dict(vit=20.54e12, proj=5.84e12, llm=38.12e12)
+
+
+def tokens_per_clip(frames, img=None):
+    """(T / 2) * floor((img / 14) / 2)^2: the visual tokens the connector hands to the decoder"""
+    return (frames // 2) * (((IMG if img is None else img) // 14) // 2) ** 2
 
 
 PMC_FILE = "profiles/r05/pmc_bench.json"            # (--fp8: pmc_bench_fp8.json beside it)
@@ -63,13 +70,13 @@ class _Tok:
         return [151645 for _ in toks]
 
 
-def build_model(device, frames=T_FRAMES):
+def build_model(device, frames=T_FRAMES, img=IMG):
     from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM, QWEN2_7B
     cfg = VideoReferQwen2Config(**QWEN2_7B, mm_vision_tower="siglip-so400m-patch14-384", mm_vision_select_layer=-2,
                                 mm_vision_select_feature="patch", mm_projector_type="stc_connector_v35", mm_hidden_size=1152,
                                 mm_region_encoder_type="pooling", image_aspect_ratio="square", train_mask_decoder=False,
                                 sam_pretrained=None, sam_out_dim=256, num_frames=frames, seg_token_id=151747, sam2_trunk=None,
-                                vision_config=VISION)
+                                vision_config=dict(VISION, image_size=img))
     model = VideoReferQwen2ForCausalLM(cfg, device=device, seed=0)
     model.get_vision_tower().load_model(device=device, seed=7)
     for m in model.modules():
@@ -77,10 +84,10 @@ def build_model(device, frames=T_FRAMES):
     return model
 
 
-def synthetic_inputs(device, frames=T_FRAMES):
+def synthetic_inputs(device, frames=T_FRAMES, img=IMG):
     """uint8 frames from default_rng(1234), (x/255-0.5)/0.5 -> bf16 NCHW; prompt from default_rng(1235)."""
     from ufvideo_amd import ops
-    u8 = np.random.default_rng(1234).integers(0, 256, (frames, IMG, IMG, 3), dtype=np.uint8)
+    u8 = np.random.default_rng(1234).integers(0, 256, (frames, img, img, 3), dtype=np.uint8)
     video = ops.preprocess_u8(torch.from_numpy(u8).to(device), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))      # HIP kernel, outside the timed region
     ids = np.random.default_rng(1235).integers(0, 151643, PROMPT_LEN).astype(np.int64)
     ids[VIDEO_POS] = -201
@@ -94,9 +101,6 @@ class KernelTimer:
 
     def __init__(self):
         self._on = False
-
-    def wrap(self, ops_mod):
-        pass
 
     @property
     def on(self):
@@ -142,7 +146,8 @@ def one_step(model, video, ids, am, cache, frameshard=False, host=None):
 
 def _cpu_clip(O, frames, img, prompt_len, vit_weights, proj_weights, llm_weights, lcfg):
     """One whole clip on the CPU oracle (fp32 torch eager): tower (26 layers) -> STC-v35 -> 28-layer decoder prefill -> last-position
-    logits.  Every layer runs; the 26 / 28 layers share one layer's synthetic weights (same arithmetic and time, 1/27 of the memory)."""
+    logits.  Every layer runs; the 26 / 28 layers share ONE layer's synthetic weights (same arithmetic and time, 1/27 of the memory) and the
+    lm_head has 4096 rows instead of 151748 (one last-position row product: 1 GFLOP of the clip's 53 TFLOP) -- stated in the JSON `sample` too."""
     vcfg = dict(VISION, image_size=img)
     x = torch.randn(frames, 3, img, img)
     h = O.siglip_embeddings(vit_weights, "", x, 14)
@@ -181,7 +186,7 @@ def cpu_baseline(threads, full_clip=True, budget_s=240.0):
         vsd224 = dict(vsd); vsd224["embeddings.position_embedding.weight"] = vsd["embeddings.position_embedding.weight"][:256]
         t0 = time.time(); _, ntok1 = _cpu_clip(O, 4, 224, PROMPT_LEN, vsd224, psd, lsd, lcfg); t_c1 = time.time() - t0
         out = dict(unit="video-tokens/s", cores=threads, kind="port",
-                   config1={"workload": "config #1: 4 frames 224x224, S = 223, every layer run", "seconds": round(t_c1, 2),
+                   config1={"workload": "config #1: 4 frames 224x224, S = 223, every layer run (the layers share one layer's synthetic weights; 4096-row lm_head)", "seconds": round(t_c1, 2),
                             "value": round(ntok1 / t_c1, 3), "extrapolated": False})
         # config #2 is 53.06 / 4.04 = 13.1 x the work of config #1 and runs at a better rate (longer rows): predicted <= 13.1 x t_c1
         if full_clip and 13.1 * t_c1 > budget_s:
@@ -190,7 +195,9 @@ def cpu_baseline(threads, full_clip=True, budget_s=240.0):
         if full_clip:
             t0 = time.time(); _cpu_clip(O, T_FRAMES, IMG, PROMPT_LEN, vsd, psd, lsd, lcfg); total = time.time() - t0
             out.update(value=round(2304.0 / total, 3), extrapolated=False,
-                       sample=f"oracle/ref_cpu.py fp32 eager, one whole config-#2 clip (32 frames 336x336, S = 2399, every layer run): {total:.1f}s")
+                       sample=(f"oracle/ref_cpu.py fp32 eager, one whole config-#2 clip (32 frames 336x336, S = 2399): all 26 tower + 28 decoder layers run, but they "
+                               f"share ONE layer's synthetic weights (same arithmetic and time, 1/27 of the memory) and the lm_head has 4096 rows instead of 151748 "
+                               f"(1 GFLOP of the clip's 53 TFLOP): {total:.1f}s"))
             return out
         FS, VL = 8, 4
         x = torch.randn(FS, 3, IMG, IMG)
@@ -226,8 +233,12 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
     inputs = inputs or synthetic_inputs
     step = step or one_step
     sync = sync or torch.cuda.synchronize
-    from ufvideo_amd import ops
-    timer = KernelTimer(); timer.wrap(ops)
+    img = getattr(args, "img", IMG)
+    if img != IMG:                                  # the secondary 384-px line: same protocol, the checkpoint's own tower geometry
+        import functools
+        build = functools.partial(build_model, img=img) if build is build_model else build      # (a test passes its own already-built 384-px model)
+        inputs = functools.partial(synthetic_inputs, img=img) if inputs is synthetic_inputs else inputs
+    timer = KernelTimer()
     model = build(device, args.frames)
     if args.fp8:
         model.set_gemm_dtype("fp8")
@@ -238,7 +249,7 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
     if cache_factory is None:
         from ufvideo_amd.model import KVCache
         cfg = model.config
-        cache = KVCache(cfg.num_hidden_layers, 2304 * args.frames // 32 + 128, 2 * cfg.num_key_value_heads * cfg.head_dim, device)
+        cache = KVCache(cfg.num_hidden_layers, tokens_per_clip(args.frames, img) + 128, 2 * cfg.num_key_value_heads * cfg.head_dim, device)
     else:
         cache = cache_factory(model)
 
@@ -266,15 +277,15 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    tokens_per_clip = (args.frames // 2) * ((IMG // 14) // 2) ** 2
-    value = (1 if fs else world) * args.steps * tokens_per_clip / dt
+    ntok = tokens_per_clip(args.frames, img)
+    value = (1 if fs else world) * args.steps * ntok / dt
     out = {
-        "metric": "video-tokens/sec (encode+prefill), UFVideo-7B 32f@336px", "value": round(value, 1), "unit": "video-tokens/s",
+        "metric": f"video-tokens/sec (encode+prefill), UFVideo-7B 32f@{img}px", "value": round(value, 1), "unit": "video-tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "strong" if fs else "weak", "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
-        "config": {"workload": f"UFVideo-7B dims, {args.frames} frames {IMG}x{IMG}, {'W8A8 e4m3 GEMMs (config #5a), bf16 elsewhere' if args.fp8 else 'bf16'}, prompt 96 ids -> S={S}, "
+        "config": {"workload": f"UFVideo-7B dims, {args.frames} frames {img}x{img}, {'W8A8 e4m3 GEMMs (config #5a), bf16 elsewhere' if args.fp8 else 'bf16'}, prompt 96 ids -> S={S}, "
                                f"encode+project+splice+prefill to last-position logits; clip replicas per GPU",
-                   "video_tokens_per_clip": tokens_per_clip, "llm_seq_len": S,
+                   "video_tokens_per_clip": ntok, "llm_seq_len": S,
                    "prompt": "device tensors + the caller's host copy of the ids / mask, as ufvideo_amd.mm_infer passes them (no per-tensor cache between steps)", "parallelism": (f"frameshard{world}+allgather" if fs else f"clip-dp{world}")},
     }
     if REHEARSAL():
@@ -307,10 +318,13 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
                                "traffic": traffic, "traffic_source": pmc_note,
                                "mfma_busy_pmc": busy,
                                "launch_ms": round(ks["mean_ms"], 4), "launches": ks["launches"]}
-        step_tf = sum(FLOPS.values()) * args.frames / 32 / (dt / args.steps) / 1e12
+        step_tf = sum((FLOPS_384 if img == 384 else FLOPS).values()) * args.frames / 32 / (dt / args.steps) / 1e12
         out["step_tflops"] = round(step_tf, 1)
         out["step_frac_of_mfma_peak"] = round(step_tf / (2 * MFMA_PEAK_TFLOPS if args.fp8 else MFMA_PEAK_TFLOPS), 4)
-        if world == 1 and not args.no_cpu_baseline:
+        if img != IMG:
+            out["secondary"] = (f"NOT the headline: BASELINE config #2 is quoted at 336 px; this line is the released checkpoint's own tower geometry "
+                                f"(siglip-so400m-patch14-384, ufvideo/model/encoder.py:108: {(img // 14) ** 2} tokens per frame, {ntok} visual tokens)")
+        if world == 1 and not args.no_cpu_baseline and img == IMG:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 64), full_clip=not args.cpu_quick)
     return out
 
@@ -321,6 +335,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=T_FRAMES)
+    ap.add_argument("--img", type=int, default=IMG, choices=[IMG, 384], help="384: the released checkpoint's own tower geometry (729 tokens per frame, 2704 visual tokens) as a SECONDARY line; the headline metric is quoted at 336")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-quick", action="store_true", help="cpu_baseline: a bounded sample of config #2 (about 15 s, extrapolated by frames x layers) instead of one whole clip on the CPU oracle (about 1.5 min)")
     ap.add_argument("--cpu-full-clip", action="store_true", help=argparse.SUPPRESS)      # the default since round 3; accepted and ignored

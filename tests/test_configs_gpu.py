@@ -111,6 +111,93 @@ def test_config1_pixrqa_sample_4f_224_7b_dims():
     assert float(lo.max() - lo[tok]) <= 2 * rows[-1][2] * float(lo.abs().max())
 
 
+def test_native_384_geometry_7b_dims_vs_oracle():
+    """The RELEASED checkpoint's tower is siglip-so400m-patch14-384 (ufvideo/model/encoder.py:108,114,120-121): 384 x 384 frames, 27 x 27 = 729 tokens per frame,
+    the STC-v35 sampler floors the odd grid 27 -> 13, (T / 2) * 169 visual tokens.  7B layer dimensions, 4 frames, tower truncated to 3 layers (2 run), 2 decoder
+    layers, so that the oracle finishes in seconds: visual tokens, spliced inputs and last-position logits against oracle.ref_cpu (fp32 and bf16 mirror -- the
+    mirror follows the 729-token attention kernel tile for tile, `_flash_vit72_mirror`), splice bookkeeping exact.  The bench compares at 336 px (BASELINE
+    config #2); this is the geometry `model_init` on the released model runs."""
+    import bench
+    from ufvideo_amd import ops
+    from ufvideo_amd.model import VideoReferQwen2Config, VideoReferQwen2ForCausalLM, QWEN2_7B
+    vis = dict(bench.VISION, image_size=384, num_hidden_layers=3)
+    llm = dict(QWEN2_7B, num_hidden_layers=2)
+    cfg = VideoReferQwen2Config(**llm, mm_vision_tower="siglip-so400m-patch14-384", mm_vision_select_layer=-2,
+                                mm_vision_select_feature="patch", mm_projector_type="stc_connector_v35", mm_hidden_size=1152,
+                                mm_region_encoder_type="pooling", image_aspect_ratio="square", train_mask_decoder=False,
+                                sam_pretrained=None, sam_out_dim=256, num_frames=4, seg_token_id=151747, sam2_trunk=None,
+                                vision_config=vis)
+    dev = torch.device("cuda", 0)
+    model = VideoReferQwen2ForCausalLM(cfg, device=dev, seed=0)
+    model.get_vision_tower().load_model(device=dev, seed=7)
+    for m in model.modules():
+        m.tokenizer = bench._Tok()
+    tower = model.get_model().get_vision_tower()
+    assert tower.num_patches == 729 and tower.image_size == 384
+    rng = np.random.default_rng(4384)
+    u8 = rng.integers(0, 256, (4, 384, 384, 3), dtype=np.uint8)
+    video = ops.preprocess_u8(torch.from_numpy(u8).to(dev), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))          # bf16 [4,3,384,384]
+    text = rng.integers(0, 151643, 40).astype(np.int64)
+    ids = torch.from_numpy(np.concatenate([text[:10], [-201], text[10:]]))[None].to(dev)
+    am = torch.ones_like(ids)
+    with torch.no_grad():
+        feats = tower.encode(video)
+        mm = model.encode_images_or_videos([(video, "video")])
+        _, am2, _, emb, _, mark = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, [(video, "video")], None, None, None, None)
+        logits, cache, hs, normed = model._decode_batch(emb, am2, None, False, 1)
+    NT = (4 // 2) * 13 * 13
+    assert feats.shape == (4, 729, 1152) and mm.shape == (1, NT, 3584)
+    S = NT + ids.shape[1] - 1
+    assert emb.shape == (1, S, 3584) and int(am2.sum()) == S and mark[0] == [NT + 10, ids.shape[1] - 11]
+    sd = _cpu_sd(model, drop=("model.text_hidden_fcs",))
+    vt = "model.vision_tower.vision_tower.vision_model."
+    vcpu = video.float().cpu()
+
+    def oracle():
+        f = O.siglip_tower(sd, vis, vcpu, prefix=vt)
+        mmo = O.stc_connector(sd, f[None], prefix="model.mm_projector.")
+        amo, embo, _, marko = O.splice(O._rb(sd["model.embed_tokens.weight"].float()), ids.cpu(), am.cpu(), None, mmo, [], [], REGION_ID, False)
+        out = O.qwen2_forward(sd, llm, embo, amo, all_logits=False)
+        return dict(feats=f, mm=mmo, am=amo, emb=embo, mark=marko, logits=out["logits"][0, -1])
+    with O.bf16_mirror():
+        om = oracle()
+    o32 = oracle()
+    assert mark == om["mark"] == o32["mark"] and torch.equal(am2.cpu().to(o32["am"].dtype), o32["am"])
+    text_rows = [i for i in range(S) if not (10 <= i < 10 + NT)]
+    assert torch.equal(emb[0, text_rows].cpu(), o32["emb"][0, text_rows])
+    # bounds ~2 x what MI355X measures (chains of bf16 storage points: DESIGN.md section 2); the tower rows are the new arithmetic (729-token attention, 27 x 27 grid)
+    for name, got, km, b_m, b_32 in (("tower 2 L, 4 f x 729 x 1152", feats, "feats", 6e-3, 9e-3), ("visual tokens (338 x 3584)", mm, "mm", 2.5e-2, 2e-2),
+                                     ("inputs_embeds", emb, "emb", 2.5e-2, 2e-2), ("last-position logits", logits[0, -1], "logits", 1.6e-2, 1.6e-2)):
+        g = got.float().cpu().reshape(om[km].shape)
+        em, e32 = rel_err(g, om[km]), rel_err(g, o32[km])
+        print(f"GEOM384 {name:28s} vs mirror {em:.2e}   vs fp32 {e32:.2e}   (mirror vs fp32 {rel_err(om[km], o32[km]):.2e})")
+        assert em <= b_m and e32 <= b_32, (name, em, e32)
+    assert int(torch.argmax(logits[0, -1])) == int(torch.argmax(om["logits"])) or float(o32["logits"].max() - o32["logits"][int(torch.argmax(logits[0, -1]))]) <= 3.2e-2 * float(o32["logits"].abs().max())
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_native_384_geometry_32_frames_full_depth_properties():
+    """bench.build_model(img=384): the 26-layer tower and 28-layer decoder at 32 frames 384 x 384 -> 2704 visual tokens, S = 2799; finite logits, the clip's tokens land in
+    the spliced sequence untouched, and 8-way aligned frame chunks (what the frame-sharded encoder computes per rank) equal the whole clip BIT for bit."""
+    import bench
+    dev = torch.device("cuda", 0)
+    model = bench.build_model(dev, img=384)
+    video, ids, am = bench.synthetic_inputs(dev, img=384)
+    assert bench.tokens_per_clip(32, 384) == 2704
+    with torch.no_grad():
+        whole = model.encode_images_or_videos([(video, "video")])[0]
+        enc = lambda fr: model.temporal_aggregator(model.get_model().get_vision_tower().encode(fr)[None])[0]   # noqa: E731
+        eighths = torch.cat([enc(video[i:i + 4]) for i in range(0, 32, 4)], 0)
+        _, am2, _, emb, _, mark = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, [(video, "video")], None, None, None, None)
+        logits, cache, _, _ = model._decode_batch(emb, am2, None, False, 1)
+    assert whole.shape == (2704, 3584) and torch.equal(eighths, whole)
+    assert emb.shape == (1, 2704 + 95, 3584) and mark[0] == [2704 + 14, 81] and cache.get_seq_length() == 2799
+    assert torch.isfinite(logits).all() and torch.equal(emb[0, 14:14 + 2704], whole)
+    del model, cache
+    torch.cuda.empty_cache()
+
+
 @pytest.fixture(scope="module")
 def full():
     import bench
@@ -273,7 +360,7 @@ def test_config4_training_step_16_frames_7b_dims():
     assert float(r["loss"]) == losses[0] and float(r["grad_norm"]) == norms[0]       # bit-reproducible
 
 
-CONFIG4_STEP_FLOOR_MS = 153.0      # recorded on MI355X with this tree (profiles/r05/perf_floors.json): the step is held to this + 10 %
+CONFIG4_STEP_FLOOR_MS = 153.0      # recorded on MI355X with this tree (profiles/r05/perf_floors.json): the step is held to this + 5 %
 
 CONFIG4_28_CHILD = r'''
 import gc, os, sys
@@ -302,8 +389,8 @@ for _ in range(3):
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
 ts.sort()
 FLOOR = float(os.environ.get("UFV_CONFIG4_FLOOR_MS", "0"))
-print(f"PERF_FLOOR config4_train_step_ms: measured {ts[1]:.1f} ms, recorded {FLOOR:.1f} ms, limit {FLOOR * 1.10:.1f} ms", flush=True)
-assert FLOOR == 0 or ts[1] <= FLOOR * 1.10, f"config #4 training step {ts[1]:.1f} ms is more than 10 % over the recorded {FLOOR:.1f} ms"
+print(f"PERF_FLOOR config4_train_step_ms: measured {ts[1]:.1f} ms, recorded {FLOOR:.1f} ms, limit {FLOOR * 1.05:.1f} ms", flush=True)
+assert FLOOR == 0 or ts[1] <= FLOOR * 1.05, f"config #4 training step {ts[1]:.1f} ms is more than 5 % over the recorded {FLOOR:.1f} ms"
 tr.detach()
 del model, tr, batch, r
 gc.collect(); torch.cuda.empty_cache()
@@ -333,5 +420,5 @@ def test_config4_training_step_at_its_real_depth_28_layers():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", CONFIG4_28_CHILD], env=dict(os.environ, UFV_ROOT=root, UFV_CONFIG4_FLOOR_MS=str(CONFIG4_STEP_FLOOR_MS)),
                        capture_output=True, text=True, timeout=1200)
-    print(r.stdout[-900:])
+    print("\n".join(r.stdout.splitlines()[-12:]))          # whole lines: tests/conftest.py re-prints the PERF_FLOOR / CONFIG4 ones at the end of the run
     assert r.returncode == 0 and "CONFIG4_28_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

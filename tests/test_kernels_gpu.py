@@ -450,6 +450,13 @@ def test_patchify(dt):
     ref = torch.nn.functional.unfold(x.float(), P, stride=P).transpose(1, 2).reshape(T * 16, C * P * P)
     assert torch.equal(out[:, :588].float(), bf(ref).float())
     assert out[:, 588:].abs().sum() == 0
+    # a size that is no multiple of the patch (SigLIP so400m at 384 px: 384 = 27 x 14 + 6): the stride-P convolution without padding drops the right / bottom remainder;
+    # both forms of the kernel (dword runs for even widths, the scalar one for odd widths)
+    for Hh, Ww in ((62, 62), (59, 61)):
+        x = g(T, C, Hh, Ww, seed=35).to(dt)
+        out = ops.patchify(x, P, 640)
+        ref = torch.nn.functional.unfold(x.float(), P, stride=P).transpose(1, 2).reshape(T * (Hh // P) * (Ww // P), C * P * P)
+        assert out.shape[0] == T * 16 and torch.equal(out[:, :588].float(), bf(ref).float()) and out[:, 588:].abs().sum() == 0
 
 
 @pytest.mark.parametrize("F,H,W,C", [(3, 6, 6, 256), (2, 5, 7, 3584), (1, 24, 24, 896), (2, 3, 1, 64)])

@@ -493,6 +493,7 @@ __global__ __launch_bounds__(256) void patchify_k(const void* px, bf16* out, int
     const int n = C * P * W;
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
         const int x = e % W, py = (e / W) % P, c = e / (W * P);
+        if (x >= gw * P) continue;                                    // W % P pixels on the right belong to no patch (a stride-P convolution without padding: 384 = 27 x 14 + 6)
         const int64_t src = (((int64_t)t * C + c) * H + (gy * P + py)) * W + x;
         float v;
         if (DT == UFV_DT_F32) v = reinterpret_cast<const float*>(px)[src];
@@ -1209,7 +1210,8 @@ extern "C" int ufv_rope_kv_table(void* qkv, int ldqkv, int S, int Hq, int Hkv, i
 }
 
 extern "C" int ufv_patchify(const void* pixels, int dtype, void* out, int T, int C, int H, int W, int P, int Kpad, void* stream) {
-    UFV_REQUIRE(pixels && out && T > 0 && H % P == 0 && W % P == 0 && Kpad >= C * P * P, "ufv_patchify: bad arguments");
+    // H, W need not be multiples of P: nn.Conv2d(kernel = stride = P, padding 'valid') drops the H % P bottom rows and W % P right columns (SigLIP so400m at 384 px: 27 x 27 patches)
+    UFV_REQUIRE(pixels && out && T > 0 && P > 0 && H >= P && W >= P && Kpad >= C * P * P, "ufv_patchify: bad arguments");
     dim3 g(H / P, T), blk(256);
     // runs of P pixels as dwords when rows and runs are dword-aligned (P, W even: 14 / 336) and 8-byte aligned for fp32 pixels
     const bool runs = P % 2 == 0 && W % 2 == 0 && Kpad % 2 == 0 && (uintptr_t)pixels % 8 == 0 && (uintptr_t)out % 4 == 0 && (dtype == UFV_DT_F32 || dtype == UFV_DT_BF16);

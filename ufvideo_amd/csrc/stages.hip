@@ -97,7 +97,7 @@ extern "C" int ufv_vit_forward(const ufv_vit_model* m, const void* pixels, int d
                                void* ws, int64_t ws_bytes, void* stream) {
     UFV_REQUIRE(m && pixels && x && ws && T > 0, "ufv_vit_forward: bad arguments");
     UFV_REQUIRE(n_layers >= 0 && n_layers <= m->n_layers, "ufv_vit_forward: %d layers asked of a %d-layer tower", n_layers, m->n_layers);
-    UFV_REQUIRE(H % m->patch == 0 && W % m->patch == 0 && (H / m->patch) * (W / m->patch) == m->n_patches,
+    UFV_REQUIRE(H >= m->patch && W >= m->patch && (H / m->patch) * (W / m->patch) == m->n_patches,      // floor: a stride-P convolution without padding (384 px -> 27 x 27)
                 "ufv_vit_forward: tower built for %d patches, image %dx%d gives %d", m->n_patches, H, W, (H / m->patch) * (W / m->patch));
     UFV_REQUIRE(ws_bytes >= ufv_vit_forward_ws_bytes(m, T), "ufv_vit_forward: workspace too small");
     const int D = m->d, Hh = m->n_heads, hd = D / Hh, S = m->n_patches, Ip = m->d_ff_pad;
