@@ -399,11 +399,11 @@ def test_generated_kernel_bodies_are_what_their_generators_emit(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("UFV_")}
-    for gen, inc in (("gen_attn_p2.py", "attn_vit_p2_asm.inc"), ("gen_attn_c128.py", "attn_c128_asm.inc")):
-        work = tmp_path / gen
+    for gen, inc, opts in (("gen_attn_p2.py", "attn_vit_p2_asm.inc", []), ("gen_attn_p2.py", "attn_vit_p2_s729_asm.inc", ["--seq", "729"]), ("gen_attn_c128.py", "attn_c128_asm.inc", [])):
+        work = tmp_path / (gen + "".join(opts))
         (work / "tools").mkdir(parents=True)
         (work / "ufvideo_amd" / "csrc").mkdir(parents=True)
         shutil.copy(os.path.join(root, "tools", gen), work / "tools" / gen)
-        subprocess.run([sys.executable, str(work / "tools" / gen)], check=True, env=env, stdout=subprocess.DEVNULL)
+        subprocess.run([sys.executable, str(work / "tools" / gen)] + opts, check=True, env=env, stdout=subprocess.DEVNULL)
         fresh = (work / "ufvideo_amd" / "csrc" / inc).read_text()
         assert fresh == open(os.path.join(root, "ufvideo_amd", "csrc", inc)).read(), f"{inc} is stale: run tools/{gen}"

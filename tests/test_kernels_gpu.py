@@ -276,7 +276,10 @@ def test_vit72_third_generation_bit_identical_and_rescale_paths():
         S = 576
         q, k, v = g(B, S, H, hd, seed=seed), g(B, S, H, hd, seed=seed + 100), g(B, S, H, hd, seed=seed + 200)
         # growing spikes: tile 1 (key 70), tile 4 (key 300), tile 8 (key 560), seen by rows of every unit and pass (0..95, 96..191, 192..287, and the second half)
-        for row, key, amp in ((5, 70, 3.0), (5, 300, 6.0), (40, 560, 5.0), (70, 130, 4.0), (100, 300, 5.0), (200, 450, 6.0), (250, 70, 4.0), (300, 520, 7.0), (500, 200, 5.0), (575, 575, 6.0)):
+        for row, key, amp in ((5, 70, 3.0), (5, 300, 6.0), (40, 560, 5.0), (70, 130, 4.0), (100, 300, 5.0), (200, 450, 6.0), (250, 70, 4.0), (300, 520, 7.0), (500, 200, 5.0), (575, 575, 6.0),
+                              # round 6: LAST-tile spikes for unit-2 rows of passes that have a successor (rows 64..95, 160..191; 352..383, 448..479): the rescale path that used
+                              # to write into the next pass's in-flight Q registers (tools/gen_attn_p2.py rescale_math); frequent only with few blocks on the chip, hence the repeats below
+                              (70, 565, 6.0), (170, 540, 7.0), (360, 570, 6.0), (460, 530, 7.0)):
             k[:, key] = q[:, row] * amp
         k[:, :64] = -q[:, 150:214].abs().mean(dim=(1, 2), keepdim=True) * torch.sign(q[:, 150:151]) * 2.0      # tile 0 strongly negative for row 150
         q, k, v = bf(q), bf(k), bf(v)
@@ -290,7 +293,9 @@ def test_vit72_third_generation_bit_identical_and_rescale_paths():
             d = (new != old).nonzero()
             raise AssertionError(dict(B=B, H=H, new_vs_old=int(d.shape[0]), first=d[:4].tolist(), last=d[-1:].tolist(), auto_vs_old=int((auto != old).sum()),
                                       kernel14_repeatable=bool(torch.equal(new2, new)), kernel11_repeatable=bool(torch.equal(old2, old)), rerun_equal=bool(torch.equal(new2, old2))))
-        assert torch.isfinite(new.float()).all() and rel(new, attn_ref(q, k, v, False)) <= 2 * ATTN_TOL
+        assert torch.isfinite(new.float()).all() and rel(new, attn_ref(q, k, v, False)) <= 3 * ATTN_TOL
+        for _ in range(20):                     # the round-5 mismatch was a race: the same launch again and again (small grids are the sensitive ones)
+            assert torch.equal(ops.attention(q, k, v, B, H, H, S, S, hd, *st, kernel=14), old)
     q, k, v = bf(g(1, 288, 2, hd, seed=60)), bf(g(1, 288, 2, hd, seed=61)), bf(g(1, 288, 2, hd, seed=62))
     with pytest.raises(_lib.UfvError):
         ops.attention(q, k, v, 1, 2, 2, 288, 288, hd, (288 * 2 * hd, 2 * hd), (288 * 2 * hd, 2 * hd), (288 * 2 * hd, 2 * hd), kernel=14)
@@ -325,6 +330,8 @@ def test_vit72_third_generation_at_729_tokens_bit_identical_masked_tail_and_ragg
             assert (buf[B * S:] == 7.0).all(), f"kernel {kern} wrote past the last row"
             outs[kern] = buf[:B * S].clone()
         assert torch.equal(outs[14], outs[11]) and torch.equal(outs[0], outs[11]), (B, H, int((outs[14] != outs[11]).sum()), (outs[14] != outs[11]).nonzero()[:4].tolist())
+        for _ in range(20):                     # (a race shows up as a launch that differs from the one before it: this is how the round-5 mismatch was caught)
+            assert torch.equal(ops.attention(qv, kv, vv, B, H, H, S, S, hd, *st, kernel=14), outs[11])
         qb, kb, vb = bf(q), bf(k), bf(v)
         # spikes of 7 x |q|^2 are scores of +-85 in the log2 domain: the one extra bf16 rounding of q' moves a dominant key's weight by ~1 % -- the oracle's own mirror of
         # this arithmetic is 1.2e-2 from fp32 on these inputs (ordinary inputs: test_attention at 729 tokens, <= ATTN_TOL); the tight bound is the mirror's, below

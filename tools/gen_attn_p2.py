@@ -502,7 +502,7 @@ def build(simple=False):
                 else:
                     stub, back = G.label("RS"), G.label("BK")
                     body = mx + [f"v_cmp_lt_f32 vcc, 0x{THR:08x}, {vr(T0)}", "s_nop 1", f"s_cbranch_vccnz {stub}", f"{back}:"]
-                    G.stubs.append((stub, back, u, j == NT - 1))
+                    G.stubs.append((stub, back, u, j == NT - 1 and "lastq" not in OPT))      # UFV_P2_OPT=lastq: the pre-round-6 text (negative control of tools/isa_p2_audit.py)
                 ex = sm_exp_cvt(u)
                 if "exp" in DROP:
                     ex = []
