@@ -21,7 +21,7 @@ import sys
 
 VM_STORE = re.compile(r'^(buffer_store|global_store|flat_store|scratch_store)')
 VM_LOAD = re.compile(r'^(buffer_load|global_load|flat_load|scratch_load)')
-KERNEL = re.compile(r'gemm_nt_256ILb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELi(\d)E')
+KERNEL = re.compile(r'gemm_nt_256ILb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)E')
 
 
 def kernels(listing):
@@ -36,7 +36,7 @@ def kernels(listing):
                 body = body[:j + 1]
                 break
         m = KERNEL.search(name)
-        t = dict(zip(("OUT_F32", "SWIGLU", "FP8", "SKT", "MA0", "MA1", "NB1", "PH2", "KSPL", "ROPE", "MX"), (int(x) for x in m.groups())))
+        t = dict(zip(("OUT_F32", "SWIGLU", "FP8", "SKT", "MA0", "MA1", "NB1", "PH2", "KSPL", "ROPE", "MX", "HALF"), (int(x) for x in m.groups())))
         out.append((name, t, body))
     return out
 

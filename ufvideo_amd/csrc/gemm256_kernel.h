@@ -554,6 +554,7 @@ struct StreamK {
     int gm;             // row-tiles per group of the tile order (concurrent tiles of a group share A / W panels in L2)
     int ksplit;         // KSPL kernels: K parts per tile (items = tiles x parts, part-major), turn flags in `flags` (this launch's own slice), `epoch` = this launch's ticket base
     int* err;           // pinned host word: set when a bounded turn wait expires (gemm_state.hip)
+    int half;           // HALF kernels: 1 = the launch ends with ONE round of half-tile items (see gemm_nt_256: HALF); 0 = whole tiles only
 };
 
 // Bounded waits on another block's flag.  A turn can only fail to come when the launch's blocks are not all resident (some other kernel
@@ -587,7 +588,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // ROPE: the fused QKV + RoPE + KV-append form (epilogue256_rope): B fragments re-mapped so that the rotate-half partners of a head share a lane.
 // MX (e4m3 operands only): bit 0 = the A operand carries MX block scales (one e8m0 byte per row and 32 K-elements, staged per K-tile beside the operand tiles and
 // handed to v_mfma_scale_f32_16x16x128_f8f6f4, whose lanes own exactly one such block each); bit 1 = the epilogue emits e4m3 codes + block scales (epilogue256_*_mx).
-template <bool OUT_F32, bool SWIGLU, bool FP8, bool SKT, int MA0 = 4, int MA1 = 4, int NB1 = 2, bool PH2 = false, bool KSPL = false, bool ROPE = false, int MX = 0>
+// HALF (round 6; the decoder's gate/up projection at M = 2399: 10 x 148 = 1480 tiles on 256 CUs are 5.78 rounds, and the 148 tiles of the last row band hold 95 valid rows
+// -- 9.7 % of the launch's MFMA work was padding plus an idle last round): the launch's tiles are dealt as whole tiles for as many FULL rounds as there are, and the
+// rest as ONE round of half-tile items when they fit one round: a leftover whole tile becomes two items of 32 MA0 rows each, a tile of a row band with <= 32 MA0 valid
+// rows one item.  A half-tile item runs the same two-phase K loop with phase B's fragment reads and MFMAs left out (no A1 half is staged: the counted waits take L_ALL - LA1 operations per K-tile; the barriers
+// and the ring's stages are the tile's own) and the same epilogue with the row limit at the item's
+// end, so that the untouched A1 accumulators are stored nowhere (every store instruction is still issued: the relaxed seam waits hold).  Every output element is
+// the same sum in the same order as in a whole tile: bit-identical.  M = 2399 x N = 37888: 5 rounds + one round of 2 x 52 + 148 = 252 half items instead of 6 rounds.
+template <bool OUT_F32, bool SWIGLU, bool FP8, bool SKT, int MA0 = 4, int MA1 = 4, int NB1 = 2, bool PH2 = false, bool KSPL = false, bool ROPE = false, int MX = 0, bool HALF = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ Av, const void* __restrict__ Wv, Epi e, int M,
                                                        int N, int K, int lda, int ldw, StreamK sk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -597,6 +605,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     static_assert(!SKT || (MA0 == 4 && MA1 == 4 && NB1 == 2), "the stream-K fix-up is written for the 256x256 tile image");
     static_assert(!KSPL || (OUT_F32 && !SWIGLU && !FP8 && !SKT && PH2), "split-K parts accumulate into an fp32 output");
     static_assert(MX == 0 || (FP8 && PH2 && !SKT && !KSPL && !ROPE), "MX block scales belong to the e4m3 kernels");
+    static_assert(!HALF || (PH2 && !SKT && !KSPL && (MX & 1) == 0), "half-tile items: the two-phase whole-tile kernels");
     static_assert(!(ROPE && FP8) || MX == 0, "the fused RoPE form of the e4m3 QKV GEMM takes per-row-scaled activations");
     static_assert(!(MX & 2) || (!OUT_F32 && MA0 == 4 && MA1 == 4 && NB1 == 2), "the MX-emitting epilogues are built for the 256 x 256 tile");
     constexpr bool MXA = (MX & 1) != 0;
@@ -617,10 +626,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     const int G = gridDim.x;                       // persistent: block b walks tiles b, b+G, ...
     // tile sequence position -> (tm, tn): within a round of G tiles give each XCD (launch id % 8) a contiguous run,
     // and order the sequence in groups of 8 row-tiles so that concurrent tiles share A/W panels in L2.
+    // HALF: row bands dealt as whole tiles (all but a last band with <= 32 MA0 valid rows), whole tiles, full rounds of them, leftover whole tiles, band tiles
+    const bool half_on = HALF && sk.half != 0;
+    const int light = (half_on && M - (tiles_m - 1) * BM <= 32 * MA0) ? 1 : 0;
+    const int rows_full = half_on ? tiles_m - light : tiles_m, n_full = rows_full * tiles_n, n_light = light * tiles_n;
+    const int full_rounds = half_on ? n_full / (int)gridDim.x : 0, left_full = half_on ? n_full - full_rounds * (int)gridDim.x : 0;
+    bool item_half = false;                    // the item next_item() handed out last is a half-tile item
     auto tile_coords = [&](int id, int& m0_, int& n0_) {
         const int GM = sk.gm;
         const int gsz = GM * tiles_n, g = id / gsz, first_m = g * GM;
-        const int gm = min(tiles_m - first_m, GM);
+        const int gm = min(rows_full - first_m, GM);
         m0_ = (first_m + (id % gsz) % gm) * BM;
         n0_ = ((id % gsz) / gm) * BN;
     };
@@ -645,14 +660,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             tile_coords(tile, m0_, n0_);
             return true;
         }
+        const bool last_half_round = half_on && round == full_rounds;
+        if (half_on && round > full_rounds) return false;
         const int items = KSPL ? nwg * sk.ksplit : nwg;
         const int base = round * G;
-        const int cnt = min(G, items - base);        // items in this round
+        const int cnt = last_half_round ? 2 * left_full + n_light : min(G, items - base);        // items in this round
         const int bid = blockIdx.x;
         ++round;
         if (bid >= cnt) return false;
         const int q = cnt >> 3, r = cnt & 7, x = bid & 7;
         const int id = base + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+        if constexpr (HALF) {
+            item_half = last_half_round;
+            if (last_half_round) {                   // item i of the round: the two halves of a leftover tile are neighbours on ONE XCD (they share the tile's W panel)
+                const int i = id - base;
+                if (i < 2 * left_full) {
+                    tile_coords(base + (i >> 1), m0_, n0_);
+                    m0_ += (i & 1) * 32 * MA0;
+                } else {
+                    m0_ = (tiles_m - 1) * BM;
+                    n0_ = (i - 2 * left_full) * BN;
+                }
+                k0_ = 0; k1_ = nk;
+                return true;
+            }
+        }
         if constexpr (KSPL) {
             const int per = (nk + sk.ksplit - 1) / sk.ksplit;
             item_part = id / nwg; item_tile = id - item_part * nwg;
@@ -697,6 +729,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     const char* src[4][2];
     const unsigned char* ssrc = nullptr;           // MXA: this lane's row of the A block scales (rows 64 (wave & 3) + lane of the tile; waves 4-7 stage the same bytes again)
     auto set_src = [&](int m0_, int n0_) {
+        const int Mc = (HALF && item_half) ? min(M, m0_ + 32 * MA0) : M;        // a half-tile item: its A1 pieces fetch (and re-fetch) the item's last row
         if constexpr (X2) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -724,7 +757,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             for (int i = 0; i < 2; ++i) {
                 const int la = h ? T::LA1 : T::LA0, lb = h ? T::LB1 : T::LB0;
                 const int ra = h * 32 * MA0 + (wave * la + i) * 8 + lrow, rb = h * 128 + (wave * lb + i) * 8 + lrow;
-                src[h][i] = A + (size_t)min(m0_ + ra, M - 1) * lda * ES + lchunk * 16;
+                src[h][i] = A + (size_t)min(m0_ + ra, Mc - 1) * lda * ES + lchunk * 16;
                 src[2 + h][i] = W + (size_t)min(n0_ + rb, N - 1) * ldw * ES + lchunk * 16;
             }
     };
@@ -747,6 +780,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             }
         }
         const int l = which == 0 ? T::LA0 : which == 1 ? T::LA1 : which == 2 ? T::LB0 : T::LB1;
+        if constexpr (HALF) { if (which == 1 && item_half) return; }      // a half-tile item stages no A1 half: its K loop's waits count L_ALL - LA1 operations per K-tile
         if (kt < kend) {
             char* dst = smem + d * 65536 + which * 16384 + wave * (1024 * l);
             __builtin_amdgcn_global_load_lds(GLB_PTR(src[which][0] + kt * 128), LDS_PTR(dst), 16, 0, 0);
@@ -932,6 +966,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         } else if constexpr (X2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the A1 count differs by wave there: wait for all of it
         else wait_vmcnt<T::LA1>();
     } else if constexpr (PH2) {
+        constexpr int LH = L_ALL - T::LA1;             // half-tile items: no A1 pieces in flight
+        if (HALF && item_half) {
+            if (len > 1) {
+                if (RELAX_OK && relax == 1) wait_vmcnt<RELAX_OK ? LH + NST : 0>();
+                else if (RELAX_OK && relax == 2) wait_vmcnt<RELAX_OK ? LH + NSTW : 0>();
+                else if (RELAX_OK && relax == 3) wait_vmcnt<RELAX_OK ? LH + NSTS : 0>();
+                else if (RELAX_OK && relax == 4) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? LH + NSTM : LH>();
+                else wait_vmcnt<LH>();
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else
         if (len > 1) {                                 // A0 / B0 / B1 of the first K-tile; its A1 and the second tile's three stay in flight
             if (RELAX_OK && relax == 1) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
             else if (RELAX_OK && relax == 2) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
@@ -1025,8 +1069,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
     // SANK phase A's MFMAs below the next load step's waits -- the two wave groups then multiplied at the same time and waited at the same time (fc2: 101 -> 130 us;
     // the listing showed `s_setprio 1; s_setprio 0` with nothing between them).  Left uncounted the piece made two waits per four K-tiles retire an operand piece issued
     // one phase earlier: a memory latency each.
-    auto ktile2 = [&](auto qc, int tt) {
+    // SKIPB (HALF kernels, half-tile items): phase B keeps its load step (DMA, counted wait) and its two barriers, and has no fragment reads and no MFMAs
+    auto ktile2 = [&](auto qc, auto skipc, int tt) {
         constexpr int Q = decltype(qc)::value;
+        constexpr bool SKIPB = decltype(skipc)::value;
+        constexpr int LW = L_ALL - (SKIPB ? T::LA1 : 0);          // DMA instructions of one K-tile of this kind of item
         const int t = k0 + tt, d = tt & 1;
         const char* buf = smem + d * 65536;
         // phase A: A0, B0, B1 -> top half; prefetch A1[t+1]; retire A1[t]
@@ -1052,16 +1099,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         stage(d ^ 1, 1, t + 1);
         UFV_GSTAMP(10);
         if (tt + 1 < len) {                            // behind A1[t]: A0/B0/B1[t+1] and A1[t+1] (+ at the item's first K-tile the previous epilogue's stores)
-            if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
-            else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
-            else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
-            else if (RELAX_OK && relax == 4 && tt == 0) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? L_ALL + NSTM : L_ALL>();
-            else wait_vmcnt<L_ALL + ((MXA && Q == 3) ? 1 : 0)>();          // (Q == 3: the scale piece that joined [A0 B0 B1][t+1]; it was issued iff tt + 1 < len)
+            if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? LW + NST : 0>();
+            else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? LW + NSTW : 0>();
+            else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? LW + NSTS : 0>();
+            else if (RELAX_OK && relax == 4 && tt == 0) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? LW + NSTM : LW>();
+            else wait_vmcnt<LW + ((MXA && Q == 3) ? 1 : 0)>();          // (Q == 3: the scale piece that joined [A0 B0 B1][t+1]; it was issued iff tt + 1 < len)
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         UFV_SYNC_THEN_MMA(0, NT, 0, MA0, 1, 2, 3)
         // phase B: A1 -> bottom half; prefetch A0 / B0 / B1 [t+2]; retire A0 / B0 / B1 [t+1]
         UFV_GSTAMP(4);
-        read_a(buf + 16384, H1{});
+        if constexpr (!SKIPB) read_a(buf + 16384, H1{});
         UFV_GSTAMP(11);
         stage(d, 0, t + 2);
         stage(d, 2, t + 2);
@@ -1069,25 +1116,37 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         if constexpr (MXA && Q == 2) stage(d, 4, t + 2);           // K-tiles t + 2 .. t + 5 (issued iff t + 2 < kend, i.e. tt + 2 < len: the branch of the wait below)
         UFV_GSTAMP(12);
         if (tt + 2 < len) {                            // behind them: A1[t+1] and A0/B0/B1[t+2]
-            if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NST : 0>();
-            else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTW : 0>();
-            else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? L_ALL + NSTS : 0>();
-            else if (RELAX_OK && relax == 4 && tt == 0) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? L_ALL + NSTM : L_ALL>();
-            else wait_vmcnt<L_ALL + ((MXA && Q == 2) ? 1 : 0)>();
+            if (RELAX_OK && relax == 1 && tt == 0) wait_vmcnt<RELAX_OK ? LW + NST : 0>();
+            else if (RELAX_OK && relax == 2 && tt == 0) wait_vmcnt<RELAX_OK ? LW + NSTW : 0>();
+            else if (RELAX_OK && relax == 3 && tt == 0) wait_vmcnt<RELAX_OK ? LW + NSTS : 0>();
+            else if (RELAX_OK && relax == 4 && tt == 0) wait_vmcnt<(RELAX_OK && L_ALL + NSTM <= 63) ? LW + NSTM : LW>();
+            else wait_vmcnt<LW + ((MXA && Q == 2) ? 1 : 0)>();
         } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        UFV_SYNC_THEN_MMA(0, NT, MA0, MA1, 5, 6, 7)
+        if constexpr (SKIPB) {
+            // the step's two barriers (the other wave group is in its load step between them), nothing to multiply
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        } else {
+            UFV_SYNC_THEN_MMA(0, NT, MA0, MA1, 5, 6, 7)
+        }
         UFV_GSTAMP(8);
         UFV_TSTAMP_K(tt);
     };
+    using NOSKIP = std::integral_constant<bool, false>;
     if constexpr (MXA) {
         for (int tt = 0; tt < len; tt += 4) {           // (every MX-A item starts at K-tile 0: tt & 3 == t & 3)
-            ktile2(std::integral_constant<int, 0>{}, tt);
-            if (tt + 1 < len) ktile2(std::integral_constant<int, 1>{}, tt + 1);
-            if (tt + 2 < len) ktile2(std::integral_constant<int, 2>{}, tt + 2);
-            if (tt + 3 < len) ktile2(std::integral_constant<int, 3>{}, tt + 3);
+            ktile2(std::integral_constant<int, 0>{}, NOSKIP{}, tt);
+            if (tt + 1 < len) ktile2(std::integral_constant<int, 1>{}, NOSKIP{}, tt + 1);
+            if (tt + 2 < len) ktile2(std::integral_constant<int, 2>{}, NOSKIP{}, tt + 2);
+            if (tt + 3 < len) ktile2(std::integral_constant<int, 3>{}, NOSKIP{}, tt + 3);
         }
+    } else if (HALF && item_half) {                      // (block-uniform; a loop of its own, so that the whole-tile loop's code is what it was)
+        if constexpr (HALF)
+            for (int tt = 0; tt < len; ++tt) ktile2(std::integral_constant<int, -1>{}, std::integral_constant<bool, true>{}, tt);
     } else {
-        for (int tt = 0; tt < len; ++tt) ktile2(std::integral_constant<int, -1>{}, tt);
+        for (int tt = 0; tt < len; ++tt) ktile2(std::integral_constant<int, -1>{}, NOSKIP{}, tt);
     }
     } else {
     for (int tt = 0; tt < len; ++tt) {
@@ -1181,6 +1240,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
         for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(rcos[mt]), "+v"(rsin[mt]));
     }
     const int cm0 = m0, cn0 = n0, cpart = item_part, ctile = item_tile, clen = len;
+    const int rowlim = (HALF && item_half) ? min(M, m0 + 32 * MA0) : M;      // row limit of THIS item's epilogue: a half-tile item ends behind its 32 MA0 rows (the A1 accumulators are dropped)
     UFV_TSTAMP(8);
     have = next_item(m0, n0, k0, k1);
     if (have) { set_src(m0, n0); kbeg = k0; kend = k1; UFV_TSTAMP(9); prologue_loads(); }
@@ -1241,32 +1301,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(const void* __restrict__ A
             swide = e.resid == nullptr && e.ldc % 8 == 0 && ((uintptr_t)e.out & 15) == 0 && (int64_t)M * e.ldc < (1ll << 30);
         bool wide = false;
         if constexpr (!OUT_F32 && !SWIGLU) wide = e.resid == nullptr && e.ldc % 8 == 0 && ((uintptr_t)e.out & 15) == 0 && (int64_t)M * e.ldc < (1ll << 30);
-        const bool interior = cm0 + BM <= M && cn0 + BN <= N;     // every store instruction of the epilogue is issued
+        const bool interior = cm0 + BM <= rowlim && cn0 + BN <= N;     // every store instruction of the epilogue is issued
         if constexpr (ROPE) {
-            epilogue256_rope<MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias, rcos, rsin);
+            epilogue256_rope<MA0, MA1>(acc, e, rowlim, N, cm0, cn0, wr, wc, frow, fq, bias, rcos, rsin);
             relax = RELAX_OK ? 2 : 0;                             // 2 MT sixteen-byte buffer stores, every one issued on every tile
         } else if constexpr ((MX & 2) != 0) {
-            if constexpr (SWIGLU) epilogue256_swiglu_mx<MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq);
-            else { UFV_ACT_SWITCH(e.act, (epilogue256_wide_mx<ACT_, MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias))) }
+            if constexpr (SWIGLU) epilogue256_swiglu_mx<MA0, MA1>(acc, e, rowlim, N, cm0, cn0, wr, wc, frow, fq);
+            else { UFV_ACT_SWITCH(e.act, (epilogue256_wide_mx<ACT_, MA0, MA1>(acc, e, rowlim, N, cm0, cn0, wr, wc, frow, fq, bias))) }
             relax = RELAX_OK ? 4 : 0;
         } else if (by_rows) {
             if constexpr (!SWIGLU && !FP8) {
                 if constexpr (!OUT_F32) {
-                    if (e.resid_bf16) epilogue256_resid<OUT_F32, MA0, MA1, NB1, true>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
-                    else epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
+                    if (e.resid_bf16) epilogue256_resid<OUT_F32, MA0, MA1, NB1, true>(acc, e, rowlim, N, cm0, cn0, wr, wc, frow, fq, bias);
+                    else epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, rowlim, N, cm0, cn0, wr, wc, frow, fq, bias);
                 } else {
-                    epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias);
+                    epilogue256_resid<OUT_F32, MA0, MA1, NB1>(acc, e, rowlim, N, cm0, cn0, wr, wc, frow, fq, bias);
                 }
             }
             relax = RELAX_OK ? 1 : 0;                             // this form issues every store instruction, edge tiles included
         } else if (swide) {
-            if constexpr (!OUT_F32 && SWIGLU && MA0 % 2 == 0 && MA1 % 2 == 0 && NB1 == 2) epilogue256_swiglu_wide<MA0, MA1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq);
+            if constexpr (!OUT_F32 && SWIGLU && MA0 % 2 == 0 && MA1 % 2 == 0 && NB1 == 2) epilogue256_swiglu_wide<MA0, MA1>(acc, e, rowlim, N, cm0, cn0, wr, wc, frow, fq);
             relax = RELAX_OK ? 3 : 0;                             // every store instruction is issued on every tile (round 5: dropped offsets, no branches)
         } else if (wide) {
-            if constexpr (!OUT_F32 && !SWIGLU) { UFV_ACT_SWITCH(e.act, (epilogue256_wide<ACT_, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias))) }
+            if constexpr (!OUT_F32 && !SWIGLU) { UFV_ACT_SWITCH(e.act, (epilogue256_wide<ACT_, MA0, MA1, NB1>(acc, e, rowlim, N, cm0, cn0, wr, wc, frow, fq, bias))) }
             relax = RELAX_OK ? 2 : 0;                             // buffer stores: every store instruction is issued on row- and column-edge tiles too (rows >= M and a half past N are dropped by the descriptor)
         } else {
-            UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_, false, MA0, MA1, NB1>(acc, e, M, N, cm0, cn0, wr, wc, frow, fq, bias)))
+            UFV_ACT_SWITCH(e.act, (epilogue256<OUT_F32, SWIGLU, ACT_, false, MA0, MA1, NB1>(acc, e, rowlim, N, cm0, cn0, wr, wc, frow, fq, bias)))
             relax = RELAX_OK && interior ? 1 : 0;
         }
     }
@@ -1285,11 +1345,11 @@ static inline int pp_n_cu() { return ufv_dev_n_cu(); }
 // made its XCDs fetch 16 W panels per round instead of 4; 1203 -> 1244 TF/s on gate/up), else ~8 in equal groups
 static inline int pp_group(int tiles_m) { return tiles_m <= 16 ? tiles_m : cdiv(tiles_m, cdiv(tiles_m, 8)); }
 
-template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false, bool ROPE = false, int MX = 0>
+template <bool F, bool S, bool Q, int MA0, int MA1, int NB1, bool PH2 = false, bool KSPL = false, bool ROPE = false, int MX = 0, bool HALF = false>
 static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, int K, int lda, int ldw, hipStream_t st, int ksplit = 1) {
     constexpr int SMEM = SMEM256 + (((MX & 1) && NB1 != 1) ? 8192 : 0);          // MX & 1: two slots of A block scales (four K-tiles each) above the operand ring unless they fit inside it
     UFV_ONCE_PER_DEVICE(
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE, MX>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE, MX, HALF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     );
     using T = PP<MA0, MA1, NB1>;
@@ -1299,8 +1359,18 @@ static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, i
         return UFV_EUNSUPPORTED;
     }
     const int tiles_m = cdiv(M, T::BM), tiles = tiles_m * cdiv(N, T::BN), n_cu = pp_n_cu();
-    StreamK sk = {nullptr, nullptr, 0, pp_group(tiles_m), 1, nullptr};
+    StreamK sk = {nullptr, nullptr, 0, pp_group(tiles_m), 1, nullptr, 0};
     int items = tiles;
+    if constexpr (HALF) {
+        // the launch's last round as half-tile items (gemm_nt_256: HALF) when the leftover whole tiles (two items each) and the tiles of a last row band with <= 32 MA0
+        // valid rows (one item each) fit ONE round: the round then costs what half a tile costs instead of a whole one.  UFV_GEMM_NO_HALF: same-process A/B switch (tests, lab).
+        const int tiles_n = cdiv(N, T::BN), light = (M - (tiles_m - 1) * T::BM <= 32 * MA0) ? 1 : 0;
+        const int n_full = (tiles_m - light) * tiles_n, n_light = light * tiles_n, left = n_full % n_cu;
+        if (tiles >= n_cu && left + n_light > 0 && 2 * left + n_light <= n_cu && getenv("UFV_GEMM_NO_HALF") == nullptr) {
+            sk.half = 1;
+            sk.gm = pp_group(tiles_m - light);
+        }
+    }
     if constexpr (KSPL) {
         const int nk = K / 64;
         if (e.act != ACT_NONE || ksplit < 2 || ksplit > 32 || (ksplit - 1) * cdiv(nk, ksplit) >= nk) {
@@ -1312,7 +1382,7 @@ static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, i
         sk.ksplit = ksplit;
         items = tiles * ksplit;
     }
-    hipLaunchKernelGGL((gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE, MX>), dim3(items < n_cu ? items : n_cu), dim3(512), SMEM, st, A, W, e, M, N, K,
+    hipLaunchKernelGGL((gemm_nt_256<F, S, Q, false, MA0, MA1, NB1, PH2, KSPL, ROPE, MX, HALF>), dim3(items < n_cu ? items : n_cu), dim3(512), SMEM, st, A, W, e, M, N, K,
                        lda, ldw, sk);
     UFV_CHECK_LAUNCH();
     return UFV_OK;
