@@ -290,6 +290,14 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
     }
     if REHEARSAL():
         out["rehearsal"] = f"TEST ONLY: {world} ranks share cuda:0 over gloo (UFV_BENCH_REHEARSAL); not a multi-GPU measurement"
+        if fs:      # behind the timed region: what every rank gathered == what ONE process computes from all the frames (tests/test_parallel_gpu.py reads the flag)
+            from ufvideo_amd.parallel import encode_frame_sharded
+            with torch.no_grad():
+                gathered = encode_frame_sharded(model, video)
+                whole = model.encode_images_or_videos([(video, "video")])[0]
+            ok = torch.tensor([int(torch.equal(gathered, whole))], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            out["frameshard_tokens_equal_single_process"] = bool(ok.item())
     if rank == 0:
         ks = timer.summary()
         if ks:
@@ -320,6 +328,10 @@ def run(args, rank, world, dist, device, build=None, inputs=None, step=None, syn
                                "launch_ms": round(ks["mean_ms"], 4), "launches": ks["launches"]}
         step_tf = sum((FLOPS_384 if img == 384 else FLOPS).values()) * args.frames / 32 / (dt / args.steps) / 1e12
         out["step_tflops"] = round(step_tf, 1)
+        # peak HBM of this process (weights + packed copies + activations + the KV cache): the W8A8 mode keeps the bf16 matrices for the one-call decode step BESIDE the e4m3
+        # ones, and down_proj twice in e4m3 (row-scaled for decode / short prompts, column-permuted for the MX chain): about +9.5 GB at 7B -- reported, not hidden
+        if device.type == "cuda":
+            out["hbm_peak_gb"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
         out["step_frac_of_mfma_peak"] = round(step_tf / (2 * MFMA_PEAK_TFLOPS if args.fp8 else MFMA_PEAK_TFLOPS), 4)
         if img != IMG:
             out["secondary"] = (f"NOT the headline: BASELINE config #2 is quoted at 336 px; this line is the released checkpoint's own tower geometry "

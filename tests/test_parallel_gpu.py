@@ -221,3 +221,24 @@ def test_bench_gpus2_real_run_rehearsal_two_ranks_on_one_gpu():
     assert "rehearsal" in d and "roofline" in d and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 2304 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]      # whole-job tokens of BOTH ranks / the MAX time
     assert d["config"]["llm_seq_len"] == 2399
+
+
+def test_bench_frameshard_64_frames_real_run_rehearsal_two_ranks_on_one_gpu():
+    """BASELINE config #3's command, `python bench.py --gpus N --mode frameshard --frames 64`, through the real run(): each rank encodes its contiguous 32 of the 64 frames
+    (26-layer tower + STC-v35 at 7B dims), ONE all-gather of visual tokens inside the timed step (`encode_frame_sharded` from `one_step`), the 28-layer decoder on every
+    rank; the line says `scaling: strong`, `frameshard2+allgather`, and its value is ONE clip's 4608 tokens over the MAX time (not world x).  Rehearsal mode (two ranks
+    on cuda:0 over gloo, the tokens cross the host): the gathered tokens are compared with the single-process 64-frame encode on every rank, bit for bit."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(UFV_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "frameshard", "--frames", "64", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "frameshard2+allgather" and "rehearsal" in d
+    assert d["config"]["video_tokens_per_clip"] == 4608 and d["config"]["llm_seq_len"] == 4703
+    assert abs(d["value"] - 4608 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]            # ONE clip per step, whatever the world size
+    assert d["frameshard_tokens_equal_single_process"] is True

@@ -1117,7 +1117,7 @@ extern "C" int ufv_gemm_fp8_mx(const void* A, int lda, const float* a_scale, con
         return rc;
     }
     UFV_REQUIRE(!swiglu, "ufv_gemm_fp8_mx: SwiGLU with a block-scaled input is not built");
-    UFV_REQUIRE(e.ldc % 4 == 0 && (!resid || ((uintptr_t)resid % 16 == 0 && ldr % (resid_bf16 ? 8 : 4) == 0)), "ufv_gemm_fp8_mx: output / residual pitch %% 4 == 0");
+    UFV_REQUIRE(e.ldc % 4 == 0 && e.ldc >= N && (!resid || ((uintptr_t)resid % 16 == 0 && ldr >= N && ldr % (resid_bf16 ? 8 : 4) == 0)), "ufv_gemm_fp8_mx: output / residual pitch >= N, %% 4 == 0 (N=%d ldc=%d)", N, ldc);
     int pick = choose_kernel(M, N, K / 2, out_f32 != 0, false, false);
     // (the block-scaled A operand costs 14 registers: the 256 x 256 and 224 x 256 tiles spill with it -- 124 / 8 bytes of scratch -- and are not offered)
     if (pick == 0 || pick >= 10000 || pick == 1442) pick = N % 192 == 0 || N % 192 == 128 ? 1441 : 1332;

@@ -279,6 +279,8 @@ __global__ __launch_bounds__(256) void dequantize_mx_k(const uint8_t* __restrict
 extern "C" int ufv_quantize_mx(const void* x, int x_dtype, int64_t ldx, void* q, int64_t ldq, void* bscale, int64_t ldb, int M, int K, void* stream) {
     UFV_REQUIRE(x && q && bscale && M > 0 && K > 0 && K % 128 == 0 && ldx % 4 == 0 && ldq % 4 == 0 && ldb % 1024 == 0 && ldb >= 1024 * ((K + 511) / 512) && (uintptr_t)q % 4 == 0 && (uintptr_t)x % 8 == 0,
                 "ufv_quantize_mx: K %% 128 == 0, row pitches multiples of 4, ldb = bytes per 64-row block >= 1024 ceil(K / 512) (K=%d)", K);
+    // the fp32 instantiation reads 16 bytes per lane (four floats), the bf16 one 8: an fp32 row view must start on a 16-byte boundary
+    UFV_REQUIRE(x_dtype != UFV_DT_F32 || (uintptr_t)x % 16 == 0, "ufv_quantize_mx: an fp32 input must be 16-byte aligned (sliced views: pass a column offset that is a multiple of 4 floats)");
     const int nb = K / 32;
     const int64_t total = (int64_t)M * nb;
     const dim3 grid((unsigned)((total + 255) / 256));
@@ -291,6 +293,7 @@ extern "C" int ufv_quantize_mx(const void* x, int x_dtype, int64_t ldx, void* q,
 
 extern "C" int ufv_dequantize_mx(const void* q, int64_t ldq, const void* bscale, int64_t ldb, float* out, int64_t ldo, int M, int K, void* stream) {
     UFV_REQUIRE(q && bscale && out && M > 0 && K > 0 && K % 128 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && (uintptr_t)q % 4 == 0 && (uintptr_t)out % 16 == 0, "ufv_dequantize_mx: bad arguments");
+    UFV_REQUIRE(ldb % 1024 == 0 && ldb >= 1024 * ((K + 511) / 512), "ufv_dequantize_mx: ldb = bytes per 64-row block of scales >= 1024 ceil(K / 512) (K=%d, ldb=%lld)", K, (long long)ldb);
     const int64_t total = (int64_t)M * (K / 4);
     hipLaunchKernelGGL(dequantize_mx_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), (const uint8_t*)q, ldq, (const uint8_t*)bscale, ldb, out, ldo, M, K);
     UFV_CHECK_LAUNCH();

@@ -139,6 +139,9 @@ class _VitBody(PackedModule):
         # fp32 oracle (LABNOTES round 5, tests/test_kernels_gpu.py::test_tower_bf16_stream_option); the default stream is fp32
         # (works in the W8A8 mode too -- ufv_gemm_fp8_mx takes a bf16 residual --, where it is worth -0.2 ms: 33.5 -> 33.3, same box)
         sb = os.environ.get("UFV_TOWER_STREAM") == "bf16" and not self.clip
+        if sb and any(isinstance(L["w2"], ops.Fp8Weight) for L in pk["layers"][:n_layers]) and (
+                os.environ.get("UFV_FP8_NO_MX") is not None or T * n < 256 or pk["Ip"] % 256 != 0):
+            sb = False        # W8A8 without the MX chain (switched off, < 256 rows, unaligned d_ff): fc2 would meet an e4m3 weight in the bf16-stream GEMM -- the fp32 stream there
         if (not self.clip and not any(isinstance(L["wqkv"], ops.Fp8Weight) for L in pk["layers"][:n_layers])
                 and os.environ.get("UFV_STAGE_CALLS", "1") != "0" and not sb):
             # the whole tower as ONE C call (ufv_vit_forward, csrc/stages.hip): the same launches in the same order, bit-identical

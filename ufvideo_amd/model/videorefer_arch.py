@@ -281,12 +281,16 @@ class VideoReferMetaForCausalLM(ABC):
         caller that tokenised on the host still has (mm_infer does: the ids are built on the CPU and then moved) -- used instead of reading the device tensor back,
         which is a device-to-host copy AND a full stream synchronisation per call.  No cache: rounds 3-4 remembered `t.tolist()` per tensor object and `_version`,
         which a write through `.data`, DLPack, shared numpy memory or this library's own raw-pointer kernels does not bump (a stale plan, silently), and which
-        only ever hit for a loop that passes the same tensor again.  The host copy is the CALLER's statement of what the device tensor holds; its shape is checked."""
+        only ever hit for a loop that passes the same tensor again.  The host copy is the CALLER's statement of what the device tensor holds: its SHAPE is
+        checked, its CONTENTS are trusted -- a host copy that no longer matches the device tensor (edited in place after `.to(dev)`, a reused buffer) gives a splice
+        plan for the wrong prompt, silently.  UFV_CHECK_HOST_IDS=1 (debug) compares the two on every call (one synchronising read-back, what the host copy avoids)."""
         if host is None:
             return t.tolist()
         val = host.tolist() if torch.is_tensor(host) else [list(r) for r in host]
         if len(val) != t.shape[0] or any(len(r) != t.shape[1] for r in val):
             raise ValueError(f"{what}_host has shape {len(val)} x {len(val[0]) if val else 0}, the device tensor {tuple(t.shape)}")
+        if os.environ.get("UFV_CHECK_HOST_IDS") == "1" and t.tolist() != val:
+            raise ValueError(f"{what}_host does not hold what the device tensor holds (UFV_CHECK_HOST_IDS=1)")
         return val
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, attention_mask, past_key_values, labels, images, masks, frame,

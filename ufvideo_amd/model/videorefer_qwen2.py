@@ -180,7 +180,8 @@ class VideoReferQwen2Model(VideoReferMetaModel, PackedModule):
                 for k in ("wqkv", "wo", "wgu", "wd"):
                     layers[-1][k + "8"] = self.gw(layers[-1][k])
                 # round 5: the prefill's gate/up GEMM emits its SwiGLU output as e4m3 codes + MX block scales (no quantise launch in front of down_proj); that
-                # output's columns are in the epilogue's block order, which down_proj's weight carries on its K axis (a second e4m3 copy: 68 MB per layer at 7B)
+                # output's columns are in the epilogue's block order, which down_proj's weight carries on its K axis (a second e4m3 copy: 68 MB per layer at 7B, 1.9 GB in
+                # all; `wd8`, the row-scaled copy, stays: it is what the decode step streams and what prompts under 256 rows multiply with.  bench.py reports `hbm_peak_gb`.)
                 wd8 = layers[-1]["wd8"]
                 if isinstance(wd8, ops.Fp8Weight) and layers[-1]["wd"].shape[1] % 128 == 0 and os.environ.get("UFV_FP8_NO_MX") is None:
                     layers[-1]["wd8m"] = ops.Fp8Weight(layers[-1]["wd"], mx_swiglu_cols=True)

@@ -43,6 +43,10 @@ def all_gather_tokens(local_tokens, counts, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     assert len(counts) == world and local_tokens.shape[0] == counts[dist.get_rank(group)]
+    if local_tokens.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo has no device all-gather: the exchange goes through the host (the one-GPU rehearsals of tests/test_parallel_gpu.py -- two ranks on one device, which RCCL
+        # refuses; on a multi-GPU node the backend is "nccl" = RCCL and the tokens never leave HBM)
+        return all_gather_tokens(local_tokens.cpu(), counts, group).to(local_tokens.device)
     n_max = max(counts)
     D = local_tokens.shape[-1]
     if min(counts) == n_max:
