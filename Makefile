@@ -23,7 +23,30 @@ $(LIB): $(OBJS) $(CSRC)/ufv_exports.map
 
 -include $(DEPS)
 
+# ---- `make asan`: the library's HOST code under AddressSanitizer + UBSan, on the CPU.  Every source is compiled host-only (kernel bodies become launch stubs),
+# linked against tests/asan/hip_stub.cpp instead of libamdhip64, and tests/asan/host_logic.cpp drives the cost model, ufv_gemm's dispatch, the split-K flag ring
+# (wrap-around, two threads), the error word and the no-device path.  The __hip_fatbin_* symbols the host objects refer to (the embedded device code of a normal
+# build) are defined as empty arrays.
+ASAN_DIR   := build/asan
+ASAN_FLAGS := --cuda-host-only -O1 -g -fPIC -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -Iinclude -Wno-unused-command-line-argument
+ASAN_OBJS  := $(patsubst $(CSRC)/%.hip,$(ASAN_DIR)/%.o,$(SRCS))
+
+$(ASAN_DIR)/%.o: $(CSRC)/%.hip Makefile
+	@mkdir -p $(ASAN_DIR)
+	$(HIPCC) $(ASAN_FLAGS) -c $< -o $@
+
+$(ASAN_DIR)/host_logic: $(ASAN_OBJS) tests/asan/hip_stub.cpp tests/asan/host_logic.cpp
+	nm -u $(ASAN_OBJS) | grep -o '__hip_fatbin_[0-9a-f]*' | sort -u | sed 's/.*/extern "C" { char &[8]; }/' > $(ASAN_DIR)/fatbin_syms.cpp
+	$(HIPCC) $(ASAN_FLAGS) -c $(ASAN_DIR)/fatbin_syms.cpp -o $(ASAN_DIR)/fatbin_syms.o
+	$(HIPCC) $(ASAN_FLAGS) -c tests/asan/hip_stub.cpp -o $(ASAN_DIR)/hip_stub.o
+	$(HIPCC) $(ASAN_FLAGS) -c tests/asan/host_logic.cpp -o $(ASAN_DIR)/host_logic.o
+	$(HIPCC) -fsanitize=address,undefined -o $@ $(ASAN_DIR)/host_logic.o $(ASAN_DIR)/hip_stub.o $(ASAN_DIR)/fatbin_syms.o $(ASAN_OBJS) -lpthread
+
+asan: $(ASAN_DIR)/host_logic
+	ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 $(ASAN_DIR)/host_logic
+
 clean:
 	rm -f $(OBJS) $(DEPS) $(LIB)
+	rm -rf $(ASAN_DIR)
 
-.PHONY: all clean
+.PHONY: all clean asan
