@@ -49,7 +49,7 @@ def tokens_per_clip(frames, img=None):
     return (frames // 2) * (((IMG if img is None else img) // 14) // 2) ** 2
 
 
-PMC_FILE = "profiles/r05/pmc_bench.json"            # (--fp8: pmc_bench_fp8.json beside it)
+PMC_FILE = "profiles/r06/pmc_bench.json"            # (--fp8: pmc_bench_fp8.json beside it)
 GEMM_SOURCES = ("ufvideo_amd/csrc/gemm256_kernel.h", "ufvideo_amd/csrc/gemm256.hip", "ufvideo_amd/csrc/gemm_epi.h", "ufvideo_amd/csrc/gemm.hip",
                 "ufvideo_amd/csrc/common.h", "ufvideo_amd/csrc/gemm256_m.hip", "ufvideo_amd/csrc/gemm256_m2.hip")
 

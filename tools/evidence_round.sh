@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the round's evidence directory holds, in one GPU call (run on the GPU box; outputs under gpurun_out/<tag>/, copied into profiles/<tag>/ afterwards by
 # tools/evidence_collect.py, which also runs tools/pmc_summarize.py on the merged counter files).   usage: tools/evidence_round.sh <tag>
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -20,5 +20,5 @@ LAB_P2_CLOCK=1 tools/lab/attn_lab_clock 14 > $OUT/attn_vit_clock.txt 2>&1
 UFV_PARITY_REPORT_BENCH=$OUT/parity_table_bench_full.json UFV_PARITY_FULL=mirror python3 -m pytest tests/test_bench_workload_gpu.py -m gpu -q -s > $OUT/parity_full.log 2>&1
 UFV_PARITY_REPORT_BENCH=$OUT/parity_table_bench.json python3 -m pytest tests/test_bench_workload_gpu.py -m gpu -q -s > $OUT/parity_bench.log 2>&1
 UFV_PARITY_REPORT=$OUT/parity_table.json python3 -m pytest tests/test_parity_bf16_gpu.py -m gpu -q -s > $OUT/parity_bf16.log 2>&1
-(time python3 -m pytest tests -m gpu -q -s 2>&1 | grep -E "PERF_FLOOR|TOWER_STREAM|passed|failed|FAILED|error|AssertionError" ) > $OUT/pytest_gpu_tail.txt 2>&1
+(time python3 -m pytest tests -m gpu -q 2>&1 | grep -E "^PERF_FLOOR|^PARITY|^CONFIG|^GEOM384|^ROUNDING|TOWER_STREAM|passed|failed|FAILED|error|AssertionError|measured by the tests" ) > $OUT/pytest_gpu_tail.txt 2>&1
 tail -3 $OUT/pytest_gpu_tail.txt

@@ -4,7 +4,7 @@
 # usage (GPU box): [UFV_BENCH_ARGS=--fp8] tools/native_per_step.sh <tag> [out-name]    (out-name: per_step | per_step_fp8 ...)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 NAME=${2:-per_step}
 ARGS=${UFV_BENCH_ARGS:-}
 OUT=$R/gpurun_out/$TAG/$NAME.d

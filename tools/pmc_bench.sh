@@ -3,7 +3,7 @@
 # from, as MI355X_MICROARCH.md prescribes (no trace domains beside the counters).  usage: [UFV_BENCH_ARGS=--fp8] tools/pmc_bench.sh <tag> [pmc | pmc_fp8]  -> profiles/<tag>/pmc_bench[_fp8].json
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 ARGS=${UFV_BENCH_ARGS:-}
 SUB=${2:-pmc}
 OUT=$R/gpurun_out/$TAG/$SUB

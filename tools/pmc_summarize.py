@@ -7,7 +7,7 @@ memory side (Infinity-Cache hits included); GRBM_GUI_ACTIVE sums the 8 XCDs (/ 8
 1024 SIMDs (/ 1024 = busy cycles of one matrix pipe)."""
 import collections, csv, glob, json, os, re, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 sub = sys.argv[2] if len(sys.argv) > 2 else "pmc"          # "pmc" (bf16 bench) | "pmc_fp8" (bench.py --fp8): the sub-directory tools/pmc_bench.sh wrote
 fp8 = sub.endswith("fp8")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Evidence for the paths outside the headline metric (GPU box): rocprofv3 kernel-trace stats + the tools' own timing lines for greedy decode, the SAM2-L
 # segmentation path and the decoder training step, all at full dimensions.  usage: tools/profile_aux.sh <tag>  -> gpurun_out/<tag>/{decode,sam2,train}_*
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
