@@ -48,7 +48,7 @@ int main() {
     unsigned grid[3], block[3];
     // ---- dispatch: the launches the clip issues, and what the device would have been asked to run
     long n0 = ufv_stub_launches();
-    CHECK(gemm(2399, 37888, 3584, 0, 1, false, UFV_GEMM_AUTO, A, W, C, R) == 0);           // gate/up: persistent, one block per CU, last round as half-tile items
+    CHECK(gemm(2399, 37888, 3584, 0, 1, false, UFV_GEMM_AUTO, A, W, C, R) == 0);           // gate/up: persistent, one block per CU
     ufv_stub_last_launch(grid, block);
     CHECK(ufv_stub_launches() == n0 + 1 && grid[0] == 256 && block[0] == 512);
     CHECK(gemm(2799, 37888, 3584, 0, 1, false, UFV_GEMM_AUTO, A, W, C, R) == 0);           // 384 px

@@ -1,4 +1,4 @@
-"""gate/up GEMM (SwiGLU epilogue) with and without the last round of half-tile items (csrc/gemm256_kernel.h HALF; UFV_GEMM_NO_HALF is read per call): M = 2399 / 2799 / 4703,
+"""gate/up GEMM (SwiGLU epilogue) with and without the last round of half-tile items (csrc/gemm256_kernel.h HALF; UFV_GEMM_HALF=1 is read per call): M = 2399 / 2799 / 4703,
 28 distinct weight matrices in rotation as in the decoder.  usage: python tools/lab/gateup_half_time.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -12,10 +12,10 @@ for M in [int(x) for x in (sys.argv[1:] or "2399 2799 4703 1200".split())]:
     res = {}
     for rep in range(2):
         for mode in ("half", "whole"):
-            if mode == "whole":
-                os.environ["UFV_GEMM_NO_HALF"] = "1"
+            if mode == "half":
+                os.environ["UFV_GEMM_HALF"] = "1"
             else:
-                os.environ.pop("UFV_GEMM_NO_HALF", None)
+                os.environ.pop("UFV_GEMM_HALF", None)
             for i in range(8):
                 ops.gemm(a, ws[i % 8], swiglu=True, out=out)
             torch.cuda.synchronize()
@@ -25,7 +25,7 @@ for M in [int(x) for x in (sys.argv[1:] or "2399 2799 4703 1200".split())]:
                 ops.gemm(a, ws[i % 8], swiglu=True, out=out)
             e1.record(); torch.cuda.synchronize()
             res.setdefault(mode, []).append(e0.elapsed_time(e1) / 56 * 1e3)
-    os.environ.pop("UFV_GEMM_NO_HALF", None)
+    os.environ.pop("UFV_GEMM_HALF", None)
     fl = 2.0 * M * N2 * K
     h, w = min(res["half"]), min(res["whole"])
     print(f"M={M}: half-item round {h:.1f} us ({fl / h / 1e6:.0f} TF/s, {fl / h / 1e6 / 2500:.3f})   whole tiles {w:.1f} us ({fl / w / 1e6:.0f} TF/s, {fl / w / 1e6 / 2500:.3f})   {100 * (h / w - 1):+.1f} %", flush=True)

@@ -24,7 +24,8 @@ static int launch256_t(const void* A, const void* W, const Epi& e, int M, int N,
     }
     static const bool four_phase = getenv("UFV_GEMM_4PHASE") != nullptr;      // A/B switch (diagnostics): the first-generation schedule
     if (!streamk && four_phase) return launch_pp<F, S, Q, 4, 4, 2, false>(A, W, e, M, N, K, lda, ldw, st);
-    // the SwiGLU form (the decoder's gate/up projection: 37888 columns, a ragged last row band at every prompt length) deals its last round as half-tile items
+    // the SwiGLU form (the decoder's gate/up projection: 37888 columns, a ragged last row band at every prompt length) CAN deal its last round as half-tile items (HALF:
+    // opt-in by UFV_GEMM_HALF=1; measured, not the default -- gemm256_kernel.h launch_pp)
     if (!streamk) return launch_pp<F, S, Q, 4, 4, 2, true, false, false, 0, S>(A, W, e, M, N, K, lda, ldw, st);
     if constexpr (S) {
         ufv_set_error("ufv_gemm: the stream-K split is not built for the SwiGLU epilogue (its tile counts are large anyway)");

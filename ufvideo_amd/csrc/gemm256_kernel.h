@@ -1363,10 +1363,14 @@ static int launch_pp(const void* A, const void* W, const Epi& e, int M, int N, i
     int items = tiles;
     if constexpr (HALF) {
         // the launch's last round as half-tile items (gemm_nt_256: HALF) when the leftover whole tiles (two items each) and the tiles of a last row band with <= 32 MA0
-        // valid rows (one item each) fit ONE round: the round then costs what half a tile costs instead of a whole one.  UFV_GEMM_NO_HALF: same-process A/B switch (tests, lab).
+        // valid rows (one item each) fit ONE round: the round then costs what half a tile costs instead of a whole one.  
         const int tiles_n = cdiv(N, T::BN), light = (M - (tiles_m - 1) * T::BM <= 32 * MA0) ? 1 : 0;
         const int n_full = (tiles_m - light) * tiles_n, n_light = light * tiles_n, left = n_full % n_cu;
-        if (tiles >= n_cu && left + n_light > 0 && 2 * left + n_light <= n_cu && getenv("UFV_GEMM_NO_HALF") == nullptr) {
+        // OPT-IN (UFV_GEMM_HALF=1, read per call): measured -1.2 % on the gate/up launch at M = 2399 for +14 % fabric traffic (the band's 148 tiles leave their W panels'
+        // rounds: 1443 against 1265 MB per launch by the PMC counters) -- a half-tile item costs 0.85 of a whole tile, not 0.5, because the K loop's issue-to-wait distance is one
+        // K-tile (LABNOTES round 6).  Not the default.
+        const char* half_env = getenv("UFV_GEMM_HALF");
+        if (tiles >= n_cu && left + n_light > 0 && 2 * left + n_light <= n_cu && half_env != nullptr && half_env[0] == '1') {
             sk.half = 1;
             sk.gm = pp_group(tiles_m - light);
         }
