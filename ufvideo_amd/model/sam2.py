@@ -236,16 +236,14 @@ class Hiera(PackedModule):
         o = self._zbuf("o", (Bw * Sq, dop), dev) if dop != do else None
         o = ops.attention(q, qkv[:, dop:], qkv[:, 2 * dop:], Bw, heads, heads, Sq, Sk, hd, (Sq * ldq, ldq), (Sk * 3 * dop, 3 * dop),
                           (Sk * 3 * dop, 3 * dop), out=o)
-        # output projection + window un-partition + residual
+        y = ops.gemm(o, w["wo"], bias=w["bo"])            # [Bw*Sq, dop] in window order
+        # window un-partition + residual
         if ws > 0 and order != ws:
-            y = ops.gemm(o, w["wo"], bias=w["bo"])        # [Bw*Sq, dop] in window order
             ws2 = ws // 2 if qs else ws
             idx2, _ = self._windows(B, Ho, Wo, ws2, dev)
             ops.add_rows(y, x, idx2)
         else:
-            # the stream is in the attention's own row order (kept window order, or global attention): the residual add is the GEMM's epilogue, in place on the fp32
-            # stream -- round 6: one launch and one bf16 rounding of the projection less per block (the sum is formed in fp32, as the reference's `x + attn(x)` in fp32 would)
-            ops.gemm(o, w["wo"], bias=w["bo"], resid=x, out=x)
+            ops.add_rows(y, x, None)
         # MLP
         h2 = self._zbuf("h2", (x.shape[0], dop), dev) if dop != do else torch.empty((x.shape[0], dop), device=dev, dtype=torch.bfloat16)
         ops.layernorm(x[:, :do] if dop != do else x, w["n2"][0], w["n2"][1], 1e-6, out=h2[:, :do] if dop != do else h2)
