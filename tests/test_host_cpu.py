@@ -155,6 +155,18 @@ def test_c_abi_exports_every_declared_symbol():
     assert _lib.load().ufv_abi_version() == _lib.ABI_VERSION == 3
 
 
+def test_library_path_cannot_be_swapped_by_the_environment_outside_lab_runs():
+    """UFV_LIBRARY alone is ignored (and said so); only UFV_LAB=1 UFV_LIBRARY=... loads another build (tools/lab/ab_bench.sh)"""
+    import subprocess
+    import sys
+    code = "from ufvideo_amd import _lib; print(_lib.LIB_PATH)"
+    env = {k: v for k, v in os.environ.items() if k not in ("UFV_LAB", "UFV_LIBRARY")}
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, UFV_LIBRARY="/tmp/other.so"), capture_output=True, text=True)
+    assert r.stdout.strip().endswith("ufvideo_amd/libufv_hip.so") and "ignored" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, UFV_LIBRARY="/tmp/other.so", UFV_LAB="1"), capture_output=True, text=True)
+    assert r.stdout.strip() == "/tmp/other.so" and "LAB RUN" in r.stderr
+
+
 def test_ops_fail_loudly_without_gpu_tensors():
     from ufvideo_amd import ops, _lib
     if torch.cuda.is_available():

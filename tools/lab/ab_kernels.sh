@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for arm in A B; do
-  if [ $arm = A ]; then export UFV_LIBRARY=$R/${UFV_AB_BASE:-tools/scratch/libufv_r03.so}; else unset UFV_LIBRARY; fi
+  if [ $arm = A ]; then export UFV_LAB=1 UFV_LIBRARY=$R/${UFV_AB_BASE:-tools/scratch/libufv_r03.so}; else unset UFV_LIBRARY; fi
   UFV_BENCH_NO_TIMER=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$arm -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/line_$arm.json 2> $OUT/err_$arm.txt
   cp $(find $OUT/prof_$arm -name "*kernel_stats.csv" | head -1) $OUT/stats_$arm.csv
   rm -rf $OUT/prof_$arm

@@ -1,6 +1,6 @@
 """Lab: the decode step's kernels one at a time, as the step runs them -- inside a captured HIP graph, 28 launches of ONE kind back to back, each on its own
 layer's weights (15 GB are streamed per token: nothing is cache-resident in the real step and nothing may be here).  Prints microseconds per launch
-(launch gaps included: that is what the step pays) and the weight-stream rate.  UFV_LIBRARY=<other .so> times another build for an A/B on the same box."""
+(launch gaps included: that is what the step pays) and the weight-stream rate.  UFV_LAB=1 UFV_LIBRARY=<other .so> times another build for an A/B on the same box."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

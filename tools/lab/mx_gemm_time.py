@@ -1,5 +1,5 @@
 """Lab (GPU box): the e4m3 GEMMs of the fused W8A8 chain one at a time: per-row-scaled A (ufv_gemm_fp8) against block-scaled A (ufv_gemm_fp8_mx) at the decoder's
-down_proj and the tower's fc2, and the bf16-output against the MX-emitting epilogue at gate/up and fc1.  UFV_LIBRARY=<variant .so> times another build."""
+down_proj and the tower's fc2, and the bf16-output against the MX-emitting epilogue at gate/up and fc1.  UFV_LAB=1 UFV_LIBRARY=<variant .so> times another build."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

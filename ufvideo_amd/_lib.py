@@ -4,8 +4,16 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (UFV_LIBRARY overrides the in-tree build: lab A/B runs of two builds on one box, tools/lab/ab_bench.sh; unset in every product / test / bench run)
-LIB_PATH = os.environ.get("UFV_LIBRARY") or os.path.join(_HERE, "libufv_hip.so")
+# The product loads the in-tree build, always.  Lab A/B runs of two builds on one box (tools/lab/ab_bench.sh) may name another one with UFV_LIBRARY -- honoured ONLY beside
+# UFV_LAB=1, and announced on stderr, so that no environment variable can silently swap the library under a product, test or bench run.
+LIB_PATH = os.path.join(_HERE, "libufv_hip.so")
+if os.environ.get("UFV_LIBRARY"):
+    import sys as _sys
+    if os.environ.get("UFV_LAB") == "1":
+        LIB_PATH = os.environ["UFV_LIBRARY"]
+        print(f"ufvideo_amd: LAB RUN -- loading {LIB_PATH} instead of the in-tree library (UFV_LAB=1 UFV_LIBRARY=...)", file=_sys.stderr, flush=True)
+    else:
+        print("ufvideo_amd: UFV_LIBRARY is set but UFV_LAB=1 is not: ignored, the in-tree library is loaded", file=_sys.stderr, flush=True)
 
 ACT = {None: 0, "none": 0, "gelu_pytorch_tanh": 1, "gelu_tanh": 1, "gelu": 2, "gelu_erf": 2, "silu": 3, "relu": 4,
        "quick_gelu": 5, "sigmoid": 6}
