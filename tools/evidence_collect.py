@@ -69,6 +69,16 @@ def main():
             print("copied", name)
         else:
             print("absent", name)
+    lab = os.path.join(src, "lab")
+    if os.path.isdir(lab):
+        os.makedirs(os.path.join(dst, "lab"), exist_ok=True)
+        for name in sorted(os.listdir(lab)):
+            if name.endswith(".txt") and os.path.getsize(os.path.join(lab, name)) > 0:
+                with open(os.path.join(lab, name)) as f:
+                    text = "".join(l for l in f if "amdgpu.ids" not in l)
+                with open(os.path.join(dst, "lab", name), "w") as f:
+                    f.write(text)
+                print("copied lab/" + name)
     write_perf_floors(dst)
     for sub in ("pmc", "pmc_fp8"):
         if os.path.isdir(os.path.join(src, sub)):

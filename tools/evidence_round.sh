@@ -17,6 +17,12 @@ bash $R/tools/profile_aux.sh $TAG > $OUT/profile_aux.log 2>&1
 cd $R
 python3 tools/probe_blaslt.py $TAG > $OUT/gemm_vs_vendor.log 2>&1
 LAB_P2_CLOCK=1 tools/lab/attn_lab_clock 14 > $OUT/attn_vit_clock.txt 2>&1
+# the lab runs LABNOTES (round 6) quotes: raw outputs, copied to profiles/<tag>/lab/ by tools/evidence_collect.py
+mkdir -p $OUT/lab
+python3 tools/lab/gateup_half_time.py 2399 2799 4703 2304 1536 > $OUT/lab/gateup_half_time.txt 2>&1
+python3 tools/lab/attn_729_time.py > $OUT/lab/attn_729_time.txt 2>&1
+python3 tools/lab/seg_grad_norms.py > $OUT/lab/seg_grad_norms.txt 2>&1
+tools/lab/grid_barrier_probe > $OUT/lab/grid_barrier_probe.txt 2>&1
 UFV_PARITY_REPORT_BENCH=$OUT/parity_table_bench_full.json UFV_PARITY_FULL=mirror python3 -m pytest tests/test_bench_workload_gpu.py -m gpu -q -s > $OUT/parity_full.log 2>&1
 UFV_PARITY_REPORT_BENCH=$OUT/parity_table_bench.json python3 -m pytest tests/test_bench_workload_gpu.py -m gpu -q -s > $OUT/parity_bench.log 2>&1
 UFV_PARITY_REPORT=$OUT/parity_table.json python3 -m pytest tests/test_parity_bf16_gpu.py -m gpu -q -s > $OUT/parity_bf16.log 2>&1
