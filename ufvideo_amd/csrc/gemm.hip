@@ -717,12 +717,13 @@ constexpr PPShape PP_SHAPES[] = {{1442, 4, 4, 2}, {1432, 4, 3, 2}, {1332, 3, 3, 
 // carries the turn-ordered read-modify-write of its tile (+12000 ticks); taken when the model sees at least 5 % over the best unsplit kernel --
 // in practice the decoder's `down` projection (M = 2399: 140 tiles of 256x256 for 296 K-tiles; 348 -> ~270 us) and its 64-frame form.
 // rope_cost (optional out): the model's ticks of the shape the fused QKV + RoPE kernel is built for (1332) and that shape's code in rope_pick
+// pp_only: N is no multiple of 128 (but of 192: Hiera-L's 576-wide stage runs unpadded since round 6): the 128-wide kernel is no candidate
 inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool can_split = false, double* best_cost = nullptr, double* rope_cost = nullptr,
-                         int* rope_pick = nullptr) {
+                         int* rope_pick = nullptr, bool pp_only = false) {
     const double nk = K / 64.0, c_out = out_f32 ? 0.21 : 0.183;      // (fp32 + residual: 0.33 before the row-pipelined residual epilogue of round 3)
     double best = 1e30, rbest = 1e30;
     int pick = 0, rpick = 0;
-    for (int mt = 4; mt <= 6; ++mt) {
+    for (int mt = 4; mt <= 6 && !pp_only; ++mt) {
         const long t = (long)cdiv(M, 32 * mt) * (N / BN);
         const double area = 32.0 * mt * 128;
         const double c = (double)((t + 511) / 512) * (nk * 2.0 * area / 21.4 + 9000.0 + 2.0 * area * c_out);
@@ -752,6 +753,7 @@ inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool ca
     // (round 4: bf16 outputs too -- the connector's Conv3d as a GEMM, 2304 x 3584 x 28672, 228 tiles: 427 us against 580 on the 128-wide kernel the model picked)
     // (round 5: bf16 outputs from K = 2048 when ONE round of 192 x 192 tiles fills the chip -- the connector's stage-2 1x1 convolutions and readout, 2304 x 3584 x 3584,
     // 228 tiles: 57.2 us against 61.3 on the 128-wide kernel the model picked, tools/gemm_shapes.py proj_ro)
+    if (pp_only) return pick;
     if (!swiglu && K >= (out_f32 ? 8192 : 2048) && M >= 256 && (N % 192 == 0 || N % 192 == 128)) {
         const long t = (long)cdiv(M, 192) * cdiv(N, 192);
         if ((out_f32 || t <= 256) && (double)t / (256.0 * ((t + 255) / 256)) >= (out_f32 ? 0.9 : 0.85)) return 1331;
@@ -851,6 +853,14 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
     if (force == UFV_GEMM_AUTO && big_ok) {
         const int pick = choose_kernel(M, N, Q ? K / 2 : K, F, S, !Q && e.act == ACT_NONE && e.resid_rows == 0 && splitk_enabled());
         if (pick) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, pick, st);
+    }
+    // N a multiple of 192 but not of 128 (576, 1728: the unpadded widths of Hiera-L's third stage): the ping-pong kernel's 192-wide tile shapes take it (their N
+    // condition is N % 192 in {0, 128}); bf16 operands only (e4m3 K-tiles are 128 deep: that mode keeps its widths padded to 128)
+    if constexpr (!Q && !S) {
+        if (force == UFV_GEMM_AUTO && aligned && !fast_ok && N % 192 == 0 && K % KE == 0 && M >= 256) {
+            const int pick = choose_kernel(M, N, K, F, false, false, nullptr, nullptr, nullptr, true);
+            if (pick) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, false, false, false, pick, st);
+        }
     }
     if ((force == UFV_GEMM_AUTO && fast_ok && M > 64) || force == UFV_GEMM_FAST)
         return launch_fast<F, S, Q>(A, W, e, M, N, K, lda, ldw, st);

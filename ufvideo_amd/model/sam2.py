@@ -25,8 +25,13 @@ from .. import ops
 from ._params import Holder, PackedModule, init_tensor, bf, f32, round_up
 
 
-def _pad_dim(d):
-    return d if (d < 128 or d % 128 == 0) else round_up(d, 128)
+def _pad_dim(d, wide192=False):
+    """width a channel dimension is padded to for the GEMM kernels: multiples of 128; with `wide192` (bf16 operands) a multiple of 192 stays as it is -- Hiera-L's third
+    stage (36 of 48 blocks) is 576 = 3 x 192 wide and ran padded to 640 (+11 % on every K and N of its GEMMs) until round 6: the ping-pong kernel's 192-wide tile shapes take
+    N % 192 == 0 and K % 64 == 0 (csrc/gemm.hip launch_any).  The e4m3 mode keeps 128 (its K-tiles are 128 elements deep)."""
+    if d < 128 or d % 128 == 0 or (wide192 and d % 192 == 0):
+        return d
+    return round_up(d, 128)
 
 
 def _pad2(w, n, k):
@@ -127,7 +132,8 @@ class Hiera(PackedModule):
     # ---- packing -----------------------------------------------------------------------------------------------
     def _pack(self):
         E = self.schedule[0]["dim"]
-        Ep = _pad_dim(E)
+        w192 = getattr(self, "gemm_dtype", "bf16") != "fp8"
+        Ep = _pad_dim(E, w192)
         K = 3 * 49
         pk = {"Kp": round_up(K, 64), "Ep": Ep}
         pk["patch_w"] = bf(_pad2(self.patch_embed.proj.weight.reshape(E, K), Ep, pk["Kp"]))
@@ -136,7 +142,7 @@ class Hiera(PackedModule):
         for i, b in enumerate(self.schedule):
             L = self.blocks.get(str(i))
             d, do = b["dim"], b["dim_out"]
-            dp, dop, hp = _pad_dim(d), _pad_dim(do), _pad_dim(4 * do)
+            dp, dop, hp = _pad_dim(d, w192), _pad_dim(do, w192), _pad_dim(4 * do, w192)
             wq = L.attn.qkv.weight
             bq = L.attn.qkv.bias
             wqkv = torch.cat([_pad2(wq[j * do:(j + 1) * do], dop, dp) for j in range(3)], 0)
@@ -324,8 +330,11 @@ class FpnNeck(PackedModule):
         out = []
         for i, c in enumerate(self.backbone_channel_list):
             cv = self.convs.get(str(i)).conv
-            out.append((self.gw(_pad2(cv.weight.reshape(self.d_model, c), self.d_model, _pad_dim(c))), f32(cv.bias)))
+            out.append((self.gw(_pad2(cv.weight.reshape(self.d_model, c), self.d_model, _pad_dim(c, self._w192()))), f32(cv.bias)))
         return out
+
+    def _w192(self):
+        return getattr(self, "gemm_dtype", "bf16") != "fp8"
 
     def forward_tokens(self, feats, B):
         """feats: [(tokens fp32 [B*h*w, Cpad], h, w, C)] highest resolution first -> [(tokens fp32 [B*h*w, d_model], h, w)]"""
@@ -345,14 +354,14 @@ class FpnNeck(PackedModule):
     def forward(self, xs):
         B = xs[0].shape[0]
         feats = [(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous().float(), x.shape[2], x.shape[3], x.shape[1]) for x in xs]
-        feats = [(self._pad_tokens(t, C), h, w, C) for t, h, w, C in feats]
+        feats = [(self._pad_tokens(t, C, self._w192()), h, w, C) for t, h, w, C in feats]
         outs = self.forward_tokens(feats, B)
         maps = [t.view(B, h, w, self.d_model).permute(0, 3, 1, 2) for t, h, w in outs]
         return maps, [self.position_encoding(m).to(m.dtype) for m in maps]
 
     @staticmethod
-    def _pad_tokens(t, C):
-        Cp = _pad_dim(C)
+    def _pad_tokens(t, C, w192=False):
+        Cp = _pad_dim(C, w192)
         if Cp == C:
             return t
         out = torch.zeros((t.shape[0], Cp), device=t.device, dtype=t.dtype)
