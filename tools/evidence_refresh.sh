@@ -1,10 +1,10 @@
-cd $GRAFT_REPO_ROOT; OUT=$GRAFT_REPO_ROOT/gpurun_out/r05; mkdir -p $OUT
-bash tools/pmc_bench.sh r05 pmc > $OUT/pmc.log 2>&1
-UFV_BENCH_ARGS=--fp8 bash tools/pmc_bench.sh r05 pmc_fp8 > $OUT/pmc_fp8.log 2>&1
+# After a late change to a GEMM source or the SAM2 path: the PMC passes (fingerprinted to the GEMM sources), the aux profiles and the bench lines again -- not the whole round.
+cd $GRAFT_REPO_ROOT; TAG=${1:-r06}; OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
+bash tools/pmc_bench.sh $TAG pmc > $OUT/pmc.log 2>&1
+UFV_BENCH_ARGS=--fp8 bash tools/pmc_bench.sh $TAG pmc_fp8 > $OUT/pmc_fp8.log 2>&1
+bash tools/profile_aux.sh $TAG > $OUT/profile_aux.log 2>&1
 cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench.err
+python3 bench.py --steps 10 --warmup 3 > $OUT/bench_line.json 2> $OUT/bench.err
 python3 bench.py --steps 10 --warmup 3 --fp8 --no-cpu-baseline > $OUT/bench_line_fp8.json 2>> $OUT/bench.err
-python3 bench.py --steps 5 --warmup 2 --frames 64 --no-cpu-baseline > $OUT/bench_line_64f.json 2>> $OUT/bench.err
-(time python3 -m pytest tests -m gpu -q -s 2>&1 | grep -E "PERF_FLOOR|TOWER_STREAM|passed|failed|FAILED|error|AssertionError" ) > $OUT/pytest_gpu_tail.txt 2>&1
-tail -4 $OUT/pytest_gpu_tail.txt
-for f in bench_line.json bench_line_fp8.json bench_line_64f.json; do tail -1 $OUT/$f | cut -c1-150; done
+python3 -m pytest tests/test_perf_floor_gpu.py tests/test_sam2_gpu.py -m gpu -q 2>&1 | tail -16 > $OUT/refresh_tests.txt
+tail -c 600 $OUT/bench_line.json; tail -16 $OUT/refresh_tests.txt
