@@ -717,7 +717,7 @@ constexpr PPShape PP_SHAPES[] = {{1442, 4, 4, 2}, {1432, 4, 3, 2}, {1332, 3, 3, 
 // carries the turn-ordered read-modify-write of its tile (+12000 ticks); taken when the model sees at least 5 % over the best unsplit kernel --
 // in practice the decoder's `down` projection (M = 2399: 140 tiles of 256x256 for 296 K-tiles; 348 -> ~270 us) and its 64-frame form.
 // rope_cost (optional out): the model's ticks of the shape the fused QKV + RoPE kernel is built for (1332) and that shape's code in rope_pick
-// pp_only: N is no multiple of 128 (but of 192: Hiera-L's 576-wide stage runs unpadded since round 6): the 128-wide kernel is no candidate
+// pp_only: N is no multiple of 128 (but N % 192 is 0 or 128: Hiera-L's widths since round 6): the 128-wide kernel is no candidate
 inline int choose_kernel(int M, int N, int K, bool out_f32, bool swiglu, bool can_split = false, double* best_cost = nullptr, double* rope_cost = nullptr,
                          int* rope_pick = nullptr, bool pp_only = false) {
     const double nk = K / 64.0, c_out = out_f32 ? 0.21 : 0.183;      // (fp32 + residual: 0.33 before the row-pipelined residual epilogue of round 3)
@@ -854,10 +854,11 @@ int launch_any(const void* A, const void* W, const Epi& e, int M, int N, int K, 
         const int pick = choose_kernel(M, N, Q ? K / 2 : K, F, S, !Q && e.act == ACT_NONE && e.resid_rows == 0 && splitk_enabled());
         if (pick) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, S, Q, false, pick, st);
     }
-    // N a multiple of 192 but not of 128 (576, 1728: the unpadded widths of Hiera-L's third stage): the ping-pong kernel's 192-wide tile shapes take it (their N
-    // condition is N % 192 in {0, 128}); bf16 operands only (e4m3 K-tiles are 128 deep: that mode keeps its widths padded to 128)
+    // N no multiple of 128 but a multiple of 192, or 128 past one (192, 320, 576, 960, 1728: the widths of Hiera-L's stages since round 6, ufvideo_amd/model/sam2.py
+    // _pad_dim): the ping-pong kernel's 192-wide tile shapes take it (their N condition is N % 192 in {0, 128}); bf16 operands only (e4m3 K-tiles are 128 deep: that
+    // mode keeps its widths padded to 128)
     if constexpr (!Q && !S) {
-        if (force == UFV_GEMM_AUTO && aligned && !fast_ok && N % 192 == 0 && K % KE == 0 && M >= 256) {
+        if (force == UFV_GEMM_AUTO && aligned && !fast_ok && (N % 192 == 0 || N % 192 == 128) && K % KE == 0 && M >= 256) {
             const int pick = choose_kernel(M, N, K, F, false, false, nullptr, nullptr, nullptr, true);
             if (pick) return ufv_launch_gemm256(A, W, e, M, N, K, lda, ldw, F, false, false, false, pick, st);
         }

@@ -26,12 +26,18 @@ from ._params import Holder, PackedModule, init_tensor, bf, f32, round_up
 
 
 def _pad_dim(d, wide192=False):
-    """width a channel dimension is padded to for the GEMM kernels: multiples of 128; with `wide192` (bf16 operands) a multiple of 192 stays as it is -- Hiera-L's third
-    stage (36 of 48 blocks) is 576 = 3 x 192 wide and ran padded to 640 (+11 % on every K and N of its GEMMs) until round 6: the ping-pong kernel's 192-wide tile shapes take
-    N % 192 == 0 and K % 64 == 0 (csrc/gemm.hip launch_any).  The e4m3 mode keeps 128 (its K-tiles are 128 elements deep)."""
-    if d < 128 or d % 128 == 0 or (wide192 and d % 192 == 0):
+    """width a channel dimension is padded to for the GEMM kernels.  e4m3 operands (K-tiles 128 deep): multiples of 128.  bf16 operands (`wide192`, round 6): the smallest
+    multiple of 64 (the K-tile) that a tile shape takes as an N -- a multiple of 128 (the 128- / 256-wide kernels) or, through the ping-pong kernel's 192-wide shapes, a multiple of
+    192 or 128 past one (csrc/gemm.hip launch_any).  Hiera-L's widths 144 / 288 / 576 / 1152 become 192 / 320 / 576 / 1152 instead of 256 / 384 / 640 / 1152: its third stage
+    (36 of 48 blocks) ran +11 % on every K and N of its GEMMs, the first two +33 / +78 %."""
+    if d < 128:
         return d
-    return round_up(d, 128)
+    if not wide192:
+        return round_up(d, 128)
+    k = (d + 63) // 64
+    while not (k % 2 == 0 or k % 3 in (0, 2)):
+        k += 1
+    return 64 * k
 
 
 def _pad2(w, n, k):
