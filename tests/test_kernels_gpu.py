@@ -708,6 +708,34 @@ def test_gemm256_swiglu_last_round_of_half_tile_items_bit_identical(M, N2, K):
         assert torch.equal(whole, ops.gemm(a, wp, swiglu=True, kernel=ops.GEMM_FAST))
 
 
+@pytest.mark.parametrize("M,N,K,f32", [(4096, 576, 576, False), (4900, 1728, 576, False), (2048, 320, 320, False), (3000, 960, 320, False), (8192, 192, 192, False),
+                                         (4096, 576, 2304, True), (2048, 320, 1152, True)])
+def test_gemm_widths_that_are_multiples_of_192_or_128_past_one(M, N, K, f32):
+    """Round 6: an N that is no multiple of 128 but N % 192 in {0, 128} (Hiera-L's stage widths 192 / 320 / 576 and their q|k|v triples) is served by the ping-pong kernel's
+    192-wide tile shapes (csrc/gemm.hip launch_any) instead of the generic kernel.  Same sums in the same order as the zero-padded call the model used to make (N and K padded
+    to the next multiple of 128): BIT-identical on the real columns, and right against fp32."""
+    a = bf(g(M, K, seed=95))
+    w = bf(g(N, K, seed=96, scale=0.05))
+    bias = g(N, seed=97)
+    Np, Kp = -(-N // 128) * 128, -(-K // 128) * 128
+    ap = torch.zeros(M, Kp, device=DEV, dtype=torch.bfloat16); ap[:, :K] = a
+    wp = torch.zeros(Np, Kp, device=DEV, dtype=torch.bfloat16); wp[:N, :K] = w
+    bp = torch.zeros(Np, device=DEV); bp[:N] = bias
+    if f32:
+        x = g(M, N, seed=98)
+        xp = torch.zeros(M, Np, device=DEV); xp[:, :N] = x
+        got = ops.gemm(a, w, bias=bias, resid=x.clone(), out_dtype=torch.float32)
+        pad = ops.gemm(ap, wp, bias=bp, resid=xp, out_dtype=torch.float32)[:, :N]
+        ref = a.float() @ w.float().t() + bias + x
+        assert rel(got, ref) <= 2e-5
+    else:
+        got = ops.gemm(a, w, bias=bias, act="gelu")
+        pad = ops.gemm(ap, wp, bias=bp, act="gelu")[:, :N]
+        ref = torch.nn.functional.gelu(a.float() @ w.float().t() + bias)
+        assert rel(got, ref) <= ONE_ULP
+    assert torch.equal(got, pad)
+
+
 def test_rope_kv_scalar_path():
     # head_dim 24 (hd/2 not a multiple of 8) takes the scalar kernel
     S, Hq, Hkv, hd, pos0 = 5, 2, 1, 24, 3

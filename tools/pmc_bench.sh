@@ -7,6 +7,7 @@ TAG=${1:-r06}
 ARGS=${UFV_BENCH_ARGS:-}
 SUB=${2:-pmc}
 OUT=$R/gpurun_out/$TAG/$SUB
+rm -rf $OUT          # (gpurun merges gpurun_out/ back file by file: counter files of an earlier pass would be averaged in)
 mkdir -p $OUT
 for C in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline $ARGS > /dev/null 2> $OUT/$C.err
