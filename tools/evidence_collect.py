@@ -82,6 +82,14 @@ def main():
     write_perf_floors(dst)
     for sub in ("pmc", "pmc_fp8"):
         if os.path.isdir(os.path.join(src, sub)):
+            # gpurun merges the box's gpurun_out/ into the local one file by file: the counter files of EARLIER passes (another tree) stay beside the newest ones.
+            # Keep the newest pass of every counter directory only -- a summary that averages two trees is no evidence for either.
+            import glob
+            for d in glob.glob(os.path.join(src, sub, "*", "*")):
+                files = sorted(glob.glob(os.path.join(d, "*_counter_collection.csv")), key=os.path.getmtime)
+                for old in files[:-1]:
+                    for f in glob.glob(old.replace("_counter_collection.csv", "_*")):
+                        os.remove(f)
             subprocess.call([sys.executable, os.path.join(ROOT, "tools", "pmc_summarize.py"), tag, sub], env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
 
 
