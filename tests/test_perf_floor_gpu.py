@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 FLOOR_MS = {
     "headline_step_ms": 52.6,                   # bench.run, 32 frames 336 x 336 bf16: the driver's ms_per_step (50.8 / 51.6 / 52.6 by box)
     "img384_step_ms": 64.4,                     # bench.run --img 384: the released checkpoint's own geometry (729 tokens per frame, S = 2799); 0.40 of 2.5 PF (63.7 / 64.2 / 64.4)
-    "vit_attention_576_us": 78.9,               # attn_fwd_vit72_p2<576>, 32 frames x 16 heads, fused-qkv column views, rotating buffers (78.4 / 78.9)
+    "vit_attention_576_us": 81.2,               # attn_fwd_vit72_p2<576>, 32 frames x 16 heads, fused-qkv column views, rotating buffers (78.4 / 78.9 / 81.2)
     "vit_attention_729_us": 122.9,              # attn_fwd_vit72_p2<729>: <= 1.7 x the 576 launch (work ratio 1.60) (119.2 / 122.9)
     "decode_bf16_ms_per_token": 3.88,           # (3.74 / 3.88)
     "decode_fp8_ms_per_token": 3.23,            # (3.21 / 3.23)
