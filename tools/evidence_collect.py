@@ -43,8 +43,11 @@ def write_perf_floors(dst):
                margin=margin, floors={})
     for k, rec in sorted(floors.items()):
         r = rows.get(k)
-        out["floors"][k] = dict(recorded=rec, limit=round(rec * margin, 4), measured=r["measured"] if r else None, unit=r["unit"] if r else ("us" if k.endswith("_us") else "ms"),
-                                consistent=(r is None or (abs(r["recorded"] - rec) < 1e-6 and r["measured"] <= r["limit"])))
+        row = dict(recorded=rec, limit=round(rec * margin, 4), measured=r["measured"] if r else None, unit=r["unit"] if r else ("us" if k.endswith("_us") else "ms"),
+                   within_limit=(r is None or r["measured"] <= rec * margin))
+        if r and abs(r["recorded"] - rec) > 1e-6:           # the test's figure was moved AFTER the committed run (to the slow end that run showed): say so
+            row["recorded_when_the_tail_was_taken"] = r["recorded"]
+        out["floors"][k] = row
     with open(os.path.join(dst, "perf_floors.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote perf_floors.json:", sum(1 for v in out["floors"].values() if v["measured"] is not None), "of", len(out["floors"]), "floors measured in the tail")
