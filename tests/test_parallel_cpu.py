@@ -98,6 +98,39 @@ def test_frame_sharded_encode_world2_gloo(T):
         assert tmax == 2.0 and shape == (2 * T, 8)
 
 
+def test_frame_sharded_token_counts_at_the_checkpoints_384_px_geometry():
+    """siglip-so400m-patch14-384: 384 // 14 = 27 patches per side (the stride-14 convolution drops 6 pixels), the STC-v35 sampler floors 27 -> 13: 169 tokens per frame pair.
+    Every rank derives every rank's count from that arithmetic alone (no size exchange): one process group of one rank, 32 frames -> 16 x 169 = 2704 tokens."""
+    class Tower384:
+        class config:
+            patch_size = 14
+
+    class Inner384(_Inner):
+        def get_vision_tower(self):
+            return Tower384()
+
+    class Model384(_Model):
+        def get_model(self):
+            return Inner384()
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        video = torch.zeros(32, 3, 384, 384)
+        seen = []
+
+        def enc(frames):
+            seen.append(frames.shape[0])
+            return torch.ones((frames.shape[0] // 2) * 169, 8)
+        out = P.encode_frame_sharded(Model384(), video, encode_fn=enc)
+        assert seen == [32] and out.shape == (2704, 8)
+        with pytest.raises(AssertionError):                     # an encoder that returned the 336-px count (144 per pair) is caught by the geometry check
+            P.encode_frame_sharded(Model384(), video, encode_fn=lambda fr: torch.ones((fr.shape[0] // 2) * 144, 8))
+    finally:
+        dist.destroy_process_group()
+
+
 def test_frame_sharding_refuses_projectors_that_look_across_frame_groups():
     """Conv3d padding 1 (stc_connector, spatial_conv) and the mean-over-all-frames MLP projectors would silently give other tokens"""
     class Pad1:
