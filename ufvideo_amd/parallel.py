@@ -7,7 +7,7 @@ Two modes:
     temporal stride (2 for stc_connector_v35), so each rank encodes a contiguous, stride-aligned chunk of frames and
     ONE all-gather of the visual tokens (rank order = temporal order) feeds the decoder, which every rank then
     runs (it does not frame-shard; Amdahl cap 1.5x at 8 GPUs): `frame_chunks`, `encode_frame_sharded`.
-No scaling curve has been measured on hardware yet (no multi-GPU node in rounds 1-2): the exchange is covered by
+No scaling curve has been measured on hardware yet (no multi-GPU node in any round so far): the exchange is covered by
 world-size-2 gloo tests (tests/test_parallel_cpu.py), and the same calls run on RCCL with the one rank a 1-GPU box offers
 (tests/test_parallel_gpu.py).
 """
