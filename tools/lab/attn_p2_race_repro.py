@@ -1,3 +1,6 @@
+"""lab: the reproducer of the round-5 / round-6 race of the generated ViT attention kernel: late-tile spikes for rows of every unit and pass, small grids, the SAME launch repeated and compared
+with the second-generation kernel.  Before the fix (tools/gen_attn_p2.py rescale_math last_tile; UFV_P2_OPT=lastq regenerates the old text) S = 729 with 3-4 blocks showed 500-4700 differing elements
+per launch in rows of unit 2; after it nothing differs.  usage: python tools/lab/attn_p2_race_repro.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
