@@ -137,36 +137,44 @@ def test_native_384_geometry_7b_dims_vs_oracle():
     rng = np.random.default_rng(4384)
     u8 = rng.integers(0, 256, (4, 384, 384, 3), dtype=np.uint8)
     video = ops.preprocess_u8(torch.from_numpy(u8).to(dev), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))          # bf16 [4,3,384,384]
+    # a PixRQA-style sample (ufvideo/eval/inference_PixRQA.py:122-148): one region mask on one frame -> one '<region>' token pooled from the 27 x 27 feature grid
+    frame = video[0:1].clone()
+    Hm = Wm = 200
+    mask = torch.zeros(1, 1, Hm, Wm); mask[0, 0, 30:150, 50:170] = 1
     text = rng.integers(0, 151643, 40).astype(np.int64)
-    ids = torch.from_numpy(np.concatenate([text[:10], [-201], text[10:]]))[None].to(dev)
+    ids = torch.from_numpy(np.concatenate([text[:10], [-201], text[10:25], [REGION_ID], text[25:]]))[None].to(dev)
     am = torch.ones_like(ids)
+    kw = dict(images=[(video, "video")], masks=mask.to(dev), frame=[frame], ann_indices=[[[0]]], frame_nums=[1])
     with torch.no_grad():
         feats = tower.encode(video)
         mm = model.encode_images_or_videos([(video, "video")])
-        _, am2, _, emb, _, mark = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, [(video, "video")], None, None, None, None)
+        _, am2, _, emb, _, mark = model.prepare_inputs_labels_for_multimodal(ids, am, None, None, kw["images"], kw["masks"], kw["frame"], kw["ann_indices"], kw["frame_nums"])
         logits, cache, hs, normed = model._decode_batch(emb, am2, None, False, 1)
     NT = (4 // 2) * 13 * 13
     assert feats.shape == (4, 729, 1152) and mm.shape == (1, NT, 3584)
-    S = NT + ids.shape[1] - 1
-    assert emb.shape == (1, S, 3584) and int(am2.sum()) == S and mark[0] == [NT + 10, ids.shape[1] - 11]
+    S = NT + ids.shape[1] - 1                                                        # <video> -> 338 tokens, <region> -> 1 region token
+    assert emb.shape == (1, S, 3584) and int(am2.sum()) == S
     sd = _cpu_sd(model, drop=("model.text_hidden_fcs",))
     vt = "model.vision_tower.vision_tower.vision_model."
-    vcpu = video.float().cpu()
+    vcpu, fcpu = video.float().cpu(), frame.float().cpu()
 
     def oracle():
         f = O.siglip_tower(sd, vis, vcpu, prefix=vt)
         mmo = O.stc_connector(sd, f[None], prefix="model.mm_projector.")
-        amo, embo, _, marko = O.splice(O._rb(sd["model.embed_tokens.weight"].float()), ids.cpu(), am.cpu(), None, mmo, [], [], REGION_ID, False)
+        mf, nums = O.mask_extractor(sd, O.siglip_tower(sd, vis, fcpu, prefix=vt), [mask[0]], [[[0]]], prefix="model.region_encoder.")
+        amo, embo, _, marko = O.splice(O._rb(sd["model.embed_tokens.weight"].float()), ids.cpu(), am.cpu(), None, mmo, mf, nums, REGION_ID, True)
         out = O.qwen2_forward(sd, llm, embo, amo, all_logits=False)
-        return dict(feats=f, mm=mmo, am=amo, emb=embo, mark=marko, logits=out["logits"][0, -1])
+        return dict(feats=f, mm=mmo, region=mf, nums=nums, am=amo, emb=embo, mark=marko, logits=out["logits"][0, -1])
     with O.bf16_mirror():
         om = oracle()
     o32 = oracle()
-    assert mark == om["mark"] == o32["mark"] and torch.equal(am2.cpu().to(o32["am"].dtype), o32["am"])
-    text_rows = [i for i in range(S) if not (10 <= i < 10 + NT)]
+    assert om["nums"] == o32["nums"] == [1] and mark == om["mark"] == o32["mark"] and torch.equal(am2.cpu().to(o32["am"].dtype), o32["am"])
+    rrow = 10 + NT + 15                                                              # where the region token lands
+    text_rows = [i for i in range(S) if not (10 <= i < 10 + NT) and i != rrow]
     assert torch.equal(emb[0, text_rows].cpu(), o32["emb"][0, text_rows])
     # bounds ~2 x what MI355X measures (chains of bf16 storage points: DESIGN.md section 2); the tower rows are the new arithmetic (729-token attention, 27 x 27 grid)
     for name, got, km, b_m, b_32 in (("tower 2 L, 4 f x 729 x 1152", feats, "feats", 6e-3, 9e-3), ("visual tokens (338 x 3584)", mm, "mm", 2.5e-2, 2e-2),
+                                     ("region token (27 x 27 grid)", emb[0, rrow][None], "region", 6e-3, 6e-3),
                                      ("inputs_embeds", emb, "emb", 2.5e-2, 2e-2), ("last-position logits", logits[0, -1], "logits", 1.6e-2, 1.6e-2)):
         g = got.float().cpu().reshape(om[km].shape)
         em, e32 = rel_err(g, om[km]), rel_err(g, o32[km])
