@@ -118,6 +118,28 @@ def test_siglip_tiny_tower_vs_reference_golden():
     assert tower.num_patches == 16 and tower.hidden_size == 64 and tower.image_size == 56 and tower.num_patches_per_side == 4
 
 
+def test_tower_and_v35_sampler_at_the_checkpoints_kind_of_geometry_vs_reference_golden():
+    """golden/geom_odd.npz (oracle/gen_fixtures_geom.py: the REFERENCE's SiglipVisionTower at 76 px = 5 x 14 + 6, and its STCConnectorV35(depth 0) on the odd 5 x 5 grid): the HIP
+    tower drops the 6 remainder pixels as HF's stride-14 convolution does (what 384 = 27 x 14 + 6 needs) and the connector floors the odd grid (27 -> 13 in production, 5 -> 2 here)."""
+    a, w = load_golden("geom_odd")
+    cfg = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2, image_size=76, patch_size=14)
+    tower = SiglipVisionTower("siglip", Args(), vision_config=cfg)
+    tower.load_hf_state_dict({k: v for k, v in w.items() if not k.startswith("proj.")})
+    tower = tower.to(DEV)
+    x = t(a["x"]).to(DEV)
+    y = tower(x)
+    assert y.shape == (4, 25, 32) and tower.num_patches == 25 and rel_err(y.cpu(), t(a["y"])) < 1e-2
+    x2 = x.clone(); x2[:, :, 70:, :] = 9.0; x2[:, :, :, 70:] = -9.0
+    assert torch.equal(tower(x2), y)
+
+    class Cfg:
+        mm_hidden_size = 32
+        hidden_size = 32
+    m = STCConnectorV35(Cfg(), depth=0); m.load_state_dict(_sub(w, "proj.")); m = m.to(DEV)
+    z = m(t(a["y"])[None].to(DEV))
+    assert z.shape == (1, 8, 32) and rel_err(z.cpu(), t(a["z"])) < 1e-2
+
+
 def test_clip_tiny_tower_vs_reference_golden():
     a, w = load_golden("clip_tiny")
     cfg = dict(TINY_VIT, hidden_act="quick_gelu", layer_norm_eps=1e-5)

@@ -48,6 +48,27 @@ def test_siglip_tiny_tower():
     assert torch.equal(hs[2], O.siglip_tower(w, TINY_VIT, x, prefix=pre))      # select_layer=-2 of 3 layers
 
 
+def _sub0(w, pre):
+    return {k[len(pre):]: v for k, v in w.items() if k.startswith(pre)}
+
+
+GEOM_VIT = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2, image_size=76, patch_size=14)
+
+
+def test_geometry_of_the_released_checkpoint_remainder_pixels_and_odd_grid_vs_reference_golden():
+    """oracle/gen_fixtures_geom.py ran the REFERENCE's own SiglipVisionTower at 76 px (76 = 5 x 14 + 6: the remainder of 384 = 27 x 14 + 6) and its STCConnectorV35 (depth 0) on the
+    odd 5 x 5 grid (floors to 2 x 2, as 27 -> 13): the stride-14 convolution drops the 6 remainder pixels and the sampler drops the odd row / column, in the oracle as in the reference."""
+    a, w = load_golden("geom_odd")
+    pre = bytes(a["prefix"]).decode()
+    x = t(a["x"])
+    y = O.siglip_tower(w, GEOM_VIT, x, prefix=pre)
+    assert y.shape == (4, 25, 32) and rel_err(y, t(a["y"])) < TOL
+    x2 = x.clone(); x2[:, :, 70:, :] = 9.0; x2[:, :, :, 70:] = -9.0                # the remainder pixels reach nothing
+    assert torch.equal(O.siglip_tower(w, GEOM_VIT, x2, prefix=pre), y)
+    z = O.stc_connector(_sub0(w, "proj."), t(a["y"])[None], downsample=(2, 2, 2), padding=0, depth=0)
+    assert z.shape == (1, 8, 32) and rel_err(z, t(a["z"])) < TOL
+
+
 def test_clip_tiny_tower():
     a, w = load_golden("clip_tiny")
     cfg = dict(TINY_VIT, hidden_act="quick_gelu", layer_norm_eps=1e-5)
